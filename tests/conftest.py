@@ -1,0 +1,41 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The plain-C CPU restatement (test infrastructure, oracle/)."""
+    from oracle import oracle as orc
+    orc.build(ref=False)
+    return orc.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The unmodified reference compiled under oracle/_ref (skips when absent)."""
+    from oracle import oracle as orc
+    if not orc.have_ref():
+        if os.path.isdir("/root/reference/imutil"):
+            orc.build(ref=True)
+        if not orc.have_ref():
+            pytest.skip("oracle/_ref not built (reference sources not present)")
+    return orc.load_ref()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library through the reference's C API (fails loudly when not built / no GPU)."""
+    import sift3d_amd
+    return sift3d_amd.load()

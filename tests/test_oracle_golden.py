@@ -1,0 +1,86 @@
+"""CPU: the oracle restatement (oracle/s3d_oracle.c) against golden vectors captured from the
+unmodified reference build (tests/golden/make_golden.py).  Bit-exact everywhere."""
+import os
+
+import numpy as np
+
+from sift3d_amd import synth
+from tests.conftest import GOLDEN
+from tests.util import nbitdiff, sha
+
+
+def test_gauss_taps(oracle):
+    g = np.load(os.path.join(GOLDEN, "gauss_taps.npz"))
+    for i, s in enumerate(g["sigmas"]):
+        t = oracle.gauss_taps(float(s))
+        assert t.size == g[f"taps_{i}"].size
+        assert nbitdiff(t, g[f"taps_{i}"]) == 0, s
+    # default filter bank widths
+    assert [g[f"taps_{i}"].size for i in range(2, 8)] == [5, 7, 9, 11, 13, 17]
+
+
+def test_sep_fir(oracle):
+    g = np.load(os.path.join(GOLDEN, "sep_fir.npz"))
+    for i in range(int(g["n"])):
+        taps = oracle.gauss_taps(float(g[f"sigma_{i}"]))
+        out = oracle.sep_fir(g[f"in_{i}"], taps, tuple(g[f"units_{i}"]), float(g[f"unit_{i}"]))
+        assert nbitdiff(out, g[f"out_{i}"]) == 0, i
+
+
+def _detect_case(oracle, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nx, ny, nz = (int(v) for v in g["dims"])
+    vol = synth.blobs(nx, ny, nz, int(g["nblobs"]), int(g["seed"]))
+    assert sha(vol) == str(g["input_sha256"]), "synthetic generator drifted"
+    xyzos, sd, R = oracle.detect(vol, tuple(g["units"]))
+    assert np.array_equal(xyzos, g["xyzos"])           # indices bit-exact and in reference order
+    assert np.array_equal(sd, g["sd"])
+    assert nbitdiff(R, g["R"]) == 0
+    assert oracle.num_octaves() == int(g["num_octaves"])
+    k = 0
+    for o in range(oracle.num_octaves()):
+        for s in range(-1, 5):
+            assert sha(oracle.level("gss", o, s)[0]) == str(g["gss_sha256"][k]), (o, s)
+            k += 1
+    k = 0
+    for o in range(oracle.num_octaves()):
+        for s in range(-1, 4):
+            assert sha(oracle.level("dog", o, s)[0]) == str(g["dog_sha256"][k]), (o, s)
+            k += 1
+    assert nbitdiff(oracle.level("gss", 1, 1)[0], g["gss_o1_s1"]) == 0
+    bins, xyzs = oracle.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
+    assert nbitdiff(bins, g["desc_bins"]) == 0
+    assert np.array_equal(xyzs, g["desc_xyzs"])
+
+
+def test_detect_describe_iso(oracle):
+    _detect_case(oracle, "detect_iso64")
+
+
+def test_detect_describe_aniso(oracle):
+    _detect_case(oracle, "detect_aniso")
+
+
+def test_dense(oracle):
+    g = np.load(os.path.join(GOLDEN, "dense.npz"))
+    nx, ny, nz = (int(v) for v in g["dims"])
+    vol = synth.blobs(nx, ny, nz, int(g["nblobs"]), int(g["seed"])) * float(g["scale"]) + float(g["offset"])
+    vol = vol.astype(np.float32)
+    assert sha(vol) == str(g["input_sha256"])
+    out = oracle.dense(vol, tuple(g["units"]))
+    assert nbitdiff(out, g["out"]) == 0
+
+
+def test_eig3_against_numpy(oracle):
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        m = rng.standard_normal((3, 3))
+        a = m @ m.T
+        L = np.zeros(3)
+        Q = np.zeros((3, 3))
+        oracle.L.orc_eig3(a.ctypes.data_as(C.POINTER(C.c_double)), L.ctypes.data_as(C.POINTER(C.c_double)),
+                          Q.ctypes.data_as(C.POINTER(C.c_double)))
+        w, v = np.linalg.eigh(a)
+        assert np.allclose(L, w, rtol=1e-12, atol=1e-13)
+        assert np.allclose(np.abs(np.sum(Q * v, axis=0)), 1.0, atol=1e-9)

@@ -1,0 +1,51 @@
+"""CPU (this container only): the oracle restatement against the live reference build oracle/_ref,
+on seeded inputs beyond the committed goldens.  Skips where oracle/_ref cannot be built."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sift3d_amd import abi, synth
+from tests.util import nbitdiff
+
+
+@pytest.mark.parametrize("dims,units,nc,sigma", [((23, 31, 27), (1, 1, 1), 1, 1.94659),
+                                                 ((23, 31, 27), (2, 2, 2), 1, 2.45255),
+                                                 ((22, 25, 21), (1, 0.7, 2), 3, 1.22627)])
+def test_sep_fir_live(oracle, reference, dims, units, nc, sigma):
+    rng = np.random.default_rng(99)
+    nx, ny, nz = dims
+    vol = rng.standard_normal((nz, ny, nx) + ((nc,) if nc > 1 else ())).astype(np.float32)
+    g = abi.Gauss_filter()
+    assert reference.imutil.init_Gauss_filter(C.byref(g), sigma, 3) == 0
+    src = reference.image_from_numpy(vol, units)
+    dst = abi.Image()
+    reference.imutil.init_im(C.byref(dst))
+    assert reference.imutil.apply_Sep_FIR_filter(C.byref(src), C.byref(dst), C.byref(g.f), 1.0) == 0
+    want = reference.image_to_numpy(dst)
+    got = oracle.sep_fir(vol, oracle.gauss_taps(sigma), units, 1.0)
+    assert nbitdiff(got, want) == 0
+
+
+@pytest.mark.parametrize("dims,units,nblobs,seed", [((70, 66, 75), (1, 1, 1), 300, 0),
+                                                    ((64, 64, 64), (1, 1, 2), 250, 1)])
+def test_detect_describe_live(oracle, reference, dims, units, nblobs, seed):
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    s = abi.SIFT3D()
+    assert reference.sift.init_SIFT3D(C.byref(s)) == 0
+    im = reference.image_from_numpy(vol, units)
+    kp = abi.Keypoint_store()
+    reference.sift.init_Keypoint_store(C.byref(kp))
+    assert reference.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+    xyzos, sd, R = reference.keypoints_to_numpy(kp)
+    x2, sd2, R2 = oracle.detect(vol, units)
+    assert np.array_equal(xyzos, x2) and np.array_equal(sd, sd2) and nbitdiff(R, R2) == 0
+    assert len(xyzos) > 10
+    d = abi.SIFT3D_Descriptor_store()
+    reference.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert reference.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    b, c = reference.descriptors_to_numpy(d)
+    b2, c2 = oracle.describe(x2[:, :3].astype(np.float64), x2[:, 3:5], sd2, R2)
+    assert nbitdiff(b, b2) == 0 and np.array_equal(c, c2)
+    reference.sift.cleanup_SIFT3D(C.byref(s))
