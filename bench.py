@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- detect+describe throughput of the HIP path and the roofline of its dominant kernel.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU under torchrun)
+
+A step = one pass of the hot path over one synthetic volume that is ALREADY RESIDENT IN HBM:
+SIFT3D_detect_keypoints (copy + scale + 36 Gaussian applications + extrema + orientation; the small
+keypoint list is downloaded because the API returns it) followed by SIFT3D_extract_descriptors for
+every keypoint with the descriptors left in HBM.  At N = 1 the workload is BASELINE.json configs[1]:
+512^3 float32, "blobs+noise" generator, 128 000 blobs (31 207 keypoints).  At N > 1 every rank runs
+the same-shaped volume of its own (seed = rank): weak scaling, no data-path collective -- the
+Z-slab + RCCL-halo decomposition of one large volume is a later row of SURVEY.md section 8(e).
+
+One JSON line on stdout (rank 0).  Besides the driver's contract it carries
+  roofline      the fused X+Y Gaussian kernel at 512^3 (dominant kernel of the north-star Gaussian),
+                timed with HIP events on the stream it is launched on; per-width application
+                numbers ride along in config.gauss_apps.
+  cpu_baseline  the unmodified reference (oracle/_ref, kind "reference") or, if that is not
+                available, the oracle port -- timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import sift3d_amd                      # noqa: E402
+from sift3d_amd import abi, synth      # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GAUSS_APP_BYTES_PER_VOXEL = 24.0       # 3 passes x (4 B read + 4 B write), SURVEY.md 8(d)
+GAUSS_XY_BYTES_PER_VOXEL = 16.0        # the fused kernel performs 2 of the 3 algorithmic passes
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def gauss_roofline(dev, n, widths_sigmas, reps=5):
+    """Time one Gaussian application per filter of the default bank on an n^3 volume in HBM."""
+    from sift3d_amd.device import _vp
+    rng = np.random.default_rng(0)
+    vol = rng.standard_normal((n, n, n)).astype(np.float32)
+    d_src = dev.upload(vol)
+    d_dst = dev.malloc(vol.nbytes)
+    d_tmp = dev.malloc(vol.nbytes)
+    ev = [_vp() for _ in range(3)]
+    for e in ev:
+        dev.check(dev.L.s3d_rt_event_create(C.byref(e)))
+    lib = sift3d_amd.load()
+    out = []
+    nvox = float(n) ** 3
+    for sigma in widths_sigmas:
+        g = abi.Gauss_filter()
+        assert lib.imutil.init_Gauss_filter(C.byref(g), sigma, 3) == 0
+        taps = np.ctypeslib.as_array(g.f.kernel, shape=(g.f.width,)).copy()
+        dev.sep_fir(d_src, d_dst, d_tmp, n, n, n, 1, (1, 1, 1), taps, path=2)      # warm-up
+        dev.sync()
+        t_xy = t_z = 0.0
+        for _ in range(reps):
+            dev.L.s3d_k_gauss_set_events(ev[0], ev[1], ev[2])
+            dev.sep_fir(d_src, d_dst, d_tmp, n, n, n, 1, (1, 1, 1), taps, path=2)
+            dev.L.s3d_k_gauss_set_events(None, None, None)
+            ms = C.c_float()
+            dev.check(dev.L.s3d_rt_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+            t_xy += ms.value
+            dev.check(dev.L.s3d_rt_event_elapsed_ms(ev[1], ev[2], C.byref(ms)))
+            t_z += ms.value
+        t_xy /= reps
+        t_z /= reps
+        out.append({"width": int(g.f.width), "xy_ms": round(t_xy, 4), "z_ms": round(t_z, 4),
+                    "app_GBs": round(GAUSS_APP_BYTES_PER_VOXEL * nvox / ((t_xy + t_z) * 1e-3) / 1e9, 1),
+                    "app_frac_of_8TBs": round(GAUSS_APP_BYTES_PER_VOXEL * nvox / ((t_xy + t_z) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        lib.imutil.cleanup_Gauss_filter(C.byref(g))
+    for e in ev:
+        dev.L.s3d_rt_event_destroy(e)
+    for p in (d_src, d_dst, d_tmp):
+        dev.free(p)
+    return out
+
+
+def cpu_baseline(sample_n=160):
+    """Reference (or port) detect+describe on a bounded sample of the same generator, host cores."""
+    from oracle import oracle as orc
+    vol = synth.blobs(sample_n, sample_n, sample_n, synth.default_nblobs(sample_n, sample_n, sample_n), 0)
+    cores = os.cpu_count() or 1
+    if orc.have_ref():
+        ref = orc.load_ref()
+        s = abi.SIFT3D()
+        assert ref.sift.init_SIFT3D(C.byref(s)) == 0
+        im = ref.image_from_numpy(vol)
+        kp = abi.Keypoint_store()
+        ref.sift.init_Keypoint_store(C.byref(kp))
+        d = abi.SIFT3D_Descriptor_store()
+        ref.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+        t0 = time.perf_counter()
+        assert ref.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        if kp.slab.num:
+            assert ref.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        dt = time.perf_counter() - t0
+        k = int(kp.slab.num)
+        kind = "reference"
+    else:
+        O = orc.Oracle()
+        t0 = time.perf_counter()
+        xyzos, sd, R = O.detect(vol)
+        if len(xyzos):
+            O.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
+        dt = time.perf_counter() - t0
+        k = len(xyzos)
+        kind = "port"
+    return {"value": round(sample_n ** 3 / dt / 1e6, 4), "unit": "Mvox/s", "cores": cores, "kind": kind,
+            "sample": f"detect+describe on one {sample_n}^3 volume of the same generator ({k} keypoints, {dt:.1f} s, "
+                      f"OpenMP default threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512, help="volume edge (default 512 = BASELINE configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = sift3d_amd.load()
+    dev = sift3d_amd.load_device()
+    if dev.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device -- the HIP path has no CPU fallback")
+    dev.check(dev.L.s3d_rt_set_device(local_rank), "set_device")
+
+    def full_sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        dev.check(dev.L.s3d_rt_sync(None))
+
+    n = args.size
+    nblobs = synth.default_nblobs(n, n, n)            # 128 000 at 512^3
+    t0 = time.perf_counter()
+    vol = synth.blobs(n, n, n, nblobs, seed=rank)
+    log(f"[rank {rank}] synthesised {n}^3 ({nblobs} blobs) in {time.perf_counter() - t0:.1f} s")
+    d_vol = dev.upload(vol)
+
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    kp = abi.Keypoint_store()
+    lib.sift.init_Keypoint_store(C.byref(kp))
+    d_desc = C.c_void_p()
+
+    def step():
+        rc = lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
+        if rc != 0:
+            raise SystemExit("detect failed: " + lib.sift.sift3d_amd_last_error().decode())
+        if kp.slab.num:
+            rc = lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
+            if rc != 0:
+                raise SystemExit("describe failed: " + lib.sift.sift3d_amd_last_error().decode())
+
+    for _ in range(args.warmup):
+        step()
+    # split timing of one extra untimed step (detect vs describe), for the record
+    full_sync()
+    t0 = time.perf_counter()
+    lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
+    dev.sync()
+    t_detect = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if kp.slab.num:
+        lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
+    dev.sync()
+    t_describe = time.perf_counter() - t0
+
+    full_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    K = int(kp.slab.num)
+    ncand = int(lib.sift.sift3d_amd_last_num_candidates(C.byref(s)))
+
+    result = None
+    if rank == 0:
+        nvox = float(n) ** 3
+        value = world * nvox * args.steps / elapsed / 1e6
+        result = {
+            "metric": "Mvoxels/s detect+describe on 512^3 float32; 3D Gaussian achieved HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}^3 float32 blobs+noise ({nblobs} blobs, seed=rank), unit voxels, default SIFT3D "
+                                   f"parameters; detect + describe all keypoints, input and descriptors resident in HBM",
+                       "keypoints": K, "extrema_candidates": ncand,
+                       "detect_ms": round(t_detect * 1e3, 3), "describe_ms": round(t_describe * 1e3, 3),
+                       "parallelism": "1 volume per GPU (weak), no data-path collective" if world > 1 else "1 GPU"},
+        }
+    if rank == 0 and not args.no_roofline:
+        sig = [0.538701, 0.973294, 1.22627, 1.54501, 1.94659, 2.45255]      # default bank: widths 5..17
+        apps = gauss_roofline(dev, 512 if n >= 512 else n, sig)
+        worst = max(apps, key=lambda a: a["xy_ms"])                       # widest filter = slowest fused kernel
+        nv = float(512 if n >= 512 else n) ** 3
+        ach = GAUSS_XY_BYTES_PER_VOXEL * nv / (worst["xy_ms"] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                              "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
+                                        f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
+        result["config"]["gauss_apps"] = apps
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline()
+        except Exception as e:            # the baseline is a report, never a reason to lose the GPU number
+            result["cpu_baseline"] = {"value": None, "unit": "Mvox/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    dev.free(d_vol)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/* s3d_device.h -- the thin C-ABI seam between the host C code and the hand-written HIP kernels.
+ *
+ * Plain pointers and sizes only (no HIP or torch types): every `d_*` pointer is device (HBM)
+ * memory, every other pointer is host memory.  All launches are asynchronous on `stream`
+ * (an opaque hipStream_t; NULL = the default stream) and return 0 on success, -1 on a HIP error
+ * (text via s3d_rt_last_error()).  Nothing here falls back to the CPU: without a usable gfx950
+ * device every call fails.
+ *
+ * Each kernel cites the reference routine whose arithmetic it reproduces (paths relative to the
+ * reference tree, bbrister/SIFT3D v1.4.6).
+ */
+#ifndef S3D_DEVICE_H
+#define S3D_DEVICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *s3d_stream;
+
+#define S3D_MAX_TAPS 129     /* widest separable filter accepted (half width 64) */
+#define S3D_MAX_OCTAVES 16
+#define S3D_MAX_LEVELS 16    /* GSS levels per octave (num_kp_levels + 3) */
+#define S3D_DESC_NUMEL 768
+#define S3D_NFACES 20
+#define S3D_NVERT 12
+
+/* ---- runtime ----------------------------------------------------------------------------------- */
+int s3d_rt_device_count(int *count);
+int s3d_rt_set_device(int dev);
+int s3d_rt_get_device(int *dev);
+int s3d_rt_malloc(void **d_ptr, size_t bytes);
+int s3d_rt_free(void *d_ptr);
+int s3d_rt_h2d(void *d_dst, const void *src, size_t bytes, s3d_stream stream);
+int s3d_rt_d2h(void *dst, const void *d_src, size_t bytes, s3d_stream stream);
+int s3d_rt_d2d(void *d_dst, const void *d_src, size_t bytes, s3d_stream stream);
+int s3d_rt_memset(void *d_ptr, int value, size_t bytes, s3d_stream stream);
+int s3d_rt_sync(s3d_stream stream);
+int s3d_rt_stream_create(s3d_stream *stream);
+int s3d_rt_stream_destroy(s3d_stream stream);
+/* HIP events on `stream`, for timing the kernels where they run (bench.py) */
+int s3d_rt_event_create(void **ev);
+int s3d_rt_event_destroy(void *ev);
+int s3d_rt_event_record(void *ev, s3d_stream stream);
+int s3d_rt_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchronises on ev_stop */
+const char *s3d_rt_last_error(void);
+
+/* ---- image ops ---------------------------------------------------------------------------------- */
+/* *d_max = max |v[i]|     (im_max_abs, imutil/imutil.c:1959-1973).  d_max is overwritten. */
+int s3d_k_absmax(const float *d_v, size_t n, float *d_max, s3d_stream stream);
+/* v[i] = v[i] / *d_max unless *d_max == 0   (im_scale, imutil/imutil.c:1977-1991; true division) */
+int s3d_k_scale_div(float *d_v, size_t n, const float *d_max, s3d_stream stream);
+/* dst(x,y,z) = src(2x,2y,2z), dst dims = floor(n/2)   (im_downsample_2x, imutil/imutil.c:1742-1768) */
+int s3d_k_decimate2(const float *d_src, int nx, int ny, int nz, float *d_dst, s3d_stream stream);
+/* dst = a - b   (im_subtract, imutil/imutil.c:1997-2017) */
+int s3d_k_subtract(const float *d_a, const float *d_b, float *d_dst, size_t n, s3d_stream stream);
+
+/* ---- separable FIR / Gaussian  (apply_Sep_FIR_filter imutil.c:3459-3544,
+ *      convolve_sep_gen imutil.c:2274-2393) ------------------------------------------------------- */
+/* One axis pass with the reference's exact per-element arithmetic: tap spacing `uf` voxels
+ * (unit / units[axis] as float), 2-point interpolation, asymmetric mirror boundary.  Any nc. */
+int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny, int nz, int nc, int axis,
+                    const float *taps, int width, float uf, s3d_stream stream);
+/* All three axes (x, y, z; each pass rounded to f32).  d_tmp: scratch of the same size.
+ * d_src may equal d_dst.  Uses the fused streaming kernels when uf == (1,1,1) and nc == 1
+ * (octave 0 of a unit-voxel volume: the roofline configuration), the generic pass otherwise. */
+int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,
+                  const float uf[3], const float *taps, int width, s3d_stream stream);
+/* Force a code path (tests / profiling): 0 = auto, 1 = generic per-axis passes, 2 = fused fast path
+ * (fails if the configuration is not eligible). */
+/* rows (planes) per marching chunk of the fused kernels: occupancy vs warm-up re-reads */
+void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z);
+/* record HIP events (from s3d_rt_event_create) before k_gauss_xy, between, and after k_gauss_z of the
+ * next fused applications; NULLs switch it off.  For bench.py's per-kernel timing. */
+void s3d_k_gauss_set_events(void *before_xy, void *between, void *after_z);
+int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz,
+                       int nc, const float uf[3], const float *taps, int width, int path,
+                       s3d_stream stream);
+
+/* ---- DoG + extrema  (build_dog sift3d/sift.c:1052-1071, detect_extrema sift.c:1074-1212) -------- */
+/* *d_max = max |a - b|  : per-level `dogmax` (sift.c:1161-1166) without materialising the DoG. */
+int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float *d_max, s3d_stream stream);
+/* Extrema of DoG(s) = L1 - L2 against DoG(s-1) = L0 - L1 and DoG(s+1) = L2 - L3 for one level:
+ * bit i of d_bits (64-bit words, little-endian bit order) is set iff linear voxel i is a candidate
+ * (strict 6-neighbour + prev/next centre test, |v| > (float)(peak_thresh * *d_dogmax)).
+ * d_bits must hold ceil(n/64) words; every word is written. */
+int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3,
+                  int nx, int ny, int nz, double peak_thresh, const float *d_dogmax,
+                  unsigned long long *d_bits, s3d_stream stream);
+/* Ordered compaction of a bitmap: appends the indices of set bits, ascending, to d_idx starting at
+ * position *d_count, tags each with `tag` in d_tag, and advances *d_count.  Entries past `capacity`
+ * are dropped (the count still advances, so overflow is detectable).  d_scratch: >= nwords/1024+2
+ * uint32. */
+int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nwords, uint32_t *d_idx,
+                       uint32_t *d_tag, uint32_t tag, uint32_t capacity, uint32_t *d_count,
+                       uint32_t *d_scratch, s3d_stream stream);
+
+/* ---- keypoints ----------------------------------------------------------------------------------- */
+typedef struct {
+    const float *d_level[S3D_MAX_OCTAVES * S3D_MAX_LEVELS]; /* GSS level data, [o*num_levels + (s-first_level)] */
+    int dims[S3D_MAX_OCTAVES][3];                           /* per octave nx, ny, nz */
+    float unitsf[S3D_MAX_OCTAVES][3];                       /* per octave (float) ux, uy, uz */
+    int num_octaves, num_levels, first_level;
+} s3d_pyramid_desc;
+
+/* assign_eig_ori (sift.c:1354-1514) + assign_orientation_thresh (sift.c:1331-1342) for `num`
+ * candidates with tag = o<<8 | (s - first_level).  Window centre: the voxel of linear index
+ * d_idx[i] when d_center == NULL (detected candidates; d_sigma is then indexed per level,
+ * [o*num_levels + k], = 1.5 * level scale), else the float triple d_center[3i..] (raw-image
+ * variant, sift.c:1534-1604; d_sigma is then per candidate).
+ * Outputs: d_R[9*i] row-major rotation, d_keep[i] = 1 iff not rejected and conf >= corner_thresh,
+ * d_conf[i] (optional) = corner score, 0 when rejected. */
+int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                 const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                 float *d_R, uint32_t *d_keep, double *d_conf, s3d_stream stream);
+/* Stable compaction of kept candidates: for i with keep[i], writes x,y,z,o,s (int32 x5) and R.
+ * *d_num_out receives the number kept. */
+int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                       const float *d_R, const uint32_t *d_keep, uint32_t num, int32_t *d_xyzos,
+                       float *d_R_out, uint32_t *d_num_out, s3d_stream stream);
+
+/* One record per keypoint for the descriptor kernel; the scalar set-up mirrors
+ * extract_descrip (sift.c:1845-1851) and is done on the host in the same float arithmetic. */
+typedef struct {
+    float cx, cy, cz;        /* (float) key->xd, yd, zd */
+    float sigma;             /* (float)(sd * desc_sig_fctr) */
+    float rad;               /* (float)(desc_rad_fctr * sigma) */
+    float half;              /* (float)(rad / sqrt(2)) */
+    float binf;              /* 1.0f / ((2.0f*half) / NHIST_PER_DIM) */
+    int level;               /* index into s3d_pyramid_desc.d_level */
+    int octave;
+    float R[9];              /* key->R, row-major */
+} s3d_desc_key;
+
+/* extract_descrip (sift.c:1834-1928) incl. SIFT3D_desc_acc_interp (sift.c:1687-1791),
+ * icos_hist_bin/cart2bary (sift.c:1646-1683, 335-394) and both normalisations (sift.c:1794-1821).
+ * d_mesh: table from s3d_mesh_table().  Descriptor i is written to d_out[i*out_stride .. +768),
+ * order 12*(cx+4cy+16cz)+vertex (out_stride = 776 lays records out like SIFT3D_Descriptor). */
+int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
+                   const float *d_mesh, float *d_out, size_t out_stride /* floats, >= 768 */,
+                   s3d_stream stream);
+
+/* Icosahedron table for the kernels (host computation in f32, mirrors init_geometry sift.c:215-326
+ * incl. the v[0]<->v[1] swap quirk).  Layout per face (16 floats): e1[3] e2[3] t[3] q[3] e2q
+ * idx0 idx1 idx2 (indices stored as float bit patterns of ints).  out: 20*16 floats. */
+#define S3D_MESH_FLOATS (S3D_NFACES * 16)
+void s3d_mesh_table(float *out);
+
+/* ---- dense descriptors (SIFT3D_extract_dense_descriptors sift.c:2354-2496) ----------------------- */
+/* Gradient -> icosahedron barycentric weights into a zeroed 12-channel image (sift.c:2460-2480). */
+int s3d_k_dense_bary(const float *d_smooth, int nx, int ny, int nz, const float unitsf[3],
+                     const float *d_mesh, float *d_out12, s3d_stream stream);
+/* postproc_Hist per voxel (sift.c:2267-2292, 2396-2412): normalise, clamp, normalise, times in(x,y,z) */
+int s3d_k_dense_post(float *d_desc12, const float *d_in, size_t nvox, s3d_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

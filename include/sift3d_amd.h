@@ -1,0 +1,284 @@
+/* sift3d_amd.h -- C ABI of libsift3d_amd.so, the MI355X-native drop-in for the hot path of
+ * bbrister/SIFT3D v1.4.6 (libsift3D + the part of libimutil it stands on).
+ *
+ * The structs below are byte-for-byte layout compatible with the reference's imutil/imtypes.h
+ * (x86-64 SysV; sizes/offsets are _Static_assert'ed at the bottom), because the reference's callers
+ * allocate them on their own stack and read their fields directly.  The field names are therefore
+ * the reference's; everything else in this header is written for this repo.  A program built
+ * against the reference's headers can be relinked against libsift3d_amd.so unchanged for the
+ * entry points listed here; see INTEGRATION.md.
+ *
+ * Device state:  the reference has no opaque pointer in any struct; its only extension slots are
+ * the dummy OpenCL fields (int sized when OpenCL is compiled out, imtypes.h:49-68).  This library
+ * stores a small integer HANDLE into a process-global registry of device contexts in
+ * SIFT3D.kernels.downsample_2 (0 = none) -- never a pointer.  The Gaussian scale-space pyramid of the
+ * last SIFT3D_detect_keypoints stays resident in HBM for SIFT3D_extract_descriptors; the host-side
+ * `Pyramid` carries valid metadata (dims, units, scales) and level `data` pointers are NULL until
+ * sift3d_amd_download_pyramid() is called.
+ *
+ * Every function returns SIFT3D_SUCCESS (0) or SIFT3D_FAILURE (-1) like the reference and reports
+ * through stderr.  There is no CPU fallback: without a usable gfx950 device the compute entry
+ * points fail.
+ */
+#ifndef SIFT3D_AMD_H
+#define SIFT3D_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT3D_SUCCESS 0
+#define SIFT3D_FAILURE (-1)
+#define SIFT3D_TRUE 1
+#define SIFT3D_FALSE 0
+
+#define IM_NDIMS 3
+#define NHIST_PER_DIM 4
+#define ICOS_NFACES 20
+#define ICOS_NVERT 12
+#define HIST_NUMEL ICOS_NVERT
+#define DESC_NUM_TOTAL_HIST (NHIST_PER_DIM * NHIST_PER_DIM * NHIST_PER_DIM)
+#define DESC_NUMEL (DESC_NUM_TOTAL_HIST * HIST_NUMEL)
+
+typedef enum _Mat_rm_type { SIFT3D_DOUBLE, SIFT3D_FLOAT, SIFT3D_INT } Mat_rm_type;
+
+/* Row-major dense matrix (imtypes.h:136-149). Only the 3x3 float `Keypoint.R` is used here. */
+typedef struct _Mat_rm {
+    union {
+        double *data_double;
+        float *data_float;
+        int *data_int;
+    } u;
+    size_t size;
+    int num_cols;
+    int num_rows;
+    int static_mem;
+    Mat_rm_type type;
+} Mat_rm;
+
+/* Dense volume, x fastest, channels interleaved (imtypes.h:156-168).  Element (x,y,z,c) lives at
+ * data[x*xs + y*ys + z*zs + c]; default strides xs = nc, ys = nc*nx, zs = nc*nx*ny. */
+typedef struct _Image {
+    float *data;
+    int cl_image;     /* reference: dummy cl_mem.  Unused by this library. */
+    double s;         /* scale-space location */
+    size_t size;      /* number of floats */
+    int nx, ny, nz;
+    double ux, uy, uz;
+    size_t xs, ys, zs;
+    int nc;
+    int cl_valid;     /* reference: dummy flag.  Unused by this library. */
+} Image;
+
+typedef struct _Sep_FIR_filter {
+    int cl_apply_unrolled; /* reference: dummy cl_kernel */
+    float *kernel;
+    int dim;
+    int width;
+    int symmetric;
+} Sep_FIR_filter;
+
+typedef struct _Gauss_filter {
+    double sigma;
+    Sep_FIR_filter f;
+} Gauss_filter;
+
+typedef struct _GSS_filters {
+    Gauss_filter first_gauss;
+    Gauss_filter *gauss_octave;
+    int num_filters;
+    int first_level;
+} GSS_filters;
+
+typedef struct _SIFT_cl_kernels {
+    int downsample_2; /* reference: dummy cl_kernel.  HERE: handle of the device context (0 = none). */
+} SIFT_cl_kernels;
+
+typedef struct _Pyramid {
+    Image *levels;    /* [(o - first_octave) * num_levels + (s - first_level)] */
+    double sigma_n;
+    double sigma0;
+    int num_kp_levels;
+    int first_octave;
+    int num_octaves;
+    int first_level;
+    int num_levels;
+} Pyramid;
+
+typedef struct _Cvec { float x, y, z; } Cvec;
+
+typedef struct _Slab {
+    void *buf;
+    size_t num;
+    size_t buf_size;
+} Slab;
+
+typedef struct _Keypoint {
+    float r_data[IM_NDIMS * IM_NDIMS]; /* storage of R */
+    Mat_rm R;                          /* 3x3 float rotation, R.u.data_float == r_data */
+    double xd, yd, zd;                 /* integer voxel coordinates in octave o, stored as double */
+    double sd;                         /* scale */
+    int o, s;                          /* octave, level */
+} Keypoint;
+
+typedef struct _Keypoint_store {
+    Keypoint *buf;
+    Slab slab;
+    int nx, ny, nz;
+} Keypoint_store;
+
+typedef struct _Hist { float bins[HIST_NUMEL]; } Hist;
+
+typedef struct _Tri {
+    Cvec v[3];
+    int idx[3];
+} Tri;
+
+typedef struct _Mesh {
+    Tri *tri;
+    int num;
+} Mesh;
+
+typedef struct _SIFT3D_Descriptor {
+    Hist hists[DESC_NUM_TOTAL_HIST]; /* element 12*(cx + 4*cy + 16*cz) + vertex */
+    double xd, yd, zd, sd;
+} SIFT3D_Descriptor;
+
+typedef struct _SIFT3D_Descriptor_store {
+    SIFT3D_Descriptor *buf;
+    size_t num;
+    int nx, ny, nz;
+} SIFT3D_Descriptor_store;
+
+typedef struct _SIFT3D {
+    Mesh mesh;
+    GSS_filters gss;
+    SIFT_cl_kernels kernels;
+    Pyramid gpyr;
+    Pyramid dog;
+    Image im;
+    double peak_thresh;
+    double corner_thresh;
+    int dense_rotate;
+} SIFT3D;
+
+/* Indexing helpers (semantics of immacros.h:58-63, 157-159) */
+#define SIFT3D_IM_GET_IDX(im, x, y, z, c) \
+    ((size_t)(x) * (im)->xs + (size_t)(y) * (im)->ys + (size_t)(z) * (im)->zs + (size_t)(c))
+#define SIFT3D_IM_GET_VOX(im, x, y, z, c) ((im)->data[SIFT3D_IM_GET_IDX((im), (x), (y), (z), (c))])
+#define SIFT3D_PYR_IM_GET(pyr, o, s) \
+    ((pyr)->levels + ((o) - (pyr)->first_octave) * (pyr)->num_levels + ((s) - (pyr)->first_level))
+
+/* ======================= libimutil subset (replaces imutil/imutil.h entries) ======================= */
+void init_im(Image *const im);                                          /* imutil.c:3634 */
+int init_im_with_dims(Image *const im, const int nx, const int ny, const int nz, const int nc); /* imutil.c:1424 */
+void im_free(Image *im);                                                /* imutil.c:1916 */
+void im_default_stride(Image *const im);                                /* imutil.c:1453 */
+int im_resize(Image *const im);                                         /* imutil.c:1527 */
+int im_copy_dims(const Image *const src, Image *dst);                   /* imutil.c:1873 */
+int im_copy_data(const Image *const src, Image *const dst);             /* imutil.c:1895 */
+void im_zero(Image *im);                                                /* imutil.c:2020 */
+void *SIFT3D_safe_realloc(void *ptr, size_t size);                      /* imutil.c:247 */
+
+int init_Gauss_filter(Gauss_filter *const gauss, const double sigma, const int dim);   /* imutil.c:3657 */
+int init_Gauss_incremental_filter(Gauss_filter *const gauss, const double s_cur,
+                                  const double s_next, const int dim);                 /* imutil.c:3713 */
+void cleanup_Gauss_filter(Gauss_filter *gauss);                                          /* imutil.c:3737 */
+int init_Sep_FIR_filter(Sep_FIR_filter *const f, const int dim, const int width,
+                        const float *const kernel, const int symmetric);               /* imutil.c:3552 */
+void cleanup_Sep_FIR_filter(Sep_FIR_filter *const f);                                    /* imutil.c:3620 */
+/* The north-star "im_Gauss_filter": x, y, z passes on the GPU.  Host images in, host image out. */
+int apply_Sep_FIR_filter(const Image *const src, Image *const dst, Sep_FIR_filter *const f,
+                         const double unit);                                             /* imutil.c:3459 */
+
+void init_GSS_filters(GSS_filters *const gss);                          /* imutil.c:3744 */
+int make_gss(GSS_filters *const gss, const Pyramid *const pyr);         /* imutil.c:3752 */
+void cleanup_GSS_filters(GSS_filters *const gss);                       /* imutil.c:3806 */
+void init_Pyramid(Pyramid *const pyr);                                  /* imutil.c:3832 */
+int resize_Pyramid(const Image *const im, const int first_level, const unsigned int num_kp_levels,
+                   const unsigned int num_levels, const int first_octave,
+                   const unsigned int num_octaves, Pyramid *const pyr); /* imutil.c:3858 */
+int set_scales_Pyramid(const double sigma0, const double sigma_n, Pyramid *const pyr); /* imutil.c:3957 */
+void cleanup_Pyramid(Pyramid *const pyr);                               /* imutil.c:4051 */
+
+/* ======================= libsift3D subset (replaces sift3d/sift.h entries) ========================= */
+int init_SIFT3D(SIFT3D *sift3d);                                        /* sift.c:583 */
+void cleanup_SIFT3D(SIFT3D *const sift3d);                              /* sift.c:659 */
+int set_peak_thresh_SIFT3D(SIFT3D *const sift3d, const double peak_thresh);       /* sift.c:514 */
+int set_corner_thresh_SIFT3D(SIFT3D *const sift3d, const double corner_thresh);   /* sift.c:527 */
+int set_num_kp_levels_SIFT3D(SIFT3D *const sift3d, const unsigned int num_kp_levels); /* sift.c:542 */
+int set_sigma_n_SIFT3D(SIFT3D *const sift3d, const double sigma_n);               /* sift.c:552 */
+int set_sigma0_SIFT3D(SIFT3D *const sift3d, const double sigma0);                 /* sift.c:568 */
+
+void init_Keypoint_store(Keypoint_store *const kp);                     /* sift.c:399 */
+int init_Keypoint(Keypoint *const key);                                 /* sift.c:406 */
+int resize_Keypoint_store(Keypoint_store *const kp, const size_t num);  /* sift.c:417 */
+int copy_Keypoint(const Keypoint *const src, Keypoint *const dst);      /* sift.c:439 */
+void cleanup_Keypoint_store(Keypoint_store *const kp);                  /* sift.c:455 */
+void init_SIFT3D_Descriptor_store(SIFT3D_Descriptor_store *const desc);    /* sift.c:462 */
+void cleanup_SIFT3D_Descriptor_store(SIFT3D_Descriptor_store *const desc); /* sift.c:468 */
+
+/* THE BOUNDARY */
+int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im,
+                            Keypoint_store *const kp);                  /* sift.c:1609 */
+int SIFT3D_have_gpyr(const SIFT3D *const sift3d);                       /* sift.c:1936 */
+int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const kp,
+                               SIFT3D_Descriptor_store *const desc);    /* sift.c:2025 */
+int SIFT3D_extract_raw_descriptors(SIFT3D *const sift3d, const Image *const im,
+                                   const Keypoint_store *const kp,
+                                   SIFT3D_Descriptor_store *const desc); /* sift.c:2131 */
+int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im,
+                               Keypoint_store *const kp, double **const conf); /* sift.c:1534 */
+int SIFT3D_extract_dense_descriptors(SIFT3D *const sift3d, const Image *const in,
+                                     Image *const desc);                /* sift.c:2354 */
+
+/* ======================= extensions (not in the reference) ========================================= */
+/* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */
+int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz,
+                                    double ux, double uy, double uz, Keypoint_store *const kp);
+/* Descriptors stay in HBM: *d_desc receives a device pointer to num x 768 floats owned by the
+ * library (valid until the next call on this SIFT3D); pass the result of detect in kp. */
+int sift3d_amd_extract_descriptors_dev(SIFT3D *const sift3d, const Keypoint_store *const kp,
+                                       const float **d_desc);
+/* Dense descriptors device to device: d_in nx*ny*nz floats, d_out nx*ny*nz*12 floats.
+ * out_units = the units `desc` would carry on entry to the reference call (quirk C-17). */
+int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx, int ny, int nz,
+                                 double ux, double uy, double uz, const double out_units[3], float *d_out);
+/* One Gaussian application device to device (d_tmp: scratch of equal size). */
+int sift3d_amd_gauss_dev(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,
+                         const double units[3], const float *taps, int width, double unit);
+/* Copy GSS level data (and, if want_dog, materialise + copy the DoG levels) into the host Pyramids
+ * of sift3d, allocating level->data.  Only needed by callers that read pyramid voxels. */
+int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog);
+/* Number of extrema candidates before orientation rejection in the last detect (diagnostics). */
+long sift3d_amd_last_num_candidates(const SIFT3D *const sift3d);
+/* Stream on which this SIFT3D's kernels run (opaque hipStream_t); set before the first detect. */
+int sift3d_amd_set_stream(SIFT3D *const sift3d, void *hip_stream);
+const char *sift3d_amd_last_error(void);
+
+/* ---- ABI checks (x86-64 SysV; values measured on the compiled reference) ----------- */
+#if defined(__x86_64__) && !defined(SIFT3D_AMD_NO_ABI_ASSERT)
+#define S3D_ABI_SIZE(T, n) _Static_assert(sizeof(T) == (n), "ABI size of " #T)
+#define S3D_ABI_OFF(T, f, n) _Static_assert(offsetof(T, f) == (n), "ABI offset of " #T "." #f)
+#ifndef __cplusplus
+S3D_ABI_SIZE(Image, 104); S3D_ABI_OFF(Image, cl_image, 8); S3D_ABI_OFF(Image, s, 16);
+S3D_ABI_OFF(Image, size, 24); S3D_ABI_OFF(Image, nx, 32); S3D_ABI_OFF(Image, ux, 48);
+S3D_ABI_OFF(Image, xs, 72); S3D_ABI_OFF(Image, nc, 96); S3D_ABI_OFF(Image, cl_valid, 100);
+S3D_ABI_SIZE(Mat_rm, 32); S3D_ABI_SIZE(Keypoint, 112); S3D_ABI_OFF(Keypoint, R, 40);
+S3D_ABI_OFF(Keypoint, xd, 72); S3D_ABI_OFF(Keypoint, sd, 96); S3D_ABI_OFF(Keypoint, o, 104);
+S3D_ABI_OFF(Keypoint, s, 108); S3D_ABI_SIZE(Slab, 24); S3D_ABI_SIZE(Keypoint_store, 48);
+S3D_ABI_SIZE(Hist, 48); S3D_ABI_SIZE(SIFT3D_Descriptor, 3104); S3D_ABI_OFF(SIFT3D_Descriptor, xd, 3072);
+S3D_ABI_SIZE(SIFT3D_Descriptor_store, 32); S3D_ABI_SIZE(Sep_FIR_filter, 32); S3D_ABI_SIZE(Gauss_filter, 40);
+S3D_ABI_SIZE(GSS_filters, 56); S3D_ABI_SIZE(Pyramid, 48); S3D_ABI_SIZE(Tri, 48); S3D_ABI_SIZE(Mesh, 16);
+S3D_ABI_SIZE(SIFT3D, 304); S3D_ABI_OFF(SIFT3D, gss, 16); S3D_ABI_OFF(SIFT3D, gpyr, 80);
+S3D_ABI_OFF(SIFT3D, dog, 128); S3D_ABI_OFF(SIFT3D, im, 176); S3D_ABI_OFF(SIFT3D, peak_thresh, 280);
+S3D_ABI_OFF(SIFT3D, dense_rotate, 296);
+#endif
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,44 @@
+"""sift3d_amd -- MI355X-native (gfx950) implementation of the SIFT3D hot path behind the reference's
+C API.  This package is host-side plumbing only: it locates ``lib/libsift3d_amd.so`` (HIP kernels +
+host C, built by ``sift3d_amd.build``) and exposes it through ctypes with the reference's struct
+layouts (``abi``) and through the flat device C-ABI (``device``).
+
+There is no CPU fallback: ``load()`` raises if the library has not been built, and every compute
+entry point returns SIFT3D_FAILURE when no gfx950 device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as _C
+import os as _os
+
+from . import abi  # noqa: F401
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+LIB_PATH = _os.path.join(_HERE, "lib", "libsift3d_amd.so")
+_cdll = None
+
+
+def cdll() -> _C.CDLL:
+    """The raw shared library (loaded once)."""
+    global _cdll
+    if _cdll is None:
+        if not _os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m sift3d_amd.build` "
+                "(there is no CPU fallback for the HIP path)")
+        _cdll = _C.CDLL(LIB_PATH)
+    return _cdll
+
+
+def load() -> "abi.Sift3dLib":
+    """The product library seen through the reference's C API (init_SIFT3D, SIFT3D_detect_keypoints...)."""
+    from .device import bind_extensions
+    lib = abi.Sift3dLib(cdll(), None, "sift3d_amd")
+    bind_extensions(lib.sift)
+    return lib
+
+
+def load_device() -> "device.DeviceLib":
+    """The flat device C-ABI (s3d_rt_* / s3d_k_*) of include/s3d_device.h."""
+    from .device import DeviceLib
+    return DeviceLib(cdll())

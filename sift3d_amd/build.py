@@ -1,0 +1,82 @@
+"""Build libsift3d_amd.so (HIP kernels for gfx950 + host C) and libs3d_synth.so, in-tree.
+
+    python -m sift3d_amd.build            # or __graft_entry__.build()
+
+Host code is C (gcc -std=gnu11); device code is HIP (hipcc --offload-arch=gfx950).  Every translation
+unit that does float arithmetic on the parity path is compiled with -ffp-contract=off: the reference
+build has no fused multiply-add and contraction changes pyramid bits (hard part 1).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "lib", "obj")
+INC = os.path.join(ROOT, "include")
+
+HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
+               "s3d_dense.hip"]
+C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+             "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]
+C_FLAGS = ["-std=gnu11", "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", f"-I{INC}", f"-I{CSRC}/host",
+           "-pthread"]
+
+
+def _newer(src: str, out: str, extra=()) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(p) > t for p in (src, *extra))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + cmd[-1])
+
+
+def build(verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(INC, h) for h in os.listdir(INC)] + \
+              [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+              [os.path.join(CSRC, "host", h) for h in os.listdir(os.path.join(CSRC, "host")) if h.endswith(".h")]
+    objs = []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        o = os.path.join(OBJ, s.replace(".hip", ".o"))
+        if _newer(src, o, headers):
+            if verbose:
+                print("hipcc", s)
+            _run([HIPCC, *HIP_FLAGS, "-c", src, "-o", o])
+        objs.append(o)
+    for s in C_SOURCES:
+        src = os.path.join(CSRC, s)
+        o = os.path.join(OBJ, os.path.basename(s).replace(".c", ".o"))
+        if _newer(src, o, headers):
+            if verbose:
+                print("gcc", s)
+            _run(["gcc", *C_FLAGS, "-c", src, "-o", o])
+        objs.append(o)
+    out = os.path.join(LIB, "libsift3d_amd.so")
+    if any(_newer(o, out) for o in objs):
+        # -Bsymbolic: the library's own calls to init_im & co bind to itself even if another libimutil
+        # (e.g. the reference oracle in a test process) is loaded.
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", out, *objs, "-lm",
+              "-lpthread"])
+    synth = os.path.join(LIB, "libs3d_synth.so")
+    ssrc = os.path.join(CSRC, "synth.c")
+    if _newer(ssrc, synth):
+        _run(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-o", synth, ssrc, "-lm"])
+    return out
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

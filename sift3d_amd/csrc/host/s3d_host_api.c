@@ -1,0 +1,1028 @@
+/* s3d_host_api.c -- the drop-in entry points of libsift3d_amd: SIFT3D object lifecycle and the
+ * detect / describe / dense / Gaussian calls, orchestrating the HIP kernels through the thin C-ABI
+ * of include/s3d_device.h.  Host code is C, like the reference's; there is no CPU compute path.
+ *
+ * Data layout in HBM (per SIFT3D object, owned by a registry entry whose integer handle sits in
+ * SIFT3D.kernels.downsample_2):
+ *   d_im                         scaled copy of the input           nx*ny*nz f32
+ *   d_level[o*L + k]             GSS level (o, k-1)                 dims >> o, f32, x fastest
+ *   d_tmp                        scratch for the separable filter   octave-0 size
+ *   d_bits / d_scratch           extrema bitmap (1 bit / voxel) + block counters
+ *   d_cand_{idx,tag}, d_R, d_keep  candidate list, orientation results
+ *   d_xyzos, d_Rk                compacted keypoints
+ *   d_keys, d_desc               descriptor inputs / outputs (776-float records = SIFT3D_Descriptor)
+ * The DoG pyramid is never materialised (see s3d_extrema.hip) unless sift3d_amd_download_pyramid()
+ * asks for it.
+ */
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "s3d_host.h"
+
+/* parameters of the reference, sift.c:34-38, 48-55 */
+static const double peak_thresh_default = 0.1;
+static const int num_kp_levels_default = 3;
+static const double corner_thresh_default = 0.4;
+static const double sigma_n_default = 1.15;
+static const double sigma0_default = 1.6;
+static const double ori_sig_fctr = 1.5;
+static const double desc_sig_fctr = 7.071067812;
+static const double desc_rad_fctr = 2.0;
+
+#define DESC_REC_FLOATS (sizeof(SIFT3D_Descriptor) / sizeof(float)) /* 776 */
+
+static __thread char g_api_err[512];
+#define API_FAIL(...)                                        \
+    do {                                                     \
+        snprintf(g_api_err, sizeof(g_api_err), __VA_ARGS__); \
+        S3D_MSG("%s\n", g_api_err);                          \
+        return SIFT3D_FAILURE;                               \
+    } while (0)
+/* device-layer call: propagate its error text */
+#define DEV(call)                                                                      \
+    do {                                                                               \
+        if ((call) != 0) API_FAIL("sift3d_amd: %s failed: %s", #call, s3d_rt_last_error()); \
+    } while (0)
+
+const char *sift3d_amd_last_error(void) { return g_api_err; }
+
+/* ---- device context registry ------------------------------------------------------------------------ */
+typedef struct {
+    int in_use;
+    s3d_stream stream;
+    /* pyramid buffers */
+    int nx, ny, nz, num_octaves, num_levels;
+    float *d_im, *d_tmp;
+    float *d_level[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
+    size_t level_elems[S3D_MAX_OCTAVES];
+    unsigned long long *d_bits;
+    uint32_t *d_scratch;
+    float *d_red;           /* small reduction slots */
+    uint32_t *d_count;      /* [0] candidates, [1] keypoints */
+    uint32_t cand_cap;
+    uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
+    float *d_R, *d_Rk;
+    int32_t *d_xyzos;
+    double *d_sigma;
+    float *d_mesh;
+    int have_pyramid;
+    long last_num_candidates;
+    /* descriptor buffers */
+    size_t desc_cap;
+    s3d_desc_key *d_keys;
+    float *d_desc;
+    /* generic scratch for apply_Sep_FIR_filter / dense / raw variants */
+    size_t aux_elems[4];
+    float *d_aux[4];
+} s3d_ctx;
+
+#define S3D_MAX_CTX 256
+static s3d_ctx *g_ctx[S3D_MAX_CTX];
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+static s3d_ctx g_shared;            /* context of the struct-less entry points (apply_Sep_FIR_filter) */
+static pthread_mutex_t g_shared_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int ctx_new(void)
+{
+    int h = 0;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (int i = 0; i < S3D_MAX_CTX; i++)
+        if (g_ctx[i] == NULL) {
+            g_ctx[i] = (s3d_ctx *)calloc(1, sizeof(s3d_ctx));
+            if (g_ctx[i]) {
+                g_ctx[i]->in_use = 1;
+                h = i + 1;
+            }
+            break;
+        }
+    pthread_mutex_unlock(&g_ctx_lock);
+    return h;
+}
+
+static s3d_ctx *ctx_get(int handle)
+{
+    s3d_ctx *c = NULL;
+    if (handle < 1 || handle > S3D_MAX_CTX) return NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    c = g_ctx[handle - 1];
+    pthread_mutex_unlock(&g_ctx_lock);
+    return c;
+}
+
+static void dfree(void *pp)
+{
+    void **p = (void **)pp;
+    if (*p) s3d_rt_free(*p);
+    *p = NULL;
+}
+
+static void ctx_free_pyramid(s3d_ctx *c)
+{
+    dfree(&c->d_im); dfree(&c->d_tmp);
+    for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&c->d_level[i]);
+    dfree(&c->d_bits); dfree(&c->d_scratch);
+    dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep);
+    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_sigma);
+    c->nx = c->ny = c->nz = c->num_octaves = c->num_levels = 0;
+    c->cand_cap = 0;
+    c->have_pyramid = 0;
+}
+
+static void ctx_free_all(s3d_ctx *c)
+{
+    ctx_free_pyramid(c);
+    dfree(&c->d_red); dfree(&c->d_count); dfree(&c->d_mesh);
+    dfree(&c->d_keys); dfree(&c->d_desc);
+    c->desc_cap = 0;
+    for (int i = 0; i < 4; i++) { dfree(&c->d_aux[i]); c->aux_elems[i] = 0; }
+}
+
+static void ctx_release(int handle)
+{
+    s3d_ctx *c;
+    if (handle < 1 || handle > S3D_MAX_CTX) return;
+    pthread_mutex_lock(&g_ctx_lock);
+    c = g_ctx[handle - 1];
+    g_ctx[handle - 1] = NULL;
+    pthread_mutex_unlock(&g_ctx_lock);
+    if (c) {
+        ctx_free_all(c);
+        free(c);
+    }
+}
+
+/* small always-present buffers */
+static int ctx_base(s3d_ctx *c)
+{
+    if (!c->d_red) DEV(s3d_rt_malloc((void **)&c->d_red, 64 * sizeof(float)));
+    if (!c->d_count) DEV(s3d_rt_malloc((void **)&c->d_count, 8 * sizeof(uint32_t)));
+    if (!c->d_mesh) {
+        float mesh[S3D_MESH_FLOATS];
+        s3d_mesh_table(mesh);
+        DEV(s3d_rt_malloc((void **)&c->d_mesh, sizeof(mesh)));
+        DEV(s3d_rt_h2d(c->d_mesh, mesh, sizeof(mesh), c->stream));
+        DEV(s3d_rt_sync(c->stream));        /* `mesh` is a stack buffer */
+    }
+    return SIFT3D_SUCCESS;
+}
+
+static int ctx_aux(s3d_ctx *c, int slot, size_t elems)
+{
+    if (c->aux_elems[slot] >= elems) return SIFT3D_SUCCESS;
+    dfree(&c->d_aux[slot]);
+    c->aux_elems[slot] = 0;
+    DEV(s3d_rt_malloc((void **)&c->d_aux[slot], elems * sizeof(float)));
+    c->aux_elems[slot] = elems;
+    return SIFT3D_SUCCESS;
+}
+
+static s3d_ctx *sift_ctx(const SIFT3D *s) { return ctx_get(s->kernels.downsample_2); }
+
+/* ---- SIFT3D object ------------------------------------------------------------------------------------ */
+static int resize_SIFT3D(SIFT3D *const sift3d, const int num_kp_levels);
+
+static int set_scales_SIFT3D(SIFT3D *const sift3d, const double sigma0, const double sigma_n) /* sift.c:916-934 */
+{
+    if (set_scales_Pyramid(sigma0, sigma_n, &sift3d->gpyr) || set_scales_Pyramid(sigma0, sigma_n, &sift3d->dog))
+        return SIFT3D_FAILURE;
+    if (sift3d->im.nx <= 0) return SIFT3D_SUCCESS;       /* no image yet */
+    return make_gss(&sift3d->gss, &sift3d->gpyr);
+}
+
+int set_peak_thresh_SIFT3D(SIFT3D *const sift3d, const double peak_thresh)
+{
+    if (peak_thresh <= 0.0 || peak_thresh > 1) {
+        S3D_MSG("SIFT3D peak_thresh must be in the interval (0, 1]. Provided: %f \n", peak_thresh);
+        return SIFT3D_FAILURE;
+    }
+    sift3d->peak_thresh = peak_thresh;
+    return SIFT3D_SUCCESS;
+}
+
+int set_corner_thresh_SIFT3D(SIFT3D *const sift3d, const double corner_thresh)
+{
+    if (corner_thresh < 0.0 || corner_thresh > 1.0) {
+        S3D_MSG("SIFT3D corner_thresh must be in the interval [0, 1]. Provided: %f \n", corner_thresh);
+        return SIFT3D_FAILURE;
+    }
+    sift3d->corner_thresh = corner_thresh;
+    return SIFT3D_SUCCESS;
+}
+
+int set_num_kp_levels_SIFT3D(SIFT3D *const sift3d, const unsigned int num_kp_levels)
+{
+    if (num_kp_levels < 1 || num_kp_levels + 3 > S3D_MAX_LEVELS) {
+        S3D_MSG("SIFT3D num_kp_levels must be in [1, %d]. Provided: %u \n", S3D_MAX_LEVELS - 3, num_kp_levels);
+        return SIFT3D_FAILURE;
+    }
+    return resize_SIFT3D(sift3d, (int)num_kp_levels);
+}
+
+int set_sigma_n_SIFT3D(SIFT3D *const sift3d, const double sigma_n)
+{
+    if (sigma_n < 0.0) {
+        S3D_MSG("SIFT3D sigma_n must be nonnegative. Provided: %f \n", sigma_n);
+        return SIFT3D_FAILURE;
+    }
+    return set_scales_SIFT3D(sift3d, sift3d->gpyr.sigma0, sigma_n);
+}
+
+int set_sigma0_SIFT3D(SIFT3D *const sift3d, const double sigma0)
+{
+    if (sigma0 < 0.0) {
+        S3D_MSG("SIFT3D sigma0 must be nonnegative. Provided: %f \n", sigma0);
+        return SIFT3D_FAILURE;
+    }
+    return set_scales_SIFT3D(sift3d, sigma0, sift3d->gpyr.sigma_n);
+}
+
+/* host copy of the icosahedron (SIFT3D.mesh is part of the public struct; sift.c:215-326) */
+static int init_geometry(SIFT3D *sift3d)
+{
+    float tab[S3D_MESH_FLOATS];
+    Mesh *const mesh = &sift3d->mesh;
+    mesh->num = -1;                                       /* the reference never sets it (imutil.c:552) */
+    if ((mesh->tri = (Tri *)calloc(ICOS_NFACES, sizeof(Tri))) == NULL) return SIFT3D_FAILURE;
+    s3d_mesh_table(tab);
+    for (int i = 0; i < ICOS_NFACES; i++) {
+        const float *m = tab + 16 * i;                    /* e1 e2 t q e2q idx : v0 = -t, v1 = v0+e1, v2 = v0+e2 */
+        Tri *t = mesh->tri + i;
+        t->v[0].x = -m[6]; t->v[0].y = -m[7]; t->v[0].z = -m[8];
+        t->v[1].x = t->v[0].x + m[0]; t->v[1].y = t->v[0].y + m[1]; t->v[1].z = t->v[0].z + m[2];
+        t->v[2].x = t->v[0].x + m[3]; t->v[2].y = t->v[0].y + m[4]; t->v[2].z = t->v[0].z + m[5];
+        memcpy(t->idx, m + 13, 3 * sizeof(int));
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int init_SIFT3D(SIFT3D *sift3d) /* sift.c:583-626 */
+{
+    init_Pyramid(&sift3d->dog);
+    init_Pyramid(&sift3d->gpyr);
+    init_GSS_filters(&sift3d->gss);
+    sift3d->kernels.downsample_2 = 0;
+    if (init_geometry(sift3d)) return SIFT3D_FAILURE;
+    init_im(&sift3d->im);
+    sift3d->dog.first_level = sift3d->gpyr.first_level = -1;
+    sift3d->dense_rotate = SIFT3D_FALSE;
+    /* order of the reference: sigma_n, sigma0, thresholds, then levels */
+    sift3d->gpyr.num_kp_levels = sift3d->dog.num_kp_levels = num_kp_levels_default;
+    if (set_sigma_n_SIFT3D(sift3d, sigma_n_default) || set_sigma0_SIFT3D(sift3d, sigma0_default) ||
+        set_peak_thresh_SIFT3D(sift3d, peak_thresh_default) ||
+        set_corner_thresh_SIFT3D(sift3d, corner_thresh_default) ||
+        set_num_kp_levels_SIFT3D(sift3d, (unsigned)num_kp_levels_default))
+        return SIFT3D_FAILURE;
+    return SIFT3D_SUCCESS;
+}
+
+void cleanup_SIFT3D(SIFT3D *const sift3d) /* sift.c:659-678 */
+{
+    ctx_release(sift3d->kernels.downsample_2);
+    sift3d->kernels.downsample_2 = 0;
+    im_free(&sift3d->im);
+    cleanup_Pyramid(&sift3d->gpyr);
+    cleanup_Pyramid(&sift3d->dog);
+    cleanup_GSS_filters(&sift3d->gss);
+    free(sift3d->mesh.tri);
+    sift3d->mesh.tri = NULL;
+}
+
+int sift3d_amd_set_stream(SIFT3D *const sift3d, void *hip_stream)
+{
+    s3d_ctx *c;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    c->stream = (s3d_stream)hip_stream;
+    return SIFT3D_SUCCESS;
+}
+
+/* resize_SIFT3D (sift.c:938-986): octave count from the smallest dimension, pyramid metadata,
+ * filter bank.  Voxel storage is allocated on the device by ctx_ensure_pyramid(). */
+static int resize_SIFT3D(SIFT3D *const sift3d, const int num_kp_levels)
+{
+    const Image *const im = &sift3d->im;
+    const unsigned num_dog_levels = (unsigned)num_kp_levels + 2;
+    const unsigned num_gpyr_levels = num_dog_levels + 1;
+    int num_octaves = 0;
+    if (im->nx > 0) {
+        int mind = im->nx < im->ny ? im->nx : im->ny;
+        if (im->nz < mind) mind = im->nz;
+        const int last_octave = (int)log2((double)mind) - 3;
+        if (last_octave < 0) {
+            S3D_MSG("resize_SIFT3D: input image is too small: must have at least 8 voxels in each dimension \n");
+            return SIFT3D_FAILURE;
+        }
+        num_octaves = last_octave + 1;
+        if (num_octaves > S3D_MAX_OCTAVES) num_octaves = S3D_MAX_OCTAVES;
+    }
+    if (s3d_resize_pyramid(im, -1, (unsigned)num_kp_levels, num_gpyr_levels, 0, (unsigned)num_octaves,
+                           &sift3d->gpyr, 0) ||
+        s3d_resize_pyramid(im, -1, (unsigned)num_kp_levels, num_dog_levels, 0, (unsigned)num_octaves, &sift3d->dog, 0))
+        return SIFT3D_FAILURE;
+    if (im->nx <= 0) return SIFT3D_SUCCESS;
+    return make_gss(&sift3d->gss, &sift3d->gpyr);
+}
+
+/* (re)allocate the device pyramid for the current host metadata */
+static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
+{
+    const Pyramid *g = &sift3d->gpyr;
+    const Image *l0 = g->levels;
+    size_t n0, maxwords;
+    if (c->nx == l0->nx && c->ny == l0->ny && c->nz == l0->nz && c->num_octaves == g->num_octaves &&
+        c->num_levels == g->num_levels && c->d_im)
+        return SIFT3D_SUCCESS;
+    ctx_free_pyramid(c);
+    if (g->num_octaves > S3D_MAX_OCTAVES || g->num_levels > S3D_MAX_LEVELS) API_FAIL("sift3d_amd: pyramid too deep");
+    n0 = (size_t)l0->nx * l0->ny * l0->nz;
+    DEV(s3d_rt_malloc((void **)&c->d_im, n0 * sizeof(float)));
+    DEV(s3d_rt_malloc((void **)&c->d_tmp, n0 * sizeof(float)));
+    for (int o = 0; o < g->num_octaves; o++) {
+        const Image *lv = g->levels + o * g->num_levels;
+        c->level_elems[o] = (size_t)lv->nx * lv->ny * lv->nz;
+        for (int k = 0; k < g->num_levels; k++)
+            DEV(s3d_rt_malloc((void **)&c->d_level[o * g->num_levels + k], c->level_elems[o] * sizeof(float)));
+    }
+    maxwords = (n0 + 63) / 64;
+    DEV(s3d_rt_malloc((void **)&c->d_bits, maxwords * sizeof(unsigned long long)));
+    DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 1024 + 2) * sizeof(uint32_t)));
+    DEV(s3d_rt_malloc((void **)&c->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS));
+    c->nx = l0->nx; c->ny = l0->ny; c->nz = l0->nz;
+    c->num_octaves = g->num_octaves;
+    c->num_levels = g->num_levels;
+    return SIFT3D_SUCCESS;
+}
+
+static int ctx_ensure_candidates(s3d_ctx *c, uint32_t cap)
+{
+    if (c->cand_cap >= cap) return SIFT3D_SUCCESS;
+    dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep);
+    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos);
+    c->cand_cap = 0;
+    DEV(s3d_rt_malloc((void **)&c->d_cand_idx, (size_t)cap * sizeof(uint32_t)));
+    DEV(s3d_rt_malloc((void **)&c->d_cand_tag, (size_t)cap * sizeof(uint32_t)));
+    DEV(s3d_rt_malloc((void **)&c->d_keep, (size_t)cap * sizeof(uint32_t)));
+    DEV(s3d_rt_malloc((void **)&c->d_R, (size_t)cap * 9 * sizeof(float)));
+    DEV(s3d_rt_malloc((void **)&c->d_Rk, (size_t)cap * 9 * sizeof(float)));
+    DEV(s3d_rt_malloc((void **)&c->d_xyzos, (size_t)cap * 5 * sizeof(int32_t)));
+    c->cand_cap = cap;
+    return SIFT3D_SUCCESS;
+}
+
+static void fill_pyr_desc(const Pyramid *g, float *const *levels, s3d_pyramid_desc *pd)
+{
+    memset(pd, 0, sizeof(*pd));
+    pd->num_octaves = g->num_octaves;
+    pd->num_levels = g->num_levels;
+    pd->first_level = g->first_level;
+    for (int o = 0; o < g->num_octaves; o++) {
+        const Image *lv = g->levels + o * g->num_levels;
+        pd->dims[o][0] = lv->nx; pd->dims[o][1] = lv->ny; pd->dims[o][2] = lv->nz;
+        pd->unitsf[o][0] = (float)lv->ux; pd->unitsf[o][1] = (float)lv->uy; pd->unitsf[o][2] = (float)lv->uz;
+        for (int k = 0; k < g->num_levels; k++) pd->d_level[o * g->num_levels + k] = levels[o * g->num_levels + k];
+    }
+}
+
+/* tap spacing per axis: unit / units[axis] as float (imutil.c:2286-2287), unit = -1 -> the image's own */
+static void unit_factors(const double units[3], double unit, float uf[3])
+{
+    for (int a = 0; a < 3; a++) {
+        const double ua = unit == -1.0 ? units[a] : unit;
+        uf[a] = (float)(ua / units[a]);
+    }
+}
+
+/* set_im_SIFT3D (sift.c:883-913) for an input already on the host or on the device: metadata on the
+ * host, voxels into d_im, then im_scale on the device. */
+static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const float *d_vol, int nx, int ny,
+                         int nz, double ux, double uy, double uz)
+{
+    Image *const sim = &sift3d->im;
+    s3d_ctx *c;
+    const int had_image = sim->nx > 0;
+    const int same_dims = had_image && sim->nx == nx && sim->ny == ny && sim->nz == nz;
+    size_t n;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    if (ctx_base(c)) return SIFT3D_FAILURE;
+    /* host metadata of sift3d->im (im_copy_dims: dims, default strides, nc and units); data stays NULL */
+    sim->nx = nx; sim->ny = ny; sim->nz = nz; sim->nc = 1;
+    sim->ux = ux; sim->uy = uy; sim->uz = uz;
+    im_default_stride(sim);
+    if (!same_dims && resize_SIFT3D(sift3d, sift3d->gpyr.num_kp_levels)) return SIFT3D_FAILURE;
+    if (same_dims) {
+        /* Quirk C-12: without a resize the reference refreshes level units only where filtering copies
+         * them from the new image, i.e. in octave 0; octaves >= 1 keep the units of the last resize. */
+        for (int k = 0; k < sift3d->gpyr.num_levels; k++) {
+            Image *lv = sift3d->gpyr.levels + k;
+            lv->ux = ux; lv->uy = uy; lv->uz = uz;
+        }
+        for (int k = 0; k < sift3d->dog.num_levels; k++) {
+            Image *lv = sift3d->dog.levels + k;
+            lv->ux = ux; lv->uy = uy; lv->uz = uz;
+        }
+    }
+    if (ctx_ensure_pyramid(sift3d, c)) return SIFT3D_FAILURE;
+    n = (size_t)nx * ny * nz;
+    if (host_dense) DEV(s3d_rt_h2d(c->d_im, host_dense, n * sizeof(float), c->stream));
+    else DEV(s3d_rt_d2d(c->d_im, d_vol, n * sizeof(float), c->stream));
+    DEV(s3d_k_absmax(c->d_im, n, c->d_red, c->stream));
+    DEV(s3d_k_scale_div(c->d_im, n, c->d_red, c->stream));
+    return SIFT3D_SUCCESS;
+}
+
+/* build_gpyr (sift.c:989-1050) on the device */
+static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c)
+{
+    const Pyramid *g = &sift3d->gpyr;
+    const GSS_filters *gss = &sift3d->gss;
+    const int L = g->num_levels;
+    const Image *l0 = g->levels;
+    float uf[3];
+    double units[3] = {sift3d->im.ux, sift3d->im.uy, sift3d->im.uz};
+    unit_factors(units, 1.0, uf);
+    DEV(s3d_k_sep_fir(c->d_im, c->d_level[0], c->d_tmp, l0->nx, l0->ny, l0->nz, 1, uf, gss->first_gauss.f.kernel,
+                      gss->first_gauss.f.width, c->stream));
+    for (int o = 0; o < g->num_octaves; o++) {
+        const Image *lv = g->levels + o * L;
+        double lu[3] = {lv->ux, lv->uy, lv->uz};
+        unit_factors(lu, 1.0, uf);
+        for (int k = 1; k < L; k++) {
+            /* level s = k-1+first_level+... uses gauss_octave[s] with s counted from 0 (quirk C-11):
+             * filter index k-1 maps level k-1 -> k */
+            const Sep_FIR_filter *f = &gss->gauss_octave[k - 1].f;
+            DEV(s3d_k_sep_fir(c->d_level[o * L + k - 1], c->d_level[o * L + k], c->d_tmp, lv->nx, lv->ny, lv->nz, 1,
+                              uf, f->kernel, f->width, c->stream));
+        }
+        if (o != g->num_octaves - 1) {
+            int ds = L - 1 - 2;                           /* downsample level index: max(s_end-2, first) */
+            if (ds < 0) ds = 0;
+            DEV(s3d_k_decimate2(c->d_level[o * L + ds], lv->nx, lv->ny, lv->nz, c->d_level[(o + 1) * L], c->stream));
+        }
+    }
+    c->have_pyramid = 1;
+    return SIFT3D_SUCCESS;
+}
+
+/* detect_extrema (sift.c:1074-1212) + assign_orientations (sift.c:1264-1325) on the device */
+static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp)
+{
+    const Pyramid *g = &sift3d->gpyr;
+    const int L = g->num_levels;
+    const int nkp = g->num_kp_levels;
+    s3d_pyramid_desc pd;
+    uint32_t counts[2] = {0, 0};
+    uint32_t cap = c->cand_cap;
+    if (cap == 0) {
+        const size_t n0 = (size_t)c->nx * c->ny * c->nz;
+        cap = (uint32_t)(n0 / 256 + 4096);
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (ctx_ensure_candidates(c, cap)) return SIFT3D_FAILURE;
+        DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), c->stream));
+        for (int o = 0; o < g->num_octaves; o++) {
+            const Image *lv = g->levels + o * L;
+            const size_t n = c->level_elems[o];
+            for (int ks = 1; ks <= nkp; ks++) {          /* DoG level index ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
+                float *const *lp = &c->d_level[o * L];
+                DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + 1, c->stream));
+                DEV(s3d_k_extrema(lp[ks - 1], lp[ks], lp[ks + 1], lp[ks + 2], lv->nx, lv->ny, lv->nz,
+                                  sift3d->peak_thresh, c->d_red + 1, c->d_bits, c->stream));
+                DEV(s3d_k_compact_bits(c->d_bits, (n + 63) / 64, c->d_cand_idx, c->d_cand_tag,
+                                       ((uint32_t)o << 8) | (uint32_t)ks, c->cand_cap, c->d_count, c->d_scratch,
+                                       c->stream));
+            }
+        }
+        DEV(s3d_rt_d2h(counts, c->d_count, sizeof(uint32_t), c->stream));
+        DEV(s3d_rt_sync(c->stream));
+        if (counts[0] <= c->cand_cap) break;
+        cap = counts[0] + 1024;                           /* candidate list overflowed: grow and redo */
+        if (attempt == 1) API_FAIL("sift3d_amd: candidate buffer overflow");
+    }
+    c->last_num_candidates = (long)counts[0];
+
+    /* keypoint store metadata: dims of the first DoG keypoint level = octave 0 (sift.c:1096-1099) */
+    kp->nx = g->levels->nx; kp->ny = g->levels->ny; kp->nz = g->levels->nz;
+    if (counts[0] == 0) return resize_Keypoint_store(kp, 0);
+
+    fill_pyr_desc(g, c->d_level, &pd);
+    {
+        double sig[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
+        for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
+        DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
+        DEV(s3d_k_orient(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
+                         c->d_R, c->d_keep, NULL, c->stream));
+        DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
+                               c->d_Rk, c->d_count + 1, c->stream));
+        DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));
+        DEV(s3d_rt_sync(c->stream));                      /* also orders the reads of `sig` */
+    }
+    {
+        const uint32_t K = counts[1];
+        int32_t *xyzos;
+        float *R;
+        if (resize_Keypoint_store(kp, K)) return SIFT3D_FAILURE;
+        if (K == 0) return SIFT3D_SUCCESS;
+        xyzos = (int32_t *)malloc((size_t)K * 5 * sizeof(int32_t));
+        R = (float *)malloc((size_t)K * 9 * sizeof(float));
+        if (!xyzos || !R) { free(xyzos); free(R); API_FAIL("sift3d_amd: out of host memory"); }
+        if (s3d_rt_d2h(xyzos, c->d_xyzos, (size_t)K * 5 * sizeof(int32_t), c->stream) ||
+            s3d_rt_d2h(R, c->d_Rk, (size_t)K * 9 * sizeof(float), c->stream) || s3d_rt_sync(c->stream)) {
+            free(xyzos); free(R);
+            API_FAIL("sift3d_amd: keypoint download failed: %s", s3d_rt_last_error());
+        }
+        for (uint32_t i = 0; i < K; i++) {
+            Keypoint *key = kp->buf + i;
+            init_Keypoint(key);
+            key->xd = (double)xyzos[5 * i + 0];
+            key->yd = (double)xyzos[5 * i + 1];
+            key->zd = (double)xyzos[5 * i + 2];
+            key->o = xyzos[5 * i + 3];
+            key->s = xyzos[5 * i + 4];
+            key->sd = SIFT3D_PYR_IM_GET(&sift3d->dog, key->o, key->s)->s;
+            memcpy(key->r_data, R + 9 * i, 9 * sizeof(float));
+        }
+        free(xyzos); free(R);
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoint_store *const kp) /* sift.c:1609 */
+{
+    float *dense = NULL;
+    const float *src;
+    int rc;
+    if (im->nc != 1) {
+        S3D_MSG("SIFT3D_detect_keypoints: invalid number of image channels: %d -- only single-channel images "
+                "are supported \n", im->nc);
+        return SIFT3D_FAILURE;
+    }
+    if (im->data == NULL) return SIFT3D_FAILURE;
+    src = im->data;
+    if (!s3d_im_is_default_stride(im)) {
+        if ((dense = (float *)malloc(sizeof(float) * (size_t)im->nx * im->ny * im->nz)) == NULL) return SIFT3D_FAILURE;
+        s3d_im_gather(im, dense);
+        src = dense;
+    }
+    rc = set_im_device(sift3d, src, NULL, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz);
+    if (rc == SIFT3D_SUCCESS && dense) rc = s3d_rt_sync(sift_ctx(sift3d)->stream) ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
+    free(dense);
+    if (rc) return SIFT3D_FAILURE;
+    if (build_gpyr_dev(sift3d, sift_ctx(sift3d))) return SIFT3D_FAILURE;
+    return detect_dev(sift3d, sift_ctx(sift3d), kp);
+}
+
+int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz, double ux,
+                                    double uy, double uz, Keypoint_store *const kp)
+{
+    if (d_vol == NULL || nx < 1 || ny < 1 || nz < 1) API_FAIL("sift3d_amd_detect_keypoints_dev: bad arguments");
+    if (set_im_device(sift3d, NULL, d_vol, nx, ny, nz, ux, uy, uz)) return SIFT3D_FAILURE;
+    if (build_gpyr_dev(sift3d, sift_ctx(sift3d))) return SIFT3D_FAILURE;
+    return detect_dev(sift3d, sift_ctx(sift3d), kp);
+}
+
+long sift3d_amd_last_num_candidates(const SIFT3D *const sift3d)
+{
+    const s3d_ctx *c = sift_ctx(sift3d);
+    return c ? c->last_num_candidates : -1;
+}
+
+int SIFT3D_have_gpyr(const SIFT3D *const sift3d) /* sift.c:1936-1942, plus: the device pyramid exists */
+{
+    const Pyramid *const g = &sift3d->gpyr;
+    const s3d_ctx *c = sift_ctx(sift3d);
+    return g->levels != NULL && g->num_levels != 0 && g->num_octaves != 0 && c != NULL && c->have_pyramid;
+}
+
+/* verify_keys, sift.c:2050-2091 */
+static int verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz)
+{
+    const long num = (long)kp->slab.num;
+    if (num < 1) {
+        S3D_MSG("verify_keys: invalid number of keypoints: %ld \n", num);
+        return SIFT3D_FAILURE;
+    }
+    for (long i = 0; i < num; i++) {
+        const Keypoint *key = kp->buf + i;
+        const double f = ldexp(1.0, key->o);
+        if (key->xd < 0 || key->yd < 0 || key->zd < 0 || key->xd * f >= (double)nx || key->yd * f >= (double)ny ||
+            key->zd * f >= (double)nz) {
+            S3D_MSG("verify_keys: keypoint %ld (%f, %f, %f) octave %d exceeds image dimensions (%d, %d, %d) \n", i,
+                    key->xd, key->yd, key->zd, key->o, nx, ny, nz);
+            return SIFT3D_FAILURE;
+        }
+        if (key->sd <= 0) {
+            S3D_MSG("verify_keys: keypoint %ld has invalid scale %f \n", i, key->sd);
+            return SIFT3D_FAILURE;
+        }
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* scalar set-up of extract_descrip (sift.c:1845-1851) in the reference's float arithmetic */
+static void make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave,
+                          s3d_desc_key *out)
+{
+    const float sigma = key->sd * desc_sig_fctr;
+    const float win_radius = desc_rad_fctr * sigma;
+    const float desc_half_width = win_radius / sqrt(2);
+    const float desc_width = 2.0f * desc_half_width;
+    const float desc_hist_width = desc_width / NHIST_PER_DIM;
+    out->cx = (float)xd; out->cy = (float)yd; out->cz = (float)zd;
+    out->sigma = sigma;
+    out->rad = win_radius;
+    out->half = desc_half_width;
+    out->binf = 1.0f / desc_hist_width;
+    out->level = level;
+    out->octave = octave;
+    memcpy(out->R, key->R.u.data_float ? key->R.u.data_float : key->r_data, 9 * sizeof(float));
+}
+
+static int ctx_ensure_desc(s3d_ctx *c, size_t num)
+{
+    if (c->desc_cap >= num) return SIFT3D_SUCCESS;
+    dfree(&c->d_keys); dfree(&c->d_desc);
+    c->desc_cap = 0;
+    DEV(s3d_rt_malloc((void **)&c->d_keys, num * sizeof(s3d_desc_key)));
+    DEV(s3d_rt_malloc((void **)&c->d_desc, num * sizeof(SIFT3D_Descriptor)));
+    c->desc_cap = num;
+    return SIFT3D_SUCCESS;
+}
+
+/* _SIFT3D_extract_descriptors (sift.c:2207-2243) on the device pyramid.  host_out == NULL leaves the
+ * 776-float records in c->d_desc. */
+static int describe_dev(SIFT3D *const sift3d, s3d_ctx *c, const s3d_pyramid_desc *pd, const s3d_desc_key *keys,
+                        size_t num, SIFT3D_Descriptor *host_out)
+{
+    (void)sift3d;
+    if (ctx_base(c) || ctx_ensure_desc(c, num)) return SIFT3D_FAILURE;
+    DEV(s3d_rt_h2d(c->d_keys, keys, num * sizeof(s3d_desc_key), c->stream));
+    DEV(s3d_k_describe(pd, c->d_keys, (uint32_t)num, c->d_mesh, c->d_desc, DESC_REC_FLOATS, c->stream));
+    if (host_out) DEV(s3d_rt_d2h(host_out, c->d_desc, num * sizeof(SIFT3D_Descriptor), c->stream));
+    DEV(s3d_rt_sync(c->stream));
+    return SIFT3D_SUCCESS;
+}
+
+static int describe_from_gpyr(SIFT3D *const sift3d, const Keypoint_store *const kp, SIFT3D_Descriptor *host_out)
+{
+    const Pyramid *g = &sift3d->gpyr;
+    s3d_ctx *c = sift_ctx(sift3d);
+    const size_t num = kp->slab.num;
+    s3d_pyramid_desc pd;
+    s3d_desc_key *keys;
+    int rc;
+    if (verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
+    if (!SIFT3D_have_gpyr(sift3d)) {
+        S3D_MSG("SIFT3D_extract_descriptors: no Gaussian pyramid is available. Make sure SIFT3D_detect_keypoints "
+                "was called prior to calling this function. \n");
+        return SIFT3D_FAILURE;
+    }
+    if ((keys = (s3d_desc_key *)malloc(num * sizeof(s3d_desc_key))) == NULL) return SIFT3D_FAILURE;
+    for (size_t i = 0; i < num; i++) {
+        const Keypoint *key = kp->buf + i;
+        const int oi = key->o - g->first_octave, ki = key->s - g->first_level;
+        if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) {
+            free(keys);
+            API_FAIL("SIFT3D_extract_descriptors: keypoint %zu has no pyramid level (o=%d, s=%d)", i, key->o, key->s);
+        }
+        make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + i);
+    }
+    fill_pyr_desc(g, c->d_level, &pd);
+    rc = describe_dev(sift3d, c, &pd, keys, num, host_out);
+    free(keys);
+    return rc;
+}
+
+static void fill_desc_coords(const Keypoint_store *kp, SIFT3D_Descriptor *buf)
+{
+    for (size_t i = 0; i < kp->slab.num; i++) {           /* sift.c:1920-1925 */
+        const Keypoint *key = kp->buf + i;
+        const double f = ldexp(1.0, key->o);
+        buf[i].xd = key->xd * f; buf[i].yd = key->yd * f; buf[i].zd = key->zd * f;
+        buf[i].sd = key->sd;
+    }
+}
+
+int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const kp,
+                               SIFT3D_Descriptor_store *const desc) /* sift.c:2025-2046 */
+{
+    const Image *first;
+    if (verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
+    if (!SIFT3D_have_gpyr(sift3d)) {
+        S3D_MSG("SIFT3D_extract_descriptors: no Gaussian pyramid is available. Make sure SIFT3D_detect_keypoints "
+                "was called prior to calling this function. \n");
+        return SIFT3D_FAILURE;
+    }
+    first = sift3d->gpyr.levels;
+    desc->nx = first->nx; desc->ny = first->ny; desc->nz = first->nz;
+    if (s3d_resize_descriptor_store(desc, (long)kp->slab.num)) return SIFT3D_FAILURE;
+    if (describe_from_gpyr(sift3d, kp, desc->buf)) return SIFT3D_FAILURE;
+    fill_desc_coords(kp, desc->buf);
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_extract_descriptors_dev(SIFT3D *const sift3d, const Keypoint_store *const kp, const float **d_desc)
+{
+    if (describe_from_gpyr(sift3d, kp, NULL)) return SIFT3D_FAILURE;
+    if (d_desc) *d_desc = sift_ctx(sift3d)->d_desc;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- Gaussian entry points ------------------------------------------------------------------------------ */
+int sift3d_amd_gauss_dev(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,
+                         const double units[3], const float *taps, int width, double unit)
+{
+    float uf[3];
+    if (unit < 0 && unit != -1.0) API_FAIL("apply_Sep_FIR_filter: invalid unit: %f, use -1.0 for default", unit);
+    unit_factors(units, unit, uf);
+    DEV(s3d_k_sep_fir(d_src, d_dst, d_tmp, nx, ny, nz, nc, uf, taps, width, NULL));
+    return SIFT3D_SUCCESS;
+}
+
+int apply_Sep_FIR_filter(const Image *const src, Image *const dst, Sep_FIR_filter *const f, const double unit)
+{   /* imutil.c:3459-3544: host image in, host image out, x/y/z passes on the device */
+    const size_t n = (size_t)src->nx * src->ny * src->nz * src->nc;
+    const double units[3] = {src->ux, src->uy, src->uz};
+    float uf[3];
+    float *dense = NULL;
+    int rc = SIFT3D_FAILURE;
+    if (unit < 0 && unit != -1.0) {
+        S3D_MSG("apply_Sep_FIR_filter: invalid unit: %f, use -1.0 for default \n", unit);
+        return SIFT3D_FAILURE;
+    }
+    if (src->data == NULL) return SIFT3D_FAILURE;
+    if (dst != src) {
+        if (im_copy_dims(src, dst)) return SIFT3D_FAILURE;
+        im_default_stride(dst);
+        if (im_resize(dst)) return SIFT3D_FAILURE;
+    } else if (!s3d_im_is_default_stride(src)) {
+        return SIFT3D_FAILURE;
+    }
+    if (!s3d_im_is_default_stride(src)) {
+        if ((dense = (float *)malloc(n * sizeof(float))) == NULL) return SIFT3D_FAILURE;
+        s3d_im_gather(src, dense);
+    }
+    unit_factors(units, unit, uf);
+    pthread_mutex_lock(&g_shared_lock);
+    {
+        s3d_ctx *c = &g_shared;
+        if (ctx_aux(c, 0, n) == 0 && ctx_aux(c, 1, n) == 0 && ctx_aux(c, 2, n) == 0 &&
+            s3d_rt_h2d(c->d_aux[0], dense ? dense : src->data, n * sizeof(float), c->stream) == 0 &&
+            s3d_k_sep_fir(c->d_aux[0], c->d_aux[1], c->d_aux[2], src->nx, src->ny, src->nz, src->nc, uf, f->kernel,
+                          f->width, c->stream) == 0 &&
+            s3d_rt_d2h(dst->data, c->d_aux[1], n * sizeof(float), c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
+            rc = SIFT3D_SUCCESS;
+        else
+            S3D_MSG("apply_Sep_FIR_filter: device error: %s \n", s3d_rt_last_error());
+    }
+    pthread_mutex_unlock(&g_shared_lock);
+    free(dense);
+    return rc;
+}
+
+/* ---- raw-image variants (sift.c:1978-2006, 2131-2195, 1534-1604) --------------------------------------- */
+/* smooth_scale_raw_input on the device: d_out = im_scale(G_{sigma_n -> sigma0}(d_in)) */
+static int smooth_scale_raw_dev(const SIFT3D *sift3d, s3d_ctx *c, const float *d_in, float *d_out, float *d_tmp,
+                                int nx, int ny, int nz, const double units[3])
+{
+    Gauss_filter gauss;
+    float uf[3];
+    const size_t n = (size_t)nx * ny * nz;
+    int rc;
+    if (init_Gauss_incremental_filter(&gauss, sift3d->gpyr.sigma_n, sift3d->gpyr.sigma0, IM_NDIMS))
+        return SIFT3D_FAILURE;
+    unit_factors(units, 1.0, uf);
+    rc = s3d_k_sep_fir(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, c->stream) ||
+         s3d_k_absmax(d_out, n, c->d_red + 2, c->stream) || s3d_k_scale_div(d_out, n, c->d_red + 2, c->stream);
+    cleanup_Gauss_filter(&gauss);
+    if (rc) API_FAIL("sift3d_amd: raw smoothing failed: %s", s3d_rt_last_error());
+    return SIFT3D_SUCCESS;
+}
+
+/* upload `im` (single channel) into aux slot 0 and smooth it into slot 1 (slot 2 = scratch) */
+static int raw_prepare(const SIFT3D *sift3d, s3d_ctx *c, const Image *im, s3d_pyramid_desc *pd)
+{
+    const size_t n = (size_t)im->nx * im->ny * im->nz;
+    const double units[3] = {im->ux, im->uy, im->uz};
+    float *dense = NULL;
+    if (im->nc != 1 || im->data == NULL) API_FAIL("sift3d_amd: raw variants need a single-channel image with data");
+    if (ctx_base(c) || ctx_aux(c, 0, n) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n)) return SIFT3D_FAILURE;
+    if (!s3d_im_is_default_stride(im)) {
+        if ((dense = (float *)malloc(n * sizeof(float))) == NULL) return SIFT3D_FAILURE;
+        s3d_im_gather(im, dense);
+    }
+    if (s3d_rt_h2d(c->d_aux[0], dense ? dense : im->data, n * sizeof(float), c->stream) || s3d_rt_sync(c->stream)) {
+        free(dense);
+        API_FAIL("sift3d_amd: upload failed: %s", s3d_rt_last_error());
+    }
+    free(dense);
+    if (smooth_scale_raw_dev(sift3d, c, c->d_aux[0], c->d_aux[1], c->d_aux[2], im->nx, im->ny, im->nz, units))
+        return SIFT3D_FAILURE;
+    memset(pd, 0, sizeof(*pd));
+    pd->num_octaves = 1; pd->num_levels = 1; pd->first_level = 0;
+    pd->dims[0][0] = im->nx; pd->dims[0][1] = im->ny; pd->dims[0][2] = im->nz;
+    pd->unitsf[0][0] = (float)im->ux; pd->unitsf[0][1] = (float)im->uy; pd->unitsf[0][2] = (float)im->uz;
+    pd->d_level[0] = c->d_aux[1];
+    return SIFT3D_SUCCESS;
+}
+
+int SIFT3D_extract_raw_descriptors(SIFT3D *const sift3d, const Image *const im, const Keypoint_store *const kp,
+                                   SIFT3D_Descriptor_store *const desc)
+{
+    s3d_ctx *c;
+    s3d_pyramid_desc pd;
+    s3d_desc_key *keys;
+    const size_t num = kp->slab.num;
+    int rc;
+    if (verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    if (raw_prepare(sift3d, c, im, &pd)) return SIFT3D_FAILURE;
+    desc->nx = im->nx; desc->ny = im->ny; desc->nz = im->nz;
+    if (s3d_resize_descriptor_store(desc, (long)num)) return SIFT3D_FAILURE;
+    if ((keys = (s3d_desc_key *)malloc(num * sizeof(s3d_desc_key))) == NULL) return SIFT3D_FAILURE;
+    for (size_t i = 0; i < num; i++) {                    /* keypoint2base, sift.c:2094-2115 */
+        const Keypoint *key = kp->buf + i;
+        const double f = ldexp(1.0, key->o);
+        make_desc_key(key, key->xd * f, key->yd * f, key->zd * f, 0, 0, keys + i);
+    }
+    rc = describe_dev(sift3d, c, &pd, keys, num, desc->buf);
+    free(keys);
+    if (rc) return SIFT3D_FAILURE;
+    for (size_t i = 0; i < num; i++) {                    /* coords of the base-octave keypoint, o = 0 */
+        const Keypoint *key = kp->buf + i;
+        const double f = ldexp(1.0, key->o);
+        desc->buf[i].xd = key->xd * f; desc->buf[i].yd = key->yd * f; desc->buf[i].zd = key->zd * f;
+        desc->buf[i].sd = key->sd;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im, Keypoint_store *const kp,
+                               double **const conf)
+{
+    SIFT3D *s = (SIFT3D *)sift3d;                          /* only the (int) context handle is touched */
+    s3d_ctx *c;
+    s3d_pyramid_desc pd;
+    const size_t num = kp->slab.num;
+    float *centers = NULL, *R = NULL;
+    double *sig = NULL;
+    uint32_t *keep = NULL, *tags = NULL;
+    float *d_centers = NULL, *d_R = NULL;
+    double *d_sig = NULL, *d_conf = NULL;
+    uint32_t *d_keep = NULL, *d_tags = NULL;
+    int rc = SIFT3D_FAILURE;
+    if (verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
+    if (!s->kernels.downsample_2 && !(s->kernels.downsample_2 = ctx_new())) API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(s);
+    if ((*conf = (double *)SIFT3D_safe_realloc(*conf, num * sizeof(double))) == NULL) return SIFT3D_FAILURE;
+    if (raw_prepare(sift3d, c, im, &pd)) return SIFT3D_FAILURE;
+    centers = (float *)malloc(num * 3 * sizeof(float));
+    sig = (double *)malloc(num * sizeof(double));
+    R = (float *)malloc(num * 9 * sizeof(float));
+    keep = (uint32_t *)malloc(num * sizeof(uint32_t));
+    tags = (uint32_t *)calloc(num, sizeof(uint32_t));
+    if (!centers || !sig || !R || !keep || !tags) goto done;
+    for (size_t i = 0; i < num; i++) {
+        const Keypoint *key = kp->buf + i;
+        const double f = ldexp(1.0, key->o);
+        centers[3 * i + 0] = (float)(key->xd * f); centers[3 * i + 1] = (float)(key->yd * f);
+        centers[3 * i + 2] = (float)(key->zd * f);
+        sig[i] = key->sd;                                  /* NOT 1.5*sd here (sift.c:1579) */
+    }
+    if (s3d_rt_malloc((void **)&d_centers, num * 3 * sizeof(float)) || s3d_rt_malloc((void **)&d_sig, num * sizeof(double)) ||
+        s3d_rt_malloc((void **)&d_R, num * 9 * sizeof(float)) || s3d_rt_malloc((void **)&d_keep, num * sizeof(uint32_t)) ||
+        s3d_rt_malloc((void **)&d_tags, num * sizeof(uint32_t)) || s3d_rt_malloc((void **)&d_conf, num * sizeof(double)))
+        goto done;
+    if (s3d_rt_h2d(d_centers, centers, num * 3 * sizeof(float), c->stream) ||
+        s3d_rt_h2d(d_sig, sig, num * sizeof(double), c->stream) ||
+        s3d_rt_h2d(d_tags, tags, num * sizeof(uint32_t), c->stream) ||
+        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, c->stream) ||
+        s3d_rt_d2h(R, d_R, num * 9 * sizeof(float), c->stream) ||
+        s3d_rt_d2h(keep, d_keep, num * sizeof(uint32_t), c->stream) ||
+        s3d_rt_d2h(*conf, d_conf, num * sizeof(double), c->stream) || s3d_rt_sync(c->stream)) {
+        S3D_MSG("SIFT3D_assign_orientations: device error: %s \n", s3d_rt_last_error());
+        goto done;
+    }
+    for (size_t i = 0; i < num; i++) {
+        Keypoint *key = kp->buf + i;
+        init_Keypoint(key);
+        if (keep[i]) {
+            memcpy(key->r_data, R + 9 * i, 9 * sizeof(float));
+        } else {                                           /* REJECT: identity, conf = -1 (sift.c:1584-1589) */
+            static const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            memcpy(key->r_data, I3, sizeof(I3));
+            (*conf)[i] = -1.0;
+        }
+    }
+    rc = SIFT3D_SUCCESS;
+done:
+    free(centers); free(sig); free(R); free(keep); free(tags);
+    s3d_rt_free(d_centers); s3d_rt_free(d_sig); s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_tags);
+    s3d_rt_free(d_conf);
+    return rc;
+}
+
+/* ---- dense descriptors (sift.c:2354-2496) ----------------------------------------------------------------- */
+int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx, int ny, int nz, double ux,
+                                 double uy, double uz, const double out_units[3], float *d_out)
+{
+    s3d_ctx *c;
+    const size_t n = (size_t)nx * ny * nz;
+    const double units[3] = {ux, uy, uz};
+    const float unitsf[3] = {(float)ux, (float)uy, (float)uz};
+    const double sigma_win = sift3d->gpyr.sigma0 * desc_sig_fctr / NHIST_PER_DIM;
+    Gauss_filter gauss;
+    float uf[3];
+    int rc;
+    if (sift3d->dense_rotate) API_FAIL("sift3d_amd: dense_rotate is not implemented on the device (SURVEY row a14)");
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    /* aux 1: smoothed input, aux 2: scratch (12 channels), aux 3: 12-channel barycentric image */
+    if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n * HIST_NUMEL) || ctx_aux(c, 3, n * HIST_NUMEL))
+        return SIFT3D_FAILURE;
+    if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units)) return SIFT3D_FAILURE;
+    DEV(s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream));
+    DEV(s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream));
+    if (init_Gauss_filter(&gauss, sigma_win, 3)) return SIFT3D_FAILURE;
+    unit_factors(out_units, 1.0, uf);                      /* quirk C-17: the OUTPUT image's entry units */
+    rc = s3d_k_sep_fir(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,
+                       c->stream);
+    cleanup_Gauss_filter(&gauss);
+    if (rc) API_FAIL("sift3d_amd: dense blur failed: %s", s3d_rt_last_error());
+    DEV(s3d_k_dense_post(d_out, d_in, n, c->stream));
+    return SIFT3D_SUCCESS;
+}
+
+int SIFT3D_extract_dense_descriptors(SIFT3D *const sift3d, const Image *const in, Image *const desc)
+{
+    s3d_ctx *c;
+    size_t n;
+    float *dense = NULL, *d_out = NULL;
+    double out_units[3];
+    int rc = SIFT3D_FAILURE;
+    if (in->nc != 1) {
+        S3D_MSG("SIFT3D_extract_dense_descriptors: invalid number of channels: %d. This function only supports "
+                "single-channel images. \n", in->nc);
+        return SIFT3D_FAILURE;
+    }
+    if (in->data == NULL) return SIFT3D_FAILURE;
+    out_units[0] = desc->ux; out_units[1] = desc->uy; out_units[2] = desc->uz;
+    desc->nx = in->nx; desc->ny = in->ny; desc->nz = in->nz;   /* sift.c:2375-2380: dims only, units untouched */
+    desc->nc = HIST_NUMEL;
+    im_default_stride(desc);
+    if (im_resize(desc)) return SIFT3D_FAILURE;
+    n = (size_t)in->nx * in->ny * in->nz;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    if (ctx_aux(c, 0, n)) return SIFT3D_FAILURE;
+    if (!s3d_im_is_default_stride(in)) {
+        if ((dense = (float *)malloc(n * sizeof(float))) == NULL) return SIFT3D_FAILURE;
+        s3d_im_gather(in, dense);
+    }
+    if (s3d_rt_malloc((void **)&d_out, n * HIST_NUMEL * sizeof(float)) == 0 &&
+        s3d_rt_h2d(c->d_aux[0], dense ? dense : in->data, n * sizeof(float), c->stream) == 0 &&
+        sift3d_amd_extract_dense_dev(sift3d, c->d_aux[0], in->nx, in->ny, in->nz, in->ux, in->uy, in->uz, out_units,
+                                     d_out) == 0 &&
+        s3d_rt_d2h(desc->data, d_out, n * HIST_NUMEL * sizeof(float), c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
+        rc = SIFT3D_SUCCESS;
+    s3d_rt_free(d_out);
+    free(dense);
+    return rc;
+}
+
+/* ---- pyramid download (for callers that read pyramid voxels, e.g. write_pyramid / copy_SIFT3D) ---------- */
+int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog)
+{
+    s3d_ctx *c = sift_ctx(sift3d);
+    Pyramid *g = &sift3d->gpyr, *d = &sift3d->dog;
+    if (!SIFT3D_have_gpyr(sift3d)) API_FAIL("sift3d_amd_download_pyramid: no device pyramid");
+    for (int i = 0; i < g->num_octaves * g->num_levels; i++) {
+        Image *lv = g->levels + i;
+        if (im_resize(lv)) return SIFT3D_FAILURE;
+        DEV(s3d_rt_d2h(lv->data, c->d_level[i], lv->size * sizeof(float), c->stream));
+    }
+    if (want_dog) {
+        for (int o = 0; o < d->num_octaves; o++)
+            for (int k = 0; k < d->num_levels; k++) {
+                Image *lv = d->levels + o * d->num_levels + k;
+                const size_t n = c->level_elems[o];
+                if (im_resize(lv)) return SIFT3D_FAILURE;
+                DEV(s3d_k_subtract(c->d_level[o * g->num_levels + k], c->d_level[o * g->num_levels + k + 1], c->d_tmp,
+                                   n, c->stream));
+                DEV(s3d_rt_d2h(lv->data, c->d_tmp, n * sizeof(float), c->stream));
+                DEV(s3d_rt_sync(c->stream));
+            }
+    }
+    DEV(s3d_rt_sync(c->stream));
+    return SIFT3D_SUCCESS;
+}

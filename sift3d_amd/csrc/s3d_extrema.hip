@@ -1,0 +1,154 @@
+/* s3d_extrema.hip -- scale-space extrema without materialising the DoG pyramid.
+ *
+ * detect_extrema (sift3d/sift.c:1074-1212) scans DoG(o,s) = L(o,s) - L(o,s+1) for voxels that are
+ * strictly greater (or smaller) than their 6 face neighbours in the same DoG level and than the
+ * same voxel in DoG(s-1) and DoG(s+1), subject to |v| > (float)(peak_thresh * max|DoG(o,s)|).
+ * An f32 subtraction is deterministic, so the DoG values are recomputed on the fly from the four
+ * GSS levels L(s-1..s+2) instead of being written and re-read (the reference's build_dog pass,
+ * sift.c:1052-1071): the result is bit-identical and 5 volume writes + 9 reads per octave vanish.
+ *
+ * Output order must be the reference's scan order (z, y, x ascending).  Each wave ballots its 64
+ * consecutive voxels into one word of a bitmap; the bitmap is then compacted IN ORDER (popcount
+ * per block -> scan of block counts -> ordered emit), so no sort and no atomics on the data path.
+ */
+#include "s3d_common.h"
+
+__global__ void __launch_bounds__(256)
+k_extrema(const float *__restrict__ l0, const float *__restrict__ l1, const float *__restrict__ l2,
+          const float *__restrict__ l3, unsigned nx, unsigned ny, unsigned nz, unsigned n, double peak,
+          const float *__restrict__ d_dogmax, unsigned long long *__restrict__ bits)
+{
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const float thr = (float)(peak * (double)(*d_dogmax));      /* sift.c:1169 */
+    int pred = 0;
+    if (idx < n) {
+        const unsigned plane = nx * ny;
+        const unsigned z = idx / plane;
+        const unsigned rem = idx - z * plane;
+        const unsigned y = rem / nx;
+        const unsigned x = rem - y * nx;
+        if (x >= 1 && x + 2 <= nx && y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz) {
+            const float c1 = l1[idx], c2 = l2[idx];
+            const float v = c1 - c2;
+            if (v > thr || v < -thr) {
+                const float pv = l0[idx] - c1;                     /* DoG(s-1) centre */
+                const float nv = c2 - l3[idx];                     /* DoG(s+1) centre */
+                const float xm = l1[idx - 1] - l2[idx - 1], xp = l1[idx + 1] - l2[idx + 1];
+                const float ym = l1[idx - nx] - l2[idx - nx], yp = l1[idx + nx] - l2[idx + nx];
+                const float zm = l1[idx - plane] - l2[idx - plane], zp = l1[idx + plane] - l2[idx + plane];
+                const int is_max = v > pv && v > xp && v > xm && v > yp && v > ym && v > zm && v > zp && v > nv;
+                const int is_min = v < pv && v < xp && v < xm && v < yp && v < ym && v < zm && v < zp && v < nv;
+                pred = is_max | is_min;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(pred);
+    if ((threadIdx.x & 63) == 0 && idx < ((n + 63u) & ~63u)) bits[idx >> 6] = m;
+}
+
+extern "C" int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3, int nx,
+                             int ny, int nz, double peak_thresh, const float *d_dogmax, unsigned long long *d_bits,
+                             s3d_stream st)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    if (nx < 1 || ny < 1 || nz < 1 || n >= 0xFFFFFF00ull) S3D_FAIL("level too large for 32-bit voxel indices");
+    hipLaunchKernelGGL(k_extrema, dim3(s3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)st, d_l0, d_l1, d_l2, d_l3,
+                       (unsigned)nx, (unsigned)ny, (unsigned)nz, (unsigned)n, peak_thresh, d_dogmax, d_bits);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+/* ---- ordered bitmap compaction ---------------------------------------------------------------- */
+#define CB_WORDS_PER_THREAD 4
+#define CB_WORDS_PER_BLOCK (256 * CB_WORDS_PER_THREAD)
+
+/* inclusive scan over the 256 threads of a block (Hillis-Steele in LDS); returns the inclusive value */
+__device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *total)
+{
+    __shared__ unsigned s[256];
+    const unsigned t = threadIdx.x;
+    s[t] = v;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {
+        const unsigned a = t >= off ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    const unsigned r = s[t];
+    *total = s[255];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_cb_count(const unsigned long long *__restrict__ bits, size_t nwords, unsigned *__restrict__ block_count)
+{
+    const size_t w0 = (size_t)blockIdx.x * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
+    unsigned c = 0;
+    for (int i = 0; i < CB_WORDS_PER_THREAD; i++)
+        if (w0 + i < nwords) c += (unsigned)__popcll(bits[w0 + i]);
+    unsigned total;
+    block_scan_incl(c, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+/* single block: block_count[b] <- *count + exclusive prefix ; *count += total */
+__global__ void __launch_bounds__(256) k_cb_scan(unsigned *__restrict__ block_count, unsigned nblocks, unsigned *count)
+{
+    unsigned carry = *count;
+    __syncthreads();
+    for (unsigned b0 = 0; b0 < nblocks; b0 += 256) {
+        const unsigned b = b0 + threadIdx.x;
+        const unsigned v = b < nblocks ? block_count[b] : 0u;
+        unsigned total;
+        const unsigned incl = block_scan_incl(v, &total);
+        if (b < nblocks) block_count[b] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *count = carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_cb_emit(const unsigned long long *__restrict__ bits, size_t nwords, const unsigned *__restrict__ block_off,
+          unsigned *__restrict__ out_idx, unsigned *__restrict__ out_tag, unsigned tag, unsigned capacity)
+{
+    const size_t w0 = (size_t)blockIdx.x * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
+    unsigned long long w[CB_WORDS_PER_THREAD];
+    unsigned c = 0;
+    for (int i = 0; i < CB_WORDS_PER_THREAD; i++) {
+        w[i] = (w0 + i < nwords) ? bits[w0 + i] : 0ull;
+        c += (unsigned)__popcll(w[i]);
+    }
+    unsigned total;
+    const unsigned incl = block_scan_incl(c, &total);
+    unsigned pos = block_off[blockIdx.x] + incl - c;
+    for (int i = 0; i < CB_WORDS_PER_THREAD; i++) {
+        unsigned long long m = w[i];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < capacity) {
+                out_idx[pos] = (unsigned)((w0 + i) * 64 + (unsigned)b);
+                out_tag[pos] = tag;
+            }
+            pos++;
+        }
+    }
+}
+
+extern "C" int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nwords, uint32_t *d_idx, uint32_t *d_tag,
+                                  uint32_t tag, uint32_t capacity, uint32_t *d_count, uint32_t *d_scratch,
+                                  s3d_stream stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (nwords == 0) return S3D_OK;
+    const unsigned nb = s3d_div_up(nwords, CB_WORDS_PER_BLOCK);
+    hipLaunchKernelGGL(k_cb_count, dim3(nb), dim3(256), 0, st, d_bits, nwords, d_scratch);
+    S3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_cb_scan, dim3(1), dim3(256), 0, st, d_scratch, nb, d_count);
+    S3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_cb_emit, dim3(nb), dim3(256), 0, st, d_bits, nwords, d_scratch, d_idx, d_tag, tag, capacity);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}

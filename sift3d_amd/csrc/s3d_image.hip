@@ -1,0 +1,145 @@
+/* s3d_image.hip -- streaming element-wise / reduction kernels of the pyramid build.
+ * All are HBM-bound: float4 accesses, grid-stride, one atomic per block for reductions. */
+#include "s3d_common.h"
+
+#define RED_BLOCK 256
+#define RED_MAX_BLOCKS 4096
+
+/* wave64 max via xor-shuffles, then one LDS slot per wave */
+__device__ __forceinline__ float block_max(float v)
+{
+    __shared__ float part[RED_BLOCK / 64];
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float o = __shfl_xor(v, m);
+        v = v > o ? v : o;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    float r = part[0];
+    for (int w = 1; w < RED_BLOCK / 64; w++) r = r > part[w] ? r : part[w];
+    return r;
+}
+
+/* max|v| : non-negative floats order like their bit patterns, so atomicMax on uint is exact.
+ * mode 0: |a[i]| ; mode 1: |a[i] - b[i]|   (im_max_abs imutil.c:1959 ; dogmax sift.c:1161-1166) */
+template <int MODE>
+__global__ void __launch_bounds__(RED_BLOCK) k_absmax(const float *__restrict__ a, const float *__restrict__ b,
+                                                     size_t n, unsigned *out)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * RED_BLOCK;
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4 *>(a)[i];
+        if (MODE == 1) {
+            const float4 w = reinterpret_cast<const float4 *>(b)[i];
+            v.x = v.x - w.x; v.y = v.y - w.y; v.z = v.z - w.z; v.w = v.w - w.w;
+        }
+        const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z), aw = fabsf(v.w);
+        m = m > ax ? m : ax; m = m > ay ? m : ay; m = m > az ? m : az; m = m > aw ? m : aw;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n; i += stride) {
+        float v = a[i];
+        if (MODE == 1) v = v - b[i];
+        const float av = fabsf(v);
+        m = m > av ? m : av;
+    }
+    m = block_max(m);
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(m));
+}
+
+static int launch_absmax(const float *a, const float *b, size_t n, float *d_max, hipStream_t st)
+{
+    S3D_HIP(hipMemsetAsync(d_max, 0, sizeof(float), st));
+    if (n == 0) return S3D_OK;
+    unsigned blocks = s3d_div_up(n / 4 + 1, RED_BLOCK);
+    if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
+    if (b)
+        hipLaunchKernelGGL(k_absmax<1>, dim3(blocks), dim3(RED_BLOCK), 0, st, a, b, n, (unsigned *)d_max);
+    else
+        hipLaunchKernelGGL(k_absmax<0>, dim3(blocks), dim3(RED_BLOCK), 0, st, a, b, n, (unsigned *)d_max);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+extern "C" int s3d_k_absmax(const float *d_v, size_t n, float *d_max, s3d_stream st)
+{
+    return launch_absmax(d_v, NULL, n, d_max, (hipStream_t)st);
+}
+
+extern "C" int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float *d_max, s3d_stream st)
+{
+    return launch_absmax(d_a, d_b, n, d_max, (hipStream_t)st);
+}
+
+/* v /= max (IEEE division, like the reference -- not a multiply by the reciprocal) */
+__global__ void __launch_bounds__(256) k_scale_div(float *v, size_t n, const float *d_max)
+{
+    const float m = *d_max;
+    if (m == 0.0f) return;
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 x = reinterpret_cast<float4 *>(v)[i];
+        x.x = x.x / m; x.y = x.y / m; x.z = x.z / m; x.w = x.w / m;
+        reinterpret_cast<float4 *>(v)[i] = x;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) v[i] = v[i] / m;
+}
+
+extern "C" int s3d_k_scale_div(float *d_v, size_t n, const float *d_max, s3d_stream st)
+{
+    if (n == 0) return S3D_OK;
+    unsigned blocks = s3d_div_up(n / 4 + 1, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_scale_div, dim3(blocks), dim3(256), 0, (hipStream_t)st, d_v, n, d_max);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+__global__ void __launch_bounds__(256) k_subtract(const float *__restrict__ a, const float *__restrict__ b,
+                                                  float *__restrict__ dst, size_t n)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i];
+        const float4 y = reinterpret_cast<const float4 *>(b)[i];
+        float4 r;
+        r.x = x.x - y.x; r.y = x.y - y.y; r.z = x.z - y.z; r.w = x.w - y.w;
+        reinterpret_cast<float4 *>(dst)[i] = r;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = a[i] - b[i];
+}
+
+extern "C" int s3d_k_subtract(const float *d_a, const float *d_b, float *d_dst, size_t n, s3d_stream st)
+{
+    if (n == 0) return S3D_OK;
+    unsigned blocks = s3d_div_up(n / 4 + 1, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_subtract, dim3(blocks), dim3(256), 0, (hipStream_t)st, d_a, d_b, d_dst, n);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+/* dst(x,y,z) = src(2x,2y,2z): a row of dst per (y,z), threads along x */
+__global__ void __launch_bounds__(256) k_decimate2(const float *__restrict__ src, int nx, int ny, int mx,
+                                                   int my, int mz, float *__restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    if (x >= mx) return;
+    dst[((size_t)z * my + y) * mx + x] = src[((size_t)(2 * z) * ny + 2 * y) * nx + 2 * x];
+}
+
+extern "C" int s3d_k_decimate2(const float *d_src, int nx, int ny, int nz, float *d_dst, s3d_stream st)
+{
+    const int mx = nx / 2, my = ny / 2, mz = nz / 2;
+    if (mx < 1 || my < 1 || mz < 1) S3D_FAIL("volume too small to decimate");
+    if (my > 65535 || mz > 65535) S3D_FAIL("volume too large for the decimation grid");
+    hipLaunchKernelGGL(k_decimate2, dim3(s3d_div_up(mx, 256), my, mz), dim3(256), 0, (hipStream_t)st, d_src, nx,
+                       ny, mx, my, mz, d_dst);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}

@@ -1,0 +1,409 @@
+/* s3d_keypoint.hip -- orientation assignment and the icosahedral gradient-histogram descriptor.
+ *
+ *  k_orient    assign_eig_ori + assign_orientation_thresh (sift3d/sift.c:1354-1514, 1331-1342)
+ *  k_ckeys_*   the stable compaction of assign_orientations (sift.c:1305-1324)
+ *  k_describe  extract_descrip + SIFT3D_desc_acc_interp + normalize_desc (sift.c:1834-1928,
+ *              1687-1791, 1794-1821)
+ *
+ * Parity notes.  Which candidates survive orientation assignment decides the keypoint *indices*,
+ * which must match the reference exactly, so k_orient keeps every quantity that feeds a rejection
+ * test on the reference's arithmetic path: per-sample terms are computed 64 at a time by the wave,
+ * but the f32 window gradient sum(w*grad) is accumulated strictly in the reference's z,y,x scan
+ * order (one lane per component walks the 64 staged terms; skipped samples contribute an exact
+ * +0), the structure tensor is accumulated in f64, and the 3x3 eigen problem, the eigen-ratio test
+ * and the corner score are evaluated in f64 by one lane.  The only remaining difference is the
+ * f64 summation order of the tensor (~1e-16 relative).
+ * The descriptor has no such discrete decisions; its 768 f32 bins are accumulated with LDS float
+ * atomics in wave-private histograms (order differs from the reference: ~1e-6 relative, the
+ * contract is 1e-4) and normalised in f64 like the reference.
+ */
+#include "s3d_math.h"
+
+/* ---- icosahedron table (host) -- init_geometry, sift.c:215-326 ---------------------------------- */
+extern "C" void s3d_mesh_table(float *out)
+{
+    const double gr = 1.6180339887;                      /* sift.c:58 */
+    const float g = (float)gr;
+    const float vert[S3D_NVERT][3] = {{0, 1, g}, {0, -1, g}, {0, 1, -g}, {0, -1, -g}, {1, g, 0}, {-1, g, 0},
+                                      {1, -g, 0}, {-1, -g, 0}, {g, 0, 1}, {-g, 0, 1}, {g, 0, -1}, {-g, 0, -1}};
+    static const int faces[S3D_NFACES][3] = {{0, 1, 8}, {0, 8, 4}, {0, 4, 5}, {0, 5, 9}, {0, 9, 1},
+                                             {1, 6, 8}, {8, 6, 10}, {8, 10, 4}, {4, 10, 2}, {4, 2, 5},
+                                             {5, 2, 11}, {5, 11, 9}, {9, 11, 7}, {9, 7, 1}, {1, 7, 6},
+                                             {3, 6, 7}, {3, 7, 11}, {3, 11, 2}, {3, 2, 10}, {3, 10, 6}};
+    for (int i = 0; i < S3D_NFACES; i++) {
+        V3 v[3];
+        for (int j = 0; j < 3; j++) {
+            const int id = faces[i][j];
+            v[j] = v3(vert[id][0], vert[id][1], vert[id][2]);
+            const float mag = sqrtf(v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z);
+            const float inv = 1.0f / mag;
+            v[j] = v3(v[j].x * inv, v[j].y * inv, v[j].z * inv);
+        }
+        /* outward-normal test: swaps the vertices v[0] <-> v[1] but not their bin indices (quirk C-5) */
+        const V3 n = v3_cross(v3_sub(v[2], v[1]), v3_sub(v[1], v[0]));
+        if (v3_dot(n, v[0]) < 0) { const V3 t = v[0]; v[0] = v[1]; v[1] = t; }
+        const V3 e1 = v3_sub(v[1], v[0]), e2 = v3_sub(v[2], v[0]);
+        const V3 t = v3(v[0].x * -1.0f, v[0].y * -1.0f, v[0].z * -1.0f);
+        const V3 q = v3_cross(t, e1);
+        float *m = out + i * MESH_STRIDE;
+        m[0] = e1.x; m[1] = e1.y; m[2] = e1.z;
+        m[3] = e2.x; m[4] = e2.y; m[5] = e2.z;
+        m[6] = t.x; m[7] = t.y; m[8] = t.z;
+        m[9] = q.x; m[10] = q.y; m[11] = q.z;
+        m[12] = v3_dot(e2, q);
+        for (int j = 0; j < 3; j++) {
+            const int id = faces[i][j];
+            memcpy(&m[13 + j], &id, sizeof(int));
+        }
+    }
+}
+
+/* ---- orientation ---------------------------------------------------------------------------------- */
+/* sigma table is per level for detected candidates, per candidate for the raw-image variant */
+__device__ __forceinline__ double d_sigma_sel(const double *d_sigma, bool per_cand, unsigned cand, int li)
+{
+    return per_cand ? d_sigma[cand] : d_sigma[li];
+}
+
+/* IM_LOOP_SPHERE_START bounds (sift.c:96-109) with a double radius (assign_eig_ori) */
+__device__ __forceinline__ void ori_bounds(float vc, double rad, float uf, int n, int *s, int *e)
+{
+    const float fs = floorf((float)((double)vc - rad / (double)uf));
+    const float fe = ceilf((float)((double)vc + rad / (double)uf));
+    *s = (int)(fs > 1.0f ? fs : 1.0f);
+    *e = (int)(fe < (float)(n - 2) ? fe : (float)(n - 2));
+}
+
+__global__ void __launch_bounds__(64)
+k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
+         const float *__restrict__ d_center, uint32_t num, const double *__restrict__ d_sigma, double corner_thresh,
+         float *__restrict__ d_R, uint32_t *__restrict__ d_keep, double *__restrict__ d_conf)
+{
+    __shared__ float term[3][64];
+    __shared__ float gw_s[3];
+    const unsigned cand = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (cand >= num) return;
+    const unsigned tag = d_tag[cand];
+    const int o = (int)(tag >> 8), k = (int)(tag & 255u);
+    const int li = o * pyr.num_levels + k;
+    const float *__restrict__ im = pyr.d_level[li];
+    const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
+    const float uxf = pyr.unitsf[o][0], uyf = pyr.unitsf[o][1], uzf = pyr.unitsf[o][2];
+    const unsigned plane = (unsigned)nx * (unsigned)ny;
+    float vcx, vcy, vcz;
+    if (d_center) {                                        /* raw-image variant: arbitrary centres */
+        vcx = d_center[3 * (size_t)cand + 0]; vcy = d_center[3 * (size_t)cand + 1]; vcz = d_center[3 * (size_t)cand + 2];
+    } else {
+        const unsigned idx = d_idx[cand];
+        const int cz = (int)(idx / plane);
+        const int cy = (int)((idx - (unsigned)cz * plane) / (unsigned)nx);
+        const int cx = (int)(idx - (unsigned)cz * plane - (unsigned)cy * (unsigned)nx);
+        vcx = (float)cx; vcy = (float)cy; vcz = (float)cz;
+    }
+    const double sigma = d_sigma_sel(d_sigma, d_center != nullptr, cand, li);
+    const double rad = sigma * 3.0;                        /* ori_rad_fctr */
+    const double rad2 = rad * rad, sig2 = sigma * sigma;
+
+    int xs, xe, ys, ye, zs, ze;
+    ori_bounds(vcx, rad, uxf, nx, &xs, &xe);
+    ori_bounds(vcy, rad, uyf, ny, &ys, &ye);
+    ori_bounds(vcz, rad, uzf, nz, &zs, &ze);
+    const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
+    const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
+
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    float gsum = 0.0f;                                     /* lanes 0..2: running sum of component lane */
+    const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
+    for (int b0 = 0; b0 < nbox; b0 += 64) {
+        const int b = b0 + lane;
+        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+        if (b < nbox) {
+            const int bz = b / (wx * wy);
+            const int r = b - bz * wx * wy;
+            const int by = r / wx;
+            const int bx = r - by * wx;
+            const int x = xs + bx, y = ys + by, z = zs + bz;
+            const float dx = ((float)x - vcx) * uxf;
+            const float dy = ((float)y - vcy) * uyf;
+            const float dz = ((float)z - vcz) * uzf;
+            const float sq = dx * dx + dy * dy + dz * dz;
+            if (!((double)sq > rad2)) {
+                const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
+                const float w = s3d_expf((float)(-0.5 * (double)sq / sig2));
+                float gx = 0.5f * (p[1] - p[-1]);
+                float gy = 0.5f * (p[nx] - p[-nx]);
+                float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
+                gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
+                a00 += (double)gx * (double)gx * (double)w;
+                a01 += (double)gx * (double)gy * (double)w;
+                a02 += (double)gx * (double)gz * (double)w;
+                a11 += (double)gy * (double)gy * (double)w;
+                a12 += (double)gy * (double)gz * (double)w;
+                a22 += (double)gz * (double)gz * (double)w;
+                tx = gx * w; ty = gy * w; tz = gz * w;
+            }
+        }
+        term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
+        __syncthreads();
+        if (lane < 3) {
+            for (int i = 0; i < 64; i++) gsum = gsum + term[lane][i];   /* reference scan order */
+        }
+        __syncthreads();
+    }
+    /* wave reduction of the f64 tensor */
+    for (int m = 32; m >= 1; m >>= 1) {
+        a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
+        a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
+    }
+    if (lane < 3) gw_s[lane] = gsum;
+    __syncthreads();
+    if (lane != 0) return;
+
+    const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
+    float R[9];
+    int keep = 1;
+    double conf = 0.0;
+    for (int i = 0; i < 9; i++) R[i] = 0.0f;
+    if (gwx * gwx + gwy * gwy + gwz * gwz < (float)1E-10) keep = 0;        /* ori_grad_thresh */
+    if (keep) {
+        double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+        double L[3], Q[3][3];
+        s3d_eig3(A, L, Q);
+        if (fabs(L[0] / L[1]) > 0.90 || fabs(L[1] / L[2]) > 0.90) keep = 0; /* max_eig_ratio */
+        if (keep) {
+            float v[2][3];
+            double score = 1.7976931348623157e308;
+            for (int i = 0; i < 2; i++) {
+                const int e = 2 - i;
+                float vr[3] = {(float)Q[0][e], (float)Q[1][e], (float)Q[2][e]};
+                const double d = (double)(gwx * vr[0] + gwy * vr[1] + gwz * vr[2]);
+                const double cos_ang = d / (double)(sqrtf(vr[0] * vr[0] + vr[1] * vr[1] + vr[2] * vr[2]) *
+                                                     sqrtf(gwx * gwx + gwy * gwy + gwz * gwz));
+                const double ac = fabs(cos_ang);
+                const float sgn = d > 0.0 ? 1.0f : -1.0f;
+                score = score < ac ? score : ac;
+                for (int c = 0; c < 3; c++) {
+                    vr[c] = vr[c] * sgn;
+                    R[3 * c + i] = vr[c];
+                    v[i][c] = vr[c];
+                }
+            }
+            R[2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];
+            R[5] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
+            R[8] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
+            conf = score;
+            if (conf < corner_thresh) keep = 0;
+        }
+    }
+    for (int i = 0; i < 9; i++) d_R[(size_t)cand * 9 + i] = R[i];
+    d_keep[cand] = (uint32_t)keep;
+    if (d_conf) d_conf[cand] = conf;
+}
+
+extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                            const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                            float *d_R, uint32_t *d_keep, double *d_conf, s3d_stream st)
+{
+    if (num == 0) return S3D_OK;
+    hipLaunchKernelGGL(k_orient, dim3(num), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, num, d_sigma,
+                       corner_thresh, d_R, d_keep, d_conf);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+/* ---- stable compaction of the surviving candidates ----------------------------------------------- */
+__global__ void __launch_bounds__(256)
+k_compact_keys(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
+               const float *__restrict__ d_R, const uint32_t *__restrict__ d_keep, uint32_t num,
+               int32_t *__restrict__ xyzos, float *__restrict__ R_out, uint32_t *num_out)
+{
+    __shared__ unsigned s[256];
+    unsigned carry = 0;
+    for (uint32_t i0 = 0; i0 < num; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        const unsigned kp = (i < num && d_keep[i]) ? 1u : 0u;
+        s[threadIdx.x] = kp;
+        __syncthreads();
+        for (unsigned off = 1; off < 256; off <<= 1) {
+            const unsigned a = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += a;
+            __syncthreads();
+        }
+        const unsigned incl = s[threadIdx.x], total = s[255];
+        __syncthreads();
+        if (kp) {
+            const unsigned pos = carry + incl - 1;
+            const unsigned tag = d_tag[i], idx = d_idx[i];
+            const int o = (int)(tag >> 8), k = (int)(tag & 255u);
+            const unsigned nx = (unsigned)pyr.dims[o][0], plane = nx * (unsigned)pyr.dims[o][1];
+            const unsigned z = idx / plane, y = (idx - z * plane) / nx, x = idx - z * plane - y * nx;
+            xyzos[5 * (size_t)pos + 0] = (int)x;
+            xyzos[5 * (size_t)pos + 1] = (int)y;
+            xyzos[5 * (size_t)pos + 2] = (int)z;
+            xyzos[5 * (size_t)pos + 3] = o;
+            xyzos[5 * (size_t)pos + 4] = k + pyr.first_level;
+            for (int c = 0; c < 9; c++) R_out[9 * (size_t)pos + c] = d_R[9 * (size_t)i + c];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) *num_out = carry;
+}
+
+extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                                  const float *d_R, const uint32_t *d_keep, uint32_t num, int32_t *d_xyzos,
+                                  float *d_R_out, uint32_t *d_num_out, s3d_stream st)
+{
+    hipLaunchKernelGGL(k_compact_keys, dim3(1), dim3(256), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_R, d_keep, num,
+                       d_xyzos, d_R_out, d_num_out);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+/* ---- descriptor ------------------------------------------------------------------------------------ */
+#define DESC_THREADS 256
+#define DESC_WAVES (DESC_THREADS / 64)
+
+__device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n, int *s, int *e)
+{
+    const float fs = floorf(vc - rad / uf);
+    const float fe = ceilf(vc + rad / uf);
+    *s = (int)(fs > 1.0f ? fs : 1.0f);
+    *e = (int)(fe < (float)(n - 2) ? fe : (float)(n - 2));
+}
+
+/* sum over the block of a double; result valid in every thread */
+__device__ __forceinline__ double block_sum_f64(double v)
+{
+    __shared__ double part[DESC_WAVES];
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < DESC_WAVES; w++) r += part[w];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(DESC_THREADS)
+k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num,
+           const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride)
+{
+    __shared__ float hist[DESC_WAVES][S3D_DESC_NUMEL];
+    __shared__ float mesh[S3D_MESH_FLOATS];
+    const unsigned kid = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (kid >= num) return;
+    const s3d_desc_key key = keys[kid];
+    for (int i = tid; i < DESC_WAVES * S3D_DESC_NUMEL; i += DESC_THREADS) (&hist[0][0])[i] = 0.0f;
+    for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
+    __syncthreads();
+
+    const int o = key.octave;
+    const float *__restrict__ im = pyr.d_level[key.level];
+    const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
+    const float uxf = pyr.unitsf[o][0], uyf = pyr.unitsf[o][1], uzf = pyr.unitsf[o][2];
+    const size_t plane = (size_t)nx * ny;
+    const float sigma = key.sigma, rad = key.rad, half = key.half, binf = key.binf;
+    const float rad2 = rad * rad, sig2 = sigma * sigma;
+    /* Rt = R^T (sift.c:1853-1857) */
+    const float r00 = key.R[0], r01 = key.R[3], r02 = key.R[6];
+    const float r10 = key.R[1], r11 = key.R[4], r12 = key.R[7];
+    const float r20 = key.R[2], r21 = key.R[5], r22 = key.R[8];
+    const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
+
+    int xs, xe, ys, ye, zs, ze;
+    desc_bounds(key.cx, rad, uxf, nx, &xs, &xe);
+    desc_bounds(key.cy, rad, uyf, ny, &ys, &ye);
+    desc_bounds(key.cz, rad, uzf, nz, &zs, &ze);
+    const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
+    const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
+    float *h = hist[wave];
+
+    for (int b = tid; b < nbox; b += DESC_THREADS) {
+        const int bz = b / (wx * wy);
+        const int r = b - bz * wx * wy;
+        const int by = r / wx;
+        const int bx = r - by * wx;
+        const int x = xs + bx, y = ys + by, z = zs + bz;
+        const float dx = ((float)x - key.cx) * uxf;
+        const float dy = ((float)y - key.cy) * uyf;
+        const float dz = ((float)z - key.cz) * uzf;
+        const float sq = dx * dx + dy * dy + dz * dz;
+        if (sq > rad2) continue;
+        const float kx = r00 * dx + r01 * dy + r02 * dz;
+        const float ky = r10 * dx + r11 * dy + r12 * dz;
+        const float kz = r20 * dx + r21 * dy + r22 * dz;
+        const float vbx = (kx + half) * binf, vby = (ky + half) * binf, vbz = (kz + half) * binf;
+        if (vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f || vbz >= 4.0f) continue;
+        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
+        float gx = 0.5f * (p[1] - p[-1]);
+        float gy = 0.5f * (p[nx] - p[-nx]);
+        float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
+        gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
+        const float w = s3d_expf(-0.5f * sq / sig2);
+        gx = gx * w; gy = gy * w; gz = gz * w;
+        V3 gr;
+        gr.x = r00 * gx + r01 * gy + r02 * gz;
+        gr.y = r10 * gx + r11 * gy + r12 * gz;
+        gr.z = r20 * gx + r21 * gy + r22 * gz;
+        V3 bary;
+        const int face = s3d_icos_bin(mesh, gr, &bary);
+        if (face < 0) continue;
+        const float mag = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
+        const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
+        const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
+        const float *m = mesh + face * MESH_STRIDE;
+        const int i0 = __float_as_int(m[13]), i1 = __float_as_int(m[14]), i2 = __float_as_int(m[15]);
+        for (int ix = 0; ix < 2; ix++)
+            for (int iy = 0; iy < 2; iy++)
+                for (int iz = 0; iz < 2; iz++) {
+                    const int cx = ibx + ix, cy = iby + iy, cz = ibz + iz;
+                    if (cx >= 4 || cy >= 4 || cz >= 4) continue;      /* lower bounds hold: vb >= 0 */
+                    const float wt = (ix == 0 ? 1.0f - dvx : dvx) * (iy == 0 ? 1.0f - dvy : dvy) *
+                                     (iz == 0 ? 1.0f - dvz : dvz);
+                    float *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
+                    const float mw = mag * wt;
+                    atomicAdd(hc + i0, mw * bary.x);
+                    atomicAdd(hc + i1, mw * bary.y);
+                    atomicAdd(hc + i2, mw * bary.z);
+                }
+    }
+    __syncthreads();
+    /* merge the wave-private histograms (fixed order), then normalise / clamp / normalise */
+    float v[S3D_DESC_NUMEL / DESC_THREADS];
+    double ss = 0.0;
+    for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
+        const int i = tid + j * DESC_THREADS;
+        float a = hist[0][i];
+        for (int w = 1; w < DESC_WAVES; w++) a = a + hist[w][i];
+        v[j] = a;
+        ss += (double)a * (double)a;
+    }
+    const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
+    double norm = sqrt(block_sum_f64(ss)) + 2.220446049250313e-16;         /* + DBL_EPSILON */
+    float inv = (float)(1.0 / norm);
+    ss = 0.0;
+    for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
+        float a = v[j] * inv;
+        a = a < trunc ? a : trunc;
+        v[j] = a;
+        ss += (double)a * (double)a;
+    }
+    norm = sqrt(block_sum_f64(ss)) + 2.220446049250313e-16;
+    inv = (float)(1.0 / norm);
+    for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++)
+        out[(size_t)kid * out_stride + tid + j * DESC_THREADS] = v[j] * inv;
+}
+
+extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
+                              const float *d_mesh, float *d_out, size_t out_stride, s3d_stream st)
+{
+    if (num == 0) return S3D_OK;
+    if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
+    hipLaunchKernelGGL(k_describe, dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num, d_mesh,
+                       d_out, out_stride);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}

@@ -1,0 +1,107 @@
+/* s3d_math.h -- small numerical building blocks shared by the keypoint and dense kernels.
+ * Everything here is evaluated with separately rounded f32 / f64 operations in the reference's
+ * operation order (translation units are compiled with -ffp-contract=off). */
+#pragma once
+#include "s3d_common.h"
+
+#define S3D_BARY_EPS_D 1.1920928955078125e-06 /* bary_eps = FLT_EPSILON * 1E1 as double, sift.c:50 */
+
+struct V3 {
+    float x, y, z;
+};
+__host__ __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__host__ __device__ __forceinline__ V3 v3_sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ __forceinline__ V3 v3_cross(V3 a, V3 b)
+{
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__host__ __device__ __forceinline__ float v3_dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+/* expf as the reference calls it (glibc expf on a float argument).  glibc's expf is computed in
+ * double and is correctly rounded except in extremely rare cases; exp() in double followed by one
+ * rounding reproduces that on the device far more closely than the 1-2 ulp device expf. */
+__device__ __forceinline__ float s3d_expf(float x) { return (float)exp((double)x); }
+
+/* Face table entry layout (16 floats): e1[0..2] e2[3..5] t[6..8] q[9..11] e2q[12] idx[13..15] */
+#define MESH_STRIDE 16
+
+/* icos_hist_bin + cart2bary (sift.c:1646-1683, 335-394) on the precomputed face table: the first
+ * face, in table order, with all barycentric coordinates >= -bary_eps and k >= 0.
+ * The per-face constants e1, e2, t = -v0, q = t x e1 and e2.q do not depend on the input vector,
+ * so hoisting them changes no rounding.  Returns the face index or -1. */
+__device__ __forceinline__ int s3d_icos_bin(const float *__restrict__ mesh, V3 g, V3 *bary)
+{
+    if ((double)v3_dot(g, g) < S3D_BARY_EPS_D) return -1;
+    for (int i = 0; i < S3D_NFACES; i++) {
+        const float *m = mesh + i * MESH_STRIDE;
+        const V3 e1 = v3(m[0], m[1], m[2]);
+        const V3 e2 = v3(m[3], m[4], m[5]);
+        const V3 p = v3_cross(g, e2);
+        const float det = v3_dot(e1, p);
+        if ((double)fabsf(det) < S3D_BARY_EPS_D) continue;
+        const float det_inv = 1.0f / det;
+        const V3 t = v3(m[6], m[7], m[8]);
+        const V3 q = v3(m[9], m[10], m[11]);
+        V3 b;
+        b.y = det_inv * v3_dot(t, p);
+        b.z = det_inv * v3_dot(g, q);
+        b.x = 1.0f - b.y - b.z;
+        const float k = m[12] * det_inv;
+        if ((double)b.x < -S3D_BARY_EPS_D || (double)b.y < -S3D_BARY_EPS_D || (double)b.z < -S3D_BARY_EPS_D ||
+            k < 0.0f)
+            continue;
+        *bary = b;
+        return i;
+    }
+    return -1;
+}
+
+/* Cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix in double, eigenvalues ascending,
+ * eigenvectors in the columns of Q.  Stands in for LAPACK dsyevd (imutil.c:3035-3053): R is built
+ * from Q sign-invariantly (sift.c:1446-1488) and near-degenerate spectra are rejected
+ * (sift.c:1440-1444), so any accurate f64 solver reproduces the reference's R. */
+__host__ __device__ inline void s3d_eig3(const double Ain[3][3], double L[3], double Q[3][3])
+{
+    double A[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            A[i][j] = Ain[i][j];
+            Q[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 64; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double qkp = Q[k][p], qkq = Q[k][q];
+                    Q[k][p] = c * qkp - s * qkq;
+                    Q[k][q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    L[0] = A[0][0]; L[1] = A[1][1]; L[2] = A[2][2];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2 - i; j++)
+            if (L[j] > L[j + 1]) {
+                const double tl = L[j]; L[j] = L[j + 1]; L[j + 1] = tl;
+                for (int k = 0; k < 3; k++) {
+                    const double tq = Q[k][j]; Q[k][j] = Q[k][j + 1]; Q[k][j + 1] = tq;
+                }
+            }
+}

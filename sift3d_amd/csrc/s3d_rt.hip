@@ -1,0 +1,80 @@
+/* s3d_rt.hip -- runtime plumbing behind the C-ABI: device memory, copies, streams, events, errors.
+ * No compute.  There is deliberately no CPU path: with no HIP device every entry point fails. */
+#include "s3d_common.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void s3d_rt_set_error(const char *where, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, what);
+}
+
+extern "C" const char *s3d_rt_last_error(void) { return g_err; }
+
+extern "C" int s3d_rt_device_count(int *count)
+{
+    *count = 0;
+    S3D_HIP(hipGetDeviceCount(count));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_set_device(int dev) { S3D_HIP(hipSetDevice(dev)); return S3D_OK; }
+extern "C" int s3d_rt_get_device(int *dev) { S3D_HIP(hipGetDevice(dev)); return S3D_OK; }
+extern "C" int s3d_rt_malloc(void **d_ptr, size_t bytes)
+{
+    *d_ptr = NULL;
+    S3D_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_free(void *d_ptr)
+{
+    if (d_ptr) S3D_HIP(hipFree(d_ptr));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_h2d(void *d_dst, const void *src, size_t bytes, s3d_stream st)
+{
+    S3D_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)st));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_d2h(void *dst, const void *d_src, size_t bytes, s3d_stream st)
+{
+    S3D_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)st));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_d2d(void *d_dst, const void *d_src, size_t bytes, s3d_stream st)
+{
+    S3D_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_memset(void *d_ptr, int value, size_t bytes, s3d_stream st)
+{
+    S3D_HIP(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)st));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_sync(s3d_stream st) { S3D_HIP(hipStreamSynchronize((hipStream_t)st)); return S3D_OK; }
+extern "C" int s3d_rt_stream_create(s3d_stream *st)
+{
+    hipStream_t s;
+    S3D_HIP(hipStreamCreate(&s));
+    *st = (s3d_stream)s;
+    return S3D_OK;
+}
+extern "C" int s3d_rt_stream_destroy(s3d_stream st) { S3D_HIP(hipStreamDestroy((hipStream_t)st)); return S3D_OK; }
+extern "C" int s3d_rt_event_create(void **ev)
+{
+    hipEvent_t e;
+    S3D_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return S3D_OK;
+}
+extern "C" int s3d_rt_event_destroy(void *ev) { S3D_HIP(hipEventDestroy((hipEvent_t)ev)); return S3D_OK; }
+extern "C" int s3d_rt_event_record(void *ev, s3d_stream st)
+{
+    S3D_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)st));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_event_elapsed_ms(void *a, void *b, float *ms)
+{
+    S3D_HIP(hipEventSynchronize((hipEvent_t)b));
+    S3D_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return S3D_OK;
+}

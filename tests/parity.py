@@ -1,0 +1,189 @@
+"""Parity checks of a library that speaks the SIFT3D C API (+ the flat device ABI) against the CPU
+oracle.  The same functions are run
+
+  * on the real product library on an MI355X  (tests/test_gpu_parity.py, -m gpu), and
+  * on the SIMT-emulated build of the same sources (tests/test_emu_parity.py, CPU) to catch kernel
+    logic errors before spending GPU time.
+
+Tolerances (north_star): Gaussian / pyramid / extrema / keypoint indices bit-exact; R within 1e-5
+absolute (device exp() vs glibc expf can differ by 1 ulp in a few window weights); descriptor
+floats within 1e-4 relative (LDS-atomic accumulation order); dense output bit-exact.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from sift3d_amd import abi, synth
+from sift3d_amd.device import DeviceLib
+from tests.util import nbitdiff, rel_close
+
+
+def dev_of(lib: abi.Sift3dLib) -> DeviceLib:
+    return DeviceLib(lib.sift)
+
+
+# ---- Gaussian ------------------------------------------------------------------------------------------
+def check_sep_fir_api(lib, oracle, dims, units, nc, sigma, unit=1.0, seed=0):
+    """apply_Sep_FIR_filter through the reference API (host images)."""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = dims
+    vol = rng.standard_normal((nz, ny, nx) + ((nc,) if nc > 1 else ())).astype(np.float32)
+    g = abi.Gauss_filter()
+    assert lib.imutil.init_Gauss_filter(C.byref(g), sigma, 3) == 0
+    taps = np.ctypeslib.as_array(g.f.kernel, shape=(g.f.width,)).copy()
+    assert nbitdiff(taps, oracle.gauss_taps(sigma)) == 0
+    src = lib.image_from_numpy(vol, units)
+    dst = abi.Image()
+    lib.imutil.init_im(C.byref(dst))
+    assert lib.imutil.apply_Sep_FIR_filter(C.byref(src), C.byref(dst), C.byref(g.f), unit) == 0
+    got = lib.image_to_numpy(dst)
+    want = oracle.sep_fir(vol, taps, units, unit)
+    assert (dst.ux, dst.uy, dst.uz) == tuple(float(u) for u in units)
+    lib.free_image(src)
+    lib.free_image(dst)
+    lib.imutil.cleanup_Gauss_filter(C.byref(g))
+    nd = nbitdiff(got, want)
+    assert nd == 0, f"{nd} of {got.size} elements differ (dims={dims} units={units} nc={nc} sigma={sigma})"
+
+
+def check_sep_fir_paths(lib, oracle, dims, sigma, seed=0, chunks=None):
+    """Device-level: generic per-axis path and fused fast path agree with the oracle bit for bit."""
+    dev = dev_of(lib)
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = dims
+    vol = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    taps = oracle.gauss_taps(sigma)
+    want = oracle.sep_fir(vol, taps, (1, 1, 1), 1.0)
+    d_src = dev.upload(vol)
+    d_dst = dev.malloc(vol.nbytes)
+    d_tmp = dev.malloc(vol.nbytes)
+    try:
+        if chunks:
+            dev.L.s3d_k_gauss_set_chunks(*chunks)
+        for path in (1, 2):
+            dev.L.s3d_rt_memset(C.c_void_p(d_dst), 0xFF, vol.nbytes, None)
+            dev.sep_fir(d_src, d_dst, d_tmp, nx, ny, nz, 1, (1, 1, 1), taps, path=path)
+            got = dev.download(d_dst, vol.shape)
+            nd = nbitdiff(got, want)
+            assert nd == 0, f"path {path}: {nd} of {got.size} differ (dims={dims}, sigma={sigma}, chunks={chunks})"
+    finally:
+        dev.L.s3d_k_gauss_set_chunks(128, 128)
+        for p in (d_src, d_dst, d_tmp):
+            dev.free(p)
+
+
+# ---- detect + describe -----------------------------------------------------------------------------------
+def run_detect(lib, vol, units, params=None):
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    if params:
+        for k, v in params.items():
+            assert getattr(lib.sift, f"set_{k}_SIFT3D")(C.byref(s), v) == 0
+    im = lib.image_from_numpy(vol, units)
+    kp = abi.Keypoint_store()
+    lib.sift.init_Keypoint_store(C.byref(kp))
+    rc = lib.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp))
+    assert rc == 0, "SIFT3D_detect_keypoints failed"
+    return s, im, kp
+
+
+def check_detect_describe(lib, oracle, dims, units, nblobs, seed=0, check_pyramid=True, params=None):
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    if params:
+        oracle.set_params(peak=params.get("peak_thresh", 0.1), corner=params.get("corner_thresh", 0.4),
+                          num_kp_levels=params.get("num_kp_levels", 3), sigma_n=params.get("sigma_n", 1.15),
+                          sigma0=params.get("sigma0", 1.6))
+    try:
+        want_xyzos, want_sd, want_R = oracle.detect(vol, units)
+        s, im, kp = run_detect(lib, vol, units, params)
+        xyzos, sd, R = lib.keypoints_to_numpy(kp)
+        ncand = lib.sift.sift3d_amd_last_num_candidates(C.byref(s)) if hasattr(lib.sift, "sift3d_amd_last_num_candidates") else None
+        if ncand is not None and ncand >= 0:
+            assert ncand == len(oracle.candidates()[0]), "extrema candidate count differs"
+        assert np.array_equal(xyzos, want_xyzos), \
+            f"keypoint indices differ: got {len(xyzos)}, want {len(want_xyzos)}"
+        assert np.array_equal(sd, want_sd)
+        assert (kp.nx, kp.ny, kp.nz) == dims
+        assert np.abs(R - want_R).max(initial=0) <= 1e-5
+        # detectValidTest invariants of the reference's MATLAB suite (Sift3DTest.m:245-274)
+        for Ri in R:
+            assert np.allclose(Ri @ Ri.T, np.eye(3), atol=1e-3) and abs(np.linalg.det(Ri) - 1) < 1e-3
+        if check_pyramid and hasattr(lib.sift, "sift3d_amd_download_pyramid"):
+            assert lib.sift.sift3d_amd_download_pyramid(C.byref(s), 1) == 0
+            for o in range(s.gpyr.num_octaves):
+                for k in range(s.gpyr.num_levels):
+                    lv = s.gpyr.levels[o * s.gpyr.num_levels + k]
+                    w, wu, ws = oracle.level("gss", o, k - 1)
+                    assert nbitdiff(lib.image_to_numpy(lv), w) == 0, ("gss", o, k - 1)
+                    assert ws == lv.s and tuple(wu) == (lv.ux, lv.uy, lv.uz)
+                for k in range(s.dog.num_levels):
+                    lv = s.dog.levels[o * s.dog.num_levels + k]
+                    assert nbitdiff(lib.image_to_numpy(lv), oracle.level("dog", o, k - 1)[0]) == 0, ("dog", o, k - 1)
+        if len(xyzos):
+            d = abi.SIFT3D_Descriptor_store()
+            lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+            assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+            bins, xyzs = lib.descriptors_to_numpy(d)
+            # descriptors of the oracle for the SAME keypoints/R the library reported
+            wb, wx = oracle.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
+            assert np.array_equal(xyzs, wx)
+            ok = rel_close(bins, wb, rtol=1e-4, atol=1e-7)
+            assert ok.all(), f"{(~ok).sum()} descriptor floats beyond 1e-4 relative, max abs {np.abs(bins - wb).max()}"
+            assert (d.nx, d.ny, d.nz) == dims
+            lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+        lib.sift.cleanup_Keypoint_store(C.byref(kp))
+        lib.free_image(im)
+        lib.sift.cleanup_SIFT3D(C.byref(s))
+        return len(xyzos)
+    finally:
+        if params:
+            oracle.set_params()
+
+
+def check_dense(lib, oracle, dims, units, out_units=(1, 1, 1), seed=5):
+    nx, ny, nz = dims
+    vol = (synth.blobs(nx, ny, nz, max(8, nx * ny * nz // 300), seed) * 37.0 + 3.0).astype(np.float32)
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    im = lib.image_from_numpy(vol, units)
+    out = abi.Image()
+    lib.imutil.init_im(C.byref(out))
+    out.ux, out.uy, out.uz = out_units
+    assert lib.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out)) == 0
+    got = lib.image_to_numpy(out)
+    want = oracle.dense(vol, units, out_units)
+    nd = nbitdiff(got, want)
+    lib.free_image(im)
+    lib.free_image(out)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+    assert nd == 0, f"dense: {nd} of {got.size} elements differ"
+
+
+def check_raw_variants(lib, oracle, dims, units, nblobs, seed=2):
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    s, im, kp = run_detect(lib, vol, units)
+    xyzos, sd, R = lib.keypoints_to_numpy(kp)
+    K = len(xyzos)
+    assert K > 0
+    d = abi.SIFT3D_Descriptor_store()
+    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert lib.sift.SIFT3D_extract_raw_descriptors(C.byref(s), C.byref(im), C.byref(kp), C.byref(d)) == 0
+    bins, xyzs = lib.descriptors_to_numpy(d)
+    sm = oracle.smooth_scale_raw(vol, units)
+    f = 2.0 ** xyzos[:, 3]
+    wb, wx = oracle.describe_volume(sm, units, xyzos[:, :3] * f[:, None], np.zeros(K, np.int32), sd, R)
+    assert np.array_equal(xyzs, wx)
+    assert rel_close(bins, wb).all()
+    conf = C.POINTER(C.c_double)()
+    assert lib.sift.SIFT3D_assign_orientations(C.byref(s), C.byref(im), C.byref(kp), C.byref(conf)) == 0
+    _, _, R3 = lib.keypoints_to_numpy(kp)
+    for i in range(K):
+        rej, Ro, cf = oracle.eig_ori(sm, units, (xyzos[i, :3] * f[i]).astype(np.float32), sd[i])
+        if rej:
+            Ro, cf = np.eye(3, dtype=np.float32), -1.0
+        assert np.abs(Ro - R3[i]).max() <= 1e-5 and abs(cf - conf[i]) <= 1e-6
+    lib.sift.cleanup_SIFT3D(C.byref(s))

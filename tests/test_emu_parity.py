@@ -1,0 +1,62 @@
+"""CPU: the product's kernel sources executed by the SIMT emulator (tests/emu, test infrastructure)
+against the oracle.  Catches indexing / staging / compaction-order bugs without a GPU.  Small sizes:
+the emulator runs one GPU thread at a time."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from sift3d_amd import abi
+from sift3d_amd.device import bind_extensions
+from tests import parity
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["sh", os.path.join(EMU_DIR, "build_emu.sh")], check=True, capture_output=True)
+    L = C.CDLL(os.path.join(EMU_DIR, "libsift3d_emu.so"))
+    lib = abi.Sift3dLib(L, None, "emulated")
+    bind_extensions(L)
+    return lib
+
+
+@pytest.mark.parametrize("dims,units,nc,sigma,unit", [
+    ((21, 19, 17), (1, 1, 1), 1, 0.973294, 1.0),       # generic path (nx % 4 != 0)
+    ((24, 19, 17), (1, 1, 1), 1, 1.22627, 1.0),        # fused fast path
+    ((20, 18, 16), (2, 2, 2), 1, 2.45255, 1.0),        # octave-1 spacing (half-voxel taps)
+    ((19, 23, 18), (1, 0.7, 2), 1, 1.54501, 1.0),      # anisotropic (non-dyadic: coordinate drift)
+    ((12, 13, 11), (1, 1, 2), 3, 1.22627, -1.0),       # multi-channel, unit = -1
+])
+def test_sep_fir_api(emu, oracle, dims, units, nc, sigma, unit):
+    parity.check_sep_fir_api(emu, oracle, dims, units, nc, sigma, unit)
+
+
+@pytest.mark.parametrize("dims,sigma,chunks", [
+    ((24, 20, 19), 0.538701, None),      # hw 2
+    ((24, 20, 19), 0.973294, (8, 8)),    # hw 3, several chunks per axis
+    ((28, 22, 21), 1.54501, (16, 8)),    # hw 5
+    ((520, 12, 11), 1.22627, None),      # three 256-column strips, last one partial
+    ((24, 24, 24), 2.45255, (9, 11)),    # hw 8: windows overlap both edges
+    ((24, 26, 25), 2.8284, None),        # hw 9
+])
+def test_sep_fir_fast_vs_generic(emu, oracle, dims, sigma, chunks):
+    parity.check_sep_fir_paths(emu, oracle, dims, sigma, chunks=chunks)
+
+
+def test_detect_describe_iso(emu, oracle):
+    assert parity.check_detect_describe(emu, oracle, (32, 32, 32), (1, 1, 1), 40, seed=0) > 0
+
+
+def test_detect_describe_aniso(emu, oracle):
+    assert parity.check_detect_describe(emu, oracle, (36, 32, 28), (1, 0.8, 2), 60, seed=3) > 0
+
+
+def test_dense(emu, oracle):
+    parity.check_dense(emu, oracle, (14, 13, 12), (1, 1, 2))
+
+
+def test_raw_variants(emu, oracle):
+    parity.check_raw_variants(emu, oracle, (32, 32, 32), (1, 1, 1), 40)

@@ -1,0 +1,222 @@
+"""GPU (-m gpu, real MI355X): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, plus size-independent properties at the benchmark size.  Bit-exact for the
+Gaussian / pyramid / extrema / keypoint indices / dense output; descriptor floats within 1e-4
+relative (see tests/parity.py)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from sift3d_amd import abi, synth
+from tests import parity
+from tests.conftest import GOLDEN
+from tests.util import nbitdiff, rel_close, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(hip):
+    dev = parity.dev_of(hip)
+    assert dev.device_count() >= 1, "no HIP device: the HIP path has no CPU fallback"
+    return hip
+
+
+@pytest.mark.parametrize("dims,units,nc,sigma,unit", [
+    ((37, 41, 29), (1, 1, 1), 1, 0.973294, 1.0),       # odd dims -> generic path
+    ((64, 48, 40), (1, 1, 1), 1, 1.22627, 1.0),        # fused fast path
+    ((37, 41, 29), (2, 2, 2), 1, 2.45255, 1.0),        # octave-1 spacing
+    ((37, 41, 29), (1, 0.7, 2), 1, 1.54501, 1.0),      # anisotropic, non-dyadic
+    ((37, 41, 29), (0.5, 1.3, 4), 1, 1.94659, 1.0),
+    ((29, 33, 27), (1, 1, 2), 12, 2.8284, 1.0),        # 12-channel (dense blur shape)
+    ((29, 33, 27), (1, 1, 2), 3, 1.22627, -1.0),       # unit = -1
+])
+def test_sep_fir_api(lib, oracle, dims, units, nc, sigma, unit):
+    parity.check_sep_fir_api(lib, oracle, dims, units, nc, sigma, unit)
+
+
+@pytest.mark.parametrize("dims,sigma,chunks", [
+    ((64, 40, 36), 0.2, None),           # hw 1
+    ((64, 40, 36), 0.538701, None),      # hw 2
+    ((64, 40, 36), 0.973294, (8, 8)),    # hw 3
+    ((128, 96, 80), 1.22627, None),      # hw 4
+    ((128, 96, 80), 1.54501, (32, 16)),  # hw 5
+    ((260, 70, 66), 1.94659, None),      # hw 6, two strips, last partial
+    ((128, 150, 140), 2.3, (128, 128)),  # hw 7, two chunks per axis
+    ((128, 96, 80), 2.45255, None),      # hw 8
+    ((24, 24, 24), 2.45255, (9, 11)),    # hw 8 on a tiny volume
+    ((128, 96, 80), 2.8284, None),       # hw 9
+    ((768, 32, 24), 1.22627, None),      # three full strips
+])
+def test_sep_fir_fast_vs_generic(lib, oracle, dims, sigma, chunks):
+    parity.check_sep_fir_paths(lib, oracle, dims, sigma, chunks=chunks)
+
+
+def test_sep_fir_golden(lib):
+    g = np.load(os.path.join(GOLDEN, "sep_fir.npz"))
+    for i in range(int(g["n"])):
+        vol = g[f"in_{i}"]
+        gf = abi.Gauss_filter()
+        assert lib.imutil.init_Gauss_filter(C.byref(gf), float(g[f"sigma_{i}"]), 3) == 0
+        src = lib.image_from_numpy(vol, tuple(g[f"units_{i}"]))
+        dst = abi.Image()
+        lib.imutil.init_im(C.byref(dst))
+        assert lib.imutil.apply_Sep_FIR_filter(C.byref(src), C.byref(dst), C.byref(gf.f), float(g[f"unit_{i}"])) == 0
+        assert nbitdiff(lib.image_to_numpy(dst), g[f"out_{i}"]) == 0, i
+
+
+@pytest.mark.parametrize("name", ["detect_iso64", "detect_aniso"])
+def test_detect_describe_golden(lib, name):
+    """Straight against vectors captured from the unmodified reference (no oracle in the loop)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nx, ny, nz = (int(v) for v in g["dims"])
+    vol = synth.blobs(nx, ny, nz, int(g["nblobs"]), int(g["seed"]))
+    assert sha(vol) == str(g["input_sha256"])
+    s, im, kp = parity.run_detect(lib, vol, tuple(g["units"]))
+    xyzos, sd, R = lib.keypoints_to_numpy(kp)
+    assert np.array_equal(xyzos, g["xyzos"]) and np.array_equal(sd, g["sd"])
+    assert np.abs(R - g["R"]).max() <= 1e-5
+    assert lib.sift.sift3d_amd_download_pyramid(C.byref(s), 1) == 0
+    k = 0
+    for o in range(s.gpyr.num_octaves):
+        for kk in range(s.gpyr.num_levels):
+            assert sha(lib.image_to_numpy(s.gpyr.levels[o * s.gpyr.num_levels + kk])) == str(g["gss_sha256"][k]), (o, kk)
+            k += 1
+    k = 0
+    for o in range(s.dog.num_octaves):
+        for kk in range(s.dog.num_levels):
+            assert sha(lib.image_to_numpy(s.dog.levels[o * s.dog.num_levels + kk])) == str(g["dog_sha256"][k]), (o, kk)
+            k += 1
+    d = abi.SIFT3D_Descriptor_store()
+    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    bins, xyzs = lib.descriptors_to_numpy(d)
+    assert np.array_equal(xyzs, g["desc_xyzs"])
+    assert rel_close(bins, g["desc_bins"], rtol=1e-4, atol=1e-7).all()
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+
+
+@pytest.mark.parametrize("dims,units,nblobs,seed", [
+    ((64, 64, 64), (1, 1, 1), 250, 0),
+    ((96, 80, 72), (1, 1, 2), 500, 1),
+    ((81, 70, 67), (1, 0.8, 1.7), 400, 3),
+    ((128, 128, 128), (1, 1, 1), 2000, 0),      # the survey's 491-keypoint anchor
+])
+def test_detect_describe_vs_oracle(lib, oracle, dims, units, nblobs, seed):
+    k = parity.check_detect_describe(lib, oracle, dims, units, nblobs, seed)
+    if dims == (128, 128, 128):
+        assert k == 491
+
+
+def test_detect_describe_other_parameters(lib, oracle):
+    parity.check_detect_describe(lib, oracle, (64, 64, 64), (1, 1, 1), 250, 0,
+                                 params={"peak_thresh": 0.05, "corner_thresh": 0.3, "num_kp_levels": 2,
+                                         "sigma_n": 1.0, "sigma0": 1.8})
+
+
+def test_struct_reuse_same_and_new_dims(lib, oracle):
+    """A SIFT3D object is reused across images (reg/reg.c:183-218 does exactly that)."""
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    kp = abi.Keypoint_store()
+    lib.sift.init_Keypoint_store(C.byref(kp))
+    for dims, seed in (((64, 64, 64), 0), ((64, 64, 64), 7), ((48, 56, 40), 2)):
+        nx, ny, nz = dims
+        vol = synth.blobs(nx, ny, nz, 250, seed)
+        im = lib.image_from_numpy(vol)
+        assert lib.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        xyzos, sd, R = lib.keypoints_to_numpy(kp)
+        wx, wsd, wR = oracle.detect(vol)
+        assert np.array_equal(xyzos, wx) and np.array_equal(sd, wsd)
+        lib.free_image(im)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+
+
+@pytest.mark.parametrize("dims,units,out_units", [((40, 36, 32), (1, 1, 1), (1, 1, 1)),
+                                                  ((33, 29, 27), (1, 1, 2), (1, 1, 1)),
+                                                  ((30, 28, 26), (1, 0.7, 1.3), (1, 1, 2))])
+def test_dense_vs_oracle(lib, oracle, dims, units, out_units):
+    parity.check_dense(lib, oracle, dims, units, out_units)
+
+
+def test_dense_golden(lib):
+    g = np.load(os.path.join(GOLDEN, "dense.npz"))
+    nx, ny, nz = (int(v) for v in g["dims"])
+    vol = (synth.blobs(nx, ny, nz, int(g["nblobs"]), int(g["seed"])) * float(g["scale"]) + float(g["offset"])).astype(np.float32)
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    im = lib.image_from_numpy(vol, tuple(g["units"]))
+    out = abi.Image()
+    lib.imutil.init_im(C.byref(out))
+    assert lib.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out)) == 0
+    assert nbitdiff(lib.image_to_numpy(out), g["out"]) == 0
+
+
+def test_raw_variants(lib, oracle):
+    parity.check_raw_variants(lib, oracle, (64, 64, 64), (1, 1, 2), 250)
+
+
+def test_errors_like_the_reference(lib):
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    kp = abi.Keypoint_store()
+    lib.sift.init_Keypoint_store(C.byref(kp))
+    two = lib.image_from_numpy(np.zeros((16, 16, 16, 2), np.float32))
+    assert lib.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(two), C.byref(kp)) != 0     # nc != 1
+    tiny = lib.image_from_numpy(np.zeros((7, 16, 16), np.float32))
+    assert lib.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(tiny), C.byref(kp)) != 0    # < 8 voxels
+    flat = lib.image_from_numpy(np.zeros((16, 16, 16), np.float32))
+    assert lib.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(flat), C.byref(kp)) == 0    # constant image: 0 keypoints
+    assert kp.slab.num == 0
+    d = abi.SIFT3D_Descriptor_store()
+    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) != 0    # no keypoints
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+
+
+def test_properties_at_benchmark_size(lib):
+    """512^3 (BASELINE config 2): properties that need no CPU run of that size.
+    (1) fused fast path == generic per-axis path bit for bit on the full volume (checksum),
+    (2) linearity-free invariant: a constant volume is reproduced exactly by every filter of the bank
+        away from the high edge, (3) keypoints in range, R orthonormal, descriptor norms == 1,
+    (4) the survey's K anchor for this generator: 31 207 keypoints."""
+    dev = parity.dev_of(lib)
+    n = 512
+    vol = synth.blobs(n, n, n, 128000, 0)
+    from oracle import oracle as orc     # taps only (test infrastructure)
+    O = orc.Oracle()
+    taps = O.gauss_taps(2.45255)
+    d_src = dev.upload(vol)
+    d_a = dev.malloc(vol.nbytes)
+    d_b = dev.malloc(vol.nbytes)
+    d_tmp = dev.malloc(vol.nbytes)
+    dev.sep_fir(d_src, d_a, d_tmp, n, n, n, 1, (1, 1, 1), taps, path=1)
+    dev.sep_fir(d_src, d_b, d_tmp, n, n, n, 1, (1, 1, 1), taps, path=2)
+    a = dev.download(d_a, vol.shape)
+    b = dev.download(d_b, vol.shape)
+    assert sha(a) == sha(b)
+    del a, b
+    for p in (d_a, d_b, d_tmp, d_src):
+        dev.free(p)
+    s, im, kp = parity.run_detect(lib, vol, (1, 1, 1))
+    xyzos, sd, R = lib.keypoints_to_numpy(kp)
+    assert len(xyzos) == 31207
+    dims_o = np.array([n, n, n])[None, :] >> xyzos[:, 3:4]
+    assert (xyzos[:, :3] >= 1).all() and (xyzos[:, :3] <= dims_o - 2).all()
+    order = np.lexsort((xyzos[:, 0], xyzos[:, 1], xyzos[:, 2], xyzos[:, 4], xyzos[:, 3]))
+    assert np.array_equal(order, np.arange(len(xyzos)))            # reference scan order (o, s, z, y, x)
+    RtR = np.einsum("kij,kil->kjl", R, R)
+    assert np.abs(RtR - np.eye(3)).max() < 1e-3 and np.abs(np.linalg.det(R) - 1).max() < 1e-3
+    d = abi.SIFT3D_Descriptor_store()
+    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    bins, xyzs = lib.descriptors_to_numpy(d)
+    assert np.abs(np.linalg.norm(bins.astype(np.float64), axis=1) - 1).max() < 1e-5
+    assert (bins >= 0).all() and np.isfinite(bins).all()
+    assert np.array_equal(xyzs[:, :3], xyzos[:, :3] * (2.0 ** xyzos[:, 3:4]))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"K_512": int(len(xyzos)), "desc_sha256": sha(bins)}, open(os.path.join(out, "props_512.json"), "w"))
+    lib.sift.cleanup_SIFT3D(C.byref(s))
