@@ -143,10 +143,14 @@ int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint
                    const float *d_mesh, float *d_out, size_t out_stride /* floats, >= 768 */,
                    s3d_stream stream);
 
+/* Profiling-only ablation switch for k_orient / k_describe (see s3d_keypoint.hip); 0 = normal. */
+void s3d_k_set_variant(int v);
+
 /* Icosahedron table for the kernels (host computation in f32, mirrors init_geometry sift.c:215-326
  * incl. the v[0]<->v[1] swap quirk).  Layout per face (16 floats): e1[3] e2[3] t[3] q[3] e2q
- * idx0 idx1 idx2 (indices stored as float bit patterns of ints).  out: 20*16 floats. */
-#define S3D_MESH_FLOATS (S3D_NFACES * 16)
+ * idx0 idx1 idx2 (indices stored as float bit patterns of ints), followed by a 32-entry face lookup
+ * (int bit patterns; key = sign bits of x,y,z | type<<3, see s3d_icos_bin_fast).  out: 20*16+32 floats. */
+#define S3D_MESH_FLOATS (S3D_NFACES * 16 + 32)
 void s3d_mesh_table(float *out);
 
 /* ---- dense descriptors (SIFT3D_extract_dense_descriptors sift.c:2354-2496) ----------------------- */

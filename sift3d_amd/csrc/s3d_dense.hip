@@ -27,7 +27,7 @@ k_dense_bary(const float *__restrict__ sm, int nx, int ny, int nz, float iux, fl
     g.z = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
     g.x = g.x * iux; g.y = g.y * iuy; g.z = g.z * iuz;
     V3 bary;
-    const int face = s3d_icos_bin(mesh, g, &bary);
+    const int face = s3d_icos_bin_fast(mesh, g, &bary);
     if (face < 0) return;
     const float *m = mesh + face * MESH_STRIDE;
     float *t = out12 + vi * S3D_NVERT;

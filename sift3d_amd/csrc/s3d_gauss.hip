@@ -175,14 +175,16 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
     const int T = (p1 - p0) + 2 * HW;                 /* pushes: coordinates p0-HW .. p1-1+HW */
 
     float4 ring[W];
-    float4 nxt = z_ext<HW>(col, zs, p0 - HW, nz, ef);
+    float4 n0 = z_ext<HW>(col, zs, p0 - HW, nz, ef);
+    float4 n1 = z_ext<HW>(col, zs, p0 - HW + (1 < T ? 1 : 0), nz, ef);
     for (int tb = 0; tb < T; tb += W) {
 #pragma unroll
         for (int u = 0; u < W; u++) {
             const int t = tb + u;
             if (t < T) {
-                ring[u] = nxt;
-                if (t + 1 < T) nxt = z_ext<HW>(col, zs, p0 - HW + t + 1, nz, ef);   /* prefetch */
+                ring[u] = n0;
+                n0 = n1;
+                if (t + 2 < T) n1 = z_ext<HW>(col, zs, p0 - HW + t + 2, nz, ef);    /* two planes in flight */
                 if (t >= 2 * HW) {
                     const float4 acc = ring_dot<HW>(ring, u, taps);
                     *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * zs) = acc;
@@ -199,9 +201,11 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
            EdgeFrac efx, EdgeFrac efy)
 {
     constexpr int W = 2 * HW + 1;
-    constexpr int NR = (4 + 2 * HW + 3) / 4;          /* float4 LDS reads per lane */
-    constexpr int LINE = XY_STRIP + 4 * NR;           /* >= XY_STRIP + 2 HW, multiple of 4 */
-    __shared__ __attribute__((aligned(16))) float line[LINE];
+    constexpr int PAD = (4 - HW % 4) % 4;             /* puts the body at a 16-byte aligned LDS offset */
+    constexpr int OFF = PAD + HW;                     /* line[OFF + i] = E_x[x0 + i] ; OFF % 4 == 0 */
+    constexpr int NR = (PAD + 4 + 2 * HW + 3) / 4;    /* float4 LDS reads per lane */
+    constexpr int LINE = XY_STRIP + 4 * NR;           /* >= PAD + XY_STRIP + 2 HW, multiple of 4 */
+    __shared__ __attribute__((aligned(16))) float line2[2][LINE];   /* double buffered: one barrier per row */
 
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * XY_STRIP;
@@ -214,20 +218,20 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
     const int T = (p1 - p0) + 2 * HW;
 
     /* ---- per-lane constants of the line staging --------------------------------------------------
-     * body: line[HW + 4*lane + i] = E_x[xq + i]  for xq+i <= nx-2 (plain samples)
+     * body: line[OFF + 4*lane + i] = E_x[xq + i]  for xq+i <= nx-2 (plain samples)
      * edge roles (lanes 0 .. 3HW, one LDS slot each):
-     *   lanes [0,HW)        left halo   slot = lane              coordinate x0-HW+lane
-     *   lanes [HW,2HW)      right halo  slot = XY_STRIP+lane     coordinate x0+XY_STRIP+lane-HW
+     *   lanes [0,HW)        left halo   slot = PAD+lane          coordinate x0-HW+lane
+     *   lanes [HW,2HW)      right halo  slot = PAD+XY_STRIP+lane coordinate x0+XY_STRIP+lane-HW
      *   lanes [2HW,3HW]     high-edge blends that fall inside the body, j = lane-2HW, c = nx-1+j */
     int slot = -1, colA = 0, colB = 0, isblend = 0;
     float fj = 0.0f;
     {
         int c = 0, have = 0;
-        if (lane < HW) { c = x0 - HW + lane; slot = lane; have = 1; }
-        else if (lane < 2 * HW) { c = x0 + XY_STRIP + (lane - HW); slot = XY_STRIP + lane; have = 1; }
+        if (lane < HW) { c = x0 - HW + lane; slot = PAD + lane; have = 1; }
+        else if (lane < 2 * HW) { c = x0 + XY_STRIP + (lane - HW); slot = PAD + XY_STRIP + lane; have = 1; }
         else if (lane <= 3 * HW) {
             c = nx - 1 + (lane - 2 * HW);
-            if (c >= x0 && c < x0 + XY_STRIP) { slot = HW + (c - x0); have = 1; }
+            if (c >= x0 && c < x0 + XY_STRIP) { slot = OFF + (c - x0); have = 1; }
         }
         if (have) {
             if (c < 0) c = -c;
@@ -264,12 +268,15 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
         return r;
     };
     /* stage the row in LDS, X-filter this lane's 4 columns */
+    int lbuf = 0;
     auto xpass = [&](const Raw &r) -> float4 {
-        if (body_vec) *reinterpret_cast<float4 *>(&line[HW + 4 * lane]) = r.b;
+        float *line = line2[lbuf];
+        lbuf ^= 1;
+        if (body_vec) *reinterpret_cast<float4 *>(&line[OFF + 4 * lane]) = r.b;
         else {
-            if (xq + 0 <= nx - 2) line[HW + 4 * lane + 0] = r.b.x;
-            if (xq + 1 <= nx - 2) line[HW + 4 * lane + 1] = r.b.y;
-            if (xq + 2 <= nx - 2) line[HW + 4 * lane + 2] = r.b.z;
+            if (xq + 0 <= nx - 2) line[OFF + 4 * lane + 0] = r.b.x;
+            if (xq + 1 <= nx - 2) line[OFF + 4 * lane + 1] = r.b.y;
+            if (xq + 2 <= nx - 2) line[OFF + 4 * lane + 2] = r.b.z;
         }
         if (slot >= 0) line[slot] = isblend ? ((1.0f - fj) * r.a0 + fj * r.a1) : r.a0;
         __syncthreads();
@@ -279,16 +286,15 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
             const float4 t4 = *reinterpret_cast<const float4 *>(&line[4 * lane + 4 * q]);
             v[4 * q + 0] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
         }
-        __syncthreads();
-        /* out[xq+i] = sum_k tap[k] * E[xq+i+HW-k] ;  E[xq+i+HW-k] = line[4*lane + i + 2HW - k] */
+        /* out[xq+i] = sum_k tap[k] * E[xq+i+HW-k] ;  E[xq+i+HW-k] = line[PAD + 4*lane + i + 2HW - k] */
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int k = 0; k < W; k++) {
             const float t = taps.t[k];
-            acc.x = acc.x + t * v[0 + 2 * HW - k];
-            acc.y = acc.y + t * v[1 + 2 * HW - k];
-            acc.z = acc.z + t * v[2 + 2 * HW - k];
-            acc.w = acc.w + t * v[3 + 2 * HW - k];
+            acc.x = acc.x + t * v[PAD + 0 + 2 * HW - k];
+            acc.y = acc.y + t * v[PAD + 1 + 2 * HW - k];
+            acc.z = acc.z + t * v[PAD + 2 + 2 * HW - k];
+            acc.w = acc.w + t * v[PAD + 3 + 2 * HW - k];
         }
         return acc;
     };
@@ -298,24 +304,30 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
         return c <= ny - 2 ? c : (ny - 2 - (c - (ny - 1)));
     };
 
+    /* HBM latency is hidden by keeping three source rows in flight per wave (each wave is a serial
+     * chain of ~chunk rows; with one row of lookahead the kernel ran at memory LATENCY, not bandwidth) */
     float4 ring[W];
-    Raw nxt = load_row(first_row(p0 - HW));
+    const int c0 = p0 - HW;
+    Raw q0 = load_row(first_row(c0));
+    Raw q1 = load_row(first_row(c0 + (1 < T ? 1 : 0)));
+    Raw q2 = load_row(first_row(c0 + (2 < T ? 2 : 0)));
     for (int tb = 0; tb < T; tb += W) {
 #pragma unroll
         for (int u = 0; u < W; u++) {
             const int t = tb + u;
             if (t < T) {
-                int c = p0 - HW + t;
-                const Raw cur = nxt;
+                int c = c0 + t;
+                const Raw cur = q0;
+                q0 = q1;
+                q1 = q2;
+                if (t + 3 < T) q2 = load_row(first_row(c0 + t + 3));               /* prefetch */
                 if (c < 0) c = -c;
                 float4 e;
                 if (c <= ny - 2) {
-                    if (t + 1 < T) nxt = load_row(first_row(p0 - HW + t + 1));     /* prefetch */
                     e = xpass(cur);
                 } else {                                  /* high-side virtual row: two X-filtered rows */
                     const int j = c - (ny - 1);
                     const Raw rb = load_row(ny - 1 - j);
-                    if (t + 1 < T) nxt = load_row(first_row(p0 - HW + t + 1));
                     const float4 ea = xpass(cur);         /* row ny-2-j */
                     const float4 eb = xpass(rb);          /* row ny-1-j */
                     e = blend4(ea, eb, efy.f[j]);

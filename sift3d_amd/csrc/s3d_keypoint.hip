@@ -30,6 +30,7 @@ extern "C" void s3d_mesh_table(float *out)
                                              {1, 6, 8}, {8, 6, 10}, {8, 10, 4}, {4, 10, 2}, {4, 2, 5},
                                              {5, 2, 11}, {5, 11, 9}, {9, 11, 7}, {9, 7, 1}, {1, 7, 6},
                                              {3, 6, 7}, {3, 7, 11}, {3, 11, 2}, {3, 2, 10}, {3, 10, 6}};
+    V3 cen[S3D_NFACES];
     for (int i = 0; i < S3D_NFACES; i++) {
         V3 v[3];
         for (int j = 0; j < 3; j++) {
@@ -55,8 +56,31 @@ extern "C" void s3d_mesh_table(float *out)
             const int id = faces[i][j];
             memcpy(&m[13 + j], &id, sizeof(int));
         }
+        cen[i] = v3(v[0].x + v[1].x + v[2].x, v[0].y + v[1].y + v[2].y, v[0].z + v[1].z + v[2].z);
+    }
+    /* face lookup for s3d_icos_bin_fast: nearest face centre of each (octant, type) direction */
+    const float p2 = (float)(gr * gr);
+    for (int key = 0; key < 32; key++) {
+        const float sx = (key & 1) ? -1.0f : 1.0f, sy = (key & 2) ? -1.0f : 1.0f, sz = (key & 4) ? -1.0f : 1.0f;
+        const int t = key >> 3;
+        const V3 n = t == 0 ? v3(sx, sy, sz) : t == 1 ? v3(sx, 0.0f, sz * p2) : t == 2 ? v3(sx * p2, sy, 0.0f)
+                                                                                       : v3(0.0f, sy * p2, sz);
+        int best = 0;
+        float bd = -1e30f;
+        for (int i = 0; i < S3D_NFACES; i++) {
+            const float d = v3_dot(n, cen[i]);
+            if (d > bd) { bd = d; best = i; }
+        }
+        memcpy(&out[S3D_LUT_OFFSET + key], &best, sizeof(int));
     }
 }
+
+/* Ablation knob for profiling runs ONLY (results are wrong for any value but 0):
+ *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
+ *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
+ *   bit 3: k_describe skips phase B entirely (window tests + queue only) */
+static int g_variant = 0;
+extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
 
 /* ---- orientation ---------------------------------------------------------------------------------- */
 /* sigma table is per level for detected candidates, per candidate for the raw-image variant */
@@ -77,7 +101,7 @@ __device__ __forceinline__ void ori_bounds(float vc, double rad, float uf, int n
 __global__ void __launch_bounds__(64)
 k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
          const float *__restrict__ d_center, uint32_t num, const double *__restrict__ d_sigma, double corner_thresh,
-         float *__restrict__ d_R, uint32_t *__restrict__ d_keep, double *__restrict__ d_conf)
+         float *__restrict__ d_R, uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, int variant)
 {
     __shared__ float term[3][64];
     __shared__ float gw_s[3];
@@ -130,7 +154,8 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
             const float sq = dx * dx + dy * dy + dz * dz;
             if (!((double)sq > rad2)) {
                 const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
-                const float w = s3d_expf((float)(-0.5 * (double)sq / sig2));
+                const float wa = (float)(-0.5 * (double)sq / sig2);
+                const float w = (variant & 2) ? __expf(wa) : s3d_expf(wa);
                 float gx = 0.5f * (p[1] - p[-1]);
                 float gy = 0.5f * (p[nx] - p[-nx]);
                 float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
@@ -146,7 +171,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         }
         term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
         __syncthreads();
-        if (lane < 3) {
+        if (lane < 3 && !(variant & 1)) {
             for (int i = 0; i < 64; i++) gsum = gsum + term[lane][i];   /* reference scan order */
         }
         __syncthreads();
@@ -207,7 +232,7 @@ extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, 
 {
     if (num == 0) return S3D_OK;
     hipLaunchKernelGGL(k_orient, dim3(num), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, num, d_sigma,
-                       corner_thresh, d_R, d_keep, d_conf);
+                       corner_thresh, d_R, d_keep, d_conf, g_variant);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
@@ -264,6 +289,8 @@ extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d
 /* ---- descriptor ------------------------------------------------------------------------------------ */
 #define DESC_THREADS 256
 #define DESC_WAVES (DESC_THREADS / 64)
+#define DESC_CHUNK 1024                    /* box voxels tested per round (4 per thread) */
+#define DESC_QUEUE (DESC_CHUNK + DESC_THREADS)
 
 __device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n, int *s, int *e)
 {
@@ -286,89 +313,174 @@ __device__ __forceinline__ double block_sum_f64(double v)
     return r;
 }
 
+/* exact unsigned division by a small divisor through the f32 reciprocal, with fix-up (a < 2^24) */
+__device__ __forceinline__ int fdiv_small(int a, int d, float inv, int *rem)
+{
+    int q = (int)((float)a * inv);
+    int r = a - q * d;
+    if (r < 0) { q--; r += d; }
+    else if (r >= d) { q++; r -= d; }
+    *rem = r;
+    return q;
+}
+
+/* Per-keypoint geometry shared by the two phases */
+struct DescGeom {
+    float cx, cy, cz, uxf, uyf, uzf, rad2, half, binf;
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22;       /* Rt = R^T (sift.c:1853-1857) */
+    int xs, ys, zs;
+};
+
+/* window test of one voxel: inside the sphere and inside the 4x4x4 cell cube (sift.c:1869-1884).
+ * vb = continuous cell coordinates. */
+__device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int z, float *sq, float *vbx, float *vby,
+                                            float *vbz)
+{
+    const float dx = ((float)x - g.cx) * g.uxf;
+    const float dy = ((float)y - g.cy) * g.uyf;
+    const float dz = ((float)z - g.cz) * g.uzf;
+    *sq = dx * dx + dy * dy + dz * dz;
+    if (*sq > g.rad2) return false;
+    const float kx = g.r00 * dx + g.r01 * dy + g.r02 * dz;
+    const float ky = g.r10 * dx + g.r11 * dy + g.r12 * dz;
+    const float kz = g.r20 * dx + g.r21 * dy + g.r22 * dz;
+    *vbx = (kx + g.half) * g.binf; *vby = (ky + g.half) * g.binf; *vbz = (kz + g.half) * g.binf;
+    return !(*vbx < 0 || *vby < 0 || *vbz < 0 || *vbx >= 4.0f || *vby >= 4.0f || *vbz >= 4.0f);
+}
+
+/* One workgroup per keypoint.  Two alternating phases keep the expensive part divergence free:
+ *   A  every thread runs the cheap window test on 4 voxels of the bounding box and the accepted ones
+ *      (~1/3) are appended, via wave ballots, to an LDS queue of packed voxel offsets;
+ *   B  while the queue holds >= 256 entries, all 256 lanes each take one accepted voxel: gradient,
+ *      Gaussian weight, rotation, icosahedron face + barycentric weights, trilinear spread over 8 cells
+ *      x 3 vertices into the wave-private LDS histogram with ds_add_f32.
+ * The tail of the queue is carried into the next round, so lanes idle only once, at the very end. */
 __global__ void __launch_bounds__(DESC_THREADS)
 k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num,
-           const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride)
+           const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride, int variant)
 {
     __shared__ float hist[DESC_WAVES][S3D_DESC_NUMEL];
     __shared__ float mesh[S3D_MESH_FLOATS];
+    __shared__ unsigned queue[DESC_QUEUE];
+    __shared__ unsigned qcount;
     const unsigned kid = blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (kid >= num) return;
     const s3d_desc_key key = keys[kid];
     for (int i = tid; i < DESC_WAVES * S3D_DESC_NUMEL; i += DESC_THREADS) (&hist[0][0])[i] = 0.0f;
     for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
+    if (tid == 0) qcount = 0;
     __syncthreads();
 
     const int o = key.octave;
     const float *__restrict__ im = pyr.d_level[key.level];
     const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
-    const float uxf = pyr.unitsf[o][0], uyf = pyr.unitsf[o][1], uzf = pyr.unitsf[o][2];
     const size_t plane = (size_t)nx * ny;
-    const float sigma = key.sigma, rad = key.rad, half = key.half, binf = key.binf;
-    const float rad2 = rad * rad, sig2 = sigma * sigma;
-    /* Rt = R^T (sift.c:1853-1857) */
-    const float r00 = key.R[0], r01 = key.R[3], r02 = key.R[6];
-    const float r10 = key.R[1], r11 = key.R[4], r12 = key.R[7];
-    const float r20 = key.R[2], r21 = key.R[5], r22 = key.R[8];
-    const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
+    DescGeom g;
+    g.cx = key.cx; g.cy = key.cy; g.cz = key.cz;
+    g.uxf = pyr.unitsf[o][0]; g.uyf = pyr.unitsf[o][1]; g.uzf = pyr.unitsf[o][2];
+    g.rad2 = key.rad * key.rad; g.half = key.half; g.binf = key.binf;
+    g.r00 = key.R[0]; g.r01 = key.R[3]; g.r02 = key.R[6];
+    g.r10 = key.R[1]; g.r11 = key.R[4]; g.r12 = key.R[7];
+    g.r20 = key.R[2]; g.r21 = key.R[5]; g.r22 = key.R[8];
+    const float sig2 = key.sigma * key.sigma;
+    const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
 
-    int xs, xe, ys, ye, zs, ze;
-    desc_bounds(key.cx, rad, uxf, nx, &xs, &xe);
-    desc_bounds(key.cy, rad, uyf, ny, &ys, &ye);
-    desc_bounds(key.cz, rad, uzf, nz, &zs, &ze);
-    const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
-    const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
+    int xe, ye, ze;
+    desc_bounds(key.cx, key.rad, g.uxf, nx, &g.xs, &xe);
+    desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
+    desc_bounds(key.cz, key.rad, g.uzf, nz, &g.zs, &ze);
+    const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
+    const int nbox = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wx * wy * wz : 0;
+    const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
     float *h = hist[wave];
 
-    for (int b = tid; b < nbox; b += DESC_THREADS) {
-        const int bz = b / (wx * wy);
-        const int r = b - bz * wx * wy;
-        const int by = r / wx;
-        const int bx = r - by * wx;
-        const int x = xs + bx, y = ys + by, z = zs + bz;
-        const float dx = ((float)x - key.cx) * uxf;
-        const float dy = ((float)y - key.cy) * uyf;
-        const float dz = ((float)z - key.cz) * uzf;
-        const float sq = dx * dx + dy * dy + dz * dz;
-        if (sq > rad2) continue;
-        const float kx = r00 * dx + r01 * dy + r02 * dz;
-        const float ky = r10 * dx + r11 * dy + r12 * dz;
-        const float kz = r20 * dx + r21 * dy + r22 * dz;
-        const float vbx = (kx + half) * binf, vby = (ky + half) * binf, vbz = (kz + half) * binf;
-        if (vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f || vbz >= 4.0f) continue;
+    /* phase B body: one accepted voxel */
+    auto accumulate = [&](unsigned packed) {
+        const int x = g.xs + (int)(packed & 1023u), y = g.ys + (int)((packed >> 10) & 1023u),
+                  z = g.zs + (int)(packed >> 20);
+        float sq, vbx, vby, vbz;
+        desc_window(g, x, y, z, &sq, &vbx, &vby, &vbz);
         const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
         float gx = 0.5f * (p[1] - p[-1]);
         float gy = 0.5f * (p[nx] - p[-nx]);
         float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
-        const float w = s3d_expf(-0.5f * sq / sig2);
+        const float w = __expf(-0.5f * sq / sig2);          /* window weight: 2 ulp is ample for 1e-4 */
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
-        gr.x = r00 * gx + r01 * gy + r02 * gz;
-        gr.y = r10 * gx + r11 * gy + r12 * gz;
-        gr.z = r20 * gx + r21 * gy + r22 * gz;
+        gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
+        gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
+        gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
         V3 bary;
-        const int face = s3d_icos_bin(mesh, gr, &bary);
-        if (face < 0) continue;
+        const int face = s3d_icos_bin_fast(mesh, gr, &bary);
+        if (face < 0) return;
         const float mag = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
         const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
         const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
         const float *m = mesh + face * MESH_STRIDE;
         const int i0 = __float_as_int(m[13]), i1 = __float_as_int(m[14]), i2 = __float_as_int(m[15]);
+        const float m0 = mag * bary.x, m1 = mag * bary.y, m2 = mag * bary.z;
+#pragma unroll
         for (int ix = 0; ix < 2; ix++)
+#pragma unroll
             for (int iy = 0; iy < 2; iy++)
+#pragma unroll
                 for (int iz = 0; iz < 2; iz++) {
                     const int cx = ibx + ix, cy = iby + iy, cz = ibz + iz;
                     if (cx >= 4 || cy >= 4 || cz >= 4) continue;      /* lower bounds hold: vb >= 0 */
                     const float wt = (ix == 0 ? 1.0f - dvx : dvx) * (iy == 0 ? 1.0f - dvy : dvy) *
                                      (iz == 0 ? 1.0f - dvz : dvz);
                     float *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
-                    const float mw = mag * wt;
-                    atomicAdd(hc + i0, mw * bary.x);
-                    atomicAdd(hc + i1, mw * bary.y);
-                    atomicAdd(hc + i2, mw * bary.z);
+                    if (variant & 4) { hc[i0] = m0 * wt; continue; }
+                    atomicAdd(hc + i0, m0 * wt);
+                    atomicAdd(hc + i1, m1 * wt);
+                    atomicAdd(hc + i2, m2 * wt);
                 }
+    };
+
+    unsigned head = 0;                                       /* uniform across the block */
+    for (int b0 = 0; b0 < nbox; b0 += DESC_CHUNK) {
+        /* ---- phase A: test 4 voxels per thread, enqueue the accepted ones ---- */
+#pragma unroll
+        for (int j = 0; j < DESC_CHUNK / DESC_THREADS; j++) {
+            const int b = b0 + j * DESC_THREADS + tid;
+            bool ok = false;
+            unsigned packed = 0;
+            if (b < nbox) {
+                int r, bx;
+                const int bz = fdiv_small(b, wx * wy, inv_wxy, &r);
+                const int by = fdiv_small(r, wx, inv_wx, &bx);
+                float sq, vbx, vby, vbz;
+                ok = desc_window(g, g.xs + bx, g.ys + by, g.zs + bz, &sq, &vbx, &vby, &vbz);
+                packed = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
+            }
+            const unsigned long long mask = __ballot(ok ? 1 : 0);
+            unsigned base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&qcount, (unsigned)__popcll(mask));
+            base = __shfl(base, 0);
+            if (ok) queue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = packed;
+        }
+        __syncthreads();
+        /* ---- phase B: drain full batches ---- */
+        const unsigned cnt = qcount;
+        while (cnt - head >= DESC_THREADS) {
+            if (!(variant & 8)) accumulate(queue[head + tid]);
+            head += DESC_THREADS;
+        }
+        /* carry the tail (< 256 entries) to the front of the queue */
+        const unsigned rem = cnt - head;
+        unsigned e = 0;
+        if ((unsigned)tid < rem) e = queue[head + tid];
+        __syncthreads();
+        if ((unsigned)tid < rem) queue[tid] = e;
+        if (tid == 0) qcount = rem;
+        head = 0;
+        __syncthreads();
+    }
+    {
+        const unsigned rem = qcount;
+        if ((unsigned)tid < rem) accumulate(queue[tid]);
     }
     __syncthreads();
     /* merge the wave-private histograms (fixed order), then normalise / clamp / normalise */
@@ -403,7 +515,7 @@ extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d
     if (num == 0) return S3D_OK;
     if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
     hipLaunchKernelGGL(k_describe, dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num, d_mesh,
-                       d_out, out_stride);
+                       d_out, out_stride, g_variant);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }

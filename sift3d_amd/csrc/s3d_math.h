@@ -25,35 +25,73 @@ __device__ __forceinline__ float s3d_expf(float x) { return (float)exp((double)x
 /* Face table entry layout (16 floats): e1[0..2] e2[3..5] t[6..8] q[9..11] e2q[12] idx[13..15] */
 #define MESH_STRIDE 16
 
-/* icos_hist_bin + cart2bary (sift.c:1646-1683, 335-394) on the precomputed face table: the first
- * face, in table order, with all barycentric coordinates >= -bary_eps and k >= 0.
- * The per-face constants e1, e2, t = -v0, q = t x e1 and e2.q do not depend on the input vector,
- * so hoisting them changes no rounding.  Returns the face index or -1. */
+/* One face of cart2bary (sift.c:335-394) + the acceptance test of icos_hist_bin (sift.c:1669-1671),
+ * on the precomputed face constants (e1, e2, t = -v0, q = t x e1 and e2.q do not depend on the input
+ * vector, so hoisting them changes no rounding).  Returns 1 if the reference would accept face i. */
+__device__ __forceinline__ int s3d_face_test(const float *__restrict__ mesh, int i, V3 g, V3 *bary)
+{
+    const float *m = mesh + i * MESH_STRIDE;
+    const V3 e1 = v3(m[0], m[1], m[2]);
+    const V3 e2 = v3(m[3], m[4], m[5]);
+    const V3 p = v3_cross(g, e2);
+    const float det = v3_dot(e1, p);
+    if ((double)fabsf(det) < S3D_BARY_EPS_D) return 0;
+    const float det_inv = 1.0f / det;
+    const V3 t = v3(m[6], m[7], m[8]);
+    const V3 q = v3(m[9], m[10], m[11]);
+    V3 b;
+    b.y = det_inv * v3_dot(t, p);
+    b.z = det_inv * v3_dot(g, q);
+    b.x = 1.0f - b.y - b.z;
+    const float k = m[12] * det_inv;
+    if ((double)b.x < -S3D_BARY_EPS_D || (double)b.y < -S3D_BARY_EPS_D || (double)b.z < -S3D_BARY_EPS_D || k < 0.0f)
+        return 0;
+    *bary = b;
+    return 1;
+}
+
+/* icos_hist_bin (sift.c:1646-1683): the first face, in table order, that accepts.  -1 if none /
+ * vector too short. */
 __device__ __forceinline__ int s3d_icos_bin(const float *__restrict__ mesh, V3 g, V3 *bary)
 {
     if ((double)v3_dot(g, g) < S3D_BARY_EPS_D) return -1;
-    for (int i = 0; i < S3D_NFACES; i++) {
-        const float *m = mesh + i * MESH_STRIDE;
-        const V3 e1 = v3(m[0], m[1], m[2]);
-        const V3 e2 = v3(m[3], m[4], m[5]);
-        const V3 p = v3_cross(g, e2);
-        const float det = v3_dot(e1, p);
-        if ((double)fabsf(det) < S3D_BARY_EPS_D) continue;
-        const float det_inv = 1.0f / det;
-        const V3 t = v3(m[6], m[7], m[8]);
-        const V3 q = v3(m[9], m[10], m[11]);
-        V3 b;
-        b.y = det_inv * v3_dot(t, p);
-        b.z = det_inv * v3_dot(g, q);
-        b.x = 1.0f - b.y - b.z;
-        const float k = m[12] * det_inv;
-        if ((double)b.x < -S3D_BARY_EPS_D || (double)b.y < -S3D_BARY_EPS_D || (double)b.z < -S3D_BARY_EPS_D ||
-            k < 0.0f)
-            continue;
-        *bary = b;
-        return i;
-    }
+    for (int i = 0; i < S3D_NFACES; i++)
+        if (s3d_face_test(mesh, i, g, bary)) return i;
     return -1;
+}
+
+/* Same result as s3d_icos_bin, ~10x cheaper and (nearly) divergence free.  The central projection of
+ * a face of the regular icosahedron is the spherical Voronoi cell of its centre, and by the sign
+ * symmetries only 4 centres compete inside an octant: the octant face (1,1,1)/sqrt3 and the three
+ * faces straddling a coordinate plane, (1,0,phi^2), (phi^2,1,0), (0,phi^2,1) normalised.  The winner
+ * is looked up in a 32-entry table (3 sign bits, 2 type bits) built on the host from the same mesh
+ * table, and then put through the reference's exact test.  If that test passes with every barycentric
+ * coordinate >= 1e-4 (50x the reference's acceptance slack plus f32 rounding), no other face can
+ * accept the vector, so "first accepting face in table order" is this face; otherwise (vector within
+ * ~1e-4 of an edge: 0.06 % of samples) the sequential search decides. */
+#define S3D_LUT_OFFSET (S3D_NFACES * MESH_STRIDE)
+__device__ __forceinline__ int s3d_icos_bin_fast(const float *__restrict__ mesh, V3 g, V3 *bary)
+{
+    if ((double)v3_dot(g, g) < S3D_BARY_EPS_D) return -1;
+    const float ax = fabsf(g.x), ay = fabsf(g.y), az = fabsf(g.z);
+    const float c0 = 0.57735027f, c1 = 0.35682209f, c2 = 0.93417236f;
+    const float s0 = c0 * (ax + ay + az);
+    const float s1 = c1 * ax + c2 * az;
+    const float s2 = c2 * ax + c1 * ay;
+    const float s3 = c2 * ay + c1 * az;
+    int t = 0;
+    float best = s0;
+    if (s1 > best) { best = s1; t = 1; }
+    if (s2 > best) { best = s2; t = 2; }
+    if (s3 > best) { best = s3; t = 3; }
+    const int key = (g.x < 0.0f ? 1 : 0) | (g.y < 0.0f ? 2 : 0) | (g.z < 0.0f ? 4 : 0) | (t << 3);
+    const int face = __float_as_int(mesh[S3D_LUT_OFFSET + key]);
+    V3 b;
+    if (s3d_face_test(mesh, face, g, &b) && b.x >= 1e-4f && b.y >= 1e-4f && b.z >= 1e-4f) {
+        *bary = b;
+        return face;
+    }
+    return s3d_icos_bin(mesh, g, bary);
 }
 
 /* Cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix in double, eigenvalues ascending,

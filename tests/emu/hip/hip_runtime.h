@@ -264,3 +264,4 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) 
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+#define __expf(x) expf(x)
