@@ -87,11 +87,11 @@ def gauss_roofline(dev, n, widths_sigmas, reps=5):
     return out
 
 
-def cpu_baseline(sample_n=160):
-    """Reference (or port) detect+describe on a bounded sample of the same generator, host cores."""
+def _cpu_baseline_worker(sample_n):
+    """Runs in a child process (see cpu_baseline): reference (or port) detect+describe on the host."""
     from oracle import oracle as orc
     vol = synth.blobs(sample_n, sample_n, sample_n, synth.default_nblobs(sample_n, sample_n, sample_n), 0)
-    cores = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     if orc.have_ref():
         ref = orc.load_ref()
         s = abi.SIFT3D()
@@ -117,12 +117,30 @@ def cpu_baseline(sample_n=160):
         dt = time.perf_counter() - t0
         k = len(xyzos)
         kind = "port"
-    return {"value": round(sample_n ** 3 / dt / 1e6, 4), "unit": "Mvox/s", "cores": cores, "kind": kind,
-            "sample": f"detect+describe on one {sample_n}^3 volume of the same generator ({k} keypoints, {dt:.1f} s, "
-                      f"OpenMP default threads)"}
+    print(json.dumps({"value": round(sample_n ** 3 / dt / 1e6, 4), "unit": "Mvox/s", "cores": threads, "kind": kind,
+                      "sample": f"detect+describe on one {sample_n}^3 volume of the same generator ({k} keypoints, "
+                                f"{dt:.1f} s, {threads} OpenMP threads)"}), flush=True)
+
+
+def cpu_baseline(sample_n=160):
+    """The CPU leg runs in a child process with a bounded OpenMP team: the reference calls LAPACK from
+    inside its OpenMP loops and the OpenBLAS bundled with scipy aborts beyond 128 caller threads (this
+    box has 256 hardware threads); OPENBLAS_NUM_THREADS=1 as in BASELINE.md."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 64)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(sample_n)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise RuntimeError(f"cpu baseline worker failed (rc {r.returncode}): {r.stderr[-300:]}")
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-baseline-worker":
+        _cpu_baseline_worker(int(sys.argv[2]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

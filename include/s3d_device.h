@@ -76,6 +76,8 @@ void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z);
 /* record HIP events (from s3d_rt_event_create) before k_gauss_xy, between, and after k_gauss_z of the
  * next fused applications; NULLs switch it off.  For bench.py's per-kernel timing. */
 void s3d_k_gauss_set_events(void *before_xy, void *between, void *after_z);
+/* profiling knob, see s3d_gauss.hip */
+void s3d_k_gauss_set_mode(int mode);
 int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz,
                        int nc, const float uf[3], const float *taps, int width, int path,
                        s3d_stream stream);

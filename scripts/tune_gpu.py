@@ -36,9 +36,12 @@ def gauss_sweep():
     for e in ev:
         dev.L.s3d_rt_event_create(C.byref(e))
     res = []
-    for sigma in (0.538701, 1.22627, 1.94659, 2.45255):
+    dev.L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    for sigma, mode in ((0.538701, 0), (0.538701, 1), (1.22627, 0), (1.94659, 0), (1.94659, 1), (2.45255, 0), (2.45255, 1)):
         taps = taps_of(sigma)
-        for cxy, cz in ((32, 32), (64, 64), (96, 96), (128, 128), (171, 103), (256, 171), (512, 256), (512, 512)):
+        dev.L.s3d_k_gauss_set_mode(mode)
+        print("z-kernel mode", mode)
+        for cxy, cz in ((43, 43), (64, 64), (86, 86), (103, 103), (128, 128), (171, 171), (256, 256)):
             dev.L.s3d_k_gauss_set_chunks(cxy, cz)
             txy = tz = 0.0
             reps = 4
@@ -56,6 +59,7 @@ def gauss_sweep():
             res.append((taps.size, cxy, cz, round(txy / reps, 4), round(tz / reps, 4)))
             print("gauss width %2d chunk_xy %3d chunk_z %3d : xy %.4f ms  z %.4f ms" % res[-1], flush=True)
     dev.L.s3d_k_gauss_set_chunks(128, 128)
+    dev.L.s3d_k_gauss_set_mode(0)
     out["gauss_sweep"] = res
     for p in (d_src, d_dst, d_tmp):
         dev.free(p)
@@ -84,7 +88,7 @@ def ablate():
         print("detect", name, res["detect_" + name], "ms  K =", kp.slab.num, flush=True)
     L.s3d_k_set_variant(0)
     L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
-    for name, v in (("normal", 0), ("describe_no_atomics", 4), ("describe_no_phaseB", 8)):
+    for name, v in (("normal16", 0), ("copies8", 128), ("describe_no_atomics", 4), ("describe_no_phaseB", 8), ("noqueue", 64)):
         L.s3d_k_set_variant(v)
         L.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
         dev.sync()

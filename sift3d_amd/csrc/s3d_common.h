@@ -36,4 +36,16 @@ struct S3dTaps {
     float t[S3D_MAX_TAPS];
 };
 
+/* LDS hand-off between the lanes of ONE wave, for kernels whose workgroup is a single wavefront.
+ * __syncthreads() carries a workgroup-scope fence that drains ALL outstanding memory operations
+ * (s_waitcnt vmcnt(0)): inside a streaming loop that serialises every prefetched global load behind
+ * the LDS exchange.  LDS instructions of one wave execute in program order, so a wavefront-scope
+ * fence (no wait at all) plus a scheduling barrier is sufficient. */
+__device__ __forceinline__ void s3d_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 static inline unsigned s3d_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -158,7 +158,7 @@ __device__ __forceinline__ float4 z_ext(const float *__restrict__ col, size_t zs
     return blend4(a, b, ef.f[j]);
 }
 
-template <int HW>
+template <int HW, bool SPLIT>
 __global__ void __launch_bounds__(256)
 k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int ny, int nz, int chunk, S3dTaps taps,
           EdgeFrac ef)
@@ -174,29 +174,51 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
     const int p1 = (p0 + chunk < nz) ? p0 + chunk : nz;
     const int T = (p1 - p0) + 2 * HW;                 /* pushes: coordinates p0-HW .. p1-1+HW */
 
+    /* two planes in flight per lane; steps t < Tfast are guard free (real plane, output due, prefetch in
+     * range) so the steady state is straight-line code */
     float4 ring[W];
-    float4 n0 = z_ext<HW>(col, zs, p0 - HW, nz, ef);
-    float4 n1 = z_ext<HW>(col, zs, p0 - HW + (1 < T ? 1 : 0), nz, ef);
-    for (int tb = 0; tb < T; tb += W) {
+    const int c0 = p0 - HW;
+    float4 n0 = z_ext<HW>(col, zs, c0, nz, ef);
+    float4 n1 = z_ext<HW>(col, zs, c0 + (1 < T ? 1 : 0), nz, ef);
+    auto slow_step = [&](int t, int u) {
+        ring[u] = n0;
+        n0 = n1;
+        if (t + 2 < T) n1 = z_ext<HW>(col, zs, c0 + t + 2, nz, ef);
+        if (t >= 2 * HW) {
+            const float4 acc = ring_dot<HW>(ring, u, taps);
+            *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * zs) = acc;
+        }
+    };
+    int Tfast = T - 2;
+    if (nz - 1 - c0 - 2 < Tfast) Tfast = nz - 1 - c0 - 2;   /* prefetched plane c0+t+2 must be <= nz-2 */
+    if (!SPLIT) Tfast = 0;                                   /* variant without the straight-line loop */
+#pragma unroll
+    for (int u = 0; u < W; u++)
+        if (u < T) slow_step(u, u);
+    int tb = W;
+    for (; tb + W <= Tfast; tb += W) {
 #pragma unroll
         for (int u = 0; u < W; u++) {
             const int t = tb + u;
-            if (t < T) {
-                ring[u] = n0;
-                n0 = n1;
-                if (t + 2 < T) n1 = z_ext<HW>(col, zs, p0 - HW + t + 2, nz, ef);    /* two planes in flight */
-                if (t >= 2 * HW) {
-                    const float4 acc = ring_dot<HW>(ring, u, taps);
-                    *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * zs) = acc;
-                }
-            }
+            int c = c0 + t + 2;
+            if (c < 0) c = -c;
+            ring[u] = n0;
+            n0 = n1;
+            n1 = *reinterpret_cast<const float4 *>(col + (size_t)c * zs);
+            const float4 acc = ring_dot<HW>(ring, u, taps);
+            *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * zs) = acc;
         }
+    }
+    for (; tb < T; tb += W) {
+#pragma unroll
+        for (int u = 0; u < W; u++)
+            if (tb + u < T) slow_step(tb + u, u);
     }
 }
 
 /* ---- fused X+Y pass ----------------------------------------------------------------------------- */
 template <int HW>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
 k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
            EdgeFrac efx, EdgeFrac efy)
 {
@@ -205,7 +227,7 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
     constexpr int OFF = PAD + HW;                     /* line[OFF + i] = E_x[x0 + i] ; OFF % 4 == 0 */
     constexpr int NR = (PAD + 4 + 2 * HW + 3) / 4;    /* float4 LDS reads per lane */
     constexpr int LINE = XY_STRIP + 4 * NR;           /* >= PAD + XY_STRIP + 2 HW, multiple of 4 */
-    __shared__ __attribute__((aligned(16))) float line2[2][LINE];   /* double buffered: one barrier per row */
+    __shared__ __attribute__((aligned(16))) float line2[2][LINE];   /* double buffered */
 
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * XY_STRIP;
@@ -215,14 +237,16 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
     float *dp = dst + (size_t)blockIdx.z * plane;
     const int p0 = blockIdx.y * chunk;
     const int p1 = (p0 + chunk < ny) ? p0 + chunk : ny;
-    const int T = (p1 - p0) + 2 * HW;
+    const int T = (p1 - p0) + 2 * HW;                 /* pushes: E_y coordinates p0-HW .. p1-1+HW */
+    const int c0 = p0 - HW;
 
     /* ---- per-lane constants of the line staging --------------------------------------------------
-     * body: line[OFF + 4*lane + i] = E_x[xq + i]  for xq+i <= nx-2 (plain samples)
-     * edge roles (lanes 0 .. 3HW, one LDS slot each):
+     * body (all lanes, one ds_write_b128): line[OFF + 4*lane + i] = src[xq + i]
+     * then "edge" lanes 0 .. 3HW overwrite / add one slot each (in-order LDS makes "then" exact):
      *   lanes [0,HW)        left halo   slot = PAD+lane          coordinate x0-HW+lane
      *   lanes [HW,2HW)      right halo  slot = PAD+XY_STRIP+lane coordinate x0+XY_STRIP+lane-HW
-     *   lanes [2HW,3HW]     high-edge blends that fall inside the body, j = lane-2HW, c = nx-1+j */
+     *   lanes [2HW,3HW]     high-edge blends E_x[nx-1+j] that fall inside the body, j = lane-2HW
+     * E_x[c] = src[-c] (c<0), src[c] (c<=nx-2), (1-f_j) src[nx-2-j] + f_j src[nx-1-j] (c = nx-1+j). */
     int slot = -1, colA = 0, colB = 0, isblend = 0;
     float fj = 0.0f;
     {
@@ -241,30 +265,21 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
                 if (j <= HW) { isblend = 1; colA = nx - 2 - j; colB = nx - 1 - j; fj = efx.f[j]; }
                 else slot = -1;                        /* beyond anything a valid output reads */
             }
-            /* right-halo plain samples at c in body range of the NEXT strip are fine; but a right-halo
-             * lane whose coordinate is >= nx-1 was turned into a blend above */
         }
     }
-    const bool body_vec = (xq + 3 <= nx - 2);         /* all 4 plain: one float4 load + ds_write_b128 */
-    const bool out_vec = (xq + 3 <= nx - 1);
+    const bool live = xq < nx;                        /* nx % 4 == 0: a lane is all-in or all-out */
+    const int xq_ld = live ? xq : nx - 4;             /* clamped, aligned, always readable */
 
-    /* raw loads of one source row (prefetched one row ahead) */
+    /* Raw loads of one source row, issued three rows ahead.  They are UNCONDITIONAL on purpose: a load
+     * under a divergent `if` makes the compiler wait for it at the join (its destination registers
+     * merge with the other path), which turns every prefetch into a synchronous load. */
     struct Raw { float4 b; float a0, a1; };
     auto load_row = [&](int y) -> Raw {
         Raw r;
         const float *row = sp + (size_t)y * nx;
-        r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (body_vec) r.b = *reinterpret_cast<const float4 *>(row + xq);
-        else {
-            if (xq + 0 <= nx - 2) r.b.x = row[xq + 0];
-            if (xq + 1 <= nx - 2) r.b.y = row[xq + 1];
-            if (xq + 2 <= nx - 2) r.b.z = row[xq + 2];
-        }
-        r.a0 = 0.0f; r.a1 = 0.0f;
-        if (slot >= 0) {
-            r.a0 = row[colA];
-            if (isblend) r.a1 = row[colB];
-        }
+        r.b = *reinterpret_cast<const float4 *>(row + xq_ld);
+        r.a0 = row[colA];
+        r.a1 = row[colB];
         return r;
     };
     /* stage the row in LDS, X-filter this lane's 4 columns */
@@ -272,14 +287,10 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
     auto xpass = [&](const Raw &r) -> float4 {
         float *line = line2[lbuf];
         lbuf ^= 1;
-        if (body_vec) *reinterpret_cast<float4 *>(&line[OFF + 4 * lane]) = r.b;
-        else {
-            if (xq + 0 <= nx - 2) line[OFF + 4 * lane + 0] = r.b.x;
-            if (xq + 1 <= nx - 2) line[OFF + 4 * lane + 1] = r.b.y;
-            if (xq + 2 <= nx - 2) line[OFF + 4 * lane + 2] = r.b.z;
-        }
+        *reinterpret_cast<float4 *>(&line[OFF + 4 * lane]) = r.b;
+        s3d_wave_lds_sync();                           /* body before edge slots */
         if (slot >= 0) line[slot] = isblend ? ((1.0f - fj) * r.a0 + fj * r.a1) : r.a0;
-        __syncthreads();
+        s3d_wave_lds_sync();
         float v[4 * NR];
 #pragma unroll
         for (int q = 0; q < NR; q++) {
@@ -298,53 +309,71 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
         }
         return acc;
     };
-    /* source row(s) behind E_y[c]:  mirrored / plain -> one row; c >= ny-1 -> blend of two rows */
+    /* source row behind E_y[c]:  mirrored / plain -> that row; c = ny-1+j -> the LOWER of its two rows */
     auto first_row = [&](int c) -> int {
         if (c < 0) c = -c;
         return c <= ny - 2 ? c : (ny - 2 - (c - (ny - 1)));
     };
 
     /* HBM latency is hidden by keeping three source rows in flight per wave (each wave is a serial
-     * chain of ~chunk rows; with one row of lookahead the kernel ran at memory LATENCY, not bandwidth) */
+     * chain of ~chunk rows; with no lookahead the kernel runs at memory LATENCY, not bandwidth). */
+    constexpr int DEPTH = HW >= 7 ? 2 : 3;              /* rows in flight; bounded by the VGPR budget */
     float4 ring[W];
-    const int c0 = p0 - HW;
-    Raw q0 = load_row(first_row(c0));
-    Raw q1 = load_row(first_row(c0 + (1 < T ? 1 : 0)));
-    Raw q2 = load_row(first_row(c0 + (2 < T ? 2 : 0)));
-    for (int tb = 0; tb < T; tb += W) {
+    Raw q[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) q[d] = load_row(first_row(c0 + (d < T ? d : 0)));
+
+    /* one march step with every special case (chunk ends, virtual high-side rows) */
+    auto slow_step = [&](int t, int u) {
+        int c = c0 + t;
+        const Raw cur = q[0];
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; d++) q[d] = q[d + 1];
+        if (t + DEPTH < T) q[DEPTH - 1] = load_row(first_row(c0 + t + DEPTH));
+        if (c < 0) c = -c;
+        float4 e;
+        if (c <= ny - 2) {
+            e = xpass(cur);
+        } else {                                          /* high-side virtual row: two X-filtered rows */
+            const int j = c - (ny - 1);
+            const Raw rb = load_row(ny - 1 - j);
+            const float4 ea = xpass(cur);                 /* row ny-2-j */
+            const float4 eb = xpass(rb);                  /* row ny-1-j */
+            e = blend4(ea, eb, efy.f[j]);
+        }
+        ring[u] = e;
+        if (t >= 2 * HW) {
+            const float4 acc = ring_dot<HW>(ring, u, taps);
+            if (live) *reinterpret_cast<float4 *>(dp + (size_t)(p0 + t - 2 * HW) * nx + xq) = acc;
+        }
+    };
+
+    /* steps t < Tfast need no guard: the row is real, an output is due and the prefetch is in range */
+    int Tfast = T - DEPTH;
+    if (ny - 1 - c0 < Tfast) Tfast = ny - 1 - c0;
+
+    int tb = 0;
+#pragma unroll
+    for (int u = 0; u < W; u++)                           /* group 0: ring fill + first output */
+        if (u < T) slow_step(u, u);
+    tb = W;
+    for (; tb + W <= Tfast; tb += W) {                    /* steady state, branch free */
 #pragma unroll
         for (int u = 0; u < W; u++) {
             const int t = tb + u;
-            if (t < T) {
-                int c = c0 + t;
-                const Raw cur = q0;
-                q0 = q1;
-                q1 = q2;
-                if (t + 3 < T) q2 = load_row(first_row(c0 + t + 3));               /* prefetch */
-                if (c < 0) c = -c;
-                float4 e;
-                if (c <= ny - 2) {
-                    e = xpass(cur);
-                } else {                                  /* high-side virtual row: two X-filtered rows */
-                    const int j = c - (ny - 1);
-                    const Raw rb = load_row(ny - 1 - j);
-                    const float4 ea = xpass(cur);         /* row ny-2-j */
-                    const float4 eb = xpass(rb);          /* row ny-1-j */
-                    e = blend4(ea, eb, efy.f[j]);
-                }
-                ring[u] = e;
-                if (t >= 2 * HW) {
-                    const float4 acc = ring_dot<HW>(ring, u, taps);
-                    float *o = dp + (size_t)(p0 + t - 2 * HW) * nx + xq;
-                    if (out_vec) *reinterpret_cast<float4 *>(o) = acc;
-                    else {
-                        if (xq + 0 <= nx - 1) o[0] = acc.x;
-                        if (xq + 1 <= nx - 1) o[1] = acc.y;
-                        if (xq + 2 <= nx - 1) o[2] = acc.z;
-                    }
-                }
-            }
+            const Raw cur = q[0];
+#pragma unroll
+            for (int d = 0; d + 1 < DEPTH; d++) q[d] = q[d + 1];
+            q[DEPTH - 1] = load_row(first_row(c0 + t + DEPTH));
+            ring[u] = xpass(cur);
+            const float4 acc = ring_dot<HW>(ring, u, taps);
+            if (live) *reinterpret_cast<float4 *>(dp + (size_t)(p0 + t - 2 * HW) * nx + xq) = acc;
         }
+    }
+    for (; tb < T; tb += W) {                             /* tail groups */
+#pragma unroll
+        for (int u = 0; u < W; u++)
+            if (tb + u < T) slow_step(tb + u, u);
     }
 }
 
@@ -374,7 +403,10 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
     return 1;
 }
 
-static int g_chunk_xy = 128, g_chunk_z = 128;
+static int g_chunk_xy = 128, g_chunk_z = 128, g_gauss_mode = 0;
+
+/* profiling knob: bit 0 = Z kernel without the guard-free steady-state loop (fewer VGPRs) */
+extern "C" void s3d_k_gauss_set_mode(int mode) { g_gauss_mode = mode; }
 
 /* tuning knobs for profiling runs (rows / planes per marching chunk) */
 extern "C" void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z)
@@ -404,8 +436,12 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
                        nx, ny, cy, t, ex, ey);
     S3D_CHECK_LAUNCH();
     if (g_ev[1]) S3D_HIP(hipEventRecord(g_ev[1], st));
-    hipLaunchKernelGGL((k_gauss_z<HW>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st, d_tmp,
-                       d_dst, nx / 4, ny, nz, cz, t, ez);
+    if (g_gauss_mode & 1)
+        hipLaunchKernelGGL((k_gauss_z<HW, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
+                           d_tmp, d_dst, nx / 4, ny, nz, cz, t, ez);
+    else
+        hipLaunchKernelGGL((k_gauss_z<HW, true>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
+                           d_tmp, d_dst, nx / 4, ny, nz, cz, t, ez);
     S3D_CHECK_LAUNCH();
     if (g_ev[2]) S3D_HIP(hipEventRecord(g_ev[2], st));
     return S3D_OK;

@@ -78,7 +78,10 @@ extern "C" void s3d_mesh_table(float *out)
 /* Ablation knob for profiling runs ONLY (results are wrong for any value but 0):
  *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
  *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
- *   bit 3: k_describe skips phase B entirely (window tests + queue only) */
+ *   bit 3: k_describe skips phase B entirely (window tests + queue only)
+ * Debug bisection (results stay correct): bit 4: sequential face search; bit 5: f64 exp;
+ *   bit 6: no queue (accepted voxels are accumulated straight from the window test)
+ *   bit 7: 8 histogram copies per block instead of 16 */
 static int g_variant = 0;
 extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
 
@@ -103,7 +106,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
          const float *__restrict__ d_center, uint32_t num, const double *__restrict__ d_sigma, double corner_thresh,
          float *__restrict__ d_R, uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, int variant)
 {
-    __shared__ float term[3][64];
+    __shared__ __attribute__((aligned(16))) float term[3][64];
     __shared__ float gw_s[3];
     const unsigned cand = blockIdx.x;
     const int lane = threadIdx.x;
@@ -170,11 +173,19 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
             }
         }
         term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
-        __syncthreads();
+        s3d_wave_lds_sync();
         if (lane < 3 && !(variant & 1)) {
-            for (int i = 0; i < 64; i++) gsum = gsum + term[lane][i];   /* reference scan order */
+            /* reference scan order.  The 64 staged terms are first pulled into registers with 16
+             * independent ds_read_b128, so the dependent chain is 64 adds, not 64 LDS round trips. */
+            float4 q[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(&term[lane][4 * i]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                gsum = gsum + q[i].x; gsum = gsum + q[i].y; gsum = gsum + q[i].z; gsum = gsum + q[i].w;
+            }
         }
-        __syncthreads();
+        s3d_wave_lds_sync();
     }
     /* wave reduction of the f64 tensor */
     for (int m = 32; m >= 1; m >>= 1) {
@@ -182,7 +193,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
     }
     if (lane < 3) gw_s[lane] = gsum;
-    __syncthreads();
+    s3d_wave_lds_sync();
     if (lane != 0) return;
 
     const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
@@ -353,21 +364,29 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  *      (~1/3) are appended, via wave ballots, to an LDS queue of packed voxel offsets;
  *   B  while the queue holds >= 256 entries, all 256 lanes each take one accepted voxel: gradient,
  *      Gaussian weight, rotation, icosahedron face + barycentric weights, trilinear spread over 8 cells
- *      x 3 vertices into the wave-private LDS histogram with ds_add_f32.
- * The tail of the queue is carried into the next round, so lanes idle only once, at the very end. */
+ *      x 3 vertices into LDS histograms with ds_add_f32.
+ * The tail of the queue is carried into the next round, so lanes idle only once, at the very end.
+ *
+ * LDS atomics were 88 % of this kernel with one histogram per wave: x-neighbouring voxels fall into
+ * the same cell and -- the field being smooth -- onto the same icosahedron face, so the 64 lanes of a
+ * ds_add_f32 hit a handful of addresses and serialise.  The block therefore keeps NCOPY histograms,
+ * lane l adding into copy l % NCOPY, with a row stride of 769 floats so that equal bins of different
+ * copies sit in different banks: same-address collisions drop from 64-way to (64/NCOPY)-way. */
+template <int NCOPY>
 __global__ void __launch_bounds__(DESC_THREADS)
 k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num,
            const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride, int variant)
 {
-    __shared__ float hist[DESC_WAVES][S3D_DESC_NUMEL];
+    constexpr int HSTRIDE = S3D_DESC_NUMEL + 1;
+    __shared__ float hist[NCOPY * HSTRIDE];
     __shared__ float mesh[S3D_MESH_FLOATS];
     __shared__ unsigned queue[DESC_QUEUE];
     __shared__ unsigned qcount;
     const unsigned kid = blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     if (kid >= num) return;
     const s3d_desc_key key = keys[kid];
-    for (int i = tid; i < DESC_WAVES * S3D_DESC_NUMEL; i += DESC_THREADS) (&hist[0][0])[i] = 0.0f;
+    for (int i = tid; i < NCOPY * HSTRIDE; i += DESC_THREADS) hist[i] = 0.0f;
     for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
     if (tid == 0) qcount = 0;
     __syncthreads();
@@ -393,7 +412,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
     const int nbox = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wx * wy * wz : 0;
     const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
-    float *h = hist[wave];
+    float *h = hist + (lane & (NCOPY - 1)) * HSTRIDE;
 
     /* phase B body: one accepted voxel */
     auto accumulate = [&](unsigned packed) {
@@ -406,14 +425,15 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         float gy = 0.5f * (p[nx] - p[-nx]);
         float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
-        const float w = __expf(-0.5f * sq / sig2);          /* window weight: 2 ulp is ample for 1e-4 */
+        const float wa = -0.5f * sq / sig2;
+        const float w = (variant & 32) ? s3d_expf(wa) : __expf(wa);   /* window weight: 2 ulp is ample for 1e-4 */
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
         gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
         gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
         gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
         V3 bary;
-        const int face = s3d_icos_bin_fast(mesh, gr, &bary);
+        const int face = (variant & 16) ? s3d_icos_bin(mesh, gr, &bary) : s3d_icos_bin_fast(mesh, gr, &bary);
         if (face < 0) return;
         const float mag = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
         const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
@@ -454,6 +474,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
                 float sq, vbx, vby, vbz;
                 ok = desc_window(g, g.xs + bx, g.ys + by, g.zs + bz, &sq, &vbx, &vby, &vbz);
                 packed = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
+                if ((variant & 64) && ok) { accumulate(packed); ok = false; }
             }
             const unsigned long long mask = __ballot(ok ? 1 : 0);
             unsigned base = 0;
@@ -483,13 +504,13 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         if ((unsigned)tid < rem) accumulate(queue[tid]);
     }
     __syncthreads();
-    /* merge the wave-private histograms (fixed order), then normalise / clamp / normalise */
+    /* merge the histogram copies (fixed order), then normalise / clamp / normalise */
     float v[S3D_DESC_NUMEL / DESC_THREADS];
     double ss = 0.0;
     for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
         const int i = tid + j * DESC_THREADS;
-        float a = hist[0][i];
-        for (int w = 1; w < DESC_WAVES; w++) a = a + hist[w][i];
+        float a = hist[i];
+        for (int w = 1; w < NCOPY; w++) a = a + hist[w * HSTRIDE + i];
         v[j] = a;
         ss += (double)a * (double)a;
     }
@@ -514,8 +535,12 @@ extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d
 {
     if (num == 0) return S3D_OK;
     if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
-    hipLaunchKernelGGL(k_describe, dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num, d_mesh,
-                       d_out, out_stride, g_variant);
+    if (g_variant & 128)
+        hipLaunchKernelGGL((k_describe<8>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
+                           d_mesh, d_out, out_stride, g_variant);
+    else
+        hipLaunchKernelGGL((k_describe<16>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
+                           d_mesh, d_out, out_stride, g_variant);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
