@@ -14,6 +14,7 @@ L = lib.sift; L.s3d_k_set_variant.argtypes = [C.c_int]
 vol = synth.blobs(64, 64, 64, 250, 0)
 s, im, kp = parity.run_detect(lib, vol, (1, 1, 1))
 xyzos, sd, R = lib.keypoints_to_numpy(kp)
+O.detect(vol)
 wb, wx = O.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
 for name, v in (("default", 0), ("seq_face", 16), ("f64_exp", 32), ("no_queue", 64), ("seq_face+f64exp", 48), ("all", 112)):
     L.s3d_k_set_variant(v)
@@ -26,6 +27,7 @@ for name, v in (("default", 0), ("seq_face", 16), ("f64_exp", 32), ("no_queue", 
               f"{(np.abs(bins - wb) / np.maximum(np.abs(wb), 1e-3)).max():.3e}", flush=True)
         if bad.any() and rep == 0:
             ks = np.unique(np.nonzero(bad)[0])
+            print("   keypoints with bad bins:", ks, "per-kp max abs", [float(np.abs(bins[k]-wb[k]).max()) for k in ks])
             for k in ks[:3]:
                 idx = np.nonzero(bad[k])[0]
                 print("   kp", k, xyzos[k], "bins", idx[:12], "got", bins[k, idx[:6]], "want", wb[k, idx[:6]])

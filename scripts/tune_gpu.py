@@ -58,7 +58,7 @@ def gauss_sweep():
                     tz += ms.value
             res.append((taps.size, cxy, cz, round(txy / reps, 4), round(tz / reps, 4)))
             print("gauss width %2d chunk_xy %3d chunk_z %3d : xy %.4f ms  z %.4f ms" % res[-1], flush=True)
-    dev.L.s3d_k_gauss_set_chunks(128, 128)
+    dev.L.s3d_k_gauss_set_chunks(176, 176)
     dev.L.s3d_k_gauss_set_mode(0)
     out["gauss_sweep"] = res
     for p in (d_src, d_dst, d_tmp):
@@ -88,7 +88,7 @@ def ablate():
         print("detect", name, res["detect_" + name], "ms  K =", kp.slab.num, flush=True)
     L.s3d_k_set_variant(0)
     L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
-    for name, v in (("normal16", 0), ("copies8", 128), ("describe_no_atomics", 4), ("describe_no_phaseB", 8), ("noqueue", 64)):
+    for name, v in (("normal4", 0), ("copies2", 128), ("copies8", 256), ("describe_no_atomics", 4), ("describe_no_phaseB", 8)):
         L.s3d_k_set_variant(v)
         L.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
         dev.sync()

@@ -403,9 +403,9 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
     return 1;
 }
 
-static int g_chunk_xy = 128, g_chunk_z = 128, g_gauss_mode = 0;
+static int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk() */
 
-/* profiling knob: bit 0 = Z kernel without the guard-free steady-state loop (fewer VGPRs) */
+/* profiling knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower) */
 extern "C" void s3d_k_gauss_set_mode(int mode) { g_gauss_mode = mode; }
 
 /* tuning knobs for profiling runs (rows / planes per marching chunk) */
@@ -428,7 +428,9 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
 {
     EdgeFrac ex, ey, ez;
     if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
-    const int cy = g_chunk_xy, cz = g_chunk_z;
+    /* split the marching axis into equal chunks of about the target length (512 -> 3 x 171) */
+    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
+    const int cz = (nz + (int)s3d_div_up(nz, g_chunk_z) - 1) / (int)s3d_div_up(nz, g_chunk_z);
     const unsigned ncy = s3d_div_up(ny, cy), ncz = s3d_div_up(nz, cz);
     if (ncy > 65535 || (unsigned)nz > 65535u) S3D_FAIL("volume too large for the fast-path grid");
     if (g_ev[0]) S3D_HIP(hipEventRecord(g_ev[0], st));
@@ -436,7 +438,7 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
                        nx, ny, cy, t, ex, ey);
     S3D_CHECK_LAUNCH();
     if (g_ev[1]) S3D_HIP(hipEventRecord(g_ev[1], st));
-    if (g_gauss_mode & 1)
+    if (!(g_gauss_mode & 1))
         hipLaunchKernelGGL((k_gauss_z<HW, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
                            d_tmp, d_dst, nx / 4, ny, nz, cz, t, ez);
     else

@@ -81,7 +81,7 @@ extern "C" void s3d_mesh_table(float *out)
  *   bit 3: k_describe skips phase B entirely (window tests + queue only)
  * Debug bisection (results stay correct): bit 4: sequential face search; bit 5: f64 exp;
  *   bit 6: no queue (accepted voxels are accumulated straight from the window test)
- *   bit 7: 8 histogram copies per block instead of 16 */
+ *   bit 7 / bit 8: 2 / 8 histogram copies per block instead of 4 */
 static int g_variant = 0;
 extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
 
@@ -367,18 +367,23 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  *      x 3 vertices into LDS histograms with ds_add_f32.
  * The tail of the queue is carried into the next round, so lanes idle only once, at the very end.
  *
- * LDS atomics were 88 % of this kernel with one histogram per wave: x-neighbouring voxels fall into
- * the same cell and -- the field being smooth -- onto the same icosahedron face, so the 64 lanes of a
- * ds_add_f32 hit a handful of addresses and serialise.  The block therefore keeps NCOPY histograms,
- * lane l adding into copy l % NCOPY, with a row stride of 769 floats so that equal bins of different
- * copies sit in different banks: same-address collisions drop from 64-way to (64/NCOPY)-way. */
+ * Histogram arithmetic.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on gfx950 whatever the address
+ * pattern (measured, scripts/ubench_lds.hip) -- it was 88 % of this kernel -- while the integer LDS
+ * atomics run 9-20x faster.  Bins are therefore accumulated in 64-bit fixed point (scale 2^40:
+ * range +-8.4e6, resolution 9e-13; a contribution c*2^40 converts exactly unless c < 7.6e-6) with
+ * ds_add_u64 and converted to f32 once at the end.  Integer addition is associative, so -- unlike the
+ * f32 atomics -- the result is bitwise reproducible from run to run, and it is closer to the exact sum
+ * than the reference's sequential f32 accumulation (difference to the reference ~1e-6 relative).
+ * The block keeps NCOPY histograms (lane l adds into copy l % NCOPY, row stride 769) to thin out the
+ * same-address collisions of x-neighbouring voxels, which share cell and icosahedron face. */
 template <int NCOPY>
 __global__ void __launch_bounds__(DESC_THREADS)
 k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num,
            const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride, int variant)
 {
     constexpr int HSTRIDE = S3D_DESC_NUMEL + 1;
-    __shared__ float hist[NCOPY * HSTRIDE];
+    constexpr float FIX_SCALE = 1099511627776.0f;          /* 2^40 */
+    __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ float mesh[S3D_MESH_FLOATS];
     __shared__ unsigned queue[DESC_QUEUE];
     __shared__ unsigned qcount;
@@ -386,7 +391,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const int tid = threadIdx.x, lane = tid & 63;
     if (kid >= num) return;
     const s3d_desc_key key = keys[kid];
-    for (int i = tid; i < NCOPY * HSTRIDE; i += DESC_THREADS) hist[i] = 0.0f;
+    for (int i = tid; i < NCOPY * HSTRIDE; i += DESC_THREADS) hist[i] = 0ull;
     for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
     if (tid == 0) qcount = 0;
     __syncthreads();
@@ -412,7 +417,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
     const int nbox = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wx * wy * wz : 0;
     const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
-    float *h = hist + (lane & (NCOPY - 1)) * HSTRIDE;
+    unsigned long long *h = hist + (lane & (NCOPY - 1)) * HSTRIDE;
 
     /* phase B body: one accepted voxel */
     auto accumulate = [&](unsigned packed) {
@@ -425,8 +430,10 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         float gy = 0.5f * (p[nx] - p[-nx]);
         float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
+        /* window weight.  expf (<= 1 ulp), not the v_exp_f32 shortcut __expf: the latter pushed one
+         * keypoint of the 64^3 golden case to 1e-2 relative error on the GPU (debug run, round 1). */
         const float wa = -0.5f * sq / sig2;
-        const float w = (variant & 32) ? s3d_expf(wa) : __expf(wa);   /* window weight: 2 ulp is ample for 1e-4 */
+        const float w = (variant & 32) ? s3d_expf(wa) : expf(wa);
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
         gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
@@ -451,11 +458,14 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
                     if (cx >= 4 || cy >= 4 || cz >= 4) continue;      /* lower bounds hold: vb >= 0 */
                     const float wt = (ix == 0 ? 1.0f - dvx : dvx) * (iy == 0 ? 1.0f - dvy : dvy) *
                                      (iz == 0 ? 1.0f - dvz : dvz);
-                    float *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
-                    if (variant & 4) { hc[i0] = m0 * wt; continue; }
-                    atomicAdd(hc + i0, m0 * wt);
-                    atomicAdd(hc + i1, m1 * wt);
-                    atomicAdd(hc + i2, m2 * wt);
+                    unsigned long long *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
+                    const unsigned long long a0 = (unsigned long long)(long long)(m0 * wt * FIX_SCALE);
+                    const unsigned long long a1 = (unsigned long long)(long long)(m1 * wt * FIX_SCALE);
+                    const unsigned long long a2 = (unsigned long long)(long long)(m2 * wt * FIX_SCALE);
+                    if (variant & 4) { hc[i0] = a0; continue; }
+                    atomicAdd(hc + i0, a0);
+                    atomicAdd(hc + i1, a1);
+                    atomicAdd(hc + i2, a2);
                 }
     };
 
@@ -509,8 +519,9 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     double ss = 0.0;
     for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
         const int i = tid + j * DESC_THREADS;
-        float a = hist[i];
-        for (int w = 1; w < NCOPY; w++) a = a + hist[w * HSTRIDE + i];
+        unsigned long long acc64 = hist[i];
+        for (int w = 1; w < NCOPY; w++) acc64 += hist[w * HSTRIDE + i];
+        const float a = (float)((double)(long long)acc64 * (1.0 / (double)FIX_SCALE));
         v[j] = a;
         ss += (double)a * (double)a;
     }
@@ -536,10 +547,13 @@ extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d
     if (num == 0) return S3D_OK;
     if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
     if (g_variant & 128)
+        hipLaunchKernelGGL((k_describe<2>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
+                           d_mesh, d_out, out_stride, g_variant);
+    else if (g_variant & 256)
         hipLaunchKernelGGL((k_describe<8>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
                            d_mesh, d_out, out_stride, g_variant);
     else
-        hipLaunchKernelGGL((k_describe<16>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
+        hipLaunchKernelGGL((k_describe<4>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
                            d_mesh, d_out, out_stride, g_variant);
     S3D_CHECK_LAUNCH();
     return S3D_OK;

@@ -69,7 +69,7 @@ def check_sep_fir_paths(lib, oracle, dims, sigma, seed=0, chunks=None):
             nd = nbitdiff(got, want)
             assert nd == 0, f"path {path}: {nd} of {got.size} differ (dims={dims}, sigma={sigma}, chunks={chunks})"
     finally:
-        dev.L.s3d_k_gauss_set_chunks(128, 128)
+        dev.L.s3d_k_gauss_set_chunks(176, 176)
         for p in (d_src, d_dst, d_tmp):
             dev.free(p)
 
