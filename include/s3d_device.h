@@ -119,10 +119,10 @@ int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint3
                  const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
                  float *d_R, uint32_t *d_keep, double *d_conf, s3d_stream stream);
 /* Stable compaction of kept candidates: for i with keep[i], writes x,y,z,o,s (int32 x5) and R.
- * *d_num_out receives the number kept. */
+ * *d_num_out receives the number kept.  d_scratch: >= num/256 + 2 uint32. */
 int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                        const float *d_R, const uint32_t *d_keep, uint32_t num, int32_t *d_xyzos,
-                       float *d_R_out, uint32_t *d_num_out, s3d_stream stream);
+                       float *d_R_out, uint32_t *d_num_out, uint32_t *d_scratch, s3d_stream stream);
 
 /* One record per keypoint for the descriptor kernel; the scalar set-up mirrors
  * extract_descrip (sift.c:1845-1851) and is done on the host in the same float arithmetic. */

@@ -88,7 +88,7 @@ def ablate():
         print("detect", name, res["detect_" + name], "ms  K =", kp.slab.num, flush=True)
     L.s3d_k_set_variant(0)
     L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
-    for name, v in (("normal4", 0), ("copies2", 128), ("copies8", 256), ("describe_no_atomics", 4), ("describe_no_phaseB", 8)):
+    for name, v in (("normal4", 0), ("copies2", 128), ("describe_no_atomics", 4), ("describe_no_phaseB", 8)):
         L.s3d_k_set_variant(v)
         L.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
         dev.sync()

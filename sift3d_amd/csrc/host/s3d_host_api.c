@@ -350,7 +350,7 @@ static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
     }
     maxwords = (n0 + 63) / 64;
     DEV(s3d_rt_malloc((void **)&c->d_bits, maxwords * sizeof(unsigned long long)));
-    DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 1024 + 2) * sizeof(uint32_t)));
+    DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 256 + 4096) * sizeof(uint32_t)));   /* bitmap + keypoint block counters */
     DEV(s3d_rt_malloc((void **)&c->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS));
     c->nx = l0->nx; c->ny = l0->ny; c->nz = l0->nz;
     c->num_octaves = g->num_octaves;
@@ -519,7 +519,7 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         DEV(s3d_k_orient(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
                          c->d_R, c->d_keep, NULL, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
-                               c->d_Rk, c->d_count + 1, c->stream));
+                               c->d_Rk, c->d_count + 1, c->d_scratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));
         DEV(s3d_rt_sync(c->stream));                      /* also orders the reads of `sig` */
     }

@@ -79,8 +79,7 @@ extern "C" void s3d_mesh_table(float *out)
  *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
  *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
  *   bit 3: k_describe skips phase B entirely (window tests + queue only)
- * Debug bisection (results stay correct): bit 4: sequential face search; bit 5: f64 exp;
- *   bit 6: no queue (accepted voxels are accumulated straight from the window test)
+ *   (bits 4-6 were debug bisection switches, removed)
  *   bit 7 / bit 8: 2 / 8 histogram copies per block instead of 4 */
 static int g_variant = 0;
 extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
@@ -249,50 +248,87 @@ extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, 
 }
 
 /* ---- stable compaction of the surviving candidates ----------------------------------------------- */
-__global__ void __launch_bounds__(256)
-k_compact_keys(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
-               const float *__restrict__ d_R, const uint32_t *__restrict__ d_keep, uint32_t num,
-               int32_t *__restrict__ xyzos, float *__restrict__ R_out, uint32_t *num_out)
+/* count -> scan -> emit over blocks of 256 candidates (order preserving, no atomics on the data path) */
+__device__ __forceinline__ unsigned ck_block_scan(unsigned v, unsigned *total)
 {
     __shared__ unsigned s[256];
+    const unsigned t = threadIdx.x;
+    s[t] = v;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {
+        const unsigned a = t >= off ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    const unsigned r = s[t];
+    *total = s[255];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_ck_count(const uint32_t *__restrict__ d_keep, uint32_t num, unsigned *__restrict__ block_count)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    unsigned total;
+    ck_block_scan((i < num && d_keep[i]) ? 1u : 0u, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_ck_scan(unsigned *__restrict__ block_count, unsigned nblocks, uint32_t *num_out)
+{
     unsigned carry = 0;
-    for (uint32_t i0 = 0; i0 < num; i0 += 256) {
-        const uint32_t i = i0 + threadIdx.x;
-        const unsigned kp = (i < num && d_keep[i]) ? 1u : 0u;
-        s[threadIdx.x] = kp;
-        __syncthreads();
-        for (unsigned off = 1; off < 256; off <<= 1) {
-            const unsigned a = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s[threadIdx.x] += a;
-            __syncthreads();
-        }
-        const unsigned incl = s[threadIdx.x], total = s[255];
-        __syncthreads();
-        if (kp) {
-            const unsigned pos = carry + incl - 1;
-            const unsigned tag = d_tag[i], idx = d_idx[i];
-            const int o = (int)(tag >> 8), k = (int)(tag & 255u);
-            const unsigned nx = (unsigned)pyr.dims[o][0], plane = nx * (unsigned)pyr.dims[o][1];
-            const unsigned z = idx / plane, y = (idx - z * plane) / nx, x = idx - z * plane - y * nx;
-            xyzos[5 * (size_t)pos + 0] = (int)x;
-            xyzos[5 * (size_t)pos + 1] = (int)y;
-            xyzos[5 * (size_t)pos + 2] = (int)z;
-            xyzos[5 * (size_t)pos + 3] = o;
-            xyzos[5 * (size_t)pos + 4] = k + pyr.first_level;
-            for (int c = 0; c < 9; c++) R_out[9 * (size_t)pos + c] = d_R[9 * (size_t)i + c];
-        }
+    for (unsigned b0 = 0; b0 < nblocks; b0 += 256) {
+        const unsigned b = b0 + threadIdx.x;
+        const unsigned v = b < nblocks ? block_count[b] : 0u;
+        unsigned total;
+        const unsigned incl = ck_block_scan(v, &total);
+        if (b < nblocks) block_count[b] = carry + incl - v;
         carry += total;
     }
     if (threadIdx.x == 0) *num_out = carry;
 }
 
+__global__ void __launch_bounds__(256)
+k_ck_emit(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
+          const float *__restrict__ d_R, const uint32_t *__restrict__ d_keep, uint32_t num,
+          const unsigned *__restrict__ block_off, int32_t *__restrict__ xyzos, float *__restrict__ R_out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned kp = (i < num && d_keep[i]) ? 1u : 0u;
+    unsigned total;
+    const unsigned incl = ck_block_scan(kp, &total);
+    if (!kp) return;
+    const size_t pos = block_off[blockIdx.x] + incl - 1;
+    const unsigned tag = d_tag[i], idx = d_idx[i];
+    const int o = (int)(tag >> 8), k = (int)(tag & 255u);
+    const unsigned nx = (unsigned)pyr.dims[o][0], plane = nx * (unsigned)pyr.dims[o][1];
+    const unsigned z = idx / plane, y = (idx - z * plane) / nx, x = idx - z * plane - y * nx;
+    xyzos[5 * pos + 0] = (int)x;
+    xyzos[5 * pos + 1] = (int)y;
+    xyzos[5 * pos + 2] = (int)z;
+    xyzos[5 * pos + 3] = o;
+    xyzos[5 * pos + 4] = k + pyr.first_level;
+    for (int c = 0; c < 9; c++) R_out[9 * pos + c] = d_R[9 * (size_t)i + c];
+}
+
 extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                                   const float *d_R, const uint32_t *d_keep, uint32_t num, int32_t *d_xyzos,
-                                  float *d_R_out, uint32_t *d_num_out, s3d_stream st)
+                                  float *d_R_out, uint32_t *d_num_out, uint32_t *d_scratch, s3d_stream stream)
 {
-    hipLaunchKernelGGL(k_compact_keys, dim3(1), dim3(256), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_R, d_keep, num,
-                       d_xyzos, d_R_out, d_num_out);
+    hipStream_t st = (hipStream_t)stream;
+    if (num == 0) {
+        S3D_HIP(hipMemsetAsync(d_num_out, 0, sizeof(uint32_t), st));
+        return S3D_OK;
+    }
+    const unsigned nb = s3d_div_up(num, 256);
+    hipLaunchKernelGGL(k_ck_count, dim3(nb), dim3(256), 0, st, d_keep, num, d_scratch);
+    S3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ck_scan, dim3(1), dim3(256), 0, st, d_scratch, nb, d_num_out);
+    S3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ck_emit, dim3(nb), dim3(256), 0, st, *pyr, d_idx, d_tag, d_R, d_keep, num, d_scratch,
+                       d_xyzos, d_R_out);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
@@ -382,7 +418,6 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
            const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride, int variant)
 {
     constexpr int HSTRIDE = S3D_DESC_NUMEL + 1;
-    constexpr float FIX_SCALE = 1099511627776.0f;          /* 2^40 */
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ float mesh[S3D_MESH_FLOATS];
     __shared__ unsigned queue[DESC_QUEUE];
@@ -410,6 +445,17 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const float sig2 = key.sigma * key.sigma;
     const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
 
+    /* Fixed-point scales.  Level voxels are bounded by 1 (scaled input, convex filters), so a central
+     * difference is <= 1/u per axis and a contribution mag*wt*bary <= |grad| <= bound.  mag*bary is
+     * rounded to an int of < 26 bits, the trilinear weight to 20 bits; their exact 64-bit product is
+     * what goes into the histogram: < 2^46 per contribution, so > 1.3e5 contributions per bin before
+     * overflow (a bin sees < 2.5e4). */
+    int bexp;
+    (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);   /* bound < 2^bexp */
+    const float mscale = ldexpf(1.0f, 25 - bexp);
+    const float wscale = 1048576.0f;                                        /* 2^20 */
+    const double unscale = 1.0 / ((double)mscale * (double)wscale);
+
     int xe, ye, ze;
     desc_bounds(key.cx, key.rad, g.uxf, nx, &g.xs, &xe);
     desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
@@ -419,7 +465,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
     unsigned long long *h = hist + (lane & (NCOPY - 1)) * HSTRIDE;
 
-    /* phase B body: one accepted voxel */
+    /* phase B body: one accepted voxel (single call site: this is the bulk of the kernel's code) */
     auto accumulate = [&](unsigned packed) {
         const int x = g.xs + (int)(packed & 1023u), y = g.ys + (int)((packed >> 10) & 1023u),
                   z = g.zs + (int)(packed >> 20);
@@ -432,22 +478,24 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
         /* window weight.  expf (<= 1 ulp), not the v_exp_f32 shortcut __expf: the latter pushed one
          * keypoint of the 64^3 golden case to 1e-2 relative error on the GPU (debug run, round 1). */
-        const float wa = -0.5f * sq / sig2;
-        const float w = (variant & 32) ? s3d_expf(wa) : expf(wa);
+        const float w = expf(-0.5f * sq / sig2);
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
         gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
         gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
         gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
         V3 bary;
-        const int face = (variant & 16) ? s3d_icos_bin(mesh, gr, &bary) : s3d_icos_bin_fast(mesh, gr, &bary);
+        const int face = s3d_icos_bin_fast(mesh, gr, &bary);
         if (face < 0) return;
         const float mag = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
         const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
         const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
         const float *m = mesh + face * MESH_STRIDE;
         const int i0 = __float_as_int(m[13]), i1 = __float_as_int(m[14]), i2 = __float_as_int(m[15]);
-        const float m0 = mag * bary.x, m1 = mag * bary.y, m2 = mag * bary.z;
+        const long long m0 = (long long)__float2int_rn(mag * bary.x * mscale);
+        const long long m1 = (long long)__float2int_rn(mag * bary.y * mscale);
+        const long long m2 = (long long)__float2int_rn(mag * bary.z * mscale);
+        const float wxs[2] = {1.0f - dvx, dvx}, wys[2] = {1.0f - dvy, dvy}, wzs[2] = {1.0f - dvz, dvz};
 #pragma unroll
         for (int ix = 0; ix < 2; ix++)
 #pragma unroll
@@ -456,48 +504,50 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
                 for (int iz = 0; iz < 2; iz++) {
                     const int cx = ibx + ix, cy = iby + iy, cz = ibz + iz;
                     if (cx >= 4 || cy >= 4 || cz >= 4) continue;      /* lower bounds hold: vb >= 0 */
-                    const float wt = (ix == 0 ? 1.0f - dvx : dvx) * (iy == 0 ? 1.0f - dvy : dvy) *
-                                     (iz == 0 ? 1.0f - dvz : dvz);
+                    const long long wt = (long long)__float2int_rn(wxs[ix] * wys[iy] * wzs[iz] * wscale);
                     unsigned long long *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
-                    const unsigned long long a0 = (unsigned long long)(long long)(m0 * wt * FIX_SCALE);
-                    const unsigned long long a1 = (unsigned long long)(long long)(m1 * wt * FIX_SCALE);
-                    const unsigned long long a2 = (unsigned long long)(long long)(m2 * wt * FIX_SCALE);
-                    if (variant & 4) { hc[i0] = a0; continue; }
-                    atomicAdd(hc + i0, a0);
-                    atomicAdd(hc + i1, a1);
-                    atomicAdd(hc + i2, a2);
+                    if (variant & 4) { hc[i0] = (unsigned long long)(m0 * wt); continue; }
+                    atomicAdd(hc + i0, (unsigned long long)(m0 * wt));
+                    atomicAdd(hc + i1, (unsigned long long)(m1 * wt));
+                    atomicAdd(hc + i2, (unsigned long long)(m2 * wt));
                 }
     };
 
     unsigned head = 0;                                       /* uniform across the block */
     for (int b0 = 0; b0 < nbox; b0 += DESC_CHUNK) {
-        /* ---- phase A: test 4 voxels per thread, enqueue the accepted ones ---- */
-#pragma unroll
-        for (int j = 0; j < DESC_CHUNK / DESC_THREADS; j++) {
-            const int b = b0 + j * DESC_THREADS + tid;
-            bool ok = false;
-            unsigned packed = 0;
+        /* ---- phase A: each thread tests 4 consecutive voxels of the box, enqueues the accepted ---- */
+        {
+            int b = b0 + 4 * tid;
+            int r, bx = 0, by = 0, bz = 0;
             if (b < nbox) {
-                int r, bx;
-                const int bz = fdiv_small(b, wx * wy, inv_wxy, &r);
-                const int by = fdiv_small(r, wx, inv_wx, &bx);
-                float sq, vbx, vby, vbz;
-                ok = desc_window(g, g.xs + bx, g.ys + by, g.zs + bz, &sq, &vbx, &vby, &vbz);
-                packed = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
-                if ((variant & 64) && ok) { accumulate(packed); ok = false; }
+                bz = fdiv_small(b, wx * wy, inv_wxy, &r);
+                by = fdiv_small(r, wx, inv_wx, &bx);
             }
-            const unsigned long long mask = __ballot(ok ? 1 : 0);
-            unsigned base = 0;
-            if (lane == 0 && mask) base = atomicAdd(&qcount, (unsigned)__popcll(mask));
-            base = __shfl(base, 0);
-            if (ok) queue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = packed;
+#pragma unroll
+            for (int j = 0; j < DESC_CHUNK / DESC_THREADS; j++, b++) {
+                bool ok = false;
+                unsigned packed = 0;
+                if (b < nbox) {
+                    float sq, vbx, vby, vbz;
+                    ok = desc_window(g, g.xs + bx, g.ys + by, g.zs + bz, &sq, &vbx, &vby, &vbz);
+                    packed = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
+                    if (++bx == wx) { bx = 0; if (++by == wy) { by = 0; bz++; } }
+                }
+                const unsigned long long mask = __ballot(ok ? 1 : 0);
+                unsigned base = 0;
+                if (lane == 0 && mask) base = atomicAdd(&qcount, (unsigned)__popcll(mask));
+                base = __shfl(base, 0);
+                if (ok) queue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = packed;
+            }
         }
         __syncthreads();
-        /* ---- phase B: drain full batches ---- */
+        /* ---- phase B: drain full batches; on the last round also the partial one ---- */
         const unsigned cnt = qcount;
-        while (cnt - head >= DESC_THREADS) {
-            if (!(variant & 8)) accumulate(queue[head + tid]);
-            head += DESC_THREADS;
+        const bool last = b0 + DESC_CHUNK >= nbox;
+        while (cnt - head >= DESC_THREADS || (last && cnt > head)) {
+            const unsigned nb = cnt - head < DESC_THREADS ? cnt - head : DESC_THREADS;
+            if ((unsigned)tid < nb && !(variant & 8)) accumulate(queue[head + tid]);
+            head += nb;
         }
         /* carry the tail (< 256 entries) to the front of the queue */
         const unsigned rem = cnt - head;
@@ -509,19 +559,14 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         head = 0;
         __syncthreads();
     }
-    {
-        const unsigned rem = qcount;
-        if ((unsigned)tid < rem) accumulate(queue[tid]);
-    }
-    __syncthreads();
-    /* merge the histogram copies (fixed order), then normalise / clamp / normalise */
+    /* merge the histogram copies (integers: order free), then normalise / clamp / normalise */
     float v[S3D_DESC_NUMEL / DESC_THREADS];
     double ss = 0.0;
     for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
         const int i = tid + j * DESC_THREADS;
         unsigned long long acc64 = hist[i];
         for (int w = 1; w < NCOPY; w++) acc64 += hist[w * HSTRIDE + i];
-        const float a = (float)((double)(long long)acc64 * (1.0 / (double)FIX_SCALE));
+        const float a = (float)((double)(long long)acc64 * unscale);
         v[j] = a;
         ss += (double)a * (double)a;
     }

@@ -55,6 +55,7 @@ __device__ __forceinline__ int s3d_face_test(const float *__restrict__ mesh, int
 __device__ __forceinline__ int s3d_icos_bin(const float *__restrict__ mesh, V3 g, V3 *bary)
 {
     if ((double)v3_dot(g, g) < S3D_BARY_EPS_D) return -1;
+#pragma unroll 1
     for (int i = 0; i < S3D_NFACES; i++)
         if (s3d_face_test(mesh, i, g, bary)) return i;
     return -1;

@@ -265,6 +265,7 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
 #define __expf(x) expf(x)
+static inline int __float2int_rn(float x) { return (int)nearbyintf(x); }
 /* wave-scope sync used by single-wave workgroups: a wave-collective rendezvous in the emulator */
 #define __builtin_amdgcn_fence(...) ((void)0)
 static inline void __builtin_amdgcn_wave_barrier() { uint64_t m; emu::wave_exchange(0, 0, true, &m); }
