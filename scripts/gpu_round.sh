@@ -14,6 +14,12 @@ if [ -z "$SKIP_PROF" ]; then
   ( cd /tmp && export TMPDIR=/tmp && timeout ${T_PROF:-600} rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/bench_prof.json" 2> "$R/gpurun_out/bench_prof.err"; echo "prof exit $?" >> "$R/gpurun_out/bench_prof.err" )
   find gpurun_out/prof -name "*kernel_stats*" | head -3
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 30 "$f"
+  if [ -n "$DO_PMC" ]; then
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace -d "$R/gpurun_out/pmc_$c" -o pmc -- python "$R/scripts/gauss_only.py" > "$R/gpurun_out/pmc_$c.log" 2>&1; echo "pmc $c exit $?" >> "$R/gpurun_out/pmc_$c.log" )
+      tail -n 2 "$R/gpurun_out/pmc_$c.log"
+    done
+  fi
   # keep the merge small: drop the raw per-dispatch trace
   find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
 fi

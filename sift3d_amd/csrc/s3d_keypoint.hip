@@ -79,7 +79,7 @@ extern "C" void s3d_mesh_table(float *out)
  *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
  *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
  *   bit 3: k_describe skips phase B entirely (window tests + queue only)
- *   (bits 4-6 were debug bisection switches, removed)
+ *   bit 4: k_orient always takes the ordered-sum pass (timing of the bound-based shortcut)
  *   bit 7 / bit 8: 2 / 8 histogram copies per block instead of 4 */
 static int g_variant = 0;
 extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
@@ -138,102 +138,170 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
     const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
 
-    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-    float gsum = 0.0f;                                     /* lanes 0..2: running sum of component lane */
     const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
-    for (int b0 = 0; b0 < nbox; b0 += 64) {
-        const int b = b0 + lane;
-        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-        if (b < nbox) {
-            const int bz = b / (wx * wy);
-            const int r = b - bz * wx * wy;
-            const int by = r / wx;
-            const int bx = r - by * wx;
-            const int x = xs + bx, y = ys + by, z = zs + bz;
-            const float dx = ((float)x - vcx) * uxf;
-            const float dy = ((float)y - vcy) * uyf;
-            const float dz = ((float)z - vcz) * uzf;
-            const float sq = dx * dx + dy * dy + dz * dz;
-            if (!((double)sq > rad2)) {
-                const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
-                const float wa = (float)(-0.5 * (double)sq / sig2);
-                const float w = (variant & 2) ? __expf(wa) : s3d_expf(wa);
-                float gx = 0.5f * (p[1] - p[-1]);
-                float gy = 0.5f * (p[nx] - p[-nx]);
-                float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
-                gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
-                a00 += (double)gx * (double)gx * (double)w;
-                a01 += (double)gx * (double)gy * (double)w;
-                a02 += (double)gx * (double)gz * (double)w;
-                a11 += (double)gy * (double)gy * (double)w;
-                a12 += (double)gy * (double)gz * (double)w;
-                a22 += (double)gz * (double)gz * (double)w;
-                tx = gx * w; ty = gy * w; tz = gz * w;
-            }
-        }
-        term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
-        s3d_wave_lds_sync();
-        if (lane < 3 && !(variant & 1)) {
-            /* reference scan order.  The 64 staged terms are first pulled into registers with 16
-             * independent ds_read_b128, so the dependent chain is 64 adds, not 64 LDS round trips. */
-            float4 q[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(&term[lane][4 * i]);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                gsum = gsum + q[i].x; gsum = gsum + q[i].y; gsum = gsum + q[i].z; gsum = gsum + q[i].w;
-            }
-        }
-        s3d_wave_lds_sync();
+    /* one window sample: weight and iso gradient exactly as the reference evaluates them */
+    auto sample = [&](int b, float *gx, float *gy, float *gz, float *w) -> bool {
+        const int bz = b / (wx * wy);
+        const int r = b - bz * wx * wy;
+        const int by = r / wx;
+        const int bx = r - by * wx;
+        const int x = xs + bx, y = ys + by, z = zs + bz;
+        const float dx = ((float)x - vcx) * uxf;
+        const float dy = ((float)y - vcy) * uyf;
+        const float dz = ((float)z - vcz) * uzf;
+        const float sq = dx * dx + dy * dy + dz * dz;
+        if ((double)sq > rad2) return false;
+        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
+        const float wa = (float)(-0.5 * (double)sq / sig2);
+        *w = (variant & 2) ? __expf(wa) : s3d_expf(wa);
+        *gx = 0.5f * (p[1] - p[-1]) * iux;
+        *gy = 0.5f * (p[nx] - p[-nx]) * iuy;
+        *gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]) * iuz;
+        return true;
+    };
+
+    /* ---- pass 1 (parallel): f64 structure tensor, and for the window gradient sum(w*grad) both its
+     * (to f64 accuracy) exact value gd and sum|term| per component, which bounds how far the
+     * reference's sequential f32 accumulation can be from gd ------------------------------------- */
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    double gdx = 0, gdy = 0, gdz = 0, sax = 0, say = 0, saz = 0;
+    int cnt = 0;
+    for (int b = lane; b < nbox; b += 64) {
+        float gx, gy, gz, w;
+        if (!sample(b, &gx, &gy, &gz, &w)) continue;
+        a00 += (double)gx * (double)gx * (double)w;
+        a01 += (double)gx * (double)gy * (double)w;
+        a02 += (double)gx * (double)gz * (double)w;
+        a11 += (double)gy * (double)gy * (double)w;
+        a12 += (double)gy * (double)gz * (double)w;
+        a22 += (double)gz * (double)gz * (double)w;
+        const float tx = gx * w, ty = gy * w, tz = gz * w;
+        gdx += (double)tx; gdy += (double)ty; gdz += (double)tz;
+        sax += fabs((double)tx); say += fabs((double)ty); saz += fabs((double)tz);
+        cnt++;
     }
-    /* wave reduction of the f64 tensor */
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = 32; m >= 1; m >>= 1) {                    /* xor butterfly: every lane ends with the totals */
         a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
         a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
+        gdx += __shfl_xor(gdx, m); gdy += __shfl_xor(gdy, m); gdz += __shfl_xor(gdz, m);
+        sax += __shfl_xor(sax, m); say += __shfl_xor(say, m); saz += __shfl_xor(saz, m);
+        cnt += __shfl_xor(cnt, m);
     }
-    if (lane < 3) gw_s[lane] = gsum;
-    s3d_wave_lds_sync();
-    if (lane != 0) return;
 
-    const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
+    /* Everything below is evaluated redundantly by all 64 lanes (identical values, no divergence). */
     float R[9];
-    int keep = 1;
-    double conf = 0.0;
     for (int i = 0; i < 9; i++) R[i] = 0.0f;
-    if (gwx * gwx + gwy * gwy + gwz * gwz < (float)1E-10) keep = 0;        /* ori_grad_thresh */
-    if (keep) {
-        double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
-        double L[3], Q[3][3];
-        s3d_eig3(A, L, Q);
-        if (fabs(L[0] / L[1]) > 0.90 || fabs(L[1] / L[2]) > 0.90) keep = 0; /* max_eig_ratio */
-        if (keep) {
-            float v[2][3];
-            double score = 1.7976931348623157e308;
-            for (int i = 0; i < 2; i++) {
-                const int e = 2 - i;
-                float vr[3] = {(float)Q[0][e], (float)Q[1][e], (float)Q[2][e]};
-                const double d = (double)(gwx * vr[0] + gwy * vr[1] + gwz * vr[2]);
-                const double cos_ang = d / (double)(sqrtf(vr[0] * vr[0] + vr[1] * vr[1] + vr[2] * vr[2]) *
-                                                     sqrtf(gwx * gwx + gwy * gwy + gwz * gwz));
-                const double ac = fabs(cos_ang);
-                const float sgn = d > 0.0 ? 1.0f : -1.0f;
-                score = score < ac ? score : ac;
-                for (int c = 0; c < 3; c++) {
-                    vr[c] = vr[c] * sgn;
-                    R[3 * c + i] = vr[c];
-                    v[i][c] = vr[c];
+    int keep = 0;
+    double conf = 0.0;
+    const float grad_thr = (float)1E-10;                   /* ori_grad_thresh, sift.c:49,1426 */
+
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    double L[3], Q[3][3];
+    s3d_eig3(A, L, Q);
+    const bool ratio_reject = fabs(L[0] / L[1]) > 0.90 || fabs(L[1] / L[2]) > 0.90;   /* max_eig_ratio */
+    float vr[2][3];                                        /* the two leading eigenvectors as f32 */
+    for (int i = 0; i < 2; i++)
+        for (int c = 0; c < 3; c++) vr[i][c] = (float)Q[c][2 - i];
+
+    /* R and the corner score from a window gradient (gwx, gwy, gwz), the reference's way (sift.c:1446-1492) */
+    auto finish = [&](float gwx, float gwy, float gwz) {
+        float v[2][3];
+        double score = 1.7976931348623157e308;
+        for (int i = 0; i < 2; i++) {
+            const double d = (double)(gwx * vr[i][0] + gwy * vr[i][1] + gwz * vr[i][2]);
+            const double cos_ang = d / (double)(sqrtf(vr[i][0] * vr[i][0] + vr[i][1] * vr[i][1] + vr[i][2] * vr[i][2]) *
+                                                 sqrtf(gwx * gwx + gwy * gwy + gwz * gwz));
+            const double ac = fabs(cos_ang);
+            const float sgn = d > 0.0 ? 1.0f : -1.0f;
+            score = score < ac ? score : ac;
+            for (int c = 0; c < 3; c++) {
+                v[i][c] = vr[i][c] * sgn;
+                R[3 * c + i] = v[i][c];
+            }
+        }
+        R[2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];
+        R[5] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
+        R[8] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
+        conf = score;
+        keep = conf < corner_thresh ? 0 : 1;
+    };
+
+    /* ---- decision without the ordered sum when it is provably the same --------------------------------
+     * Recursive f32 summation of n terms is within n*2^-24*sum|t| of the exact sum, per component.  If
+     * every test that reads the window gradient (its norm against ori_grad_thresh, the corner score
+     * against corner_thresh, the signs of the directional derivatives) has more slack than that
+     * perturbation can consume, the reference's decision -- and R, which depends on the gradient only
+     * through those signs -- is already determined.  Otherwise (a few % of candidates) pass 2 redoes the
+     * sum in the reference's order.  The raw-image variant reports the score itself: always exact. */
+    int decided = 0;
+    if (ratio_reject) {
+        decided = 1;                                       /* REJECT whatever the gradient is */
+    } else if (d_conf == nullptr && !(variant & 16)) {
+        const double gam = ((double)cnt + 3.0) * 5.9604644775390625e-08 * 1.001;
+        const double ex = gam * sax, ey = gam * say, ez = gam * saz;
+        const double del = sqrt(ex * ex + ey * ey + ez * ez);
+        const double G = sqrt(gdx * gdx + gdy * gdy + gdz * gdz);
+        if (G > 4.0 * del) {
+            const double lo2 = (G - del) * (G - del) * (1.0 - 1e-6), hi2 = (G + del) * (G + del) * (1.0 + 1e-6);
+            if (hi2 < (double)grad_thr * (1.0 - 1e-6)) {
+                decided = 1;                               /* certainly below ori_grad_thresh: REJECT */
+            } else if (lo2 > (double)grad_thr * (1.0 + 1e-6)) {
+                const double marg = 4.0 * del / G + 3e-6;
+                double cmin = 2.0, dmin = 1e300;
+                for (int i = 0; i < 2; i++) {
+                    const double nv = sqrt((double)vr[i][0] * vr[i][0] + (double)vr[i][1] * vr[i][1] +
+                                           (double)vr[i][2] * vr[i][2]);
+                    const double d = gdx * vr[i][0] + gdy * vr[i][1] + gdz * vr[i][2];
+                    const double ac = fabs(d) / (nv * G);
+                    cmin = cmin < ac ? cmin : ac;
+                    const double ds = fabs(d) - 1.01 * del * nv;
+                    dmin = dmin < ds ? dmin : ds;
+                }
+                if (cmin + marg < corner_thresh) {
+                    decided = 1;                           /* certainly below corner_thresh: REJECT */
+                } else if (cmin - marg >= corner_thresh && dmin > 0.0) {
+                    finish((float)gdx, (float)gdy, (float)gdz);   /* signs are safe: R is the reference's */
+                    keep = 1;
+                    decided = 1;
                 }
             }
-            R[2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];
-            R[5] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
-            R[8] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
-            conf = score;
-            if (conf < corner_thresh) keep = 0;
         }
     }
+
+    /* ---- pass 2 (rare): the reference's own summation order ------------------------------------------ */
+    if (!decided) {
+        float gsum = 0.0f;                                 /* lanes 0..2: running sum of component lane */
+        for (int b0 = 0; b0 < nbox; b0 += 64) {
+            const int b = b0 + lane;
+            float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+            float gx, gy, gz, w;
+            if (b < nbox && sample(b, &gx, &gy, &gz, &w)) { tx = gx * w; ty = gy * w; tz = gz * w; }
+            term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
+            s3d_wave_lds_sync();
+            if (lane < 3 && !(variant & 1)) {
+                /* scan order; skipped voxels contribute an exact +0.  The 64 staged terms are pulled into
+                 * registers with 16 independent ds_read_b128 so the dependent chain is 64 adds. */
+                float4 q[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(&term[lane][4 * i]);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    gsum = gsum + q[i].x; gsum = gsum + q[i].y; gsum = gsum + q[i].z; gsum = gsum + q[i].w;
+                }
+            }
+            s3d_wave_lds_sync();
+        }
+        if (lane < 3) gw_s[lane] = gsum;
+        s3d_wave_lds_sync();
+        const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
+        if (!(gwx * gwx + gwy * gwy + gwz * gwz < grad_thr)) finish(gwx, gwy, gwz);
+    }
+    if (lane != 0) return;
+    if (!keep)
+        for (int i = 0; i < 9; i++) R[i] = 0.0f;
     for (int i = 0; i < 9; i++) d_R[(size_t)cand * 9 + i] = R[i];
     d_keep[cand] = (uint32_t)keep;
-    if (d_conf) d_conf[cand] = conf;
+    if (d_conf) d_conf[cand] = keep || conf > 0.0 ? conf : 0.0;
 }
 
 extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
