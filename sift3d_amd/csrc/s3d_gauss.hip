@@ -41,11 +41,12 @@
  * 1. generic per-element pass
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
-k_conv_axis(const float *__restrict__ src, float *__restrict__ dst, size_t total, size_t sa, int n, int hw,
-            float uf, int uhw, S3dTaps taps)
+k_conv_axis(const float *__restrict__ src, float *__restrict__ dst, size_t idx_begin, size_t idx_end, size_t sa,
+            int n, int hw, float uf, int uhw, S3dTaps taps)
 {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    /* element range [idx_begin, idx_end) of the volume: the whole volume, or the planes of a Z-slab */
+    const size_t idx = idx_begin + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= idx_end) return;
     const int p = (int)((idx / sa) % (size_t)n);
     const float *s = src + (idx - (size_t)p * sa);
     const int dim_end = n - 1;
@@ -86,12 +87,14 @@ static int check_taps(const float *taps, int width, S3dTaps *out)
     return S3D_OK;
 }
 
-extern "C" int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny, int nz, int nc, int axis,
-                               const float *taps, int width, float uf, s3d_stream st)
+/* one axis pass over the planes [z0, z1) of a volume addressed by global z (z0 = 0, z1 = nz: all) */
+static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int nz, int nc, int axis, int z0, int z1,
+                           const float *taps, int width, float uf, s3d_stream st)
 {
     S3dTaps t;
     if (check_taps(taps, width, &t)) return S3D_ERR;
-    if (axis < 0 || axis > 2 || nx < 1 || ny < 1 || nz < 1 || nc < 1) S3D_FAIL("bad arguments");
+    if (axis < 0 || axis > 2 || nx < 1 || ny < 1 || nz < 1 || nc < 1 || z0 < 0 || z1 > nz || z0 >= z1)
+        S3D_FAIL("bad arguments");
     const int dims[3] = {nx, ny, nz};
     const size_t strides[3] = {(size_t)nc, (size_t)nc * nx, (size_t)nc * nx * ny};
     const int hw = width / 2;
@@ -99,11 +102,17 @@ extern "C" int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny,
     /* the reference indexes out of bounds here; refuse instead */
     if (uhw >= dims[axis] - 1) S3D_FAIL("image too small for this filter along the axis");
     if (d_src == d_dst) S3D_FAIL("in-place axis pass is not supported");
-    const size_t total = (size_t)nx * ny * nz * nc;
-    hipLaunchKernelGGL(k_conv_axis, dim3(s3d_div_up(total, 256)), dim3(256), 0, (hipStream_t)st, d_src, d_dst,
-                       total, strides[axis], dims[axis], hw, uf, uhw, t);
+    const size_t ib = strides[2] * (size_t)z0, ie = strides[2] * (size_t)z1;
+    hipLaunchKernelGGL(k_conv_axis, dim3(s3d_div_up(ie - ib, 256)), dim3(256), 0, (hipStream_t)st, d_src, d_dst, ib,
+                       ie, strides[axis], dims[axis], hw, uf, uhw, t);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
+}
+
+extern "C" int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny, int nz, int nc, int axis,
+                               const float *taps, int width, float uf, s3d_stream st)
+{
+    return conv_axis_range(d_src, d_dst, nx, ny, nz, nc, axis, 0, nz, taps, width, uf, st);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -160,8 +169,8 @@ __device__ __forceinline__ float4 z_ext(const float *__restrict__ col, size_t zs
 
 template <int HW, bool SPLIT>
 __global__ void __launch_bounds__(256)
-k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int ny, int nz, int chunk, S3dTaps taps,
-          EdgeFrac ef)
+k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int ny, int nz, int zbeg, int zend,
+          int chunk, S3dTaps taps, EdgeFrac ef)
 {
     constexpr int W = 2 * HW + 1;
     const size_t ncol = (size_t)nx4 * ny;
@@ -170,8 +179,9 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
     const size_t zs = ncol * 4;                       /* floats per z plane */
     const float *col = src + colid * 4;
     float *out = dst + colid * 4;
-    const int p0 = blockIdx.y * chunk;
-    const int p1 = (p0 + chunk < nz) ? p0 + chunk : nz;
+    /* output planes [zbeg, zend) of a volume addressed by global z (the whole volume, or a Z-slab) */
+    const int p0 = zbeg + blockIdx.y * chunk;
+    const int p1 = (p0 + chunk < zend) ? p0 + chunk : zend;
     const int T = (p1 - p0) + 2 * HW;                 /* pushes: coordinates p0-HW .. p1-1+HW */
 
     /* two planes in flight per lane; steps t < Tfast are guard free (real plane, output due, prefetch in
@@ -422,30 +432,76 @@ extern "C" void s3d_k_gauss_set_events(void *before_xy, void *between, void *aft
     g_ev[0] = (hipEvent_t)before_xy; g_ev[1] = (hipEvent_t)between; g_ev[2] = (hipEvent_t)after_z;
 }
 
+/* Output planes [z0, z1) of a volume addressed by global z.  The whole volume is z0 = 0, z1 = nz; a
+ * Z-slab needs valid source planes [z0-HW, z1+HW) (clamped to the volume), i.e. the neighbours' halos. */
 template <int HW>
-static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, const S3dTaps &t,
-                       hipStream_t st)
+static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
+                       const S3dTaps &t, hipStream_t st)
 {
     EdgeFrac ex, ey, ez;
     if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
+    const int za = z0 - HW > 0 ? z0 - HW : 0, zb = z1 + HW < nz ? z1 + HW : nz;
+    const int nzo = z1 - z0;
     /* split the marching axis into equal chunks of about the target length (512 -> 3 x 171) */
     const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
-    const int cz = (nz + (int)s3d_div_up(nz, g_chunk_z) - 1) / (int)s3d_div_up(nz, g_chunk_z);
-    const unsigned ncy = s3d_div_up(ny, cy), ncz = s3d_div_up(nz, cz);
-    if (ncy > 65535 || (unsigned)nz > 65535u) S3D_FAIL("volume too large for the fast-path grid");
+    const int cz = (nzo + (int)s3d_div_up(nzo, g_chunk_z) - 1) / (int)s3d_div_up(nzo, g_chunk_z);
+    const unsigned ncy = s3d_div_up(ny, cy), ncz = s3d_div_up(nzo, cz);
+    const size_t plane = (size_t)nx * ny;
+    if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
     if (g_ev[0]) S3D_HIP(hipEventRecord(g_ev[0], st));
-    hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, nz), dim3(64), 0, st, d_src, d_tmp,
-                       nx, ny, cy, t, ex, ey);
+    hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st,
+                       d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey);
     S3D_CHECK_LAUNCH();
     if (g_ev[1]) S3D_HIP(hipEventRecord(g_ev[1], st));
     if (!(g_gauss_mode & 1))
         hipLaunchKernelGGL((k_gauss_z<HW, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
-                           d_tmp, d_dst, nx / 4, ny, nz, cz, t, ez);
+                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez);
     else
         hipLaunchKernelGGL((k_gauss_z<HW, true>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
-                           d_tmp, d_dst, nx / 4, ny, nz, cz, t, ez);
+                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez);
     S3D_CHECK_LAUNCH();
     if (g_ev[2]) S3D_HIP(hipEventRecord(g_ev[2], st));
+    return S3D_OK;
+}
+
+static int fast_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
+                         int hw, const S3dTaps &t, hipStream_t st)
+{
+    switch (hw) {
+    case 1: return launch_fast<1>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 2: return launch_fast<2>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 3: return launch_fast<3>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 4: return launch_fast<4>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 5: return launch_fast<5>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 6: return launch_fast<6>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 7: return launch_fast<7>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 8: return launch_fast<8>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 9: return launch_fast<9>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    default: break;
+    }
+    S3D_FAIL("half width not instantiated");
+}
+
+/* Z-slab form of s3d_k_sep_fir.  The three pointers are VIEWS addressed by
+ * global z: element (x,y,z) of the nx x ny x nz volume lives at view[(z*ny + y)*nx + x], but only the
+ * planes the caller owns plus halos need to be backed by memory.  Produces dst planes [z0, z1); reads
+ * src planes [z0-h, z1+h) clamped to [0, nz), h = ceil(hw * uf[2]) -- i.e. the caller must have
+ * received h halo planes from each Z-neighbour; at the global ends the reference's mirror rule applies
+ * and needs no neighbour.  dst and tmp planes [z0-h, z1+h) are used as scratch.  nc == 1. */
+extern "C" int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0,
+                                  int z1, const float uf[3], const float *taps, int width, s3d_stream stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    S3dTaps t;
+    if (check_taps(taps, width, &t)) return S3D_ERR;
+    if (nx < 1 || ny < 1 || nz < 1 || z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad dimensions");
+    const int hw = width / 2;
+    if (fast_eligible(nx, ny, nz, 1, uf, width)) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, hw, t, st);
+    const int h = (int)ceilf((float)hw * uf[2]);
+    const int za = z0 - h > 0 ? z0 - h : 0, zb = z1 + h < nz ? z1 + h : nz;
+    if (conv_axis_range(d_src, d_dst, nx, ny, nz, 1, 0, za, zb, taps, width, uf[0], stream)) return S3D_ERR;
+    if (conv_axis_range(d_dst, d_tmp, nx, ny, nz, 1, 1, za, zb, taps, width, uf[1], stream)) return S3D_ERR;
+    if (conv_axis_range(d_tmp, d_dst, nx, ny, nz, 1, 2, z0, z1, taps, width, uf[2], stream)) return S3D_ERR;
     return S3D_OK;
 }
 
@@ -459,20 +515,7 @@ extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp
     if (d_tmp == d_src || d_tmp == d_dst) S3D_FAIL("scratch must not alias src/dst");
     const int fast = fast_eligible(nx, ny, nz, nc, uf, width);
     if (path == 2 && !fast) S3D_FAIL("configuration not eligible for the fused fast path");
-    if (fast && path != 1) {
-        switch (width / 2) {
-        case 1: return launch_fast<1>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 2: return launch_fast<2>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 3: return launch_fast<3>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 4: return launch_fast<4>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 5: return launch_fast<5>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 6: return launch_fast<6>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 7: return launch_fast<7>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 8: return launch_fast<8>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        case 9: return launch_fast<9>(d_src, d_dst, d_tmp, nx, ny, nz, t, st);
-        default: break;
-        }
-    }
+    if (fast && path != 1) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, 0, nz, width / 2, t, st);
     /* generic per-axis passes.  out of place: x: src -> dst ; y: dst -> tmp ; z: tmp -> dst */
     if (d_src != d_dst) {
         if (s3d_k_conv_axis(d_src, d_dst, nx, ny, nz, nc, 0, taps, width, uf[0], stream)) return S3D_ERR;

@@ -513,16 +513,13 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const float sig2 = key.sigma * key.sigma;
     const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
 
-    /* Fixed-point scales.  Level voxels are bounded by 1 (scaled input, convex filters), so a central
-     * difference is <= 1/u per axis and a contribution mag*wt*bary <= |grad| <= bound.  mag*bary is
-     * rounded to an int of < 26 bits, the trilinear weight to 20 bits; their exact 64-bit product is
-     * what goes into the histogram: < 2^46 per contribution, so > 1.3e5 contributions per bin before
-     * overflow (a bin sees < 2.5e4). */
+    /* Fixed-point format of the histogram: value * 2^(40 - bexp), where 2^bexp exceeds the largest possible
+     * contribution.  (Level voxels are bounded by 1 -- scaled input, convex filters -- so a central
+     * difference is <= 1/u per axis and a contribution mag*wt*bary <= |grad| <= bound.)  Each bin can
+     * absorb 2^23 maximal contributions before overflowing 63 bits; it receives < 2.5e4. */
     int bexp;
     (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);   /* bound < 2^bexp */
-    const float mscale = ldexpf(1.0f, 25 - bexp);
-    const float wscale = 1048576.0f;                                        /* 2^20 */
-    const double unscale = 1.0 / ((double)mscale * (double)wscale);
+    const double unscale = ldexp(1.0, bexp - 40);
 
     int xe, ye, ze;
     desc_bounds(key.cx, key.rad, g.uxf, nx, &g.xs, &xe);
@@ -560,6 +557,14 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
         const float *m = mesh + face * MESH_STRIDE;
         const int i0 = __float_as_int(m[13]), i1 = __float_as_int(m[14]), i2 = __float_as_int(m[15]);
+        /* contribution = (mag*bary_v) * wt, formed exactly in integers: the first factor rounded to 30
+         * significant bits at the sample's own exponent (gradients are 100-1000x below the bound, a
+         * fixed scale would waste those bits), the trilinear weight to 2^-24, the 64-bit product
+         * shifted to the common format.  mag >= 1.09e-3 (icos_bin's floor), so the shift is <= 31. */
+        int em;
+        (void)frexpf(mag, &em);                                       /* mag < 2^em <= 2^bexp */
+        const float mscale = ldexpf(1.0f, 29 - em);
+        const int shift = 13 - em + bexp;
         const long long m0 = (long long)__float2int_rn(mag * bary.x * mscale);
         const long long m1 = (long long)__float2int_rn(mag * bary.y * mscale);
         const long long m2 = (long long)__float2int_rn(mag * bary.z * mscale);
@@ -572,12 +577,12 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
                 for (int iz = 0; iz < 2; iz++) {
                     const int cx = ibx + ix, cy = iby + iy, cz = ibz + iz;
                     if (cx >= 4 || cy >= 4 || cz >= 4) continue;      /* lower bounds hold: vb >= 0 */
-                    const long long wt = (long long)__float2int_rn(wxs[ix] * wys[iy] * wzs[iz] * wscale);
+                    const long long wt = (long long)__float2int_rn(wxs[ix] * wys[iy] * wzs[iz] * 16777216.0f);
                     unsigned long long *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
-                    if (variant & 4) { hc[i0] = (unsigned long long)(m0 * wt); continue; }
-                    atomicAdd(hc + i0, (unsigned long long)(m0 * wt));
-                    atomicAdd(hc + i1, (unsigned long long)(m1 * wt));
-                    atomicAdd(hc + i2, (unsigned long long)(m2 * wt));
+                    if (variant & 4) { hc[i0] = (unsigned long long)((m0 * wt) >> shift); continue; }
+                    atomicAdd(hc + i0, (unsigned long long)((m0 * wt) >> shift));
+                    atomicAdd(hc + i1, (unsigned long long)((m1 * wt) >> shift));
+                    atomicAdd(hc + i2, (unsigned long long)((m2 * wt) >> shift));
                 }
     };
 
