@@ -246,8 +246,17 @@ def main():
         worst = max(apps, key=lambda a: a["xy_ms"])                       # widest filter = slowest fused kernel
         nv = float(512 if n >= 512 else n) ** 3
         ach = GAUSS_XY_BYTES_PER_VOXEL * nv / (worst["xy_ms"] * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE doubled per the
+        # gfx950 correction + WRITE_SIZE; profiles/pmc_gauss.json), valid for the 512^3 launch only
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_gauss.json")))
+            if int(nv) == int(pmc["voxels"]):
+                traffic = pmc["kernels"][f"k_gauss_xy<{worst['width'] // 2}>"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                               "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
                                         f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
         result["config"]["gauss_apps"] = apps

@@ -69,6 +69,13 @@ int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny, int nz, in
  * (octave 0 of a unit-voxel volume: the roofline configuration), the generic pass otherwise. */
 int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,
                   const float uf[3], const float *taps, int width, s3d_stream stream);
+/* Z-slab form: the pointers are VIEWS addressed by global z -- element (x,y,z)
+ * at view[(z*ny + y)*nx + x] -- of which only the caller's planes plus halos are backed by memory.
+ * Produces dst planes [z0, z1) from src planes [z0-h, z1+h) clamped to [0, nz), h = ceil(hw*uf[2]):
+ * the halo planes come from the Z-neighbours; the global ends use the reference's mirror rule.
+ * dst / tmp planes in that range are scratch.  nc == 1. */
+int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0,
+                       int z1, const float uf[3], const float *taps, int width, s3d_stream stream);
 /* Force a code path (tests / profiling): 0 = auto, 1 = generic per-axis passes, 2 = fused fast path
  * (fails if the configuration is not eligible). */
 /* rows (planes) per marching chunk of the fused kernels: occupancy vs warm-up re-reads */
@@ -92,6 +99,11 @@ int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float *d_max, s3d
 int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3,
                   int nx, int ny, int nz, double peak_thresh, const float *d_dogmax,
                   unsigned long long *d_bits, s3d_stream stream);
+/* The same for the planes [z0, z1) of a level given as views addressed by global z (needs one halo
+ * plane on each interior side); bit i of d_bits <-> voxel z0*nx*ny + i. */
+int s3d_k_extrema_slab(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3,
+                       int nx, int ny, int nz, int z0, int z1, double peak_thresh, const float *d_dogmax,
+                       unsigned long long *d_bits, s3d_stream stream);
 /* Ordered compaction of a bitmap: appends the indices of set bits, ascending, to d_idx starting at
  * position *d_count, tags each with `tag` in d_tag, and advances *d_count.  Entries past `capacity`
  * are dropped (the count still advances, so overflow is detectable).  d_scratch: >= nwords/1024+2
@@ -99,6 +111,10 @@ int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *d_l2, const
 int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nwords, uint32_t *d_idx,
                        uint32_t *d_tag, uint32_t tag, uint32_t capacity, uint32_t *d_count,
                        uint32_t *d_scratch, s3d_stream stream);
+/* as above with bit i <-> voxel idx_base + i */
+int s3d_k_compact_bits_base(const unsigned long long *d_bits, size_t nwords, uint32_t idx_base,
+                            uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
+                            uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream);
 
 /* ---- keypoints ----------------------------------------------------------------------------------- */
 typedef struct {

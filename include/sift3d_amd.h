@@ -252,6 +252,9 @@ int sift3d_amd_gauss_dev(const float *d_src, float *d_dst, float *d_tmp, int nx,
 /* Copy GSS level data (and, if want_dog, materialise + copy the DoG levels) into the host Pyramids
  * of sift3d, allocating level->data.  Only needed by callers that read pyramid voxels. */
 int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog);
+/* Host-only: size the pyramid metadata and the Gaussian bank of `sift3d` for an nx x ny x nz volume as
+ * SIFT3D_detect_keypoints would, without device work (used by the multi-GPU Z-slab driver). */
+int sift3d_amd_plan(SIFT3D *const sift3d, int nx, int ny, int nz, double ux, double uy, double uz);
 /* Number of extrema candidates before orientation rejection in the last detect (diagnostics). */
 long sift3d_amd_last_num_candidates(const SIFT3D *const sift3d);
 /* Stream on which this SIFT3D's kernels run (opaque hipStream_t); set before the first detect. */

@@ -587,6 +587,19 @@ int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, in
     return detect_dev(sift3d, sift_ctx(sift3d), kp);
 }
 
+/* Host-only planning: size the pyramids and build the filter bank for an nx x ny x nz volume exactly as
+ * set_im_SIFT3D / resize_SIFT3D would (sift.c:883-986), without touching the device.  The Z-slab driver
+ * (sift3d_amd/slab.py) reads octave dims, units, level scales and taps from the struct afterwards. */
+int sift3d_amd_plan(SIFT3D *const sift3d, int nx, int ny, int nz, double ux, double uy, double uz)
+{
+    Image *const sim = &sift3d->im;
+    if (nx < 1 || ny < 1 || nz < 1) API_FAIL("sift3d_amd_plan: bad dimensions");
+    sim->nx = nx; sim->ny = ny; sim->nz = nz; sim->nc = 1;
+    sim->ux = ux; sim->uy = uy; sim->uz = uz;
+    im_default_stride(sim);
+    return resize_SIFT3D(sift3d, sift3d->gpyr.num_kp_levels);
+}
+
 long sift3d_amd_last_num_candidates(const SIFT3D *const sift3d)
 {
     const s3d_ctx *c = sift_ctx(sift3d);

@@ -15,10 +15,11 @@
 
 __global__ void __launch_bounds__(256)
 k_extrema(const float *__restrict__ l0, const float *__restrict__ l1, const float *__restrict__ l2,
-          const float *__restrict__ l3, unsigned nx, unsigned ny, unsigned nz, unsigned n, double peak,
+          const float *__restrict__ l3, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
           const float *__restrict__ d_dogmax, unsigned long long *__restrict__ bits)
 {
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    /* voxels [idx0, n) of the level (whole level: idx0 = 0; a Z-slab: its planes); bit 0 <-> voxel idx0 */
+    const unsigned idx = idx0 + blockIdx.x * 256u + threadIdx.x;
     const float thr = (float)(peak * (double)(*d_dogmax));      /* sift.c:1169 */
     int pred = 0;
     if (idx < n) {
@@ -43,19 +44,28 @@ k_extrema(const float *__restrict__ l0, const float *__restrict__ l1, const floa
         }
     }
     const unsigned long long m = __ballot(pred);
-    if ((threadIdx.x & 63) == 0 && idx < ((n + 63u) & ~63u)) bits[idx >> 6] = m;
+    if ((threadIdx.x & 63) == 0 && idx - idx0 < ((n - idx0 + 63u) & ~63u)) bits[(idx - idx0) >> 6] = m;
+}
+
+extern "C" int s3d_k_extrema_slab(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3,
+                                  int nx, int ny, int nz, int z0, int z1, double peak_thresh, const float *d_dogmax,
+                                  unsigned long long *d_bits, s3d_stream st)
+{
+    const size_t n = (size_t)nx * ny * nz, plane = (size_t)nx * ny;
+    if (nx < 1 || ny < 1 || nz < 1 || n >= 0xFFFFFF00ull) S3D_FAIL("level too large for 32-bit voxel indices");
+    if (z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad slab");
+    hipLaunchKernelGGL(k_extrema, dim3(s3d_div_up(plane * (size_t)(z1 - z0), 256)), dim3(256), 0, (hipStream_t)st,
+                       d_l0, d_l1, d_l2, d_l3, (unsigned)nx, (unsigned)ny, (unsigned)nz, (unsigned)(plane * z0),
+                       (unsigned)(plane * z1), peak_thresh, d_dogmax, d_bits);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
 }
 
 extern "C" int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3, int nx,
                              int ny, int nz, double peak_thresh, const float *d_dogmax, unsigned long long *d_bits,
                              s3d_stream st)
 {
-    const size_t n = (size_t)nx * ny * nz;
-    if (nx < 1 || ny < 1 || nz < 1 || n >= 0xFFFFFF00ull) S3D_FAIL("level too large for 32-bit voxel indices");
-    hipLaunchKernelGGL(k_extrema, dim3(s3d_div_up(n, 256)), dim3(256), 0, (hipStream_t)st, d_l0, d_l1, d_l2, d_l3,
-                       (unsigned)nx, (unsigned)ny, (unsigned)nz, (unsigned)n, peak_thresh, d_dogmax, d_bits);
-    S3D_CHECK_LAUNCH();
-    return S3D_OK;
+    return s3d_k_extrema_slab(d_l0, d_l1, d_l2, d_l3, nx, ny, nz, 0, nz, peak_thresh, d_dogmax, d_bits, st);
 }
 
 /* ---- ordered bitmap compaction ---------------------------------------------------------------- */
@@ -111,7 +121,8 @@ __global__ void __launch_bounds__(256) k_cb_scan(unsigned *__restrict__ block_co
 
 __global__ void __launch_bounds__(256)
 k_cb_emit(const unsigned long long *__restrict__ bits, size_t nwords, const unsigned *__restrict__ block_off,
-          unsigned *__restrict__ out_idx, unsigned *__restrict__ out_tag, unsigned tag, unsigned capacity)
+          unsigned *__restrict__ out_idx, unsigned *__restrict__ out_tag, unsigned tag, unsigned capacity,
+          unsigned idx_base)
 {
     const size_t w0 = (size_t)blockIdx.x * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
     unsigned long long w[CB_WORDS_PER_THREAD];
@@ -129,7 +140,7 @@ k_cb_emit(const unsigned long long *__restrict__ bits, size_t nwords, const unsi
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
             if (pos < capacity) {
-                out_idx[pos] = (unsigned)((w0 + i) * 64 + (unsigned)b);
+                out_idx[pos] = idx_base + (unsigned)((w0 + i) * 64 + (unsigned)b);
                 out_tag[pos] = tag;
             }
             pos++;
@@ -137,9 +148,21 @@ k_cb_emit(const unsigned long long *__restrict__ bits, size_t nwords, const unsi
     }
 }
 
+extern "C" int s3d_k_compact_bits_base(const unsigned long long *d_bits, size_t nwords, uint32_t idx_base,
+                                       uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
+                                       uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream);
+
 extern "C" int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nwords, uint32_t *d_idx, uint32_t *d_tag,
                                   uint32_t tag, uint32_t capacity, uint32_t *d_count, uint32_t *d_scratch,
                                   s3d_stream stream)
+{
+    return s3d_k_compact_bits_base(d_bits, nwords, 0u, d_idx, d_tag, tag, capacity, d_count, d_scratch, stream);
+}
+
+/* as s3d_k_compact_bits, with bit i standing for voxel idx_base + i (bitmaps of a Z-slab) */
+extern "C" int s3d_k_compact_bits_base(const unsigned long long *d_bits, size_t nwords, uint32_t idx_base,
+                                       uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
+                                       uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (nwords == 0) return S3D_OK;
@@ -148,7 +171,8 @@ extern "C" int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nword
     S3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_cb_scan, dim3(1), dim3(256), 0, st, d_scratch, nb, d_count);
     S3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_cb_emit, dim3(nb), dim3(256), 0, st, d_bits, nwords, d_scratch, d_idx, d_tag, tag, capacity);
+    hipLaunchKernelGGL(k_cb_emit, dim3(nb), dim3(256), 0, st, d_bits, nwords, d_scratch, d_idx, d_tag, tag, capacity,
+                       idx_base);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
