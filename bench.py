@@ -7,9 +7,11 @@ A step = one pass of the hot path over one synthetic volume that is ALREADY RESI
 SIFT3D_detect_keypoints (copy + scale + 36 Gaussian applications + extrema + orientation; the small
 keypoint list is downloaded because the API returns it) followed by SIFT3D_extract_descriptors for
 every keypoint with the descriptors left in HBM.  At N = 1 the workload is BASELINE.json configs[1]:
-512^3 float32, "blobs+noise" generator, 128 000 blobs (31 207 keypoints).  At N > 1 every rank runs
-the same-shaped volume of its own (seed = rank): weak scaling, no data-path collective -- the
-Z-slab + RCCL-halo decomposition of one large volume is a later row of SURVEY.md section 8(e).
+512^3 float32, "blobs+noise" generator, 128 000 blobs (31 207 keypoints).  At N > 1 the workload is ONE
+512 x 512 x (512*N) volume sharded by Z-slab over the N GPUs (sift3d_amd/slab.py): 512 slices per GPU
+(weak scaling), halo planes exchanged with RCCL send/recv between Z-neighbours, all_reduce(max) for the
+scale and peak thresholds, all_gather for the replicated coarse octaves.
+`--replicas` runs one independent volume per rank instead.
 
 One JSON line on stdout (rank 0).  Besides the driver's contract it carries
   roofline      the fused X+Y Gaussian kernel at 512^3 (dominant kernel of the north-star Gaussian),
@@ -137,6 +139,97 @@ def cpu_baseline(sample_n=160):
     raise RuntimeError(f"cpu baseline worker failed (rc {r.returncode}): {r.stderr[-300:]}")
 
 
+def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
+    """N > 1: ONE volume of n x n x (n*N) voxels, Z-slab sharded over the N GPUs (sift3d_amd/slab.py):
+    per-GPU work is fixed (weak scaling), halos travel by RCCL send/recv between Z-neighbours."""
+    import torch
+    from sift3d_amd.slab import Comm, SlabSift3D
+    n = args.size
+    nz = n * world
+    comm = Comm(dist, stage_via_host=bool(os.environ.get("S3D_BENCH_SAME_GPU")))
+    sl = SlabSift3D(sift3d_amd.cdll(), f"cuda:{local_rank}", comm, n, n, nz)
+    z0, z1 = sl.part[0]
+    nblobs = synth.default_nblobs(n, n, nz)
+    t0 = time.perf_counter()
+    vol = torch.from_numpy(synth.blobs(n, n, nz, nblobs, seed=0, z0=z0, z1=z1)).to(f"cuda:{local_rank}")
+    log(f"[rank {rank}] slab z=[{z0},{z1}) of {n}x{n}x{nz} synthesised in {time.perf_counter() - t0:.1f} s")
+
+    def step():
+        sl.detect(vol)
+        return sl.describe()
+
+    for _ in range(args.warmup):
+        step()
+    full_sync()
+    t0 = time.perf_counter()
+    sl.detect(vol)
+    torch.cuda.synchronize()
+    t_detect = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sl.describe()
+    torch.cuda.synchronize()
+    t_describe = time.perf_counter() - t0
+    comm.bytes_exchanged = 0
+    full_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(len(sl.xyzos)), float(sl.num_candidates), float(comm.bytes_exchanged)],
+                     device="cuda", dtype=torch.float64)
+    tmax = t.clone()
+    if comm.stage:
+        tmax, t = tmax.cpu(), t.cpu()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax[0].item())
+    if rank == 0:
+        nvox = float(n) * n * nz
+        result = {
+            "metric": "Mvoxels/s detect+describe on 512^3 float32; 3D Gaussian achieved HBM GB/s vs roofline",
+            "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"one {n}x{n}x{nz} float32 blobs+noise volume ({nblobs} blobs), unit voxels, default "
+                                   f"SIFT3D parameters, Z-slab sharded: {n} slices per GPU; detect + describe all "
+                                   f"keypoints, slabs and descriptors resident in HBM",
+                       "keypoints": int(t[1].item()), "extrema_candidates": int(t[2].item()),
+                       "detect_ms": round(t_detect * 1e3, 3), "describe_ms": round(t_describe * 1e3, 3),
+                       "sharded_octaves": sl.o_shard + 1, "halo_planes": sl.H,
+                       "halo_MB_per_step_all_ranks": round(float(t[3].item()) / args.steps / 1e6, 1),
+                       "parallelism": f"Z-slab x{world}: RCCL send/recv halos between Z-neighbours, all_reduce(max) "
+                                      f"for the scale/peak thresholds, all_gather of the coarse-octave seed"},
+        }
+        if not args.no_roofline:
+            add_roofline(result, dev, n)
+        print(json.dumps(result), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def add_roofline(result, dev, n):
+    sig = [0.538701, 0.973294, 1.22627, 1.54501, 1.94659, 2.45255]      # default bank: widths 5..17
+    apps = gauss_roofline(dev, 512 if n >= 512 else n, sig)
+    worst = max(apps, key=lambda a: a["xy_ms"])                       # widest filter = slowest fused kernel
+    nv = float(512 if n >= 512 else n) ** 3
+    ach = GAUSS_XY_BYTES_PER_VOXEL * nv / (worst["xy_ms"] * 1e-3) / 1e9
+    # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE doubled per the
+    # gfx950 correction + WRITE_SIZE; profiles/pmc_gauss.json), valid for the 512^3 launch only
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_gauss.json")))
+        if int(nv) == int(pmc["voxels"]):
+            traffic = pmc["kernels"][f"k_gauss_xy<{worst['width'] // 2}>"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                          "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
+                                    f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
+    result["config"]["gauss_apps"] = apps
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-baseline-worker":
         _cpu_baseline_worker(int(sys.argv[2]))
@@ -148,6 +241,8 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="volume edge (default 512 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: one independent volume per rank instead of the Z-slab decomposition")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,8 +254,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("S3D_BENCH_SAME_GPU"):
+            # debugging aid for a 1-GPU box: all ranks share GPU 0, collectives staged through gloo
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = sift3d_amd.load()
     dev = sift3d_amd.load_device()
@@ -176,6 +277,9 @@ def main():
         dev.check(dev.L.s3d_rt_sync(None))
 
     n = args.size
+    if world > 1 and not args.replicas:
+        run_slab(args, dist, dev, rank, local_rank, world, full_sync)
+        return
     nblobs = synth.default_nblobs(n, n, n)            # 128 000 at 512^3
     t0 = time.perf_counter()
     vol = synth.blobs(n, n, n, nblobs, seed=rank)
@@ -241,25 +345,7 @@ def main():
                        "parallelism": "1 volume per GPU (weak), no data-path collective" if world > 1 else "1 GPU"},
         }
     if rank == 0 and not args.no_roofline:
-        sig = [0.538701, 0.973294, 1.22627, 1.54501, 1.94659, 2.45255]      # default bank: widths 5..17
-        apps = gauss_roofline(dev, 512 if n >= 512 else n, sig)
-        worst = max(apps, key=lambda a: a["xy_ms"])                       # widest filter = slowest fused kernel
-        nv = float(512 if n >= 512 else n) ** 3
-        ach = GAUSS_XY_BYTES_PER_VOXEL * nv / (worst["xy_ms"] * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE doubled per the
-        # gfx950 correction + WRITE_SIZE; profiles/pmc_gauss.json), valid for the 512^3 launch only
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_gauss.json")))
-            if int(nv) == int(pmc["voxels"]):
-                traffic = pmc["kernels"][f"k_gauss_xy<{worst['width'] // 2}>"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                              "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
-                                        f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
-        result["config"]["gauss_apps"] = apps
+        add_roofline(result, dev, n)
     if rank == 0 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline()
