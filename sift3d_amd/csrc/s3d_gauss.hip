@@ -79,6 +79,70 @@ k_conv_axis(const float *__restrict__ src, float *__restrict__ dst, size_t idx_b
     dst[idx] = acc;
 }
 
+/* Interior points for tap spacings of exactly 2^-O voxels (octave O of a unit-voxel volume): the
+ * sample positions p - d*2^-O are exact in f32, so lo = p + floor(-d/2^O) and frac = frac(-d/2^O) are
+ * compile-time constants per tap and the coordinate never drifts.  The 2*ceil(HW/2^O)+2 source values
+ * the taps touch are loaded once into registers (the generic loop issues 2 loads per tap: 34 vs 10
+ * for HW = 8, O = 1); every tap still evaluates (1-frac)*a + frac*b and accumulates in the reference's
+ * order, so the result is bit-identical.  Boundary points take the generic code. */
+template <int HW, int O>
+__global__ void __launch_bounds__(256)
+k_conv_axis_dyadic(const float *__restrict__ src, float *__restrict__ dst, size_t idx_begin, size_t idx_end,
+                   size_t sa, int n, S3dTaps taps)
+{
+    constexpr int D = 1 << O;
+    constexpr int UHW = (HW + D - 1) / D;
+    constexpr float UF = 1.0f / (float)D;
+    const size_t idx = idx_begin + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= idx_end) return;
+    const int p = (int)((idx / sa) % (size_t)n);
+    const float *s = src + (idx - (size_t)p * sa);
+    float acc = 0.0f;
+    if (p >= UHW && p <= n - 2 - UHW) {
+        float v[2 * UHW + 2];
+#pragma unroll
+        for (int m = 0; m < 2 * UHW + 2; m++) v[m] = s[(size_t)(p - UHW + m) * sa];
+#pragma unroll
+        for (int k = 0; k < 2 * HW + 1; k++) {
+            constexpr int BIAS = 64 * D;                       /* keeps the dividend positive */
+            const int num = HW - k;                            /* -d */
+            const int off = (num + BIAS) / D - 64;             /* floor(num / D) */
+            const float fr = (float)(num - off * D) * UF;
+            acc = acc + taps.t[k] * ((1.0f - fr) * v[off + UHW] + fr * v[off + UHW + 1]);
+        }
+    } else {
+        const int dim_end = n - 1;
+        for (int d = -HW; d <= HW; d++) {
+            const float tap = taps.t[d + HW];
+            const float step = (float)d * UF;
+            float coord = (float)p - step;
+            if ((int)coord < 0)
+                coord = -coord;
+            else if ((int)coord >= dim_end)
+                coord = 2.0f * (float)dim_end - coord - 0.1f;
+            const int lo = (int)coord;
+            const float frac = coord - (float)lo;
+            acc = acc + tap * ((1.0f - frac) * s[(size_t)lo * sa] + frac * s[(size_t)(lo + 1) * sa]);
+        }
+    }
+    dst[idx] = acc;
+}
+
+template <int O>
+static bool launch_dyadic(int hw, const float *src, float *dst, size_t ib, size_t ie, size_t sa, int n,
+                          const S3dTaps &t, hipStream_t st)
+{
+    const dim3 grid(s3d_div_up(ie - ib, 256)), block(256);
+    switch (hw) {
+#define S3D_DY(H) case H: hipLaunchKernelGGL((k_conv_axis_dyadic<H, O>), grid, block, 0, st, src, dst, ib, ie, sa, n, t); return true;
+    S3D_DY(1) S3D_DY(2) S3D_DY(3) S3D_DY(4) S3D_DY(5) S3D_DY(6) S3D_DY(7) S3D_DY(8) S3D_DY(9)
+#undef S3D_DY
+    default: return false;
+    }
+}
+
+static int g_no_dyadic = 0;      /* profiling / test knob: force the generic kernel */
+
 static int check_taps(const float *taps, int width, S3dTaps *out)
 {
     if (width < 1 || width > S3D_MAX_TAPS || !(width & 1)) S3D_FAIL("filter width must be odd and <= S3D_MAX_TAPS");
@@ -103,6 +167,16 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
     if (uhw >= dims[axis] - 1) S3D_FAIL("image too small for this filter along the axis");
     if (d_src == d_dst) S3D_FAIL("in-place axis pass is not supported");
     const size_t ib = strides[2] * (size_t)z0, ie = strides[2] * (size_t)z1;
+    if (nc == 1 && !g_no_dyadic) {
+        bool done = false;
+        if (uf == 0.5f) done = launch_dyadic<1>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
+        else if (uf == 0.25f) done = launch_dyadic<2>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
+        else if (uf == 0.125f) done = launch_dyadic<3>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
+        if (done) {
+            S3D_CHECK_LAUNCH();
+            return S3D_OK;
+        }
+    }
     hipLaunchKernelGGL(k_conv_axis, dim3(s3d_div_up(ie - ib, 256)), dim3(256), 0, (hipStream_t)st, d_src, d_dst, ib,
                        ie, strides[axis], dims[axis], hw, uf, uhw, t);
     S3D_CHECK_LAUNCH();
@@ -415,8 +489,9 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
 
 static int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk() */
 
-/* profiling knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower) */
-extern "C" void s3d_k_gauss_set_mode(int mode) { g_gauss_mode = mode; }
+/* profiling knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
+ * bit 1 = no dyadic-spacing specialisation of the generic axis pass */
+extern "C" void s3d_k_gauss_set_mode(int mode) { g_gauss_mode = mode; g_no_dyadic = (mode >> 1) & 1; }
 
 /* tuning knobs for profiling runs (rows / planes per marching chunk) */
 extern "C" void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z)

@@ -84,6 +84,18 @@ extern "C" void s3d_mesh_table(float *out)
 static int g_variant = 0;
 extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
 
+/* ---- small helpers ------------------------------------------------------------------------------- */
+/* exact unsigned division by a small divisor through the f32 reciprocal, with fix-up (a < 2^24) */
+__device__ __forceinline__ int fdiv_small(int a, int d, float inv, int *rem)
+{
+    int q = (int)((float)a * inv);
+    int r = a - q * d;
+    if (r < 0) { q--; r += d; }
+    else if (r >= d) { q++; r -= d; }
+    *rem = r;
+    return q;
+}
+
 /* ---- orientation ---------------------------------------------------------------------------------- */
 /* sigma table is per level for detected candidates, per candidate for the raw-image variant */
 __device__ __forceinline__ double d_sigma_sel(const double *d_sigma, bool per_cand, unsigned cand, int li)
@@ -140,11 +152,11 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
 
     const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
     /* one window sample: weight and iso gradient exactly as the reference evaluates them */
+    const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
     auto sample = [&](int b, float *gx, float *gy, float *gz, float *w) -> bool {
-        const int bz = b / (wx * wy);
-        const int r = b - bz * wx * wy;
-        const int by = r / wx;
-        const int bx = r - by * wx;
+        int r, bx;                                         /* window index -> offsets, without integer division */
+        const int bz = fdiv_small(b, wx * wy, inv_wxy, &r);
+        const int by = fdiv_small(r, wx, inv_wx, &bx);
         const int x = xs + bx, y = ys + by, z = zs + bz;
         const float dx = ((float)x - vcx) * uxf;
         const float dy = ((float)y - vcy) * uyf;
@@ -426,17 +438,6 @@ __device__ __forceinline__ double block_sum_f64(double v)
     for (int w = 0; w < DESC_WAVES; w++) r += part[w];
     __syncthreads();
     return r;
-}
-
-/* exact unsigned division by a small divisor through the f32 reciprocal, with fix-up (a < 2^24) */
-__device__ __forceinline__ int fdiv_small(int a, int d, float inv, int *rem)
-{
-    int q = (int)((float)a * inv);
-    int r = a - q * d;
-    if (r < 0) { q--; r += d; }
-    else if (r >= d) { q++; r -= d; }
-    *rem = r;
-    return q;
 }
 
 /* Per-keypoint geometry shared by the two phases */

@@ -412,7 +412,8 @@ class SlabSift3D:
         return K
 
     def keypoint_scales(self) -> np.ndarray:
-        return np.array([self.scale[o][s - self.first_level] for _, _, _, o, s in self.xyzos], np.float64)
+        tab = np.array(self.scale, np.float64)                    # [octave][level index]
+        return tab[self.xyzos[:, 3], self.xyzos[:, 4] - self.first_level]
 
     def describe(self) -> torch.Tensor:
         """Descriptors of this rank's keypoints: tensor [K, 776] on the device (768 bins + coordinate slots,
@@ -421,22 +422,22 @@ class SlabSift3D:
         out = torch.zeros(max(K, 1) * DESC_REC_FLOATS, dtype=torch.float32, device=self.dev)
         if K == 0:
             return out[:0].reshape(0, DESC_REC_FLOATS)
-        keys = (DescKey * K)()
+        # scalar set-up of extract_descrip (sift.c:1845-1851) in the reference's f32/f64 steps, vectorised
         sd = self.keypoint_scales()
-        for i in range(K):                       # scalar set-up of extract_descrip (sift.c:1845-1851), in f32
-            x, y, z, o, s = (int(v) for v in self.xyzos[i])
-            sigma = np.float32(sd[i] * 7.071067812)
-            rad = np.float32(2.0 * np.float64(sigma))
-            half = np.float32(np.float64(rad) / math.sqrt(2.0))
-            width = np.float32(2.0) * half
-            cell = width / np.float32(4)
-            k = keys[i]
-            k.cx, k.cy, k.cz = float(x), float(y), float(z)
-            k.sigma, k.rad, k.half, k.binf = sigma, rad, half, np.float32(1.0) / cell
-            k.level, k.octave = o * self.nl + (s - self.first_level), o
-            for j in range(9):
-                k.R[j] = self.R[i].reshape(-1)[j]
-        kb = torch.frombuffer(bytearray(bytes(keys)), dtype=torch.uint8).to(self.dev)
+        sigma = (sd * 7.071067812).astype(np.float32)
+        rad = (2.0 * sigma.astype(np.float64)).astype(np.float32)
+        half = (rad.astype(np.float64) / math.sqrt(2.0)).astype(np.float32)
+        cell = (np.float32(2.0) * half) / np.float32(4)
+        keys = np.zeros(K, dtype=np.dtype([("c", np.float32, 3), ("sigma", np.float32), ("rad", np.float32),
+                                           ("half", np.float32), ("binf", np.float32), ("level", np.int32),
+                                           ("octave", np.int32), ("R", np.float32, 9)]))
+        assert keys.dtype.itemsize == C.sizeof(DescKey)
+        keys["c"] = self.xyzos[:, :3].astype(np.float32)
+        keys["sigma"], keys["rad"], keys["half"], keys["binf"] = sigma, rad, half, np.float32(1.0) / cell
+        keys["level"] = self.xyzos[:, 3] * self.nl + (self.xyzos[:, 4] - self.first_level)
+        keys["octave"] = self.xyzos[:, 3]
+        keys["R"] = self.R.reshape(K, 9)
+        kb = torch.from_numpy(keys.view(np.uint8).reshape(-1)).to(self.dev)
         self._ck(self.L.s3d_k_describe(C.byref(self.pd), kb.data_ptr(), K, self.mesh.data_ptr(), out.data_ptr(),
                                        DESC_REC_FLOATS, None), "describe")
         self._ck(self.L.s3d_rt_sync(None), "sync")
