@@ -511,7 +511,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     g.r00 = key.R[0]; g.r01 = key.R[3]; g.r02 = key.R[6];
     g.r10 = key.R[1]; g.r11 = key.R[4]; g.r12 = key.R[7];
     g.r20 = key.R[2]; g.r21 = key.R[5]; g.r22 = key.R[8];
-    const float sig2 = key.sigma * key.sigma;
+    const float nhalf_inv_sig2 = -0.5f / (key.sigma * key.sigma);
     const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
 
     /* Fixed-point format of the histogram: value * 2^(40 - bexp), where 2^bexp exceeds the largest possible
@@ -544,7 +544,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
         /* window weight.  expf (<= 1 ulp), not the v_exp_f32 shortcut __expf: the latter pushed one
          * keypoint of the 64^3 golden case to 1e-2 relative error on the GPU (debug run, round 1). */
-        const float w = expf(-0.5f * sq / sig2);
+        const float w = expf(sq * nhalf_inv_sig2);           /* 1 ulp from -0.5f*sq/sig2: far inside 1e-4 */
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
         gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
@@ -589,29 +589,40 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
 
     unsigned head = 0;                                       /* uniform across the block */
     for (int b0 = 0; b0 < nbox; b0 += DESC_CHUNK) {
-        /* ---- phase A: each thread tests 4 consecutive voxels of the box, enqueues the accepted ---- */
+        /* ---- phase A: each thread tests 4 consecutive voxels of the box; the wave reserves queue space
+         * for all of them with ONE LDS atomic (ballots and prefix counts are register/scalar work) ---- */
         {
-            int b = b0 + 4 * tid;
+            constexpr int PER = DESC_CHUNK / DESC_THREADS;
+            int b = b0 + PER * tid;
             int r, bx = 0, by = 0, bz = 0;
             if (b < nbox) {
                 bz = fdiv_small(b, wx * wy, inv_wxy, &r);
                 by = fdiv_small(r, wx, inv_wx, &bx);
             }
+            unsigned packed[PER];
+            unsigned long long mask[PER];
+            unsigned total = 0;
 #pragma unroll
-            for (int j = 0; j < DESC_CHUNK / DESC_THREADS; j++, b++) {
+            for (int j = 0; j < PER; j++, b++) {
                 bool ok = false;
-                unsigned packed = 0;
+                packed[j] = 0;
                 if (b < nbox) {
                     float sq, vbx, vby, vbz;
                     ok = desc_window(g, g.xs + bx, g.ys + by, g.zs + bz, &sq, &vbx, &vby, &vbz);
-                    packed = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
+                    packed[j] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
                     if (++bx == wx) { bx = 0; if (++by == wy) { by = 0; bz++; } }
                 }
-                const unsigned long long mask = __ballot(ok ? 1 : 0);
-                unsigned base = 0;
-                if (lane == 0 && mask) base = atomicAdd(&qcount, (unsigned)__popcll(mask));
-                base = __shfl(base, 0);
-                if (ok) queue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = packed;
+                mask[j] = __ballot(ok ? 1 : 0);
+                total += (unsigned)__popcll(mask[j]);
+            }
+            unsigned base = 0;
+            if (lane == 0 && total) base = atomicAdd(&qcount, total);
+            base = __shfl(base, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                if ((mask[j] >> lane) & 1ull) queue[base + (unsigned)__popcll(mask[j] & below)] = packed[j];
+                base += (unsigned)__popcll(mask[j]);
             }
         }
         __syncthreads();
