@@ -125,8 +125,8 @@ typedef struct {
 } s3d_pyramid_desc;
 
 /* assign_eig_ori (sift.c:1354-1514) + assign_orientation_thresh (sift.c:1331-1342) for `num`
- * candidates with tag = o<<8 | (s - first_level).  Window centre: the voxel of linear index
- * d_idx[i] when d_center == NULL (detected candidates; d_sigma is then indexed per level,
+ * candidates with tag = o<<8 | (s - first_level) (d_tag == NULL: all in level 0).  Window centre: the
+ * voxel of linear index d_idx[i] (d_idx == NULL: voxel i, the dense case) when d_center == NULL (detected candidates; d_sigma is then indexed per level,
  * [o*num_levels + k], = 1.5 * level scale), else the float triple d_center[3i..] (raw-image
  * variant, sift.c:1534-1604; d_sigma is then per candidate).
  * Outputs: d_R[9*i] row-major rotation, d_keep[i] = 1 iff not rejected and conf >= corner_thresh,
@@ -175,6 +175,12 @@ void s3d_mesh_table(float *out);
 /* Gradient -> icosahedron barycentric weights into a zeroed 12-channel image (sift.c:2460-2480). */
 int s3d_k_dense_bary(const float *d_smooth, int nx, int ny, int nz, const float unitsf[3],
                      const float *d_mesh, float *d_out12, s3d_stream stream);
+/* dense_rotate = 1 (sift.c:2521-2588, 2295-2343): per-voxel sphere histogram of gradients rotated by the
+ * voxel's own orientation.  d_R / d_keep: output of s3d_k_orient run with one candidate per voxel
+ * (d_idx = d_tag = d_center = NULL); rejected voxels use the identity.  sigma = sigma0*7.0711/4. */
+int s3d_k_dense_rot_hist(const float *d_smooth, int nx, int ny, int nz, const float unitsf[3], double sigma,
+                         const float *d_R, const uint32_t *d_keep, const float *d_mesh, float *d_out12,
+                         s3d_stream stream);
 /* postproc_Hist per voxel (sift.c:2267-2292, 2396-2412): normalise, clamp, normalise, times in(x,y,z) */
 int s3d_k_dense_post(float *d_desc12, const float *d_in, size_t nvox, s3d_stream stream);
 

@@ -75,6 +75,7 @@ class Oracle:
                                           _f64p, _i32p, _f64p, _f32p, _f32p, _f64p]
         L.orc_smooth_scale_raw.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _f64p]
         L.orc_dense.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f32p]
+        L.orc_dense_rotate.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f64p, _f32p]
         L.orc_eig_ori.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f64p, _f32p, C.c_double, _f32p, _f64p]
         L.orc_icos_bin.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
         L.orc_eig3.argtypes = [_f64p, _f64p, _f64p]
@@ -198,6 +199,15 @@ class Oracle:
         out = np.empty((nz, ny, nx, 12), np.float32)
         if self.L.orc_dense(self.ctx, _p(v, _f32p), nx, ny, nz, _p(u, _f64p), _p(ou, _f64p), _p(out, _f32p)):
             raise RuntimeError("orc_dense failed")
+        return out
+
+    def dense_rotate(self, vol, units=(1., 1., 1.)):
+        v = np.ascontiguousarray(vol, np.float32)
+        nz, ny, nx = v.shape
+        u = np.asarray(units, np.float64)
+        out = np.empty((nz, ny, nx, 12), np.float32)
+        if self.L.orc_dense_rotate(self.ctx, _p(v, _f32p), nx, ny, nz, _p(u, _f64p), _p(out, _f32p)):
+            raise RuntimeError("orc_dense_rotate failed")
         return out
 
     def eig_ori(self, vol, units, vc, sigma):

@@ -889,3 +889,90 @@ done:
     free(sm); free(tmp12); free(scr12);
     return rc;
 }
+
+/* SIFT3D_extract_dense_descriptors with dense_rotate = 1: extract_dense_descriptors_rotate
+ * (sift.c:2521-2588) + extract_dense_descrip_rotate (sift.c:2295-2343), then the common
+ * post-processing (sift.c:2396-2412).  out: [nz][ny][nx][12]. */
+int orc_dense_rotate(const orc_ctx *c, const float *in, int nx, int ny, int nz, const double units[3], float *out)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    float *sm = (float *)malloc(sizeof(float) * n);
+    const double ori_sigma = c->sigma0 * 1.5;                      /* ori_sig_fctr */
+    const double desc_sigma = c->sigma0 * 7.071067812 / NHIST;
+    const float hist_trunc = (double)(0.2f * 128.0f / DESC_NUMEL) * DESC_NUMEL / NVERT;
+    level_t lv;
+    if (!sm) return ORC_FAIL;
+    if (orc_smooth_scale_raw(c, in, sm, nx, ny, nz, units)) { free(sm); return ORC_FAIL; }
+    lv.nx = nx; lv.ny = ny; lv.nz = nz; memcpy(lv.units, units, sizeof(lv.units)); lv.s = 0; lv.data = sm;
+    {
+        const float uxf = (float)units[0], uyf = (float)units[1], uzf = (float)units[2];
+        const float rad = 2.0 * desc_sigma;                        /* desc_rad_fctr * sigma -> float */
+        const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+        #pragma omp parallel for collapse(2) schedule(dynamic, 4)
+        for (int z = 0; z < nz; z++)
+            for (int y = 0; y < ny; y++)
+                for (int x = 0; x < nx; x++) {
+                    const float vc[3] = {(float)x, (float)y, (float)z};
+                    float R[9], Rt[9], h[NVERT];
+                    double conf;
+                    const int rej = eig_ori(&lv, vc, ori_sigma, R, &conf);
+                    if (rej || conf < c->corner_thresh) {          /* REJECT -> identity */
+                        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+                    }
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+                    for (int k = 0; k < NVERT; k++) h[k] = 0.0f;
+                    {
+                        const float fxs = floorf(vc[0] - rad / uxf), fxe = ceilf(vc[0] + rad / uxf);
+                        const float fys = floorf(vc[1] - rad / uyf), fye = ceilf(vc[1] + rad / uyf);
+                        const float fzs = floorf(vc[2] - rad / uzf), fze = ceilf(vc[2] + rad / uzf);
+                        const int xs = (int)(fxs > 1 ? fxs : 1), xe = (int)(fxe < nx - 2 ? fxe : nx - 2);
+                        const int ys = (int)(fys > 1 ? fys : 1), ye = (int)(fye < ny - 2 ? fye : ny - 2);
+                        const int zs = (int)(fzs > 1 ? fzs : 1), ze = (int)(fze < nz - 2 ? fze : nz - 2);
+                        for (int zz = zs; zz <= ze; zz++)
+                            for (int yy = ys; yy <= ye; yy++)
+                                for (int xx = xs; xx <= xe; xx++) {
+                                    const float dx = ((float)xx - vc[0]) * uxf;
+                                    const float dy = ((float)yy - vc[1]) * uyf;
+                                    const float dz = ((float)zz - vc[2]) * uzf;
+                                    const float sq = dx * dx + dy * dy + dz * dz;
+                                    const float *p = sm + (size_t)zz * sz + (size_t)yy * sy + xx;
+                                    vec3 g, gr, bary;
+                                    float mag, w;
+                                    int face;
+                                    if (sq > rad * rad) continue;
+                                    g.x = 0.5f * (p[1] - p[-1]);
+                                    g.y = 0.5f * (p[sy] - p[-(ptrdiff_t)sy]);
+                                    g.z = 0.5f * (p[sz] - p[-(ptrdiff_t)sz]);
+                                    g.x *= 1.0f / uxf; g.y *= 1.0f / uyf; g.z *= 1.0f / uzf;
+                                    gr.x = Rt[0] * g.x + Rt[1] * g.y + Rt[2] * g.z;
+                                    gr.y = Rt[3] * g.x + Rt[4] * g.y + Rt[5] * g.z;
+                                    gr.z = Rt[6] * g.x + Rt[7] * g.y + Rt[8] * g.z;
+                                    face = icos_bin(c->mesh, gr, &bary);
+                                    if (face < 0) continue;
+                                    mag = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+                                    w = expf(-0.5f * sq / (desc_sigma * desc_sigma));
+                                    h[c->mesh[face].idx[0]] += mag * w * bary.x;
+                                    h[c->mesh[face].idx[1]] += mag * w * bary.y;
+                                    h[c->mesh[face].idx[2]] += mag * w * bary.z;
+                                }
+                    }
+                    {   /* postproc_Hist, sift.c:2267-2292 */
+                        float *o = out + ((size_t)z * sz + (size_t)y * sy + x) * NVERT;
+                        const float val = in[(size_t)z * sz + (size_t)y * sy + x];
+                        for (int pass = 0; pass < 2; pass++) {
+                            double norm = 0.0;
+                            float inv;
+                            for (int k = 0; k < NVERT; k++) norm += (double)h[k] * h[k];
+                            norm = sqrt(norm) + DBL_EPSILON;
+                            inv = 1.0f / norm;
+                            for (int k = 0; k < NVERT; k++) h[k] *= inv;
+                            if (pass == 0)
+                                for (int k = 0; k < NVERT; k++) h[k] = h[k] < hist_trunc ? h[k] : hist_trunc;
+                        }
+                        for (int k = 0; k < NVERT; k++) o[k] = h[k] * val;
+                    }
+                }
+    }
+    free(sm);
+    return ORC_OK;
+}

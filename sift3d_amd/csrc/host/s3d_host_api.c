@@ -955,10 +955,42 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
     Gauss_filter gauss;
     float uf[3];
     int rc;
-    if (sift3d->dense_rotate) API_FAIL("sift3d_amd: dense_rotate is not implemented on the device (SURVEY row a14)");
     if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
         API_FAIL("sift3d_amd: out of device contexts");
     c = sift_ctx(sift3d);
+    if (sift3d->dense_rotate) {
+        /* extract_dense_descriptors_rotate (sift.c:2521-2588): per voxel an orientation (sigma = 1.5 sigma0,
+         * identity if rejected), then a sphere histogram of the gradients rotated by it.  Unlike the
+         * default path there is no blur, and `desc`'s units play no role. */
+        s3d_pyramid_desc pd;
+        const double ori_sigma = sift3d->gpyr.sigma0 * ori_sig_fctr;
+        float *d_R = NULL;
+        uint32_t *d_keep = NULL;
+        double *d_sig = NULL;
+        rc = SIFT3D_FAILURE;
+        if (n >= 0x7FFFFFFFull) API_FAIL("sift3d_amd: volume too large for dense_rotate");
+        if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n)) return SIFT3D_FAILURE;
+        if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units)) return SIFT3D_FAILURE;
+        memset(&pd, 0, sizeof(pd));
+        pd.num_octaves = 1; pd.num_levels = 1; pd.first_level = 0;
+        pd.dims[0][0] = nx; pd.dims[0][1] = ny; pd.dims[0][2] = nz;
+        pd.unitsf[0][0] = unitsf[0]; pd.unitsf[0][1] = unitsf[1]; pd.unitsf[0][2] = unitsf[2];
+        pd.d_level[0] = c->d_aux[1];
+        if (s3d_rt_malloc((void **)&d_R, n * 9 * sizeof(float)) == 0 &&
+            s3d_rt_malloc((void **)&d_keep, n * sizeof(uint32_t)) == 0 &&
+            s3d_rt_malloc((void **)&d_sig, sizeof(double)) == 0 &&
+            s3d_rt_h2d(d_sig, &ori_sigma, sizeof(double), c->stream) == 0 &&
+            s3d_k_orient(&pd, NULL, NULL, NULL, (uint32_t)n, d_sig, sift3d->corner_thresh, d_R, d_keep, NULL,
+                         c->stream) == 0 &&
+            s3d_k_dense_rot_hist(c->d_aux[1], nx, ny, nz, unitsf, sigma_win, d_R, d_keep, c->d_mesh, d_out,
+                                 c->stream) == 0 &&
+            s3d_k_dense_post(d_out, d_in, n, c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
+            rc = SIFT3D_SUCCESS;
+        else
+            S3D_MSG("sift3d_amd: dense_rotate failed: %s\n", s3d_rt_last_error());
+        s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_sig);
+        return rc;
+    }
     /* aux 1: smoothed input, aux 2: scratch (12 channels), aux 3: 12-channel barycentric image */
     if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n * HIST_NUMEL) || ctx_aux(c, 3, n * HIST_NUMEL))
         return SIFT3D_FAILURE;

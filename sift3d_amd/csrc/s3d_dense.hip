@@ -83,6 +83,91 @@ k_dense_post(float *__restrict__ desc, const float *__restrict__ in, size_t nvox
     q[2] = make_float4(h[8], h[9], h[10], h[11]);
 }
 
+/* ---- dense_rotate = 1 : extract_dense_descrip_rotate (sift.c:2295-2343) ------------------------------
+ * One wave per voxel: sphere of radius 2*sigma around it, gradients rotated by the voxel's own R^T
+ * (identity where orientation assignment rejected), mag * Gaussian weight * barycentric weights into a
+ * 12-bin histogram.  Bins are accumulated in 64-bit fixed point in LDS (integer atomics; exact and
+ * order independent), the reference sums in f32: differences ~1e-6 relative. */
+__global__ void __launch_bounds__(64)
+k_dense_rot_hist(const float *__restrict__ sm, int nx, int ny, int nz, float uxf, float uyf, float uzf,
+                 double sigma, const float *__restrict__ d_R, const uint32_t *__restrict__ d_keep,
+                 const float *__restrict__ mesh, float *__restrict__ out12)
+{
+    __shared__ unsigned long long h[S3D_NVERT];
+    const unsigned vox = blockIdx.x;
+    const int lane = threadIdx.x;
+    const unsigned plane = (unsigned)nx * (unsigned)ny;
+    const int cz = (int)(vox / plane);
+    const int cy = (int)((vox - (unsigned)cz * plane) / (unsigned)nx);
+    const int cx = (int)(vox - (unsigned)cz * plane - (unsigned)cy * (unsigned)nx);
+    if (lane < S3D_NVERT) h[lane] = 0ull;
+    s3d_wave_lds_sync();
+    float r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (d_keep[vox])
+        for (int i = 0; i < 9; i++) r[i] = d_R[(size_t)vox * 9 + i];
+    const float vcx = (float)cx, vcy = (float)cy, vcz = (float)cz;
+    const float rad = (float)(2.0 * sigma);                           /* desc_rad_fctr * sigma */
+    const double sig2 = sigma * sigma;
+    const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
+    int bexp;
+    (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);     /* |grad| < 2^bexp */
+    const float fscale = ldexpf(1.0f, 40 - bexp);
+    const float fxs = floorf(vcx - rad / uxf), fxe = ceilf(vcx + rad / uxf);
+    const float fys = floorf(vcy - rad / uyf), fye = ceilf(vcy + rad / uyf);
+    const float fzs = floorf(vcz - rad / uzf), fze = ceilf(vcz + rad / uzf);
+    const int xs = (int)(fxs > 1.0f ? fxs : 1.0f), xe = (int)(fxe < (float)(nx - 2) ? fxe : (float)(nx - 2));
+    const int ys = (int)(fys > 1.0f ? fys : 1.0f), ye = (int)(fye < (float)(ny - 2) ? fye : (float)(ny - 2));
+    const int zs = (int)(fzs > 1.0f ? fzs : 1.0f), ze = (int)(fze < (float)(nz - 2) ? fze : (float)(nz - 2));
+    const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
+    const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
+    for (int b = lane; b < nbox; b += 64) {
+        const int bz = b / (wx * wy);
+        const int rr = b - bz * wx * wy;
+        const int by = rr / wx;
+        const int bx = rr - by * wx;
+        const int x = xs + bx, y = ys + by, z = zs + bz;
+        const float dx = ((float)x - vcx) * uxf;
+        const float dy = ((float)y - vcy) * uyf;
+        const float dz = ((float)z - vcz) * uzf;
+        const float sq = dx * dx + dy * dy + dz * dz;
+        if (sq > rad * rad) continue;
+        const float *p = sm + ((size_t)z * plane + (size_t)y * nx + x);
+        V3 g;
+        g.x = 0.5f * (p[1] - p[-1]) * iux;
+        g.y = 0.5f * (p[nx] - p[-nx]) * iuy;
+        g.z = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]) * iuz;
+        V3 gr;                                                       /* Rt * g */
+        gr.x = r[0] * g.x + r[3] * g.y + r[6] * g.z;
+        gr.y = r[1] * g.x + r[4] * g.y + r[7] * g.z;
+        gr.z = r[2] * g.x + r[5] * g.y + r[8] * g.z;
+        V3 bary;
+        const int face = s3d_icos_bin_fast(mesh, gr, &bary);
+        if (face < 0) continue;
+        const float mag = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+        const float w = expf((float)((double)(-0.5f * sq) / sig2));
+        const float mw = mag * w;
+        const float *m = mesh + face * MESH_STRIDE;
+        atomicAdd(&h[__float_as_int(m[13])], (unsigned long long)(long long)(mw * bary.x * fscale));
+        atomicAdd(&h[__float_as_int(m[14])], (unsigned long long)(long long)(mw * bary.y * fscale));
+        atomicAdd(&h[__float_as_int(m[15])], (unsigned long long)(long long)(mw * bary.z * fscale));
+    }
+    s3d_wave_lds_sync();
+    if (lane < S3D_NVERT)
+        out12[(size_t)vox * S3D_NVERT + lane] = (float)((double)(long long)h[lane] * (1.0 / (double)fscale));
+}
+
+extern "C" int s3d_k_dense_rot_hist(const float *d_smooth, int nx, int ny, int nz, const float unitsf[3], double sigma,
+                                    const float *d_R, const uint32_t *d_keep, const float *d_mesh, float *d_out12,
+                                    s3d_stream st)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    if (nx < 1 || ny < 1 || nz < 1 || n >= 0x7FFFFFFFull) S3D_FAIL("volume too large for the dense-rotate grid");
+    hipLaunchKernelGGL(k_dense_rot_hist, dim3((unsigned)n), dim3(64), 0, (hipStream_t)st, d_smooth, nx, ny, nz,
+                       unitsf[0], unitsf[1], unitsf[2], sigma, d_R, d_keep, d_mesh, d_out12);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
 extern "C" int s3d_k_dense_post(float *d_desc12, const float *d_in, size_t nvox, s3d_stream st)
 {
     if (nvox == 0) return S3D_OK;

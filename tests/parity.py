@@ -162,6 +162,28 @@ def check_dense(lib, oracle, dims, units, out_units=(1, 1, 1), seed=5):
     assert nd == 0, f"dense: {nd} of {got.size} elements differ"
 
 
+def check_dense_rotate(lib, oracle, dims, units, seed=5):
+    """dense_rotate = 1 (sift.c:2521-2588).  Orientation decisions and R are reproduced exactly; the 12-bin
+    sphere histograms are integer-accumulated on the device vs sequential f32 in the reference -> 1e-4."""
+    nx, ny, nz = dims
+    vol = (synth.blobs(nx, ny, nz, max(8, nx * ny * nz // 300), seed) * 37.0 + 3.0).astype(np.float32)
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    s.dense_rotate = 1
+    im = lib.image_from_numpy(vol, units)
+    out = abi.Image()
+    lib.imutil.init_im(C.byref(out))
+    assert lib.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out)) == 0
+    got = lib.image_to_numpy(out)
+    want = oracle.dense_rotate(vol, units)
+    lib.free_image(im)
+    lib.free_image(out)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+    scale = np.abs(want).max()
+    ok = rel_close(got / scale, want / scale, rtol=1e-4, atol=1e-7)
+    assert ok.all(), f"dense_rotate: {(~ok).sum()} of {got.size} beyond tolerance, max abs {np.abs(got - want).max()}"
+
+
 def check_raw_variants(lib, oracle, dims, units, nblobs, seed=2):
     nx, ny, nz = dims
     vol = synth.blobs(nx, ny, nz, nblobs, seed)

@@ -58,5 +58,9 @@ def test_dense(emu, oracle):
     parity.check_dense(emu, oracle, (14, 13, 12), (1, 1, 2))
 
 
+def test_dense_rotate(emu, oracle):
+    parity.check_dense_rotate(emu, oracle, (16, 14, 12), (1, 1, 2))
+
+
 def test_raw_variants(emu, oracle):
     parity.check_raw_variants(emu, oracle, (32, 32, 32), (1, 1, 1), 40)

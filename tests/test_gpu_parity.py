@@ -141,6 +141,11 @@ def test_dense_vs_oracle(lib, oracle, dims, units, out_units):
     parity.check_dense(lib, oracle, dims, units, out_units)
 
 
+@pytest.mark.parametrize("dims,units", [((40, 36, 32), (1, 1, 1)), ((30, 28, 26), (1, 0.7, 1.3))])
+def test_dense_rotate_vs_oracle(lib, oracle, dims, units):
+    parity.check_dense_rotate(lib, oracle, dims, units)
+
+
 def test_dense_golden(lib):
     g = np.load(os.path.join(GOLDEN, "dense.npz"))
     nx, ny, nz = (int(v) for v in g["dims"])
