@@ -569,21 +569,19 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         const long long m0 = (long long)__float2int_rn(mag * bary.x * mscale);
         const long long m1 = (long long)__float2int_rn(mag * bary.y * mscale);
         const long long m2 = (long long)__float2int_rn(mag * bary.z * mscale);
-        /* the 8 cells, branch free: a cell index past the cube (reference: `continue`) gets weight 0 and
-         * is clamped onto a valid bin, so the wave never diverges here */
-        const float wxs[2] = {1.0f - dvx, ibx + 1 < 4 ? dvx : 0.0f}, wys[2] = {1.0f - dvy, iby + 1 < 4 ? dvy : 0.0f},
-                    wzs[2] = {1.0f - dvz, ibz + 1 < 4 ? dvz : 0.0f};
-        const int cxs[2] = {ibx, ibx + 1 < 4 ? ibx + 1 : 3}, cys[2] = {iby, iby + 1 < 4 ? iby + 1 : 3},
-                  czs[2] = {ibz, ibz + 1 < 4 ? ibz + 1 : 3};
+        const float wxs[2] = {1.0f - dvx, dvx}, wys[2] = {1.0f - dvy, dvy}, wzs[2] = {1.0f - dvz, dvz};
+        /* (a branch-free variant -- zero weight on a clamped bin -- measured 10 % slower: the skipped cells
+         * are worth more than the divergence costs) */
 #pragma unroll
         for (int ix = 0; ix < 2; ix++)
 #pragma unroll
             for (int iy = 0; iy < 2; iy++)
 #pragma unroll
                 for (int iz = 0; iz < 2; iz++) {
+                    const int cx = ibx + ix, cy = iby + iy, cz = ibz + iz;
+                    if (cx >= 4 || cy >= 4 || cz >= 4 || (variant & 4)) continue;   /* lower bounds hold: vb >= 0 */
                     const long long wt = (long long)__float2int_rn(wxs[ix] * wys[iy] * wzs[iz] * 16777216.0f);
-                    unsigned long long *hc = h + S3D_NVERT * (cxs[ix] + 4 * cys[iy] + 16 * czs[iz]);
-                    if (variant & 4) continue;               /* ablation: no LDS atomics */
+                    unsigned long long *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
                     atomicAdd(hc + i0, (unsigned long long)((m0 * wt) >> shift));
                     atomicAdd(hc + i1, (unsigned long long)((m1 * wt) >> shift));
                     atomicAdd(hc + i2, (unsigned long long)((m2 * wt) >> shift));
