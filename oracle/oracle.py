@@ -76,6 +76,7 @@ class Oracle:
         L.orc_smooth_scale_raw.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _f64p]
         L.orc_dense.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f32p]
         L.orc_dense_rotate.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f64p, _f32p]
+        L.orc_nn_match.argtypes = [_f32p, C.c_long, _f32p, C.c_long, C.c_float, _i32p]
         L.orc_eig_ori.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f64p, _f32p, C.c_double, _f32p, _f64p]
         L.orc_icos_bin.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
         L.orc_eig3.argtypes = [_f64p, _f64p, _f64p]
@@ -209,6 +210,14 @@ class Oracle:
         if self.L.orc_dense_rotate(self.ctx, _p(v, _f32p), nx, ny, nz, _p(u, _f64p), _p(out, _f32p)):
             raise RuntimeError("orc_dense_rotate failed")
         return out
+
+    def nn_match(self, d1, d2, nn_thresh=0.8):
+        a = np.ascontiguousarray(d1, np.float32)
+        b = np.ascontiguousarray(d2, np.float32)
+        m = np.zeros(a.shape[0], np.int32)
+        if self.L.orc_nn_match(_p(a, _f32p), a.shape[0], _p(b, _f32p), b.shape[0], nn_thresh, _p(m, _i32p)):
+            raise RuntimeError("orc_nn_match failed")
+        return m
 
     def eig_ori(self, vol, units, vc, sigma):
         v = np.ascontiguousarray(vol, np.float32)

@@ -976,3 +976,45 @@ int orc_dense_rotate(const orc_ctx *c, const float *in, int nx, int ny, int nz, 
     free(sm);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher -- SIFT3D_nn_match (sift.c:2840-2888) + match_desc (sift.c:2892-2969)  [SURVEY row f1]
+ * d1, d2: num x 768 floats.  matches[i] = index in d2 or -1.
+ * ---------------------------------------------------------------------------------------------- */
+static int orc_match_desc(const float *desc, const float *store, long num, float nn_thresh)
+{
+    double ssd_best = DBL_MAX, ssd_nearest = DBL_MAX;
+    long best = -1;
+    for (long i = 0; i < num; i++) {
+        const float *d2 = store + (size_t)i * DESC_NUMEL;
+        double ssd = 0.0;
+        for (int j = 0; j < NHIST * NHIST * NHIST; j++) {
+            for (int a = 0; a < NVERT; a++) {
+                const double diff = (double)desc[j * NVERT + a] - (double)d2[j * NVERT + a];
+                ssd += diff * diff;
+            }
+            if (ssd > ssd_nearest) break;                 /* early termination (does not change results) */
+        }
+        if (ssd < ssd_best) {
+            best = i;
+            ssd_nearest = ssd_best;
+            ssd_best = ssd;
+        } else {
+            ssd_nearest = ssd_nearest < ssd ? ssd_nearest : ssd;
+        }
+    }
+    if (ssd_best / ssd_nearest > nn_thresh * nn_thresh) return -1;
+    return (int)best;
+}
+
+int orc_nn_match(const float *d1, long n1, const float *d2, long n2, float nn_thresh, int *matches)
+{
+    if (n1 < 1) return ORC_FAIL;
+    #pragma omp parallel for schedule(dynamic, 8)
+    for (long i = 0; i < n1; i++) {
+        int m = orc_match_desc(d1 + (size_t)i * DESC_NUMEL, d2, n2, nn_thresh);
+        if (m >= 0 && orc_match_desc(d2 + (size_t)m * DESC_NUMEL, d1, n1, nn_thresh) != i) m = -1;
+        matches[i] = m;
+    }
+    return ORC_OK;
+}

@@ -217,6 +217,19 @@ class Sift3dLib:
         im.data = None
 
     @staticmethod
+    def descriptor_store_from_numpy(bins: np.ndarray, xyzs: np.ndarray | None = None):
+        """A SIFT3D_Descriptor_store over a numpy-owned buffer (returned too: keep it alive)."""
+        k = bins.shape[0]
+        raw = np.zeros((k, C.sizeof(SIFT3D_Descriptor)), np.uint8)
+        raw[:, :DESC_NUMEL * 4] = np.ascontiguousarray(bins, np.float32).view(np.uint8).reshape(k, -1)
+        if xyzs is not None:
+            raw[:, DESC_NUMEL * 4:] = np.ascontiguousarray(xyzs, np.float64).view(np.uint8).reshape(k, -1)
+        st = SIFT3D_Descriptor_store()
+        st.buf = C.cast(raw.ctypes.data, C.POINTER(SIFT3D_Descriptor))
+        st.num = k
+        return st, raw
+
+    @staticmethod
     def keypoints_to_numpy(kp: Keypoint_store):
         """Return (coords int64 [K,5] = x,y,z,o,s ; sd float64 [K] ; R float32 [K,3,3])."""
         k = int(kp.slab.num)
