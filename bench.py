@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="volume edge (default 512 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="skip the (untimed) matcher measurement")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one independent volume per rank instead of the Z-slab decomposition")
@@ -344,6 +345,15 @@ def main():
                        "detect_ms": round(t_detect * 1e3, 3), "describe_ms": round(t_describe * 1e3, 3),
                        "parallelism": "1 volume per GPU (weak), no data-path collective" if world > 1 else "1 GPU"},
         }
+    if rank == 0 and K and not args.no_match:
+        # row f1, outside the timed region: SIFT3D_nn_match of this volume's K descriptors against themselves
+        # (device resident; the cost does not depend on the data: 2 exhaustive K x K f64 SSD passes)
+        t0 = time.perf_counter()
+        m = dev.nn_match(d_desc.value, K, d_desc.value, K, 0.8)
+        t_match = time.perf_counter() - t0
+        flops = 2.0 * 3.0 * 768.0 * K * K          # forward + backward pass; sub, mul, add per element
+        result["config"]["match"] = {"pairs": K * K, "ms": round(t_match * 1e3, 2), "self_matches": int((m == np.arange(K)).sum()),
+                                     "fp64_TFLOPs": round(flops / t_match / 1e12, 2), "fp64_vector_peak_TFLOPs": 78.6}
     if rank == 0 and not args.no_roofline:
         add_roofline(result, dev, n)
     if rank == 0 and not args.no_cpu_baseline:

@@ -184,6 +184,14 @@ int s3d_k_dense_rot_hist(const float *d_smooth, int nx, int ny, int nz, const fl
 /* postproc_Hist per voxel (sift.c:2267-2292, 2396-2412): normalise, clamp, normalise, times in(x,y,z) */
 int s3d_k_dense_post(float *d_desc12, const float *d_in, size_t nvox, s3d_stream stream);
 
+/* ---- matcher (s3d_match.hip; replaces match_desc, sift.c:2892-2969) ------------------------------- */
+/* For each of the `na` query rows (row r = d_a + (d_a_sel ? d_a_sel[r] : r) * a_stride, 768 floats) the
+ * smallest and second-smallest f64 sum of squared differences over the nb rows of d_b and the index of
+ * the smallest (lowest index on ties).  Strides in floats, multiples of 4; rows 16-byte aligned. */
+int s3d_k_nn_best2(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b,
+                   size_t b_stride, uint32_t nb, double *d_best, double *d_second, int *d_idx,
+                   s3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,18 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
 int SIFT3D_extract_dense_descriptors(SIFT3D *const sift3d, const Image *const in,
                                      Image *const desc);                /* sift.c:2354 */
 
+/* Matching: exhaustive search on the device, bit-identical decisions. */
+int SIFT3D_nn_match(const SIFT3D_Descriptor_store *const d1, const SIFT3D_Descriptor_store *const d2,
+                    const float nn_thresh, int **const matches);        /* sift.c:2840 */
+int SIFT3D_matches_to_Mat_rm(SIFT3D_Descriptor_store *d1, SIFT3D_Descriptor_store *d2,
+                             const int *const matches, Mat_rm *const match1,
+                             Mat_rm *const match2);                      /* sift.c:2784 */
+int init_Mat_rm(Mat_rm *const mat, const int num_rows, const int num_cols, const Mat_rm_type type,
+                const int set_zero);                                     /* imutil.c:631 */
+int resize_Mat_rm(Mat_rm *const mat);                                    /* imutil.c:844 */
+int zero_Mat_rm(Mat_rm *const mat);                                      /* imutil.c:900 */
+void cleanup_Mat_rm(Mat_rm *mat);                                        /* imutil.c:962 */
+
 /* ======================= extensions (not in the reference) ========================================= */
 /* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */
 int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz,
@@ -255,6 +267,10 @@ int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog);
 /* Host-only: size the pyramid metadata and the Gaussian bank of `sift3d` for an nx x ny x nz volume as
  * SIFT3D_detect_keypoints would, without device work (used by the multi-GPU Z-slab driver). */
 int sift3d_amd_plan(SIFT3D *const sift3d, int nx, int ny, int nz, double ux, double uy, double uz);
+/* SIFT3D_nn_match on descriptors already in HBM (e.g. from sift3d_amd_extract_descriptors_dev): rows of
+ * 768 floats `stride` floats apart (multiple of 4); matches: host array of na ints. */
+int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const float *d_b, size_t b_stride,
+                            long nb, float nn_thresh, int *matches, void *hip_stream);
 /* Number of extrema candidates before orientation rejection in the last detect (diagnostics). */
 long sift3d_amd_last_num_candidates(const SIFT3D *const sift3d);
 /* Stream on which this SIFT3D's kernels run (opaque hipStream_t); set before the first detect. */

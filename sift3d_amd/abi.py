@@ -221,8 +221,9 @@ class Sift3dLib:
         """A SIFT3D_Descriptor_store over a numpy-owned buffer (returned too: keep it alive)."""
         k = bins.shape[0]
         raw = np.zeros((k, C.sizeof(SIFT3D_Descriptor)), np.uint8)
-        raw[:, :DESC_NUMEL * 4] = np.ascontiguousarray(bins, np.float32).view(np.uint8).reshape(k, -1)
-        if xyzs is not None:
+        if k:
+            raw[:, :DESC_NUMEL * 4] = np.ascontiguousarray(bins, np.float32).view(np.uint8).reshape(k, -1)
+        if xyzs is not None and k:
             raw[:, DESC_NUMEL * 4:] = np.ascontiguousarray(xyzs, np.float64).view(np.uint8).reshape(k, -1)
         st = SIFT3D_Descriptor_store()
         st.buf = C.cast(raw.ctypes.data, C.POINTER(SIFT3D_Descriptor))

@@ -20,8 +20,8 @@ OBJ = os.path.join(HERE, "lib", "obj")
 INC = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
-               "s3d_dense.hip"]
-C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c"]
+               "s3d_dense.hip", "s3d_match.hip"]
+C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]

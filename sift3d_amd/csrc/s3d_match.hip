@@ -14,6 +14,7 @@
  * re-used 64 times from LDS), so the kernel is FP64-ALU bound, not HBM bound.  MFMA is not usable:
  * the f64 MFMA shapes fuse multiply-add and reorder the sum, which would break bit-exactness.
  */
+#include <cfloat>
 #include "s3d_common.h"
 #include "../../include/s3d_device.h"
 

@@ -26,6 +26,8 @@ def bind_extensions(L: C.CDLL) -> None:
     L.sift3d_amd_last_num_candidates.argtypes = [P(abi.SIFT3D)]
     L.sift3d_amd_last_num_candidates.restype = C.c_long
     L.sift3d_amd_set_stream.argtypes = [P(abi.SIFT3D), _vp]
+    L.sift3d_amd_nn_match_dev.argtypes = [_vp, C.c_size_t, C.c_long, _vp, C.c_size_t, C.c_long, C.c_float,
+                                          P(C.c_int), _vp]
     L.sift3d_amd_last_error.restype = C.c_char_p
 
 
@@ -111,6 +113,15 @@ class DeviceLib:
         t = np.ascontiguousarray(taps, np.float32)
         self.check(self.L.s3d_k_conv_axis(_vp(d_src), _vp(d_dst), nx, ny, nz, nc, axis, t.ctypes.data_as(_f32p),
                                           t.size, float(uf), _vp(stream)), "s3d_k_conv_axis")
+
+    def nn_match(self, d_a: int, na: int, d_b: int, nb: int, thr: float = 0.8, stride: int = 768,
+                 stream=None) -> np.ndarray:
+        """SIFT3D_nn_match on device-resident descriptor rows (sift3d_amd_nn_match_dev)."""
+        m = np.empty(na, np.int32)
+        rc = self.L.sift3d_amd_nn_match_dev(d_a, stride, na, d_b, stride, nb, thr,
+                                            m.ctypes.data_as(C.POINTER(C.c_int)), stream)
+        self.check(rc, "sift3d_amd_nn_match_dev")
+        return m
 
     def mesh_table(self) -> np.ndarray:
         out = np.zeros(20 * 16, np.float32)

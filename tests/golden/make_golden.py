@@ -115,8 +115,35 @@ def main():
     np.savez_compressed(os.path.join(OUT, "dense.npz"), dims=np.array(dims), units=np.array(units, np.float64),
                         nblobs=np.array(30), seed=np.array(5), scale=np.array(37.0), offset=np.array(3.0),
                         input_sha256=np.array(sha(vol)), out=ref.image_to_numpy(out))
+    match_golden()
     print("done")
 
 
+def match_golden():
+    """5. matcher (SIFT3D_nn_match, sift.c:2840): the reference's matches for the iso64 descriptors against
+    a seeded perturbed/permuted copy with duplicates (ties) and distractors (tests/util.py:match_sets)."""
+    from tests.util import match_sets
+    g = np.load(os.path.join(OUT, "detect_iso64.npz"))
+    d1 = g["desc_bins"]
+    d = {"source": np.array("detect_iso64.desc_bins"), "thresholds": np.array([0.8, 0.95, 0.5], np.float32)}
+    ref.sift.SIFT3D_nn_match.argtypes = [C.POINTER(abi.SIFT3D_Descriptor_store),
+                                         C.POINTER(abi.SIFT3D_Descriptor_store), C.c_float,
+                                         C.POINTER(C.POINTER(C.c_int))]
+    for seed in (1, 2):
+        d2 = match_sets(d1, seed)
+        d[f"d2_sha256_{seed}"] = np.array(sha(d2))
+        for thr in d["thresholds"]:
+            sa, ra = abi.Sift3dLib.descriptor_store_from_numpy(d1)
+            sb, rb = abi.Sift3dLib.descriptor_store_from_numpy(d2)
+            m = C.POINTER(C.c_int)()
+            assert ref.sift.SIFT3D_nn_match(C.byref(sa), C.byref(sb), float(thr), C.byref(m)) == 0
+            d[f"matches_{seed}_{float(thr):.2f}"] = np.array([m[i] for i in range(d1.shape[0])], np.int32)
+            print("match seed", seed, "thr", thr, "matched", int((d[f"matches_{seed}_{float(thr):.2f}"] >= 0).sum()))
+    np.savez_compressed(os.path.join(OUT, "match.npz"), **d)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["match"]:
+        match_golden()
+    else:
+        main()

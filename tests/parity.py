@@ -209,3 +209,53 @@ def check_raw_variants(lib, oracle, dims, units, nblobs, seed=2):
             Ro, cf = np.eye(3, dtype=np.float32), -1.0
         assert np.abs(Ro - R3[i]).max() <= 1e-5 and abs(cf - conf[i]) <= 1e-6
     lib.sift.cleanup_SIFT3D(C.byref(s))
+
+
+def nn_match_api(lib, d1, d2, thr):
+    """SIFT3D_nn_match through the C API of `lib` on numpy descriptor sets."""
+    lib.sift.SIFT3D_nn_match.argtypes = [C.POINTER(abi.SIFT3D_Descriptor_store),
+                                         C.POINTER(abi.SIFT3D_Descriptor_store), C.c_float,
+                                         C.POINTER(C.POINTER(C.c_int))]
+    sa, ra = abi.Sift3dLib.descriptor_store_from_numpy(d1, np.arange(d1.shape[0] * 4, dtype=np.float64).reshape(-1, 4))
+    sb, rb = abi.Sift3dLib.descriptor_store_from_numpy(d2, -np.arange(d2.shape[0] * 4, dtype=np.float64).reshape(-1, 4))
+    m = C.POINTER(C.c_int)()
+    rc = lib.sift.SIFT3D_nn_match(C.byref(sa), C.byref(sb), thr, C.byref(m))
+    if rc != 0:
+        return rc, None, None
+    got = np.array([m[i] for i in range(d1.shape[0])], np.int32)
+    # coordinates of the matched pairs (SIFT3D_matches_to_Mat_rm, sift.c:2784)
+    lib.sift.SIFT3D_matches_to_Mat_rm.argtypes = [C.POINTER(abi.SIFT3D_Descriptor_store),
+                                                  C.POINTER(abi.SIFT3D_Descriptor_store), C.POINTER(C.c_int),
+                                                  C.POINTER(abi.Mat_rm), C.POINTER(abi.Mat_rm)]
+    lib.imutil.init_Mat_rm.argtypes = [C.POINTER(abi.Mat_rm), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.imutil.cleanup_Mat_rm.argtypes = [C.POINTER(abi.Mat_rm)]
+    lib.imutil.cleanup_Mat_rm.restype = None
+    m1, m2 = abi.Mat_rm(), abi.Mat_rm()
+    assert lib.imutil.init_Mat_rm(C.byref(m1), 0, 0, 0, 0) == 0
+    assert lib.imutil.init_Mat_rm(C.byref(m2), 0, 0, 0, 0) == 0
+    assert lib.sift.SIFT3D_matches_to_Mat_rm(C.byref(sa), C.byref(sb), m, C.byref(m1), C.byref(m2)) == 0
+    def mat(mm):
+        if mm.num_rows == 0:
+            return np.zeros((0, 3))
+        return np.ctypeslib.as_array(C.cast(mm.data, C.POINTER(C.c_double)), (mm.num_rows, mm.num_cols)).copy()
+    c1, c2 = mat(m1), mat(m2)
+    lib.imutil.cleanup_Mat_rm(C.byref(m1))
+    lib.imutil.cleanup_Mat_rm(C.byref(m2))
+    C.CDLL(None).free(C.cast(m, C.c_void_p))
+    return rc, got, (c1, c2)
+
+
+def check_nn_match(lib, oracle, n1, seed, thr=0.8, d1=None):
+    """Matches must equal the oracle's exactly (indices: integer work)."""
+    from tests.util import rand_desc, match_sets
+    d1 = rand_desc(n1, seed) if d1 is None else d1
+    d2 = match_sets(d1, seed + 100)
+    want = oracle.nn_match(d1, d2, thr)
+    rc, got, (c1, c2) = nn_match_api(lib, d1, d2, thr)
+    assert rc == 0
+    assert np.array_equal(got, want), (np.nonzero(got != want)[0][:10], (want >= 0).sum())
+    sel = np.nonzero(want >= 0)[0]
+    assert c1.shape == (len(sel), 3) and c2.shape == (len(sel), 3)
+    assert np.array_equal(c1, (sel[:, None] * 4 + np.arange(3)).astype(np.float64))
+    assert np.array_equal(c2, -(want[sel][:, None] * 4 + np.arange(3)).astype(np.float64))
+    return int((want >= 0).sum())

@@ -64,3 +64,19 @@ def test_dense_rotate(emu, oracle):
 
 def test_raw_variants(emu, oracle):
     parity.check_raw_variants(emu, oracle, (32, 32, 32), (1, 1, 1), 40)
+
+
+@pytest.mark.parametrize("n1,seed,thr", [(70, 1, 0.8), (9, 2, 0.95), (130, 3, 0.6)])
+def test_nn_match(emu, oracle, n1, seed, thr):
+    assert parity.check_nn_match(emu, oracle, n1, seed, thr) > 0
+
+
+def test_nn_match_empty_sets(emu):
+    from tests.util import rand_desc
+    d = rand_desc(5, 0)
+    rc, _, _ = parity.nn_match_api(emu, d[:0], d, 0.8)
+    assert rc != 0
+    rc, got, (c1, c2) = parity.nn_match_api(emu, d, d[:0], 0.8)
+    assert rc == 0 and (got == -1).all() and c1.shape[0] == 0
+    rc, got, _ = parity.nn_match_api(emu, d, d[:1], 0.8)
+    assert rc == 0 and list(got) == [0, -1, -1, -1, -1]

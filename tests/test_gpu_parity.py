@@ -163,6 +163,33 @@ def test_raw_variants(lib, oracle):
     parity.check_raw_variants(lib, oracle, (64, 64, 64), (1, 1, 2), 250)
 
 
+@pytest.mark.parametrize("n1,seed,thr", [(70, 1, 0.8), (9, 2, 0.95), (1000, 3, 0.8), (3001, 4, 0.7)])
+def test_nn_match_vs_oracle(lib, oracle, n1, seed, thr):
+    assert parity.check_nn_match(lib, oracle, n1, seed, thr) > 0
+
+
+def test_nn_match_golden(lib):
+    from tests.util import match_sets
+    g = np.load(os.path.join(GOLDEN, "match.npz"))
+    d1 = np.load(os.path.join(GOLDEN, "detect_iso64.npz"))["desc_bins"]
+    for seed in (1, 2):
+        d2 = match_sets(d1, seed)
+        for thr in g["thresholds"]:
+            rc, got, _ = parity.nn_match_api(lib, d1, d2, float(thr))
+            assert rc == 0 and np.array_equal(got, g[f"matches_{seed}_{float(thr):.2f}"])
+
+
+def test_nn_match_empty_sets(lib):
+    from tests.util import rand_desc
+    d = rand_desc(5, 0)
+    rc, _, _ = parity.nn_match_api(lib, d[:0], d, 0.8)      # d1 empty: failure (sift.c:2849)
+    assert rc != 0
+    rc, got, (c1, c2) = parity.nn_match_api(lib, d, d[:0], 0.8)   # d2 empty: no matches
+    assert rc == 0 and (got == -1).all() and c1.shape[0] == 0
+    rc, got, _ = parity.nn_match_api(lib, d, d[:1], 0.8)     # a single candidate always passes the ratio test
+    assert rc == 0 and list(got) == [0, -1, -1, -1, -1]
+
+
 def test_errors_like_the_reference(lib):
     s = abi.SIFT3D()
     assert lib.sift.init_SIFT3D(C.byref(s)) == 0

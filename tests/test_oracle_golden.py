@@ -84,3 +84,15 @@ def test_eig3_against_numpy(oracle):
         w, v = np.linalg.eigh(a)
         assert np.allclose(L, w, rtol=1e-12, atol=1e-13)
         assert np.allclose(np.abs(np.sum(Q * v, axis=0)), 1.0, atol=1e-9)
+
+
+def test_nn_match(oracle):
+    """Matcher (sift.c:2840): the restatement reproduces the reference's match indices."""
+    from tests.util import match_sets
+    g = np.load(os.path.join(GOLDEN, "match.npz"))
+    d1 = np.load(os.path.join(GOLDEN, "detect_iso64.npz"))["desc_bins"]
+    for seed in (1, 2):
+        d2 = match_sets(d1, seed)
+        assert sha(d2) == str(g[f"d2_sha256_{seed}"]), "match_sets drifted"
+        for thr in g["thresholds"]:
+            assert np.array_equal(oracle.nn_match(d1, d2, float(thr)), g[f"matches_{seed}_{float(thr):.2f}"])

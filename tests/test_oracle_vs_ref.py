@@ -49,3 +49,14 @@ def test_detect_describe_live(oracle, reference, dims, units, nblobs, seed):
     b2, c2 = oracle.describe(x2[:, :3].astype(np.float64), x2[:, 3:5], sd2, R2)
     assert nbitdiff(b, b2) == 0 and np.array_equal(c, c2)
     reference.sift.cleanup_SIFT3D(C.byref(s))
+
+
+@pytest.mark.parametrize("n1,seed,thr", [(150, 1, 0.8), (40, 2, 0.95)])
+def test_nn_match_live(oracle, reference, n1, seed, thr):
+    from tests import parity
+    from tests.util import rand_desc, match_sets
+    d1 = rand_desc(n1, seed)
+    d2 = match_sets(d1, seed + 100)
+    rc, want, _ = parity.nn_match_api(reference, d1, d2, thr)
+    assert rc == 0
+    assert np.array_equal(oracle.nn_match(d1, d2, thr), want)
