@@ -42,6 +42,16 @@ extern "C" {
 #define DESC_NUM_TOTAL_HIST (NHIST_PER_DIM * NHIST_PER_DIM * NHIST_PER_DIM)
 #define DESC_NUMEL (DESC_NUM_TOTAL_HIST * HIST_NUMEL)
 
+/* Return codes of im_read / im_write (imutil.h:20-31) and parse_gnu (imtypes.h:23-24) */
+#define SIFT3D_FILE_DOES_NOT_EXIST 1
+#define SIFT3D_UNSUPPORTED_FILE_TYPE 2
+#define SIFT3D_WRAPPER_NOT_COMPILED 3
+#define SIFT3D_HELP 1
+#define SIFT3D_VERSION 2
+
+/* Image file formats (imtypes.h:101-108) */
+typedef enum _im_format { ANALYZE, DICOM, DIRECTORY, NIFTI, UNKNOWN, FILE_ERROR } im_format;
+
 typedef enum _Mat_rm_type { SIFT3D_DOUBLE, SIFT3D_FLOAT, SIFT3D_INT } Mat_rm_type;
 
 /* Row-major dense matrix (imtypes.h:136-149). Only the 3x3 float `Keypoint.R` is used here. */
@@ -245,6 +255,30 @@ int init_Mat_rm(Mat_rm *const mat, const int num_rows, const int num_cols, const
 int resize_Mat_rm(Mat_rm *const mat);                                    /* imutil.c:844 */
 int zero_Mat_rm(Mat_rm *const mat);                                      /* imutil.c:900 */
 void cleanup_Mat_rm(Mat_rm *mat);                                        /* imutil.c:962 */
+
+/* Formats and command-line surface either side of the path. */
+im_format im_get_format(const char *path);                               /* imutil.c:1158 */
+int im_read(const char *path, Image *const im);                          /* imutil.c:1215 (.nii, .nii.gz, .img/.hdr) */
+int im_write(const char *path, const Image *const im);                   /* imutil.c:1262 (.nii, .nii.gz) */
+int read_nii(const char *path, Image *const im);                         /* nifti.c:51 */
+int write_nii(const char *path, const Image *const im);                  /* nifti.c:167 */
+int write_Mat_rm(const char *path, const Mat_rm *const mat);             /* imutil.c:1343 */
+int im_channel(const Image *const src, Image *const dst, const unsigned int chan); /* imutil.c:1893 */
+int draw_points(const Mat_rm *const in, const int *const dims, int radius,
+                Image *const out);                                       /* imutil.c:1012 */
+int Keypoint_store_to_Mat_rm(const Keypoint_store *const kp, Mat_rm *const mat);          /* sift.c:2597 */
+int SIFT3D_Descriptor_store_to_Mat_rm(const SIFT3D_Descriptor_store *const store,
+                                      Mat_rm *const mat);                /* sift.c:2674 */
+int Mat_rm_to_SIFT3D_Descriptor_store(const Mat_rm *const mat,
+                                      SIFT3D_Descriptor_store *const store); /* sift.c:2721 */
+int write_Keypoint_store(const char *path, const Keypoint_store *const kp);               /* sift.c:3143 */
+int write_SIFT3D_Descriptor_store(const char *path,
+                                  const SIFT3D_Descriptor_store *const desc);             /* sift.c:3206 */
+void print_opts_SIFT3D(void);                                            /* sift.c:703 */
+int parse_args_SIFT3D(SIFT3D *const sift3d, const int argc, char **argv,
+                      const int check_err);                              /* sift.c:754 */
+int parse_gnu(const int argc, char *const *argv);                        /* imutil.c:4891 */
+void print_bug_msg(void);                                                /* imutil.c:4925 */
 
 /* ======================= extensions (not in the reference) ========================================= */
 /* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */

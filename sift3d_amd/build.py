@@ -21,7 +21,9 @@ INC = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
                "s3d_dense.hip", "s3d_match.hip"]
-C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c"]
+C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c"]
+BIN = os.path.join(HERE, "bin")
+CLI_PROGRAMS = ["kpSift3D", "denseSift3D"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]
@@ -69,12 +71,20 @@ def build(verbose: bool = False) -> str:
     if any(_newer(o, out) for o in objs):
         # -Bsymbolic: the library's own calls to init_im & co bind to itself even if another libimutil
         # (e.g. the reference oracle in a test process) is loaded.
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", out, *objs, "-lm",
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", out, *objs, "-lm", "-lz",
               "-lpthread"])
     synth = os.path.join(LIB, "libs3d_synth.so")
     ssrc = os.path.join(CSRC, "synth.c")
     if _newer(ssrc, synth):
         _run(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-o", synth, ssrc, "-lm"])
+    # command-line programs with the reference's argument surface (cli/*.c), linked against the library
+    os.makedirs(BIN, exist_ok=True)
+    for prog in CLI_PROGRAMS:
+        src = os.path.join(ROOT, "cli", prog + ".c")
+        exe = os.path.join(BIN, prog)
+        if _newer(src, exe, (out, os.path.join(INC, "sift3d_amd.h"))):
+            _run(["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", f"-I{INC}", "-o", exe, src, f"-L{LIB}", "-lsift3d_amd",
+                  "-lm", "-Wl,-rpath,$ORIGIN/../lib"])
     return out
 
 
