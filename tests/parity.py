@@ -259,3 +259,39 @@ def check_nn_match(lib, oracle, n1, seed, thr=0.8, d1=None):
     assert np.array_equal(c1, (sel[:, None] * 4 + np.arange(3)).astype(np.float64))
     assert np.array_equal(c2, -(want[sel][:, None] * 4 + np.arange(3)).astype(np.float64))
     return int((want >= 0).sum())
+
+
+def check_two_volume_match(lib, oracle, dims, units, nblobs, seed, shift=(2, 1, 0), thr=0.8):
+    """BASELINE config 4 in miniature: detect + describe two related anisotropic volumes, then
+    SIFT3D_nn_match.  Keypoints of both volumes must equal the oracle's; the match indices must equal the
+    oracle matcher's on the very descriptors the library produced (integer work: exact)."""
+    nx, ny, nz = dims
+    a = synth.blobs(nx, ny, nz, nblobs, seed)
+    b = np.roll(a, shift, axis=(2, 1, 0)).copy()
+    b += 0.02 * synth.blobs(nx, ny, nz, max(nblobs // 10, 1), seed + 1)
+    stores, descs = [], []
+    for vol in (a, b):
+        want_xyzos, want_sd, _ = oracle.detect(vol, units)
+        s, im, kp = run_detect(lib, vol, units)
+        xyzos, sd, R = lib.keypoints_to_numpy(kp)
+        assert np.array_equal(xyzos, want_xyzos) and np.array_equal(sd, want_sd)
+        d = abi.SIFT3D_Descriptor_store()
+        lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+        assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        stores.append((s, im, kp, d))
+        descs.append(lib.descriptors_to_numpy(d)[0])
+    lib.sift.SIFT3D_nn_match.argtypes = [C.POINTER(abi.SIFT3D_Descriptor_store),
+                                         C.POINTER(abi.SIFT3D_Descriptor_store), C.c_float,
+                                         C.POINTER(C.POINTER(C.c_int))]
+    m = C.POINTER(C.c_int)()
+    assert lib.sift.SIFT3D_nn_match(C.byref(stores[0][3]), C.byref(stores[1][3]), thr, C.byref(m)) == 0
+    got = np.array([m[i] for i in range(descs[0].shape[0])], np.int32)
+    want = oracle.nn_match(descs[0], descs[1], thr)
+    assert np.array_equal(got, want)
+    C.CDLL(None).free(C.cast(m, C.c_void_p))
+    for s, im, kp, d in stores:
+        lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+        lib.sift.cleanup_Keypoint_store(C.byref(kp))
+        lib.free_image(im)
+        lib.sift.cleanup_SIFT3D(C.byref(s))
+    return int((want >= 0).sum()), len(want)

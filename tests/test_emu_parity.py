@@ -80,3 +80,8 @@ def test_nn_match_empty_sets(emu):
     assert rc == 0 and (got == -1).all() and c1.shape[0] == 0
     rc, got, _ = parity.nn_match_api(emu, d, d[:1], 0.8)
     assert rc == 0 and list(got) == [0, -1, -1, -1, -1]
+
+
+def test_two_volume_match(emu, oracle):
+    nm, n = parity.check_two_volume_match(emu, oracle, (30, 28, 24), (1, 1, 1.5), 120, 4)
+    assert n >= 2

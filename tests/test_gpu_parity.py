@@ -159,6 +159,12 @@ def test_dense_golden(lib):
     assert nbitdiff(lib.image_to_numpy(out), g["out"]) == 0
 
 
+def test_two_volume_match_anisotropic(lib, oracle):
+    """BASELINE config 4 (two anisotropic volumes: detect + describe + match) at a size the oracle finishes."""
+    nm, n = parity.check_two_volume_match(lib, oracle, (96, 80, 64), (1, 1, 1.5), 500, 21)
+    assert nm >= 10 and n >= 50
+
+
 def test_raw_variants(lib, oracle):
     parity.check_raw_variants(lib, oracle, (64, 64, 64), (1, 1, 2), 250)
 
