@@ -211,6 +211,19 @@ class Oracle:
             raise RuntimeError("orc_dense_rotate failed")
         return out
 
+    def describe_window_stats(self, xyz, os_, sd, R):
+        """(count, checksum) of the voxels accepted by the descriptor window test, per keypoint."""
+        k = len(sd)
+        cnt = np.zeros(k, np.int64)
+        chk = np.zeros(k, np.uint32)
+        self.L.orc_set_window_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orc_set_window_stats(cnt.ctypes.data, chk.ctypes.data)
+        try:
+            self.describe(xyz, os_, sd, R)
+        finally:
+            self.L.orc_set_window_stats(None, None)
+        return cnt, chk
+
     def nn_match(self, d1, d2, nn_thresh=0.8):
         a = np.ascontiguousarray(d1, np.float32)
         b = np.ascontiguousarray(d2, np.float32)

@@ -694,9 +694,17 @@ static void normalize768(float *b)
     for (int i = 0; i < DESC_NUMEL; i++) b[i] *= inv;
 }
 
+/* Optional per-keypoint window statistics of the last orc_describe (test aid): number of voxels that pass
+ * the window test and a checksum of their box-relative coordinates. */
+static long *g_win_count;
+static uint32_t *g_win_chk;
+void orc_set_window_stats(long *count, uint32_t *chk) { g_win_count = count; g_win_chk = chk; }
+
 static void descrip(const orc_ctx *c, const level_t *im, const double kxyz[3], double sd, int o,
-                    const float R[9], float *bins /*768*/, double out_xyzs[4])
+                    const float R[9], float *bins /*768*/, double out_xyzs[4], long slot)
 {
+    long wcount = 0;
+    uint32_t wchk = 0;
     const float sigma = sd * 7.071067812;               /* desc_sig_fctr */
     const float rad = 2.0 * sigma;                      /* desc_rad_fctr */
     const float half = rad / sqrt(2);
@@ -736,6 +744,8 @@ static void descrip(const orc_ctx *c, const level_t *im, const double kxyz[3], d
                 bx = (kx + half) * binf; by = (ky + half) * binf; bz = (kz + half) * binf;
                 if (bx < 0 || by < 0 || bz < 0 || bx >= (float)NHIST || by >= (float)NHIST ||
                     bz >= (float)NHIST) continue;
+                wcount++;
+                wchk += ((uint32_t)(x - xs) | ((uint32_t)(y - ys) << 10) | ((uint32_t)(z - zs) << 20)) * 2654435761u;
                 gx = 0.5f * (p[1] - p[-1]);
                 gy = 0.5f * (p[sy] - p[-(ptrdiff_t)sy]);
                 gz = 0.5f * (p[sz] - p[-(ptrdiff_t)sz]);
@@ -767,6 +777,7 @@ static void descrip(const orc_ctx *c, const level_t *im, const double kxyz[3], d
     normalize768(bins);
     for (int i = 0; i < DESC_NUMEL; i++) bins[i] = bins[i] < trunc ? bins[i] : trunc;
     normalize768(bins);
+    if (g_win_count && slot >= 0) { g_win_count[slot] = wcount; g_win_chk[slot] = wchk; }
     out_xyzs[0] = kxyz[0] * coord_factor; out_xyzs[1] = kxyz[1] * coord_factor;
     out_xyzs[2] = kxyz[2] * coord_factor; out_xyzs[3] = sd;
 }
@@ -790,7 +801,7 @@ int orc_describe(orc_ctx *c, long num, const double *xyz /*num x 3*/, const int3
     #pragma omp parallel for schedule(dynamic, 1)
     for (long i = 0; i < num; i++)
         descrip(c, gl(c, os[2 * i], os[2 * i + 1]), xyz + 3 * i, sd[i], os[2 * i], R + 9 * i,
-                bins + (size_t)DESC_NUMEL * i, xyzs + 4 * i);
+                bins + (size_t)DESC_NUMEL * i, xyzs + 4 * i, i);
     return ORC_OK;
 }
 
@@ -804,7 +815,7 @@ int orc_describe_volume(orc_ctx *c, const float *vol, int nx, int ny, int nz, co
     l.nx = nx; l.ny = ny; l.nz = nz; memcpy(l.units, units, sizeof(l.units)); l.s = 0; l.data = (float *)vol;
     #pragma omp parallel for schedule(dynamic, 1)
     for (long i = 0; i < num; i++)
-        descrip(c, &l, xyz + 3 * i, sd[i], o[i], R + 9 * i, bins + (size_t)DESC_NUMEL * i, xyzs + 4 * i);
+        descrip(c, &l, xyz + 3 * i, sd[i], o[i], R + 9 * i, bins + (size_t)DESC_NUMEL * i, xyzs + 4 * i, i);
     return ORC_OK;
 }
 

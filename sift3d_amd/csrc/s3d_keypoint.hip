@@ -79,6 +79,7 @@ extern "C" void s3d_mesh_table(float *out)
  *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
  *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
  *   bit 3: k_describe skips phase B entirely (window tests + queue only)
+ *   bit 4: k_describe returns (count, checksum) of the accepted window voxels instead of a descriptor
  *   bit 4: k_orient always takes the ordered-sum pass (timing of the bound-based shortcut)
  *   bit 7 / bit 8: 2 / 8 histogram copies per block instead of 4 */
 static int g_variant = 0;
@@ -416,8 +417,8 @@ extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d
 /* ---- descriptor ------------------------------------------------------------------------------------ */
 #define DESC_THREADS 256
 #define DESC_WAVES (DESC_THREADS / 64)
-#define DESC_CHUNK 1024                    /* box voxels tested per round (4 per thread) */
-#define DESC_QUEUE (DESC_CHUNK + DESC_THREADS)
+#define DESC_PER 4                         /* window voxels expanded per thread and sub-round */
+#define DESC_QUEUE (DESC_PER * DESC_THREADS)
 
 __device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n, int *s, int *e)
 {
@@ -464,13 +465,20 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
     return !(*vbx < 0 || *vby < 0 || *vbz < 0 || *vbx >= 4.0f || *vby >= 4.0f || *vbz >= 4.0f);
 }
 
-/* One workgroup per keypoint.  Two alternating phases keep the expensive part divergence free:
- *   A  every thread runs the cheap window test on 4 voxels of the bounding box and the accepted ones
- *      (~1/3) are appended, via wave ballots, to an LDS queue of packed voxel offsets;
- *   B  while the queue holds >= 256 entries, all 256 lanes each take one accepted voxel: gradient,
- *      Gaussian weight, rotation, icosahedron face + barycentric weights, trilinear spread over 8 cells
- *      x 3 vertices into LDS histograms with ds_add_f32.
- * The tail of the queue is carried into the next round, so lanes idle only once, at the very end.
+/* One workgroup per keypoint.  The window (sphere of radius rad intersected with the rotated 4x4x4 cell
+ * cube, sift.c:1869-1884) is convex, so along every x-row of the bounding box the accepted voxels form ONE
+ * interval.  Rounds of 256 rows:
+ *   A1  one thread per row: the interval from the closed form (sphere chord, three slab constraints),
+ *       then trimmed / extended by the reference's own float test at its two ends -- the accepted set is
+ *       exactly the reference's, but only ~4 voxels per row are tested instead of the whole row (the
+ *       per-voxel test of all 1.9e5-7.5e5 box voxels was a third of this kernel);
+ *   A2  block scan of the interval lengths -> every accepted voxel of the round gets a dense id;
+ *   A3  sub-rounds of 1024 ids: each thread finds the row of its 4 consecutive ids (binary search in the
+ *       LDS prefix array) and writes the packed voxel offsets to an LDS queue;
+ *   B   all 256 lanes each take one queued voxel (x-consecutive lanes: coalesced gathers): gradient,
+ *       Gaussian weight, rotation, icosahedron face + barycentric weights, trilinear spread over 8 cells
+ *       x 3 vertices into the LDS histograms.
+ * Lanes idle only in the last batch of a round.
  *
  * Histogram arithmetic.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on gfx950 whatever the address
  * pattern (measured, scripts/ubench_lds.hip) -- it was 88 % of this kernel -- while the integer LDS
@@ -490,14 +498,18 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ float mesh[S3D_MESH_FLOATS];
     __shared__ unsigned queue[DESC_QUEUE];
-    __shared__ unsigned qcount;
+    __shared__ unsigned seg_first[DESC_THREADS];
+    __shared__ int seg_off[DESC_THREADS + 1];
+    __shared__ int wave_tot[DESC_WAVES];
+    __shared__ unsigned win_chk;
+    unsigned win_count = 0;
     const unsigned kid = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     if (kid >= num) return;
     const s3d_desc_key key = keys[kid];
     for (int i = tid; i < NCOPY * HSTRIDE; i += DESC_THREADS) hist[i] = 0ull;
     for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
-    if (tid == 0) qcount = 0;
+    if (tid == 0) win_chk = 0;
     __syncthreads();
 
     const int o = key.octave;
@@ -527,8 +539,6 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
     desc_bounds(key.cz, key.rad, g.uzf, nz, &g.zs, &ze);
     const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
-    const int nbox = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wx * wy * wz : 0;
-    const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
     unsigned long long *h = hist + (lane & (NCOPY - 1)) * HSTRIDE;
 
     /* phase B body: one accepted voxel (single call site: this is the bulk of the kernel's code) */
@@ -588,62 +598,103 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
                 }
     };
 
-    unsigned head = 0;                                       /* uniform across the block */
-    for (int b0 = 0; b0 < nbox; b0 += DESC_CHUNK) {
-        /* ---- phase A: each thread tests 4 consecutive voxels of the box; the wave reserves queue space
-         * for all of them with ONE LDS atomic (ballots and prefix counts are register/scalar work) ---- */
-        {
-            constexpr int PER = DESC_CHUNK / DESC_THREADS;
-            int b = b0 + PER * tid;
-            int r, bx = 0, by = 0, bz = 0;
-            if (b < nbox) {
-                bz = fdiv_small(b, wx * wy, inv_wxy, &r);
-                by = fdiv_small(r, wx, inv_wx, &bx);
-            }
-            unsigned packed[PER];
-            unsigned long long mask[PER];
-            unsigned total = 0;
+    /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
+    const float slab_hi = 4.0f / g.binf - g.half;
+    const float a0 = g.r00 * g.uxf, a1 = g.r10 * g.uxf, a2 = g.r20 * g.uxf;
+    const int nrows = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wy * wz : 0;
+    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
+    for (int r0 = 0; r0 < nrows; r0 += DESC_THREADS) {
+        /* ---- A1: this thread's row ---- */
+        int len = 0;
+        unsigned first = 0;
+        if (r0 + tid < nrows) {
+            int by;
+            const int bz = fdiv_small(r0 + tid, wy, inv_wy, &by);
+            const int y = g.ys + by, z = g.zs + bz;
+            const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
+            const float s2 = g.rad2 - dy * dy - dz * dz;
+            const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) / g.uxf;
+            float lo_f = s2 < -1e-3f * g.rad2 ? 1.0f : -chord, hi_f = s2 < -1e-3f * g.rad2 ? -1.0f : chord;
+            const float c0 = g.r01 * dy + g.r02 * dz, c1 = g.r11 * dy + g.r12 * dz, c2 = g.r21 * dy + g.r22 * dz;
+            const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2};
 #pragma unroll
-            for (int j = 0; j < PER; j++, b++) {
-                bool ok = false;
-                packed[j] = 0;
-                if (b < nbox) {
-                    float sq, vbx, vby, vbz;
-                    ok = desc_window(g, g.xs + bx, g.ys + by, g.zs + bz, &sq, &vbx, &vby, &vbz);
-                    packed[j] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)bz << 20);
-                    if (++bx == wx) { bx = 0; if (++by == wy) { by = 0; bz++; } }
+            for (int i = 0; i < 3; i++)
+                if (fabsf(av[i]) > 1e-6f) {                      /* else: left to the exact tests below */
+                    const float t0 = (-g.half - cv[i]) / av[i], t1 = (slab_hi - cv[i]) / av[i];
+                    lo_f = fmaxf(lo_f, fminf(t0, t1));
+                    hi_f = fminf(hi_f, fmaxf(t0, t1));
                 }
-                mask[j] = __ballot(ok ? 1 : 0);
-                total += (unsigned)__popcll(mask[j]);
+            int lo = (int)ceilf(g.cx + lo_f - 1e-3f), hi = (int)floorf(g.cx + hi_f + 1e-3f);
+            lo = lo > g.xs ? lo : g.xs;
+            hi = hi < xe ? hi : xe;
+            auto inside = [&](int x) {
+                float sq, vx, vy, vz;
+                return desc_window(g, x, y, z, &sq, &vx, &vy, &vz);
+            };
+            while (lo <= hi && !inside(lo)) lo++;
+            while (lo <= hi && !inside(hi)) hi--;
+            if (lo <= hi) {
+                while (lo > g.xs && inside(lo - 1)) lo--;
+                while (hi < xe && inside(hi + 1)) hi++;
+                len = hi - lo + 1;
+                first = (unsigned)(lo - g.xs) | ((unsigned)by << 10) | ((unsigned)bz << 20);
             }
-            unsigned base = 0;
-            if (lane == 0 && total) base = atomicAdd(&qcount, total);
-            base = __shfl(base, 0);
-            const unsigned long long below = (1ull << lane) - 1ull;
+        }
+        /* ---- A2: exclusive scan of the lengths over the block ---- */
+        int incl = len;
 #pragma unroll
-            for (int j = 0; j < PER; j++) {
-                if ((mask[j] >> lane) & 1ull) queue[base + (unsigned)__popcll(mask[j] & below)] = packed[j];
-                base += (unsigned)__popcll(mask[j]);
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl(incl, lane >= d ? lane - d : lane);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < (tid >> 6); w++) before += wave_tot[w];
+        seg_first[tid] = first;
+        seg_off[tid] = before + incl - len;
+        if (tid == DESC_THREADS - 1) seg_off[DESC_THREADS] = before + incl;
+        __syncthreads();
+        const int total = seg_off[DESC_THREADS];
+        win_count += (unsigned)total;
+        for (int sub = 0; sub < total; sub += DESC_QUEUE) {
+            /* ---- A3: ids sub + 4*tid .. +3 -> packed voxel offsets ---- */
+            int id = sub + DESC_PER * tid;
+            if (id < total) {
+                int sg = 0;
+#pragma unroll
+                for (int step = DESC_THREADS / 2; step; step >>= 1)
+                    if (seg_off[sg + step] <= id) sg += step;       /* last row starting at or before id */
+                unsigned fv = seg_first[sg] + (unsigned)(id - seg_off[sg]);
+                int end = seg_off[sg + 1];
+#pragma unroll
+                for (int j = 0; j < DESC_PER; j++, id++, fv++) {
+                    if (id >= total) break;
+                    while (id >= end) {                               /* next non-empty row */
+                        sg++;
+                        fv = seg_first[sg];
+                        end = seg_off[sg + 1];
+                    }
+                    queue[DESC_PER * tid + j] = fv;
+                }
             }
+            __syncthreads();
+            /* ---- B ---- */
+            const int nq = total - sub < DESC_QUEUE ? total - sub : DESC_QUEUE;
+            if (variant & 16) {                                       /* test aid: checksum of the accepted set */
+                for (int k = tid; k < nq; k += DESC_THREADS) atomicAdd(&win_chk, queue[k] * 2654435761u);
+            } else if (!(variant & 8)) {
+                for (int k = tid; k < nq; k += DESC_THREADS) accumulate(queue[k]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        /* ---- phase B: drain full batches; on the last round also the partial one ---- */
-        const unsigned cnt = qcount;
-        const bool last = b0 + DESC_CHUNK >= nbox;
-        while (cnt - head >= DESC_THREADS || (last && cnt > head)) {
-            const unsigned nb = cnt - head < DESC_THREADS ? cnt - head : DESC_THREADS;
-            if ((unsigned)tid < nb && !(variant & 8)) accumulate(queue[head + tid]);
-            head += nb;
+    }
+    if (variant & 16) {              /* bit 4: out[0..1] = bit patterns of (count, checksum) of the window set */
+        if (tid == 0) {
+            out[(size_t)kid * out_stride] = __uint_as_float(win_count);
+            out[(size_t)kid * out_stride + 1] = __uint_as_float(win_chk);
         }
-        /* carry the tail (< 256 entries) to the front of the queue */
-        const unsigned rem = cnt - head;
-        unsigned e = 0;
-        if ((unsigned)tid < rem) e = queue[head + tid];
-        __syncthreads();
-        if ((unsigned)tid < rem) queue[tid] = e;
-        if (tid == 0) qcount = rem;
-        head = 0;
-        __syncthreads();
+        return;
     }
     /* merge the histogram copies (integers: order free), then normalise / clamp / normalise */
     float v[S3D_DESC_NUMEL / DESC_THREADS];

@@ -85,3 +85,9 @@ def test_nn_match_empty_sets(emu):
 def test_two_volume_match(emu, oracle):
     nm, n = parity.check_two_volume_match(emu, oracle, (30, 28, 24), (1, 1, 1.5), 120, 4)
     assert n >= 2
+
+
+@pytest.mark.parametrize("dims,units,nblobs,seed", [((26, 24, 22), (1, 1, 1), 60, 1), ((30, 22, 20), (1, 0.8, 2), 70, 4)])
+def test_describe_window_set(emu, oracle, dims, units, nblobs, seed):
+    k, nvox = parity.check_describe_window(emu, oracle, dims, units, nblobs, seed)
+    assert k >= 1 and nvox > 1000

@@ -159,6 +159,12 @@ def test_dense_golden(lib):
     assert nbitdiff(lib.image_to_numpy(out), g["out"]) == 0
 
 
+@pytest.mark.parametrize("dims,units,nblobs,seed", [((96, 96, 96), (1, 1, 1), 800, 2), ((90, 80, 64), (1, 0.8, 2), 500, 5)])
+def test_describe_window_set(lib, oracle, dims, units, nblobs, seed):
+    k, nvox = parity.check_describe_window(lib, oracle, dims, units, nblobs, seed)
+    assert k >= 50 and nvox > 1e6
+
+
 def test_two_volume_match_anisotropic(lib, oracle):
     """BASELINE config 4 (two anisotropic volumes: detect + describe + match) at a size the oracle finishes."""
     nm, n = parity.check_two_volume_match(lib, oracle, (96, 80, 64), (1, 1, 1.5), 500, 21)
