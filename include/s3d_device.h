@@ -156,7 +156,9 @@ typedef struct {
 /* extract_descrip (sift.c:1834-1928) incl. SIFT3D_desc_acc_interp (sift.c:1687-1791),
  * icos_hist_bin/cart2bary (sift.c:1646-1683, 335-394) and both normalisations (sift.c:1794-1821).
  * d_mesh: table from s3d_mesh_table().  Descriptor i is written to d_out[i*out_stride .. +768),
- * order 12*(cx+4cy+16cz)+vertex (out_stride = 776 lays records out like SIFT3D_Descriptor). */
+ * order 12*(cx+4cy+16cz)+vertex (out_stride = 776 lays records out like SIFT3D_Descriptor).
+ * The level buffers in pyr must be readable for 16 bytes past their last voxel (wide gathers;
+ * s3d_rt_malloc adds the slack itself). */
 int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
                    const float *d_mesh, float *d_out, size_t out_stride /* floats, >= 768 */,
                    s3d_stream stream);

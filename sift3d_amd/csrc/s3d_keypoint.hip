@@ -78,7 +78,7 @@ extern "C" void s3d_mesh_table(float *out)
 /* Ablation knob for profiling runs ONLY (results are wrong for any value but 0):
  *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
  *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
- *   bit 3: k_describe skips phase B entirely (window tests + queue only)
+ *   bit 3: k_describe skips phase B entirely (row intervals + scan only)
  *   bit 4: k_describe returns (count, checksum) of the accepted window voxels instead of a descriptor
  *   bit 4: k_orient always takes the ordered-sum pass (timing of the bound-based shortcut)
  *   bit 7 / bit 8: 2 / 8 histogram copies per block instead of 4 */
@@ -417,8 +417,14 @@ extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d
 /* ---- descriptor ------------------------------------------------------------------------------------ */
 #define DESC_THREADS 256
 #define DESC_WAVES (DESC_THREADS / 64)
-#define DESC_PER 4                         /* window voxels expanded per thread and sub-round */
-#define DESC_QUEUE (DESC_PER * DESC_THREADS)
+#define DESC_PER 4                         /* x-consecutive window voxels per chunk (one thread, one turn) */
+#if defined(__clang__)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   /* dword-aligned wide loads */
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#else                                      /* the g++ emulator build of the test suite */
+struct f4u { float x, y, z, w; };
+struct f2u { float x, y; };
+#endif
 
 __device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n, int *s, int *e)
 {
@@ -440,6 +446,10 @@ __device__ __forceinline__ double block_sum_f64(double v)
     __syncthreads();
     return r;
 }
+
+/* value of the low 24 bits as a signed number: tells the compiler both factors of a product fit
+ * v_mul_i32_i24 / v_mul_hi_i32_i24 (the shifts themselves fold away) */
+__device__ __forceinline__ int sext24(int v) { return (int)((unsigned)v << 8) >> 8; }
 
 /* Per-keypoint geometry shared by the two phases */
 struct DescGeom {
@@ -472,13 +482,14 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  *       then trimmed / extended by the reference's own float test at its two ends -- the accepted set is
  *       exactly the reference's, but only ~4 voxels per row are tested instead of the whole row (the
  *       per-voxel test of all 1.9e5-7.5e5 box voxels was a third of this kernel);
- *   A2  block scan of the interval lengths -> every accepted voxel of the round gets a dense id;
- *   A3  sub-rounds of 1024 ids: each thread finds the row of its 4 consecutive ids (binary search in the
- *       LDS prefix array) and writes the packed voxel offsets to an LDS queue;
- *   B   all 256 lanes each take one queued voxel (x-consecutive lanes: coalesced gathers): gradient,
- *       Gaussian weight, rotation, icosahedron face + barycentric weights, trilinear spread over 8 cells
- *       x 3 vertices into the LDS histograms.
- * Lanes idle only in the last batch of a round.
+ *   A2  block scan of the intervals' chunk counts (a chunk = 4 x-consecutive voxels of one row);
+ *   B   every thread takes whole chunks (row found by binary search in the LDS prefix array): lanes sit
+ *       16 bytes apart along x, so the six neighbour gathers of 4 voxels are five dwordx4 + one dwordx2 per
+ *       lane over contiguous memory; then per voxel: Gaussian weight, rotation, icosahedron face +
+ *       barycentric weights, trilinear spread over 8 cells x 3 vertices into the LDS histograms.  With
+ *       lanes 4 voxels apart a wave's 64 voxels straddle many cells, which also thins the same-address
+ *       collisions of the atomics (x-neighbours share cell and face).
+ * There is no voxel queue and no block barrier inside B: waves drift apart freely within a round.
  *
  * Histogram arithmetic.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on gfx950 whatever the address
  * pattern (measured, scripts/ubench_lds.hip) -- it was 88 % of this kernel -- while the integer LDS
@@ -497,11 +508,11 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     constexpr int HSTRIDE = S3D_DESC_NUMEL + 1;
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ float mesh[S3D_MESH_FLOATS];
-    __shared__ unsigned queue[DESC_QUEUE];
     __shared__ unsigned seg_first[DESC_THREADS];
+    __shared__ unsigned short seg_len[DESC_THREADS];
     __shared__ int seg_off[DESC_THREADS + 1];
     __shared__ int wave_tot[DESC_WAVES];
-    __shared__ unsigned win_chk;
+    __shared__ unsigned win_chk, win_vox;
     unsigned win_count = 0;
     const unsigned kid = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -509,7 +520,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     const s3d_desc_key key = keys[kid];
     for (int i = tid; i < NCOPY * HSTRIDE; i += DESC_THREADS) hist[i] = 0ull;
     for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
-    if (tid == 0) win_chk = 0;
+    if (tid == 0) { win_chk = 0; win_vox = 0; }
     __syncthreads();
 
     const int o = key.octave;
@@ -539,18 +550,14 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
     desc_bounds(key.cz, key.rad, g.uzf, nz, &g.zs, &ze);
     const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
-    unsigned long long *h = hist + (lane & (NCOPY - 1)) * HSTRIDE;
+    const unsigned hbase = (unsigned)(lane & (NCOPY - 1)) * HSTRIDE;
 
-    /* phase B body: one accepted voxel (single call site: this is the bulk of the kernel's code) */
-    auto accumulate = [&](unsigned packed) {
-        const int x = g.xs + (int)(packed & 1023u), y = g.ys + (int)((packed >> 10) & 1023u),
-                  z = g.zs + (int)(packed >> 20);
+    /* phase B body: one accepted voxel, its central differences already in registers (single call site:
+     * this is the bulk of the kernel's code) */
+    auto accumulate = [&](int x, int y, int z, float gx, float gy, float gz) {
         float sq, vbx, vby, vbz;
         desc_window(g, x, y, z, &sq, &vbx, &vby, &vbz);
-        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
-        float gx = 0.5f * (p[1] - p[-1]);
-        float gy = 0.5f * (p[nx] - p[-nx]);
-        float gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
+        gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
         /* window weight.  expf (<= 1 ulp), not the v_exp_f32 shortcut __expf: the latter pushed one
          * keypoint of the 64^3 golden case to 1e-2 relative error on the GPU (debug run, round 1). */
@@ -567,18 +574,23 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
         const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
         const float *m = mesh + face * MESH_STRIDE;
-        const int i0 = __float_as_int(m[13]), i1 = __float_as_int(m[14]), i2 = __float_as_int(m[15]);
-        /* contribution = (mag*bary_v) * wt, formed exactly in integers: the first factor rounded to 30
+        /* LDS word offsets of the three vertex bins of the base cell (32-bit index arithmetic only) */
+        const unsigned cell0 = hbase + (unsigned)(S3D_NVERT * (ibx + 4 * iby + 16 * ibz));
+        const unsigned o0 = cell0 + (unsigned)__float_as_int(m[13]), o1 = cell0 + (unsigned)__float_as_int(m[14]),
+                       o2 = cell0 + (unsigned)__float_as_int(m[15]);
+        /* contribution = (mag*bary_v) * wt, formed exactly in integers: the first factor rounded to 23
          * significant bits at the sample's own exponent (gradients are 100-1000x below the bound, a
-         * fixed scale would waste those bits), the trilinear weight to 2^-24, the 64-bit product
-         * shifted to the common format.  mag >= 1.09e-3 (icos_bin's floor), so the shift is <= 31. */
+         * fixed scale would waste those bits), the trilinear weight to 2^-22, both inside the signed
+         * 24-bit range so that the 46-bit product is two full-rate instructions (v_mul_i32_i24 /
+         * v_mul_hi_i32_i24; a general 64-bit multiply is quarter rate), then shifted to the common
+         * format.  mag >= 1.09e-3 (icos_bin's floor), so 4 <= shift <= 15 + bexp. */
         int em;
         (void)frexpf(mag, &em);                                       /* mag < 2^em <= 2^bexp */
-        const float mscale = ldexpf(1.0f, 29 - em);
-        const int shift = 13 - em + bexp;
-        const long long m0 = (long long)__float2int_rn(mag * bary.x * mscale);
-        const long long m1 = (long long)__float2int_rn(mag * bary.y * mscale);
-        const long long m2 = (long long)__float2int_rn(mag * bary.z * mscale);
+        const float mscale = ldexpf(1.0f, 22 - em);
+        const int shift = 4 - em + bexp;
+        const int m0 = sext24(__float2int_rn(mag * bary.x * mscale));
+        const int m1 = sext24(__float2int_rn(mag * bary.y * mscale));
+        const int m2 = sext24(__float2int_rn(mag * bary.z * mscale));
         const float wxs[2] = {1.0f - dvx, dvx}, wys[2] = {1.0f - dvy, dvy}, wzs[2] = {1.0f - dvz, dvz};
         /* (a branch-free variant -- zero weight on a clamped bin -- measured 10 % slower: the skipped cells
          * are worth more than the divergence costs) */
@@ -588,13 +600,13 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
             for (int iy = 0; iy < 2; iy++)
 #pragma unroll
                 for (int iz = 0; iz < 2; iz++) {
-                    const int cx = ibx + ix, cy = iby + iy, cz = ibz + iz;
-                    if (cx >= 4 || cy >= 4 || cz >= 4 || (variant & 4)) continue;   /* lower bounds hold: vb >= 0 */
-                    const long long wt = (long long)__float2int_rn(wxs[ix] * wys[iy] * wzs[iz] * 16777216.0f);
-                    unsigned long long *hc = h + S3D_NVERT * (cx + 4 * cy + 16 * cz);
-                    atomicAdd(hc + i0, (unsigned long long)((m0 * wt) >> shift));
-                    atomicAdd(hc + i1, (unsigned long long)((m1 * wt) >> shift));
-                    atomicAdd(hc + i2, (unsigned long long)((m2 * wt) >> shift));
+                    if (ibx + ix >= 4 || iby + iy >= 4 || ibz + iz >= 4 || (variant & 4)) continue;   /* vb >= 0 holds */
+                    /* w in [0,1]: the mantissa of w + 2 is round(w * 2^22) (bit 23 of the pattern is 0) */
+                    const int wt = sext24(__float_as_int(wxs[ix] * wys[iy] * wzs[iz] + 2.0f));
+                    const unsigned dc = (unsigned)(S3D_NVERT * (ix + 4 * iy + 16 * iz));      /* compile-time */
+                    atomicAdd(&hist[o0 + dc], (unsigned long long)(((long long)m0 * (long long)wt) >> shift));
+                    atomicAdd(&hist[o1 + dc], (unsigned long long)(((long long)m1 * (long long)wt) >> shift));
+                    atomicAdd(&hist[o2 + dc], (unsigned long long)(((long long)m2 * (long long)wt) >> shift));
                 }
     };
 
@@ -640,8 +652,9 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
                 first = (unsigned)(lo - g.xs) | ((unsigned)by << 10) | ((unsigned)bz << 20);
             }
         }
-        /* ---- A2: exclusive scan of the lengths over the block ---- */
-        int incl = len;
+        /* ---- A2: exclusive scan of the chunk counts (4 voxels per chunk) over the block ---- */
+        const int nchunk = (len + DESC_PER - 1) / DESC_PER;
+        int incl = nchunk;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl(incl, lane >= d ? lane - d : lane);
@@ -652,46 +665,55 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         int before = 0;
         for (int w = 0; w < (tid >> 6); w++) before += wave_tot[w];
         seg_first[tid] = first;
-        seg_off[tid] = before + incl - len;
+        seg_len[tid] = (unsigned short)len;
+        seg_off[tid] = before + incl - nchunk;
         if (tid == DESC_THREADS - 1) seg_off[DESC_THREADS] = before + incl;
         __syncthreads();
         const int total = seg_off[DESC_THREADS];
-        win_count += (unsigned)total;
-        for (int sub = 0; sub < total; sub += DESC_QUEUE) {
-            /* ---- A3: ids sub + 4*tid .. +3 -> packed voxel offsets ---- */
-            int id = sub + DESC_PER * tid;
-            if (id < total) {
-                int sg = 0;
+        win_count += (unsigned)total;                         /* (chunks; the test aid counts voxels below) */
+        /* ---- B: one chunk (<= 4 x-consecutive voxels of one row) per thread and turn.  Lanes are 16 bytes
+         * apart along x, so the wave's gathers are five dwordx4 and one dwordx2 over contiguous memory. ---- */
+        for (int c = tid; c < total; c += DESC_THREADS) {
+            int sg = 0;
 #pragma unroll
-                for (int step = DESC_THREADS / 2; step; step >>= 1)
-                    if (seg_off[sg + step] <= id) sg += step;       /* last row starting at or before id */
-                unsigned fv = seg_first[sg] + (unsigned)(id - seg_off[sg]);
-                int end = seg_off[sg + 1];
-#pragma unroll
-                for (int j = 0; j < DESC_PER; j++, id++, fv++) {
-                    if (id >= total) break;
-                    while (id >= end) {                               /* next non-empty row */
-                        sg++;
-                        fv = seg_first[sg];
-                        end = seg_off[sg + 1];
-                    }
-                    queue[DESC_PER * tid + j] = fv;
-                }
+            for (int step = DESC_THREADS / 2; step; step >>= 1)
+                if (seg_off[sg + step] <= c) sg += step;            /* last row starting at or before chunk c */
+            const unsigned fv = seg_first[sg];
+            const int q = c - seg_off[sg];
+            const int nval = (int)seg_len[sg] - DESC_PER * q < DESC_PER ? (int)seg_len[sg] - DESC_PER * q : DESC_PER;
+            const int x0 = g.xs + (int)(fv & 1023u) + DESC_PER * q, y = g.ys + (int)((fv >> 10) & 1023u),
+                      z = g.zs + (int)(fv >> 20);
+            if (variant & 16) {                                       /* test aid: count + checksum of the set */
+                for (int j = 0; j < nval; j++)
+                    atomicAdd(&win_chk, ((unsigned)(x0 + j - g.xs) | (fv & ~1023u)) * 2654435761u);
+                atomicAdd(&win_vox, (unsigned)nval);
+                continue;
             }
-            __syncthreads();
-            /* ---- B ---- */
-            const int nq = total - sub < DESC_QUEUE ? total - sub : DESC_QUEUE;
-            if (variant & 16) {                                       /* test aid: checksum of the accepted set */
-                for (int k = tid; k < nq; k += DESC_THREADS) atomicAdd(&win_chk, queue[k] * 2654435761u);
-            } else if (!(variant & 8)) {
-                for (int k = tid; k < nq; k += DESC_THREADS) accumulate(queue[k]);
+            if (variant & 8) continue;
+            const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
+            /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
+             * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
+            const f2u xa = *(const f2u *)(p - 1);
+            const f4u xb = *(const f4u *)(p + 1);
+            const f4u ym = *(const f4u *)(p - nx), yp = *(const f4u *)(p + nx);
+            const f4u zm = *(const f4u *)(p - (ptrdiff_t)plane), zp = *(const f4u *)(p + plane);
+            const float xr[6] = {xa.x, xa.y, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll 1
+            for (int j = 0; j < nval; j++) {
+                const float xl = j == 0 ? xr[0] : j == 1 ? xr[1] : j == 2 ? xr[2] : xr[3];
+                const float xh = j == 0 ? xr[2] : j == 1 ? xr[3] : j == 2 ? xr[4] : xr[5];
+                const float yl = j == 0 ? ym.x : j == 1 ? ym.y : j == 2 ? ym.z : ym.w;
+                const float yh = j == 0 ? yp.x : j == 1 ? yp.y : j == 2 ? yp.z : yp.w;
+                const float zl = j == 0 ? zm.x : j == 1 ? zm.y : j == 2 ? zm.z : zm.w;
+                const float zh = j == 0 ? zp.x : j == 1 ? zp.y : j == 2 ? zp.z : zp.w;
+                accumulate(x0 + j, y, z, xh - xl, yh - yl, zh - zl);
             }
-            __syncthreads();
         }
+        __syncthreads();                                      /* seg_* are rewritten by the next round */
     }
     if (variant & 16) {              /* bit 4: out[0..1] = bit patterns of (count, checksum) of the window set */
         if (tid == 0) {
-            out[(size_t)kid * out_stride] = __uint_as_float(win_count);
+            out[(size_t)kid * out_stride] = __uint_as_float(win_vox + 0u * win_count);
             out[(size_t)kid * out_stride + 1] = __uint_as_float(win_chk);
         }
         return;

@@ -5,7 +5,6 @@
 #include "s3d_common.h"
 
 #define S3D_BARY_EPS_D 1.1920928955078125e-06 /* bary_eps = FLT_EPSILON * 1E1 as double, sift.c:50 */
-
 struct V3 {
     float x, y, z;
 };
@@ -67,9 +66,11 @@ __device__ __forceinline__ int s3d_icos_bin(const float *__restrict__ mesh, V3 g
  * faces straddling a coordinate plane, (1,0,phi^2), (phi^2,1,0), (0,phi^2,1) normalised.  The winner
  * is looked up in a 32-entry table (3 sign bits, 2 type bits) built on the host from the same mesh
  * table, and then put through the reference's exact test.  If that test passes with every barycentric
- * coordinate >= 1e-4 (50x the reference's acceptance slack plus f32 rounding), no other face can
- * accept the vector, so "first accepting face in table order" is this face; otherwise (vector within
- * ~1e-4 of an edge: 0.06 % of samples) the sequential search decides. */
+ * coordinate >= 2e-5, no other face can accept the vector (a neighbour accepts only while its own
+ * coordinate across the shared edge is >= -1.2e-6, i.e. while ours is <= ~2.4e-6; f32 rounding of the
+ * test is ~1e-7), so "first accepting face in table order" is this face; otherwise (vector within 2e-5 of
+ * an edge: ~0.01 % of samples) the sequential search decides.  (1-ulp hardware forms of the division,
+ * sqrt and exp were measured on MI355X: no gain -- the descriptor kernel is bound by LDS atomics.) */
 #define S3D_LUT_OFFSET (S3D_NFACES * MESH_STRIDE)
 __device__ __forceinline__ int s3d_icos_bin_fast(const float *__restrict__ mesh, V3 g, V3 *bary)
 {
@@ -88,7 +89,7 @@ __device__ __forceinline__ int s3d_icos_bin_fast(const float *__restrict__ mesh,
     const int key = (g.x < 0.0f ? 1 : 0) | (g.y < 0.0f ? 2 : 0) | (g.z < 0.0f ? 4 : 0) | (t << 3);
     const int face = __float_as_int(mesh[S3D_LUT_OFFSET + key]);
     V3 b;
-    if (s3d_face_test(mesh, face, g, &b) && b.x >= 1e-4f && b.y >= 1e-4f && b.z >= 1e-4f) {
+    if (s3d_face_test(mesh, face, g, &b) && b.x >= 2e-5f && b.y >= 2e-5f && b.z >= 2e-5f) {
         *bary = b;
         return face;
     }

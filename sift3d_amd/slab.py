@@ -131,7 +131,7 @@ class _Level:
         self.zlo = planes_lo                  # global z of the first backed plane
         self.n = nplanes
         self.pe = plane_elems
-        self.t = torch.zeros(nplanes * plane_elems, dtype=torch.float32, device=device)
+        self.t = torch.zeros(nplanes * plane_elems + 16, dtype=torch.float32, device=device)   # +16: k_describe's wide loads
         self.view = self.t.data_ptr() - planes_lo * plane_elems * 4
 
     def planes(self, za: int, zb: int) -> torch.Tensor:   # backed planes [za, zb), global z
