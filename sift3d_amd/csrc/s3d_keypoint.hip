@@ -501,7 +501,7 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  * The block keeps NCOPY histograms (lane l adds into copy l % NCOPY, row stride 769) to thin out the
  * same-address collisions of x-neighbouring voxels, which share cell and icosahedron face. */
 template <int NCOPY>
-__global__ void __launch_bounds__(DESC_THREADS)
+__global__ void __launch_bounds__(DESC_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num,
            const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride, int variant)
 {
