@@ -120,6 +120,8 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
 {
     __shared__ __attribute__((aligned(16))) float term[3][64];
     __shared__ float gw_s[3];
+    __shared__ int row_off[65];
+    __shared__ unsigned row_first[64];
     const unsigned cand = blockIdx.x;
     const int lane = threadIdx.x;
     if (cand >= num) return;
@@ -151,26 +153,85 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
     const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
 
-    const int nbox = (wx > 0 && wy > 0 && wz > 0) ? wx * wy * wz : 0;
     /* one window sample: weight and iso gradient exactly as the reference evaluates them */
-    const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1), inv_wxy = 1.0f / (float)(wx > 0 && wy > 0 ? wx * wy : 1);
-    auto sample = [&](int b, float *gx, float *gy, float *gz, float *w) -> bool {
-        int r, bx;                                         /* window index -> offsets, without integer division */
-        const int bz = fdiv_small(b, wx * wy, inv_wxy, &r);
-        const int by = fdiv_small(r, wx, inv_wx, &bx);
-        const int x = xs + bx, y = ys + by, z = zs + bz;
+    auto sample = [&](int x, int y, int z, float *gx, float *gy, float *gz, float *w) {
         const float dx = ((float)x - vcx) * uxf;
         const float dy = ((float)y - vcy) * uyf;
         const float dz = ((float)z - vcz) * uzf;
         const float sq = dx * dx + dy * dy + dz * dz;
-        if ((double)sq > rad2) return false;
         const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
         const float wa = (float)(-0.5 * (double)sq / sig2);
         *w = (variant & 2) ? __expf(wa) : s3d_expf(wa);
         *gx = 0.5f * (p[1] - p[-1]) * iux;
         *gy = 0.5f * (p[nx] - p[-nx]) * iuy;
         *gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]) * iuz;
-        return true;
+    };
+    /* Sweep over the window samples in the reference's scan order (z, y, x) with dense lanes.  The window
+     * is a ball, so per x-row the accepted voxels are one interval: 64 rows at a time, each lane derives
+     * its row's interval from the chord and settles both ends with the reference's own test
+     * ((double)sq > rad^2 rejects, sift.c:96-109), a wave scan numbers the accepted voxels, and every
+     * lane then takes one voxel per turn (row found by binary search in the LDS prefix array).
+     * body(valid, x, y, z) is called by all 64 lanes the same number of times. */
+    const int nrows = (wx > 0 && wy > 0 && wz > 0) ? wy * wz : 0;
+    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
+    auto sweep = [&](auto &&body) {
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            int len = 0;
+            unsigned first = 0;
+            if (r0 + lane < nrows) {
+                int by;
+                const int bz = fdiv_small(r0 + lane, wy, inv_wy, &by);
+                const int y = ys + by, z = zs + bz;
+                const float dy = ((float)y - vcy) * uyf, dz = ((float)z - vcz) * uzf;
+                auto inside = [&](int x) {
+                    const float dx = ((float)x - vcx) * uxf;
+                    return !((double)(dx * dx + dy * dy + dz * dz) > rad2);
+                };
+                const double s2 = rad2 - (double)dy * (double)dy - (double)dz * (double)dz;
+                if (s2 > -1e-3 * rad2) {
+                    const float chord = sqrtf((float)(s2 > 0.0 ? s2 : 0.0)) / uxf;
+                    int lo = (int)ceilf(vcx - chord - 1e-3f), hi = (int)floorf(vcx + chord + 1e-3f);
+                    lo = lo > xs ? lo : xs;
+                    hi = hi < xe ? hi : xe;
+                    while (lo <= hi && !inside(lo)) lo++;
+                    while (lo <= hi && !inside(hi)) hi--;
+                    if (lo <= hi) {
+                        while (lo > xs && inside(lo - 1)) lo--;
+                        while (hi < xe && inside(hi + 1)) hi++;
+                        len = hi - lo + 1;
+                        first = (unsigned)(lo - xs) | ((unsigned)by << 10) | ((unsigned)bz << 20);
+                    }
+                }
+            }
+            int incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl(incl, lane >= d ? lane - d : lane);
+                if (lane >= d) incl += up;
+            }
+            row_off[lane] = incl - len;
+            row_first[lane] = first;
+            if (lane == 63) row_off[64] = incl;
+            s3d_wave_lds_sync();
+            const int total = row_off[64];
+            for (int i0 = 0; i0 < total; i0 += 64) {
+                const int id = i0 + lane;
+                const bool valid = id < total;
+                int x = 0, y = 0, z = 0;
+                if (valid) {
+                    int sg = 0;
+#pragma unroll
+                    for (int step = 32; step; step >>= 1)
+                        if (row_off[sg + step] <= id) sg += step;      /* last row starting at or before id */
+                    const unsigned fv = row_first[sg];
+                    x = xs + (int)(fv & 1023u) + (id - row_off[sg]);
+                    y = ys + (int)((fv >> 10) & 1023u);
+                    z = zs + (int)(fv >> 20);
+                }
+                body(valid, x, y, z);
+            }
+            s3d_wave_lds_sync();
+        }
     };
 
     /* ---- pass 1 (parallel): f64 structure tensor, and for the window gradient sum(w*grad) both its
@@ -179,9 +240,10 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
     double gdx = 0, gdy = 0, gdz = 0, sax = 0, say = 0, saz = 0;
     int cnt = 0;
-    for (int b = lane; b < nbox; b += 64) {
+    sweep([&](bool valid, int x, int y, int z) {
+        if (!valid) return;
         float gx, gy, gz, w;
-        if (!sample(b, &gx, &gy, &gz, &w)) continue;
+        sample(x, y, z, &gx, &gy, &gz, &w);
         a00 += (double)gx * (double)gx * (double)w;
         a01 += (double)gx * (double)gy * (double)w;
         a02 += (double)gx * (double)gz * (double)w;
@@ -192,7 +254,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         gdx += (double)tx; gdy += (double)ty; gdz += (double)tz;
         sax += fabs((double)tx); say += fabs((double)ty); saz += fabs((double)tz);
         cnt++;
-    }
+    });
     for (int m = 32; m >= 1; m >>= 1) {                    /* xor butterfly: every lane ends with the totals */
         a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
         a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
@@ -284,16 +346,19 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     /* ---- pass 2 (rare): the reference's own summation order ------------------------------------------ */
     if (!decided) {
         float gsum = 0.0f;                                 /* lanes 0..2: running sum of component lane */
-        for (int b0 = 0; b0 < nbox; b0 += 64) {
-            const int b = b0 + lane;
+        sweep([&](bool valid, int x, int y, int z) {
             float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-            float gx, gy, gz, w;
-            if (b < nbox && sample(b, &gx, &gy, &gz, &w)) { tx = gx * w; ty = gy * w; tz = gz * w; }
+            if (valid) {
+                float gx, gy, gz, w;
+                sample(x, y, z, &gx, &gy, &gz, &w);
+                tx = gx * w; ty = gy * w; tz = gz * w;
+            }
             term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
             s3d_wave_lds_sync();
             if (lane < 3 && !(variant & 1)) {
-                /* scan order; skipped voxels contribute an exact +0.  The 64 staged terms are pulled into
-                 * registers with 16 independent ds_read_b128 so the dependent chain is 64 adds. */
+                /* scan order (dense ids ascend in z, y, x); the padding of the last turn adds exact +0.  The
+                 * 64 staged terms are pulled into registers with 16 independent ds_read_b128 so the
+                 * dependent chain is 64 adds. */
                 float4 q[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(&term[lane][4 * i]);
@@ -303,7 +368,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
                 }
             }
             s3d_wave_lds_sync();
-        }
+        });
         if (lane < 3) gw_s[lane] = gsum;
         s3d_wave_lds_sync();
         const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
