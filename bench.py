@@ -354,6 +354,32 @@ def main():
         flops = 2.0 * 3.0 * 768.0 * K * K          # forward + backward pass; sub, mul, add per element
         result["config"]["match"] = {"pairs": K * K, "ms": round(t_match * 1e3, 2), "self_matches": int((m == np.arange(K)).sum()),
                                      "fp64_TFLOPs": round(flops / t_match / 1e12, 2), "fp64_vector_peak_TFLOPs": 78.6}
+    if rank == 0 and not args.no_match:
+        # BASELINE configs[2], outside the timed region: SIFT3D_extract_dense_descriptors on a 256^3 volume,
+        # device to device (12-channel output, 805 MB)
+        nd = 256
+        dvol = synth.blobs(nd, nd, nd, synth.default_nblobs(nd, nd, nd), seed=2)
+        d_in = dev.upload(dvol)
+        d_out = dev.malloc(dvol.nbytes * 12)
+        s2 = abi.SIFT3D()
+        assert lib.sift.init_SIFT3D(C.byref(s2)) == 0
+        ou = (C.c_double * 3)(1.0, 1.0, 1.0)
+        times = []
+        for _ in range(3):
+            dev.sync()
+            t0 = time.perf_counter()
+            rc = lib.sift.sift3d_amd_extract_dense_dev(C.byref(s2), C.c_void_p(d_in), nd, nd, nd, 1.0, 1.0, 1.0, ou,
+                                                       C.c_void_p(d_out))
+            dev.sync()
+            times.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise SystemExit("dense failed: " + lib.sift.sift3d_amd_last_error().decode())
+        t_dense = min(times[1:])
+        result["config"]["dense_256"] = {"ms": round(t_dense * 1e3, 3), "Mvox_s": round(nd ** 3 / t_dense / 1e6, 1),
+                                         "blur_alg_GBs": round(288.0 * nd ** 3 / t_dense / 1e9, 1)}
+        dev.free(d_in)
+        dev.free(d_out)
+        lib.sift.cleanup_SIFT3D(C.byref(s2))
     if rank == 0 and not args.no_roofline:
         add_roofline(result, dev, n)
     if rank == 0 and not args.no_cpu_baseline:

@@ -300,6 +300,90 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
     }
 }
 
+/* ---- interleaved multi-channel volumes, unit tap spacing (the 12-channel dense-descriptor blur) ------
+ * Element (x, y, z, c) lives at ((z*ny + y)*nx + x)*nc + c.  A pass along y or z treats every (x, c) pair
+ * alike, so those two passes see a single-channel volume nc*nx wide and march along it exactly like
+ * k_gauss_z (float4 column per lane, register ring, extended signal at the ends).  The x pass is a
+ * convolution with tap spacing nc floats over rows that stay L1-resident (12 KB at nx = 256). */
+template <int HW>
+__global__ void __launch_bounds__(256)
+k_march(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* float4 columns per batch */,
+        size_t stride /* floats between consecutive steps */, int n /* steps */, size_t bstride /* floats per batch */,
+        int chunk, S3dTaps taps, EdgeFrac ef)
+{
+    constexpr int W = 2 * HW + 1;
+    const size_t colid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (colid >= ncol) return;
+    const float *col = src + (size_t)blockIdx.z * bstride + colid * 4;
+    float *out = dst + (size_t)blockIdx.z * bstride + colid * 4;
+    const int p0 = blockIdx.y * chunk;
+    const int p1 = (p0 + chunk < n) ? p0 + chunk : n;
+    const int T = (p1 - p0) + 2 * HW;                 /* pushes: coordinates p0-HW .. p1-1+HW */
+    float4 ring[W];
+    const int c0 = p0 - HW;
+    float4 n0 = z_ext<HW>(col, stride, c0, n, ef);
+    float4 n1 = z_ext<HW>(col, stride, c0 + (1 < T ? 1 : 0), n, ef);
+    for (int tb = 0; tb < T; tb += W) {
+#pragma unroll
+        for (int u = 0; u < W; u++) {
+            const int t = tb + u;
+            if (t < T) {
+                ring[u] = n0;
+                n0 = n1;
+                if (t + 2 < T) n1 = z_ext<HW>(col, stride, c0 + t + 2, n, ef);
+                if (t >= 2 * HW) {
+                    const float4 acc = ring_dot<HW>(ring, u, taps);
+                    *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * stride) = acc;
+                }
+            }
+        }
+    }
+}
+
+/* E-voxel c of the x axis, channels [cq, cq+4) of an interleaved row */
+__device__ __forceinline__ float4 x_ext_mc(const float *__restrict__ row, int c, int nx, int nc, int cq, const EdgeFrac &ef)
+{
+    if (c < 0) c = -c;
+    if (c <= nx - 2) return *reinterpret_cast<const float4 *>(row + (size_t)c * nc + cq);
+    const int j = c - (nx - 1);
+    const float4 a = *reinterpret_cast<const float4 *>(row + (size_t)(nx - 2 - j) * nc + cq);
+    const float4 b = *reinterpret_cast<const float4 *>(row + (size_t)(nx - 1 - j) * nc + cq);
+    return blend4(a, b, ef.f[j]);
+}
+
+template <int HW>
+__global__ void __launch_bounds__(256)
+k_conv_x_mc(const float *__restrict__ src, float *__restrict__ dst, int nx, int nc, size_t nrows, S3dTaps taps,
+            EdgeFrac ef)
+{
+    constexpr int W = 2 * HW + 1;
+    const unsigned q4 = (unsigned)(nx * nc) >> 2;                 /* float4 per row */
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * q4) return;
+    const size_t r = i / q4;
+    const unsigned q = (unsigned)(i - r * q4) * 4u;               /* float offset inside the row */
+    const int x = (int)(q / (unsigned)nc), cq = (int)(q - (unsigned)x * (unsigned)nc);
+    const float *row = src + r * (size_t)nx * nc;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x >= HW && x + HW <= nx - 2) {                            /* interior: plain strided loads */
+        const float *p = row + q + (size_t)HW * nc;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const float4 s = *reinterpret_cast<const float4 *>(p - (size_t)k * nc);
+            const float t = taps.t[k];
+            acc.x = acc.x + t * s.x; acc.y = acc.y + t * s.y; acc.z = acc.z + t * s.z; acc.w = acc.w + t * s.w;
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < W; k++) {
+            const float4 s = x_ext_mc(row, x + HW - k, nx, nc, cq, ef);
+            const float t = taps.t[k];
+            acc.x = acc.x + t * s.x; acc.y = acc.y + t * s.y; acc.z = acc.z + t * s.z; acc.w = acc.w + t * s.w;
+        }
+    }
+    *reinterpret_cast<float4 *>(dst + r * (size_t)nx * nc + q) = acc;
+}
+
 /* ---- fused X+Y pass ----------------------------------------------------------------------------- */
 template <int HW>
 __global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
@@ -557,6 +641,57 @@ static int fast_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx,
     S3D_FAIL("half width not instantiated");
 }
 
+/* interleaved channels, unit spacing on every axis: x: src -> dst ; y: dst -> tmp ; z: tmp -> dst */
+static int fast_mc_eligible(int nx, int ny, int nz, int nc, const float uf[3], int width)
+{
+    const int hw = width / 2;
+    if (nc < 4 || (nc & 3) || uf[0] != 1.0f || uf[1] != 1.0f || uf[2] != 1.0f) return 0;
+    if (hw < 1 || hw > S3D_FAST_MAX_HW) return 0;
+    if (nx - 1 <= hw || ny - 1 <= hw || nz - 1 <= hw) return 0;
+    if (nz > 65535 || (size_t)nx * nc > (1u << 24)) return 0;
+    return 1;
+}
+
+template <int HW>
+static int launch_fast_mc(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,
+                          const S3dTaps &t, hipStream_t st)
+{
+    EdgeFrac ex, ey, ez;
+    if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
+    const size_t nxc = (size_t)nx * nc, rows = (size_t)ny * nz;
+    const size_t nblk = s3d_div_up(rows * (nxc / 4), 256);
+    if (nblk > 0x7fffffffu) S3D_FAIL("volume too large for the multi-channel fast path");
+    hipLaunchKernelGGL((k_conv_x_mc<HW>), dim3((unsigned)nblk), dim3(256), 0, st, d_src, d_dst, nx, nc, rows, t, ex);
+    S3D_CHECK_LAUNCH();
+    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
+    const int cz = (nz + (int)s3d_div_up(nz, g_chunk_z) - 1) / (int)s3d_div_up(nz, g_chunk_z);
+    hipLaunchKernelGGL((k_march<HW>), dim3(s3d_div_up(nxc / 4, 256), s3d_div_up(ny, cy), nz), dim3(256), 0, st, d_dst,
+                       d_tmp, nxc / 4, nxc, ny, nxc * ny, cy, t, ey);
+    S3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_march<HW>), dim3(s3d_div_up(nxc / 4 * ny, 256), s3d_div_up(nz, cz), 1), dim3(256), 0, st,
+                       d_tmp, d_dst, nxc / 4 * ny, nxc * ny, nz, (size_t)0, cz, t, ez);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+static int fast_mc_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc, int hw,
+                            const S3dTaps &t, hipStream_t st)
+{
+    switch (hw) {
+    case 1: return launch_fast_mc<1>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 2: return launch_fast_mc<2>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 3: return launch_fast_mc<3>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 4: return launch_fast_mc<4>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 5: return launch_fast_mc<5>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 6: return launch_fast_mc<6>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 7: return launch_fast_mc<7>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 8: return launch_fast_mc<8>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    case 9: return launch_fast_mc<9>(d_src, d_dst, d_tmp, nx, ny, nz, nc, t, st);
+    default: break;
+    }
+    S3D_FAIL("half width not instantiated");
+}
+
 /* Z-slab form of s3d_k_sep_fir.  The three pointers are VIEWS addressed by
  * global z: element (x,y,z) of the nx x ny x nz volume lives at view[(z*ny + y)*nx + x], but only the
  * planes the caller owns plus halos need to be backed by memory.  Produces dst planes [z0, z1); reads
@@ -589,8 +724,11 @@ extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp
     if (nx < 1 || ny < 1 || nz < 1 || nc < 1) S3D_FAIL("bad dimensions");
     if (d_tmp == d_src || d_tmp == d_dst) S3D_FAIL("scratch must not alias src/dst");
     const int fast = fast_eligible(nx, ny, nz, nc, uf, width);
-    if (path == 2 && !fast) S3D_FAIL("configuration not eligible for the fused fast path");
+    if (path == 2 && !fast && !(d_src != d_dst && fast_mc_eligible(nx, ny, nz, nc, uf, width)))
+        S3D_FAIL("configuration not eligible for a fast path");
     if (fast && path != 1) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, 0, nz, width / 2, t, st);
+    if (path != 1 && d_src != d_dst && fast_mc_eligible(nx, ny, nz, nc, uf, width))
+        return fast_mc_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, nc, width / 2, t, st);
     /* generic per-axis passes.  out of place: x: src -> dst ; y: dst -> tmp ; z: tmp -> dst */
     if (d_src != d_dst) {
         if (s3d_k_conv_axis(d_src, d_dst, nx, ny, nz, nc, 0, taps, width, uf[0], stream)) return S3D_ERR;

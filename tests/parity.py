@@ -48,12 +48,13 @@ def check_sep_fir_api(lib, oracle, dims, units, nc, sigma, unit=1.0, seed=0):
     assert nd == 0, f"{nd} of {got.size} elements differ (dims={dims} units={units} nc={nc} sigma={sigma})"
 
 
-def check_sep_fir_paths(lib, oracle, dims, sigma, seed=0, chunks=None):
-    """Device-level: generic per-axis path and fused fast path agree with the oracle bit for bit."""
+def check_sep_fir_paths(lib, oracle, dims, sigma, seed=0, chunks=None, nc=1):
+    """Device-level: generic per-axis path and fused fast path (single channel) / interleaved multi-channel
+    fast path (nc > 1) agree with the oracle bit for bit."""
     dev = dev_of(lib)
     rng = np.random.default_rng(seed)
     nx, ny, nz = dims
-    vol = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    vol = rng.standard_normal((nz, ny, nx) if nc == 1 else (nz, ny, nx, nc)).astype(np.float32)
     taps = oracle.gauss_taps(sigma)
     want = oracle.sep_fir(vol, taps, (1, 1, 1), 1.0)
     d_src = dev.upload(vol)
@@ -64,7 +65,7 @@ def check_sep_fir_paths(lib, oracle, dims, sigma, seed=0, chunks=None):
             dev.L.s3d_k_gauss_set_chunks(*chunks)
         for path in (1, 2):
             dev.L.s3d_rt_memset(C.c_void_p(d_dst), 0xFF, vol.nbytes, None)
-            dev.sep_fir(d_src, d_dst, d_tmp, nx, ny, nz, 1, (1, 1, 1), taps, path=path)
+            dev.sep_fir(d_src, d_dst, d_tmp, nx, ny, nz, nc, (1, 1, 1), taps, path=path)
             got = dev.download(d_dst, vol.shape)
             nd = nbitdiff(got, want)
             assert nd == 0, f"path {path}: {nd} of {got.size} differ (dims={dims}, sigma={sigma}, chunks={chunks})"

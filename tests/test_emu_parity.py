@@ -91,3 +91,11 @@ def test_two_volume_match(emu, oracle):
 def test_describe_window_set(emu, oracle, dims, units, nblobs, seed):
     k, nvox = parity.check_describe_window(emu, oracle, dims, units, nblobs, seed)
     assert k >= 1 and nvox > 1000
+
+
+@pytest.mark.parametrize("dims,sigma,nc,chunks", [
+    ((13, 12, 11), 0.973294, 4, None),       # hw 3, nx*nc not a multiple of 256
+    ((22, 21, 20), 2.8284, 12, (8, 8)),      # the dense-descriptor blur: hw 9, 12 channels, several chunks
+])
+def test_sep_fir_multichannel_fast_vs_generic(emu, oracle, dims, sigma, nc, chunks):
+    parity.check_sep_fir_paths(emu, oracle, dims, sigma, chunks=chunks, nc=nc)

@@ -54,6 +54,16 @@ def test_sep_fir_fast_vs_generic(lib, oracle, dims, sigma, chunks):
     parity.check_sep_fir_paths(lib, oracle, dims, sigma, chunks=chunks)
 
 
+@pytest.mark.parametrize("dims,sigma,nc,chunks", [
+    ((36, 33, 30), 0.973294, 4, None),
+    ((64, 48, 40), 2.8284, 12, None),        # the dense-descriptor blur: hw 9, 12 channels
+    ((40, 44, 52), 2.8284, 12, (16, 24)),
+    ((30, 29, 28), 1.94659, 8, None),
+])
+def test_sep_fir_multichannel_fast_vs_generic(lib, oracle, dims, sigma, nc, chunks):
+    parity.check_sep_fir_paths(lib, oracle, dims, sigma, chunks=chunks, nc=nc)
+
+
 def test_sep_fir_golden(lib):
     g = np.load(os.path.join(GOLDEN, "sep_fir.npz"))
     for i in range(int(g["n"])):
@@ -144,6 +154,12 @@ def test_dense_vs_oracle(lib, oracle, dims, units, out_units):
 @pytest.mark.parametrize("dims,units", [((40, 36, 32), (1, 1, 1)), ((30, 28, 26), (1, 0.7, 1.3))])
 def test_dense_rotate_vs_oracle(lib, oracle, dims, units):
     parity.check_dense_rotate(lib, oracle, dims, units)
+
+
+def test_dense_256_full_size(lib, oracle):
+    """BASELINE config 2 at its own size: SIFT3D_extract_dense_descriptors on a 256^3 volume against the
+    oracle (a few seconds of OpenMP on the host), bit for bit over all 201 M output floats."""
+    parity.check_dense(lib, oracle, (256, 256, 256), (1, 1, 1))
 
 
 def test_dense_golden(lib):
