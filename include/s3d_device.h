@@ -177,6 +177,12 @@ void s3d_mesh_table(float *out);
 /* Gradient -> icosahedron barycentric weights into a zeroed 12-channel image (sift.c:2460-2480). */
 int s3d_k_dense_bary(const float *d_smooth, int nx, int ny, int nz, const float unitsf[3],
                      const float *d_mesh, float *d_out12, s3d_stream stream);
+/* s3d_k_dense_bary followed by the 12-channel s3d_k_sep_fir, fused for unit tap spacing (the barycentric
+ * image stays in LDS).  d_dst, d_tmp: nx*ny*nz*12 floats.  Returns 1 without doing anything when the
+ * configuration is not eligible (run the two separate calls instead), 0 on success, -1 on error. */
+int s3d_k_dense_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, int nx, int ny, int nz,
+                          const float unitsf[3], const float uf[3], const float *d_mesh, const float *taps,
+                          int width, s3d_stream stream);
 /* dense_rotate = 1 (sift.c:2521-2588, 2295-2343): per-voxel sphere histogram of gradients rotated by the
  * voxel's own orientation.  d_R / d_keep: output of s3d_k_orient run with one candidate per voxel
  * (d_idx = d_tag = d_center = NULL); rejected voxels use the identity.  sigma = sigma0*7.0711/4. */

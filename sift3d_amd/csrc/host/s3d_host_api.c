@@ -995,12 +995,16 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
     if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n * HIST_NUMEL) || ctx_aux(c, 3, n * HIST_NUMEL))
         return SIFT3D_FAILURE;
     if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units)) return SIFT3D_FAILURE;
-    DEV(s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream));
-    DEV(s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream));
     if (init_Gauss_filter(&gauss, sigma_win, 3)) return SIFT3D_FAILURE;
     unit_factors(out_units, 1.0, uf);                      /* quirk C-17: the OUTPUT image's entry units */
-    rc = s3d_k_sep_fir(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,
-                       c->stream);
+    /* unit tap spacing: barycentric image + blur fused (the image never leaves LDS); otherwise the two steps */
+    rc = s3d_k_dense_bary_blur(c->d_aux[1], d_out, c->d_aux[2], nx, ny, nz, unitsf, uf, c->d_mesh, gauss.f.kernel,
+                               gauss.f.width, c->stream);
+    if (rc == 1)
+        rc = s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream) ||
+             s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream) ||
+             s3d_k_sep_fir(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,
+                           c->stream);
     cleanup_Gauss_filter(&gauss);
     if (rc) API_FAIL("sift3d_amd: dense blur failed: %s", s3d_rt_last_error());
     DEV(s3d_k_dense_post(d_out, d_in, n, c->stream));

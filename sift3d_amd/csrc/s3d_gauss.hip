@@ -36,6 +36,7 @@
  *    chunks for occupancy; each chunk re-reads 2hw warm-up rows (planes).
  */
 #include "s3d_common.h"
+#include "s3d_math.h"
 
 /* ------------------------------------------------------------------------------------------------
  * 1. generic per-element pass
@@ -384,6 +385,79 @@ k_conv_x_mc(const float *__restrict__ src, float *__restrict__ dst, int nx, int 
     *reinterpret_cast<float4 *>(dst + r * (size_t)nx * nc + q) = acc;
 }
 
+/* Dense-descriptor front end fused with the x pass of its 12-channel blur.  The barycentric image
+ * (sift.c:2412-2441: three weights per voxel into the channels of the hit face's vertices, zero elsewhere
+ * and on the volume's border) is never written to HBM: a block computes it for 64 voxels of one x-row plus
+ * HW neighbours on either side into LDS and convolves from there.  Same arithmetic, same order as
+ * k_dense_bary followed by k_conv_x_mc, so the result is bit-identical; saves 2 x 48 B/voxel of traffic. */
+#define BX_SEG 64
+template <int HW>
+__global__ void __launch_bounds__(BX_SEG * 3)
+k_bary_x_mc(const float *__restrict__ sm, float *__restrict__ dst, int nx, int ny, int nz, float iux, float iuy,
+            float iuz, const float *__restrict__ d_mesh, S3dTaps taps, EdgeFrac ef)
+{
+    constexpr int W = 2 * HW + 1, NST = BX_SEG + 2 * HW;
+    __shared__ float mesh[S3D_MESH_FLOATS];
+    __shared__ __attribute__((aligned(16))) float st[NST * S3D_NVERT];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BX_SEG, y = blockIdx.y, z = blockIdx.z;
+    for (int i = tid; i < S3D_MESH_FLOATS; i += BX_SEG * 3) mesh[i] = d_mesh[i];
+    for (int i = tid; i < NST * S3D_NVERT; i += BX_SEG * 3) st[i] = 0.0f;
+    __syncthreads();
+    /* stage voxels x0-HW .. x0+BX_SEG-1+HW (slot s <-> voxel x0-HW+s) */
+    const size_t plane = (size_t)nx * ny;
+    if (tid < NST) {
+        const int x = x0 - HW + tid;
+        if (x >= 1 && x <= nx - 2 && y >= 1 && y <= ny - 2 && z >= 1 && z <= nz - 2) {
+            const float *p = sm + ((size_t)z * plane + (size_t)y * nx + x);
+            V3 g;
+            g.x = 0.5f * (p[1] - p[-1]);
+            g.y = 0.5f * (p[nx] - p[-nx]);
+            g.z = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
+            g.x = g.x * iux; g.y = g.y * iuy; g.z = g.z * iuz;
+            V3 bary;
+            const int face = s3d_icos_bin_fast(mesh, g, &bary);
+            if (face >= 0) {
+                const float *m = mesh + face * MESH_STRIDE;
+                float *t = st + tid * S3D_NVERT;
+                t[__float_as_int(m[13])] = bary.x;
+                t[__float_as_int(m[14])] = bary.y;
+                t[__float_as_int(m[15])] = bary.z;
+            }
+        }
+    }
+    __syncthreads();
+    const int v = tid / 3, cq = (tid - 3 * v) * 4;            /* voxel of the segment, channel quad */
+    const int x = x0 + v;
+    if (x >= nx) return;
+    auto slot = [&](int c) { return *reinterpret_cast<const float4 *>(st + (c - x0 + HW) * S3D_NVERT + cq); };
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x >= HW && x + HW <= nx - 2) {
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const float4 s = slot(x + HW - k);
+            const float t = taps.t[k];
+            acc.x = acc.x + t * s.x; acc.y = acc.y + t * s.y; acc.z = acc.z + t * s.z; acc.w = acc.w + t * s.w;
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < W; k++) {
+            int c = x + HW - k;
+            if (c < 0) c = -c;
+            float4 s;
+            if (c <= nx - 2) {
+                s = slot(c);
+            } else {
+                const int j = c - (nx - 1);
+                s = blend4(slot(nx - 2 - j), slot(nx - 1 - j), ef.f[j]);
+            }
+            const float t = taps.t[k];
+            acc.x = acc.x + t * s.x; acc.y = acc.y + t * s.y; acc.z = acc.z + t * s.z; acc.w = acc.w + t * s.w;
+        }
+    }
+    *reinterpret_cast<float4 *>(dst + ((size_t)z * plane + (size_t)y * nx + x) * S3D_NVERT + cq) = acc;
+}
+
 /* ---- fused X+Y pass ----------------------------------------------------------------------------- */
 template <int HW>
 __global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
@@ -690,6 +764,53 @@ static int fast_mc_dispatch(const float *d_src, float *d_dst, float *d_tmp, int 
     default: break;
     }
     S3D_FAIL("half width not instantiated");
+}
+
+template <int HW>
+static int launch_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, int nx, int ny, int nz, const float unitsf[3],
+                            const float *d_mesh, const S3dTaps &t, hipStream_t st)
+{
+    EdgeFrac ex, ey, ez;
+    if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
+    const size_t nxc = (size_t)nx * S3D_NVERT;
+    hipLaunchKernelGGL((k_bary_x_mc<HW>), dim3(s3d_div_up(nx, BX_SEG), ny, nz), dim3(BX_SEG * 3), 0, st, d_smooth, d_dst,
+                       nx, ny, nz, 1.0f / unitsf[0], 1.0f / unitsf[1], 1.0f / unitsf[2], d_mesh, t, ex);
+    S3D_CHECK_LAUNCH();
+    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
+    const int cz = (nz + (int)s3d_div_up(nz, g_chunk_z) - 1) / (int)s3d_div_up(nz, g_chunk_z);
+    hipLaunchKernelGGL((k_march<HW>), dim3(s3d_div_up(nxc / 4, 256), s3d_div_up(ny, cy), nz), dim3(256), 0, st, d_dst,
+                       d_tmp, nxc / 4, nxc, ny, nxc * ny, cy, t, ey);
+    S3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_march<HW>), dim3(s3d_div_up(nxc / 4 * ny, 256), s3d_div_up(nz, cz), 1), dim3(256), 0, st,
+                       d_tmp, d_dst, nxc / 4 * ny, nxc * ny, nz, (size_t)0, cz, t, ez);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+/* k_dense_bary + the 12-channel blur in one go for unit tap spacing (the x pass reads the barycentric image
+ * from LDS).  Returns 1 -- and does nothing -- when the configuration is not eligible: the caller then runs
+ * s3d_k_dense_bary and s3d_k_sep_fir. */
+extern "C" int s3d_k_dense_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, int nx, int ny, int nz,
+                                     const float unitsf[3], const float uf[3], const float *d_mesh, const float *taps,
+                                     int width, s3d_stream stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    S3dTaps t;
+    if (!fast_mc_eligible(nx, ny, nz, S3D_NVERT, uf, width) || ny > 65535) return 1;
+    if (check_taps(taps, width, &t)) return S3D_ERR;
+    switch (width / 2) {
+    case 1: return launch_bary_blur<1>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 2: return launch_bary_blur<2>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 3: return launch_bary_blur<3>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 4: return launch_bary_blur<4>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 5: return launch_bary_blur<5>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 6: return launch_bary_blur<6>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 7: return launch_bary_blur<7>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 8: return launch_bary_blur<8>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    case 9: return launch_bary_blur<9>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
+    default: break;
+    }
+    return 1;
 }
 
 /* Z-slab form of s3d_k_sep_fir.  The three pointers are VIEWS addressed by
