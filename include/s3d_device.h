@@ -104,6 +104,14 @@ int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *d_l2, const
 int s3d_k_extrema_slab(const float *d_l0, const float *d_l1, const float *d_l2, const float *d_l3,
                        int nx, int ny, int nz, int z0, int z1, double peak_thresh, const float *d_dogmax,
                        unsigned long long *d_bits, s3d_stream stream);
+/* All nkp keypoint levels of one octave in a single pass over the nkp+3 GSS levels d_levels[0..nkp+2]
+ * (d_levels[0] = L(s-1) of the first keypoint level).  d_dogmax[k] / d_bits[k] belong to keypoint level k.
+ * Planes [z0, z1).  Returns 1 and does nothing when the configuration is not eligible (use the per-level
+ * call), 0 on success, -1 on error. */
+#define S3D_FUSED_KP_MAX 3
+int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                        double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
+                        s3d_stream stream);
 /* Ordered compaction of a bitmap: appends the indices of set bits, ascending, to d_idx starting at
  * position *d_count, tags each with `tag` in d_tag, and advances *d_count.  Entries past `capacity`
  * are dropped (the count still advances, so overflow is detectable).  d_scratch: >= nwords/1024+2

@@ -59,7 +59,8 @@ typedef struct {
     float *d_im, *d_tmp;
     float *d_level[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
     size_t level_elems[S3D_MAX_OCTAVES];
-    unsigned long long *d_bits;
+    unsigned long long *d_bits;             /* S3D_FUSED_KP_MAX bitmaps of bits_words words */
+    size_t bits_words;
     uint32_t *d_scratch;
     float *d_red;           /* small reduction slots */
     uint32_t *d_count;      /* [0] candidates, [1] keypoints */
@@ -349,7 +350,8 @@ static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
             DEV(s3d_rt_malloc((void **)&c->d_level[o * g->num_levels + k], c->level_elems[o] * sizeof(float)));
     }
     maxwords = (n0 + 63) / 64;
-    DEV(s3d_rt_malloc((void **)&c->d_bits, maxwords * sizeof(unsigned long long)));
+    c->bits_words = maxwords;
+    DEV(s3d_rt_malloc((void **)&c->d_bits, S3D_FUSED_KP_MAX * maxwords * sizeof(unsigned long long)));
     DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 256 + 4096) * sizeof(uint32_t)));   /* bitmap + keypoint block counters */
     DEV(s3d_rt_malloc((void **)&c->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS));
     c->nx = l0->nx; c->ny = l0->ny; c->nz = l0->nz;
@@ -489,12 +491,29 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         for (int o = 0; o < g->num_octaves; o++) {
             const Image *lv = g->levels + o * L;
             const size_t n = c->level_elems[o];
-            for (int ks = 1; ks <= nkp; ks++) {          /* DoG level index ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
-                float *const *lp = &c->d_level[o * L];
+            float *const *lp = &c->d_level[o * L];
+            const size_t nwords = (n + 63) / 64;
+            int fused = 1;                               /* all keypoint levels in one pass over the GSS levels */
+            if (nkp <= S3D_FUSED_KP_MAX) {
+                unsigned long long *bits[S3D_FUSED_KP_MAX];
+                for (int ks = 1; ks <= nkp; ks++) {
+                    bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
+                    DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + ks, c->stream));
+                }
+                fused = s3d_k_extrema_fused((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz,
+                                            sift3d->peak_thresh, c->d_red + 1, bits, c->stream);
+                if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
+                if (fused == 0)
+                    for (int ks = 1; ks <= nkp; ks++)
+                        DEV(s3d_k_compact_bits(bits[ks - 1], nwords, c->d_cand_idx, c->d_cand_tag,
+                                               ((uint32_t)o << 8) | (uint32_t)ks, c->cand_cap, c->d_count, c->d_scratch,
+                                               c->stream));
+            }
+            for (int ks = 1; fused != 0 && ks <= nkp; ks++) {   /* DoG level ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
                 DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + 1, c->stream));
                 DEV(s3d_k_extrema(lp[ks - 1], lp[ks], lp[ks + 1], lp[ks + 2], lv->nx, lv->ny, lv->nz,
                                   sift3d->peak_thresh, c->d_red + 1, c->d_bits, c->stream));
-                DEV(s3d_k_compact_bits(c->d_bits, (n + 63) / 64, c->d_cand_idx, c->d_cand_tag,
+                DEV(s3d_k_compact_bits(c->d_bits, nwords, c->d_cand_idx, c->d_cand_tag,
                                        ((uint32_t)o << 8) | (uint32_t)ks, c->cand_cap, c->d_count, c->d_scratch,
                                        c->stream));
             }

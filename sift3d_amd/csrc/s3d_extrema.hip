@@ -68,6 +68,125 @@ extern "C" int s3d_k_extrema(const float *d_l0, const float *d_l1, const float *
     return s3d_k_extrema_slab(d_l0, d_l1, d_l2, d_l3, nx, ny, nz, 0, nz, peak_thresh, d_dogmax, d_bits, st);
 }
 
+/* ---- all keypoint levels of an octave in one pass ------------------------------------------------
+ * The per-level kernel above reads four GSS levels per DoG level (12 level reads per octave with the
+ * default three keypoint levels) and spends most of its time on index arithmetic.  Here a thread takes 4
+ * x-consecutive voxels (float4 loads), reads the NKP+3 GSS levels once, forms the NKP+2 DoG centre
+ * values in registers and tests the NKP middle ones against the threshold, both scale neighbours and both
+ * x neighbours; the y and z neighbours are fetched only for the ~1 % that survive, one survivor per lane
+ * and turn.  Same comparisons on the same f32 differences as the reference: identical bitmaps. */
+template <int NKP>
+struct ExtArgs {
+    const float *l[NKP + 3];              /* L(s-1) .. L(s+NKP+1), s = first keypoint level */
+    unsigned long long *bits[NKP];        /* one bitmap per keypoint level */
+    float thr_scale_unused;
+};
+
+template <int NKP>
+__global__ void __launch_bounds__(256)
+k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
+                const float *__restrict__ d_dogmax /* [NKP], per keypoint level */)
+{
+    /* voxels idx0 + 4*g .. +3 ; a wave covers 256 consecutive voxels = 4 bitmap words */
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    const unsigned idx = idx0 + 4u * g;
+    const int lane = threadIdx.x & 63;
+    const unsigned plane = nx * ny;
+    /* phase 1 (streaming, no dependent loads): everything that can be decided from this thread's own
+     * float4s and its two x-neighbours -- peak threshold, the two scale neighbours, the two x neighbours.
+     * Survivors (~1 %) are remembered as bits s*4+j of pmax / pmin. */
+    unsigned pmax = 0u, pmin = 0u;
+    bool row_ok = false;
+    if (idx < n) {                                         /* n - idx0 is a multiple of 4 (nx % 4 == 0) */
+        const unsigned z = idx / plane;
+        const unsigned rem = idx - z * plane;
+        const unsigned y = rem / nx;
+        const unsigned x = rem - y * nx;
+        row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
+        float4 c[NKP + 3];
+#pragma unroll
+        for (int k = 0; k < NKP + 3; k++) c[k] = *reinterpret_cast<const float4 *>(a.l[k] + idx);
+        float d[NKP + 2][4];                               /* DoG centres, level k: L(k) - L(k+1) */
+#pragma unroll
+        for (int k = 0; k < NKP + 2; k++) {
+            d[k][0] = c[k].x - c[k + 1].x; d[k][1] = c[k].y - c[k + 1].y;
+            d[k][2] = c[k].z - c[k + 1].z; d[k][3] = c[k].w - c[k + 1].w;
+        }
+#pragma unroll
+        for (int s = 0; s < NKP; s++) {
+            const float thr = (float)(peak * (double)d_dogmax[s]);        /* sift.c:1169 */
+            /* x neighbours of the thread's end voxels: one scalar pair each (same cache lines as the
+             * neighbouring threads' float4s); idx-1 / idx+4 stay inside the level for every tested voxel */
+            const float *l1 = a.l[s + 1], *l2 = a.l[s + 2];
+            const float left = (row_ok && x >= 1) ? l1[idx - 1] - l2[idx - 1] : 0.0f;
+            const float right = (row_ok && x + 5 <= nx) ? l1[idx + 4] - l2[idx + 4] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned xj = x + (unsigned)j;
+                const float v = d[s + 1][j];
+                const float pv = d[s][j], nv = d[s + 2][j];
+                const float xm = j == 0 ? left : d[s + 1][j - 1];
+                const float xp = j == 3 ? right : d[s + 1][j + 1];
+                const bool live = row_ok && (v > thr || v < -thr) && xj >= 1 && xj + 2 <= nx;
+                if (live && v > pv && v > nv && v > xm && v > xp) pmax |= 1u << (4 * s + j);
+                if (live && v < pv && v < nv && v < xm && v < xp) pmin |= 1u << (4 * s + j);
+            }
+        }
+    }
+    /* phase 2: the y and z neighbours of the survivors, one survivor per lane and turn (all lanes' gathers of
+     * a turn are in flight together; the wave needs as many turns as its busiest lane has survivors) */
+    unsigned pend = pmax | pmin, res = 0u;
+    while (__ballot(pend != 0u) != 0ull) {
+        if (pend) {
+            const int b = __ffs((int)pend) - 1;
+            pend &= pend - 1u;
+            const int s = b >> 2;
+            const unsigned i = idx + (unsigned)(b & 3);
+            const float *l1 = s == 0 ? a.l[1] : s == 1 ? a.l[2] : a.l[3];
+            const float *l2 = s == 0 ? a.l[2] : s == 1 ? a.l[3] : a.l[4];
+            const float v = l1[i] - l2[i];
+            const float ym = l1[i - nx] - l2[i - nx], yp = l1[i + nx] - l2[i + nx];
+            const float zm = l1[i - plane] - l2[i - plane], zp = l1[i + plane] - l2[i + plane];
+            const bool ok = ((pmax >> b) & 1u) ? (v > yp && v > ym && v > zm && v > zp)
+                                               : (v < yp && v < ym && v < zm && v < zp);
+            if (ok) res |= 1u << b;
+        }
+    }
+    unsigned nib[NKP];
+#pragma unroll
+    for (int s = 0; s < NKP; s++) nib[s] = (res >> (4 * s)) & 15u;
+    /* lanes 16w .. 16w+15 hold the 16 nibbles of word w: OR them together inside each 16-lane row */
+#pragma unroll
+    for (int s = 0; s < NKP; s++) {
+        unsigned long long w = (unsigned long long)nib[s] << (4 * (lane & 15));
+        w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4); w |= __shfl_xor(w, 8);
+        const unsigned word = (4u * g) >> 6;
+        if ((lane & 15) == 0 && 4u * g < ((n - idx0 + 63u) & ~63u)) a.bits[s][word] = w;
+    }
+}
+
+/* Keypoint levels s = 0 .. nkp-1 of one octave at once.  d_levels: nkp+3 GSS levels starting at L(s-1) of
+ * the first keypoint level; d_dogmax: nkp maxima (max|DoG| of each keypoint level); d_bits: nkp bitmaps.
+ * Returns 1 without doing anything when not eligible (nx % 4 != 0, nkp not instantiated). */
+extern "C" int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                   double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
+                                   s3d_stream st)
+{
+    const size_t n = (size_t)nx * ny * nz, plane = (size_t)nx * ny;
+    if (nkp != 3 || (nx & 3)) return 1;
+    if (nx < 1 || ny < 1 || nz < 1 || n >= 0xFFFFFF00ull) S3D_FAIL("level too large for 32-bit voxel indices");
+    if (z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad slab");
+    ExtArgs<3> a;
+    for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];
+    for (int k = 0; k < 3; k++) a.bits[k] = d_bits[k];
+    a.thr_scale_unused = 0.0f;
+    hipLaunchKernelGGL((k_extrema_fused<3>), dim3(s3d_div_up(plane * (size_t)(z1 - z0) / 4, 256)), dim3(256), 0,
+                       (hipStream_t)st, a, (unsigned)nx, (unsigned)ny, (unsigned)nz, (unsigned)(plane * z0),
+                       (unsigned)(plane * z1), peak_thresh, d_dogmax);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
 /* ---- ordered bitmap compaction ---------------------------------------------------------------- */
 #define CB_WORDS_PER_THREAD 4
 #define CB_WORDS_PER_BLOCK (256 * CB_WORDS_PER_THREAD)
