@@ -211,7 +211,8 @@ class SlabSift3D:
         self.im = _Level(z0 - hal, (z1 - z0) + 2 * hal, nx * ny, self.dev)
         self.tmp = _Level(z0 - hal, (z1 - z0) + 2 * hal, nx * ny, self.dev)      # big enough for every octave
         nmax = (z1 - z0) * nx * ny
-        self.bits = torch.zeros(nmax // 64 + 2, dtype=torch.int64, device=self.dev)
+        self.bits_words = nmax // 64 + 2
+        self.bits = torch.zeros(3 * self.bits_words, dtype=torch.int64, device=self.dev)   # one bitmap per keypoint level
         self.scratch = torch.zeros(nmax // 64 // 256 + 4096, dtype=torch.int32, device=self.dev)
         self.red = torch.zeros(8, dtype=torch.float32, device=self.dev)
         self.count = torch.zeros(8, dtype=torch.int32, device=self.dev)
@@ -251,6 +252,8 @@ class SlabSift3D:
         L.s3d_k_sep_fir.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, _vp]
         L.s3d_k_sep_fir_slab.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
                                          C.c_int, _vp]
+        L.s3d_k_extrema_fused.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, _vp, C.POINTER(C.c_void_p), _vp]
         L.s3d_k_extrema_slab.argtypes = [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                          _vp, _vp, _vp]
         L.s3d_k_compact_bits_base.argtypes = [_vp, C.c_size_t, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
@@ -370,23 +373,41 @@ class SlabSift3D:
                 pe = nxo * nyo
                 za, zb = self.part[o]
                 shard_o = comm.world > 1 and o <= self.o_shard
+                if zb <= za:
+                    continue
+                nwords = ((zb - za) * pe + 63) // 64
+                fused = self.nkp == 3 and nxo % 4 == 0          # all keypoint levels in one pass (s3d_k_extrema_fused)
                 for ks in range(1, self.nkp + 1):
-                    if zb <= za:
-                        continue
+                    red = self.red[ks:] if fused else self.red[1:]
                     if shard_o:     # max |DoG| over my planes, then over the ranks (sift.c:1161-1169)
                         self._ck(L.s3d_k_dogmax(lev[o][ks].ptr(za), lev[o][ks + 1].ptr(za), (zb - za) * pe,
-                                                self.red[1:].data_ptr(), None), "dogmax")
-                        comm.allreduce_max_(self.red[1:2])
+                                                red.data_ptr(), None), "dogmax")
+                        if not fused:
+                            comm.allreduce_max_(self.red[1:2])
                     else:           # replicated octave: every rank sees the whole level
-                        self._ck(L.s3d_k_dogmax(lev[o][ks].view, lev[o][ks + 1].view, nzo * pe, self.red[1:].data_ptr(),
-                                                None), "dogmax")
+                        self._ck(L.s3d_k_dogmax(lev[o][ks].view, lev[o][ks + 1].view, nzo * pe, red.data_ptr(), None),
+                                 "dogmax")
+                    if fused:
+                        continue
                     self._ck(L.s3d_k_extrema_slab(lev[o][ks - 1].view, lev[o][ks].view, lev[o][ks + 1].view,
                                                   lev[o][ks + 2].view, nxo, nyo, nzo, za, zb, float(self.s.peak_thresh),
                                                   self.red[1:].data_ptr(), self.bits.data_ptr(), None), "extrema")
-                    nwords = ((zb - za) * pe + 63) // 64
                     self._ck(L.s3d_k_compact_bits_base(self.bits.data_ptr(), nwords, za * pe, self.cand_idx.data_ptr(),
                                                        self.cand_tag.data_ptr(), (o << 8) | ks, self.cap,
                                                        self.count.data_ptr(), self.scratch.data_ptr(), None), "compact")
+                if fused:
+                    if shard_o:
+                        comm.allreduce_max_(self.red[1:4])         # the three maxima in one collective
+                    levels = (C.c_void_p * 6)(*[lev[o][k].view for k in range(6)])
+                    bits = (C.c_void_p * 3)(*[self.bits.data_ptr() + 8 * k * self.bits_words for k in range(3)])
+                    rc = L.s3d_k_extrema_fused(levels, 3, nxo, nyo, nzo, za, zb, float(self.s.peak_thresh),
+                                               self.red[1:].data_ptr(), bits, None)
+                    self._ck(rc, "extrema_fused")
+                    for ks in range(1, 4):
+                        self._ck(L.s3d_k_compact_bits_base(bits[ks - 1], nwords, za * pe, self.cand_idx.data_ptr(),
+                                                           self.cand_tag.data_ptr(), (o << 8) | ks, self.cap,
+                                                           self.count.data_ptr(), self.scratch.data_ptr(), None),
+                                 "compact")
             ncand = int(self.count[0].item())
             # the redo decision must be collective: a rank that looped alone would re-enter the all-reduces
             over = torch.tensor([1.0 if ncand > self.cap else 0.0], dtype=torch.float32, device=self.dev)
