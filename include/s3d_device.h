@@ -200,6 +200,12 @@ int s3d_k_dense_rot_hist(const float *d_smooth, int nx, int ny, int nz, const fl
 /* postproc_Hist per voxel (sift.c:2267-2292, 2396-2412): normalise, clamp, normalise, times in(x,y,z) */
 int s3d_k_dense_post(float *d_desc12, const float *d_in, size_t nvox, s3d_stream stream);
 
+/* ---- inverse affine warp (s3d_resample.hip; im_inv_transform, imutil.c:2040-2175) --------------------- */
+/* d_dst(x,y,z,c) = sample of d_src at A [x y z 1]^T; A: 3 x 4 row-major doubles; interp 0 = tri-linear
+ * (bit-identical to the reference), 1 = Lanczos-2; zero outside the source. */
+int s3d_k_inv_affine(const float *d_src, int snx, int sny, int snz, int nc, float *d_dst, int dnx, int dny, int dnz,
+                     const double A[12], int interp, s3d_stream stream);
+
 /* ---- matcher (s3d_match.hip; replaces match_desc, sift.c:2892-2969) ------------------------------- */
 /* For each of the `na` query rows (row r = d_a + (d_a_sel ? d_a_sel[r] : r) * a_stride, 768 floats) the
  * smallest and second-smallest f64 sum of squared differences over the nb rows of d_b and the index of

@@ -280,6 +280,76 @@ int parse_args_SIFT3D(SIFT3D *const sift3d, const int argc, char **argv,
 int parse_gnu(const int argc, char *const *argv);                        /* imutil.c:4891 */
 void print_bug_msg(void);                                                /* imutil.c:4925 */
 
+/* Registration tail: types of imutil/imtypes.h:337-391 and reg/reg.h. */
+typedef enum _tform_type { AFFINE, TPS } tform_type;
+typedef enum _interp_type { LINEAR, LANCZOS2 } interp_type;
+typedef struct _Tform_vtable {
+    int (*copy)(const void *const, void *const);
+    void (*apply_xyz)(const void *const, const double, const double, const double, double *const, double *const,
+                      double *const);
+    int (*apply_Mat_rm)(const void *const, const Mat_rm *const, Mat_rm *const);
+    size_t (*get_size)(void);
+    int (*write)(const char *, const void *const);
+    void (*cleanup)(void *const);
+} Tform_vtable;
+typedef struct _Tform {
+    tform_type type;
+    const Tform_vtable *vtable;
+} Tform;
+typedef struct _Affine {
+    Tform tform;
+    Mat_rm A;                          /* dim x (dim+1) doubles: x' = A [x 1]^T */
+} Affine;
+typedef struct _Ransac {
+    double err_thresh;                 /* inlier threshold (its square bounds the squared error) */
+    int num_iter;
+} Ransac;
+typedef struct _Reg_SIFT3D {
+    double src_units[IM_NDIMS], ref_units[IM_NDIMS];
+    SIFT3D sift3d;
+    Ransac ran;
+    SIFT3D_Descriptor_store desc_src, desc_ref;
+    Mat_rm match_src, match_ref;
+    double nn_thresh;
+    int verbose;
+} Reg_SIFT3D;
+#define SIFT3D_SINGULAR 1              /* imutil.h:19 */
+
+void init_Ransac(Ransac *const ran);                                     /* imutil.c:4238 */
+int set_err_thresh_Ransac(Ransac *const ran, double err_thresh);         /* imutil.c:4245 */
+int set_num_iter_Ransac(Ransac *const ran, int num_iter);                /* imutil.c:4260 */
+int copy_Ransac(const Ransac *const src, Ransac *const dst);             /* imutil.c:4274 */
+int init_Affine(Affine *const affine, const int dim);                    /* imutil.c:2560 */
+int Affine_set_mat(const Mat_rm *const mat, Affine *const affine);       /* imutil.c:2620 */
+int init_tform(void *const tform, const tform_type type);                /* imutil.c:2540 */
+void cleanup_tform(void *const tform);
+int copy_tform(const void *const src, void *const dst);
+size_t tform_get_size(const void *const tform);
+size_t tform_type_get_size(const tform_type type);
+tform_type tform_get_type(const void *const tform);
+void apply_tform_xyz(const void *const tform, const double x_in, const double y_in, const double z_in,
+                     double *const x_out, double *const y_out, double *const z_out);
+int write_tform(const char *path, const void *const tform);
+int find_tform_ransac(const Ransac *const ran, const Mat_rm *const src, const Mat_rm *const ref,
+                      void *const tform);                                /* imutil.c:4757 */
+int im_inv_transform(const void *const tform, const Image *const src, const interp_type interp,
+                     const int resize, Image *const dst);                /* imutil.c:2040 (resampling on the device) */
+int im_resample(const Image *const src, const double *const units, const interp_type interp,
+                Image *const dst);                                       /* imutil.c:2191 */
+int copy_Mat_rm(const Mat_rm *const src, Mat_rm *const dst);             /* imutil.c:775 */
+int concat_Mat_rm(const Mat_rm *const src1, const Mat_rm *const src2, Mat_rm *const dst, const int dim);
+int init_Reg_SIFT3D(Reg_SIFT3D *const reg);                              /* reg.c:121 */
+void cleanup_Reg_SIFT3D(Reg_SIFT3D *const reg);
+int set_nn_thresh_Reg_SIFT3D(Reg_SIFT3D *const reg, const double nn_thresh);
+int set_Ransac_Reg_SIFT3D(Reg_SIFT3D *const reg, const Ransac *const ran);
+int set_SIFT3D_Reg_SIFT3D(Reg_SIFT3D *const reg, const SIFT3D *const sift3d);
+int set_src_Reg_SIFT3D(Reg_SIFT3D *const reg, const Image *const src);
+int set_ref_Reg_SIFT3D(Reg_SIFT3D *const reg, const Image *const ref);
+int register_SIFT3D(Reg_SIFT3D *const reg, void *const tform);           /* reg.c:239 */
+int register_SIFT3D_resample(Reg_SIFT3D *const reg, const Image *const src, const Image *const ref,
+                             const interp_type interp, void *const tform); /* reg.c:366 */
+int get_matches_Reg_SIFT3D(const Reg_SIFT3D *const reg, Mat_rm *const match_src, Mat_rm *const match_ref);
+
 /* ======================= extensions (not in the reference) ========================================= */
 /* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */
 int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz,
@@ -319,6 +389,9 @@ const char *sift3d_amd_last_error(void);
 S3D_ABI_SIZE(Image, 104); S3D_ABI_OFF(Image, cl_image, 8); S3D_ABI_OFF(Image, s, 16);
 S3D_ABI_OFF(Image, size, 24); S3D_ABI_OFF(Image, nx, 32); S3D_ABI_OFF(Image, ux, 48);
 S3D_ABI_OFF(Image, xs, 72); S3D_ABI_OFF(Image, nc, 96); S3D_ABI_OFF(Image, cl_valid, 100);
+S3D_ABI_SIZE(Reg_SIFT3D, 512); S3D_ABI_OFF(Reg_SIFT3D, sift3d, 48); S3D_ABI_OFF(Reg_SIFT3D, ran, 352);
+S3D_ABI_OFF(Reg_SIFT3D, desc_src, 368); S3D_ABI_OFF(Reg_SIFT3D, match_src, 432); S3D_ABI_OFF(Reg_SIFT3D, nn_thresh, 496);
+S3D_ABI_SIZE(Ransac, 16); S3D_ABI_SIZE(Tform, 16); S3D_ABI_SIZE(Affine, 48); S3D_ABI_OFF(Affine, A, 16); S3D_ABI_SIZE(Tform_vtable, 48);
 S3D_ABI_SIZE(Mat_rm, 32); S3D_ABI_SIZE(Keypoint, 112); S3D_ABI_OFF(Keypoint, R, 40);
 S3D_ABI_OFF(Keypoint, xd, 72); S3D_ABI_OFF(Keypoint, sd, 96); S3D_ABI_OFF(Keypoint, o, 104);
 S3D_ABI_OFF(Keypoint, s, 108); S3D_ABI_SIZE(Slab, 24); S3D_ABI_SIZE(Keypoint_store, 48);

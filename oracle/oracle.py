@@ -38,8 +38,10 @@ def load_ref():
     """The unmodified reference as a ``Sift3dLib`` (same API object the product exposes)."""
     from sift3d_amd import abi
     im = C.CDLL(os.path.join(REF_DIR, "libimutil.so"), mode=C.RTLD_GLOBAL)
-    s = C.CDLL(os.path.join(REF_DIR, "libsift3D.so"))
-    return abi.Sift3dLib(s, im, "reference")
+    s = C.CDLL(os.path.join(REF_DIR, "libsift3D.so"), mode=C.RTLD_GLOBAL)
+    reg_path = os.path.join(REF_DIR, "libreg.so")
+    reg = C.CDLL(reg_path) if os.path.exists(reg_path) else None
+    return abi.Sift3dLib(s, im, "reference", reg)
 
 
 def _p(a, t):

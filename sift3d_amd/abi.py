@@ -115,6 +115,24 @@ class SIFT3D(C.Structure):
                 ("corner_thresh", C.c_double), ("dense_rotate", C.c_int)]
 
 
+class Ransac(C.Structure):
+    _fields_ = [("err_thresh", C.c_double), ("num_iter", C.c_int)]
+
+
+class Tform(C.Structure):
+    _fields_ = [("type", C.c_int), ("vtable", C.c_void_p)]
+
+
+class Affine(C.Structure):
+    _fields_ = [("tform", Tform), ("A", Mat_rm)]
+
+
+class Reg_SIFT3D(C.Structure):
+    _fields_ = [("src_units", C.c_double * 3), ("ref_units", C.c_double * 3), ("sift3d", SIFT3D), ("ran", Ransac),
+                ("desc_src", SIFT3D_Descriptor_store), ("desc_ref", SIFT3D_Descriptor_store), ("match_src", Mat_rm),
+                ("match_ref", Mat_rm), ("nn_thresh", C.c_double), ("verbose", C.c_int)]
+
+
 # (struct, sizeof, {field: offset}) measured on the compiled reference.
 ABI_LAYOUT = [
     (Image, 104, {"data": 0, "cl_image": 8, "s": 16, "size": 24, "nx": 32, "ux": 48, "xs": 72,
@@ -132,6 +150,11 @@ ABI_LAYOUT = [
     (Pyramid, 48, {}),
     (Tri, 48, {}),
     (Mesh, 16, {}),
+    (Ransac, 16, {"num_iter": 8}),
+    (Tform, 16, {"vtable": 8}),
+    (Affine, 48, {"A": 16}),
+    (Reg_SIFT3D, 512, {"ref_units": 24, "sift3d": 48, "ran": 352, "desc_src": 368, "desc_ref": 400, "match_src": 432,
+                       "match_ref": 464, "nn_thresh": 496, "verbose": 504}),
     (SIFT3D, 304, {"gss": 16, "gpyr": 80, "dog": 128, "im": 176, "peak_thresh": 280,
                    "dense_rotate": 296}),
 ]
@@ -144,9 +167,10 @@ class Sift3dLib:
     reference splits libimutil / libsift3D; the product exports both layers from one library).
     """
 
-    def __init__(self, sift: C.CDLL, imutil: C.CDLL | None = None, name: str = "?"):
+    def __init__(self, sift: C.CDLL, imutil: C.CDLL | None = None, name: str = "?", reg: C.CDLL | None = None):
         self.sift = sift
         self.imutil = imutil if imutil is not None else sift
+        self.reg = reg if reg is not None else sift          # registration layer (libreg in the reference)
         self.name = name
         s, u = self.sift, self.imutil
         P = C.POINTER

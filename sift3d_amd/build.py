@@ -20,10 +20,10 @@ OBJ = os.path.join(HERE, "lib", "obj")
 INC = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
-               "s3d_dense.hip", "s3d_match.hip"]
-C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c"]
+               "s3d_dense.hip", "s3d_match.hip", "s3d_resample.hip"]
+C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c"]
 BIN = os.path.join(HERE, "bin")
-CLI_PROGRAMS = ["kpSift3D", "denseSift3D"]
+CLI_PROGRAMS = ["kpSift3D", "denseSift3D", "regSift3D"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]

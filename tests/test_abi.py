@@ -23,6 +23,7 @@ def _declared_functions(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"^\s*#.*$", "", txt, flags=re.M)
+    txt = re.sub(r"\(\s*\*\s*\w+\s*\)\s*\([^;{}]*\)\s*;", ";", txt)      # function-pointer members of structs
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", txt)
     return sorted(set(n for n in names if n not in ("_Static_assert", "S3D_ABI_SIZE", "S3D_ABI_OFF", "sizeof")))
 
