@@ -380,6 +380,29 @@ def main():
         dev.free(d_in)
         dev.free(d_out)
         lib.sift.cleanup_SIFT3D(C.byref(s2))
+    if rank == 0 and not args.no_match:
+        # BASELINE configs[4] flavour, outside the timed region: the same volume read as anisotropic slices
+        # (units 1 x 1 x 1.5): in-plane passes on the fused kernel, the z pass on the generic one
+        s3 = abi.SIFT3D()
+        assert lib.sift.init_SIFT3D(C.byref(s3)) == 0
+        kp3 = abi.Keypoint_store()
+        lib.sift.init_Keypoint_store(C.byref(kp3))
+        d3 = C.c_void_p()
+        ta = []
+        for _ in range(3):
+            dev.sync()
+            t0 = time.perf_counter()
+            lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(s3), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.5, C.byref(kp3))
+            dev.sync()
+            t1 = time.perf_counter()
+            if kp3.slab.num:
+                lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s3), C.byref(kp3), C.byref(d3))
+            dev.sync()
+            ta.append((t1 - t0, time.perf_counter() - t1))
+        result["config"]["aniso_1x1x1.5"] = {"detect_ms": round(min(t[0] for t in ta[1:]) * 1e3, 2),
+                                             "describe_ms": round(min(t[1] for t in ta[1:]) * 1e3, 2),
+                                             "keypoints": int(kp3.slab.num)}
+        lib.sift.cleanup_SIFT3D(C.byref(s3))
     if rank == 0 and not args.no_roofline:
         add_roofline(result, dev, n)
     if rank == 0 and not args.no_cpu_baseline:

@@ -129,6 +129,50 @@ k_conv_axis_dyadic(const float *__restrict__ src, float *__restrict__ dst, size_
     dst[idx] = acc;
 }
 
+/* k_conv_axis for an axis other than x, four x-consecutive elements per thread: tap coordinates depend only
+ * on the position along the filtered axis, so they are computed once for the four and the two samples of
+ * every tap are float4 loads.  Element for element the same arithmetic as k_conv_axis. */
+__global__ void __launch_bounds__(256)
+k_conv_axis_v4(const float *__restrict__ src, float *__restrict__ dst, size_t i4_begin, size_t i4_end, size_t sa4, int n,
+               int hw, float uf, int uhw, S3dTaps taps)
+{
+    const size_t i4 = i4_begin + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= i4_end) return;
+    const int p = (int)((i4 / sa4) % (size_t)n);
+    const float4 *s = reinterpret_cast<const float4 *>(src) + (i4 - (size_t)p * sa4);
+    const int dim_end = n - 1;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto tap_in = [&](float tap, float coord) {
+        const int lo = (int)coord;
+        const float frac = coord - (float)lo;
+        const float4 a = s[(size_t)lo * sa4], b = s[(size_t)(lo + 1) * sa4];
+        acc.x = acc.x + tap * ((1.0f - frac) * a.x + frac * b.x);
+        acc.y = acc.y + tap * ((1.0f - frac) * a.y + frac * b.y);
+        acc.z = acc.z + tap * ((1.0f - frac) * a.z + frac * b.z);
+        acc.w = acc.w + tap * ((1.0f - frac) * a.w + frac * b.w);
+    };
+    if (p >= uhw && p <= n - 2 - uhw) {
+        float coord = (float)p;
+        for (int d = -hw; d <= hw; d++) {
+            const float step = (float)d * uf;
+            coord = coord - step;
+            tap_in(taps.t[d + hw], coord);
+            coord = coord + step;
+        }
+    } else {
+        for (int d = -hw; d <= hw; d++) {
+            const float step = (float)d * uf;
+            float coord = (float)p - step;
+            if ((int)coord < 0)
+                coord = -coord;
+            else if ((int)coord >= dim_end)
+                coord = 2.0f * (float)dim_end - coord - 0.1f;
+            tap_in(taps.t[d + hw], coord);
+        }
+    }
+    reinterpret_cast<float4 *>(dst)[i4] = acc;
+}
+
 template <int O>
 static bool launch_dyadic(int hw, const float *src, float *dst, size_t ib, size_t ie, size_t sa, int n,
                           const S3dTaps &t, hipStream_t st)
@@ -177,6 +221,12 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
             S3D_CHECK_LAUNCH();
             return S3D_OK;
         }
+    }
+    if (axis != 0 && (strides[1] & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15) && !g_no_dyadic) {
+        hipLaunchKernelGGL(k_conv_axis_v4, dim3(s3d_div_up((ie - ib) / 4, 256)), dim3(256), 0, (hipStream_t)st, d_src,
+                           d_dst, ib / 4, ie / 4, strides[axis] / 4, dims[axis], hw, uf, uhw, t);
+        S3D_CHECK_LAUNCH();
+        return S3D_OK;
     }
     hipLaunchKernelGGL(k_conv_axis, dim3(s3d_div_up(ie - ib, 256)), dim3(256), 0, (hipStream_t)st, d_src, d_dst, ib,
                        ie, strides[axis], dims[axis], hw, uf, uhw, t);
@@ -697,6 +747,47 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
     return S3D_OK;
 }
 
+/* X+Y only (planes [za, zb)): the in-plane half of a filter whose z spacing is not 1 (anisotropic slices) */
+template <int HW>
+static int launch_fast_xy(const float *d_src, float *d_dst, int nx, int ny, int za, int zb, const S3dTaps &t, hipStream_t st)
+{
+    EdgeFrac ex, ey;
+    if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey)) S3D_FAIL("edge table");
+    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
+    const unsigned ncy = s3d_div_up(ny, cy);
+    const size_t plane = (size_t)nx * ny;
+    if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
+    hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st, d_src + za * plane,
+                       d_dst + za * plane, nx, ny, cy, t, ex, ey);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+static int fast_xy_dispatch(const float *d_src, float *d_dst, int nx, int ny, int za, int zb, int hw, const S3dTaps &t,
+                            hipStream_t st)
+{
+    switch (hw) {
+    case 1: return launch_fast_xy<1>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 2: return launch_fast_xy<2>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 3: return launch_fast_xy<3>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 4: return launch_fast_xy<4>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 5: return launch_fast_xy<5>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 6: return launch_fast_xy<6>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 7: return launch_fast_xy<7>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 8: return launch_fast_xy<8>(d_src, d_dst, nx, ny, za, zb, t, st);
+    case 9: return launch_fast_xy<9>(d_src, d_dst, nx, ny, za, zb, t, st);
+    default: break;
+    }
+    S3D_FAIL("half width not instantiated");
+}
+
+/* in-plane unit spacing, any z spacing: fused X+Y + generic Z */
+static int fast_xy_eligible(int nx, int ny, int nz, int nc, const float uf[3], int width)
+{
+    const float u1[3] = {1.0f, 1.0f, 1.0f};
+    return uf[0] == 1.0f && uf[1] == 1.0f && uf[2] != 1.0f && nz >= 1 && fast_eligible(nx, ny, width + 2, nc, u1, width);
+}
+
 static int fast_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
                          int hw, const S3dTaps &t, hipStream_t st)
 {
@@ -830,6 +921,10 @@ extern "C" int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp
     if (fast_eligible(nx, ny, nz, 1, uf, width)) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, hw, t, st);
     const int h = (int)ceilf((float)hw * uf[2]);
     const int za = z0 - h > 0 ? z0 - h : 0, zb = z1 + h < nz ? z1 + h : nz;
+    if (fast_xy_eligible(nx, ny, nz, 1, uf, width) && !g_no_dyadic) {
+        if (fast_xy_dispatch(d_src, d_tmp, nx, ny, za, zb, hw, t, st)) return S3D_ERR;
+        return conv_axis_range(d_tmp, d_dst, nx, ny, nz, 1, 2, z0, z1, taps, width, uf[2], stream);
+    }
     if (conv_axis_range(d_src, d_dst, nx, ny, nz, 1, 0, za, zb, taps, width, uf[0], stream)) return S3D_ERR;
     if (conv_axis_range(d_dst, d_tmp, nx, ny, nz, 1, 1, za, zb, taps, width, uf[1], stream)) return S3D_ERR;
     if (conv_axis_range(d_tmp, d_dst, nx, ny, nz, 1, 2, z0, z1, taps, width, uf[2], stream)) return S3D_ERR;
@@ -850,6 +945,10 @@ extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp
     if (fast && path != 1) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, 0, nz, width / 2, t, st);
     if (path != 1 && d_src != d_dst && fast_mc_eligible(nx, ny, nz, nc, uf, width))
         return fast_mc_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, nc, width / 2, t, st);
+    if (path != 1 && fast_xy_eligible(nx, ny, nz, nc, uf, width)) {      /* x, y fused: src -> tmp ; z generic: tmp -> dst */
+        if (fast_xy_dispatch(d_src, d_tmp, nx, ny, 0, nz, width / 2, t, st)) return S3D_ERR;
+        return s3d_k_conv_axis(d_tmp, d_dst, nx, ny, nz, nc, 2, taps, width, uf[2], stream);
+    }
     /* generic per-axis passes.  out of place: x: src -> dst ; y: dst -> tmp ; z: tmp -> dst */
     if (d_src != d_dst) {
         if (s3d_k_conv_axis(d_src, d_dst, nx, ny, nz, nc, 0, taps, width, uf[0], stream)) return S3D_ERR;
