@@ -7,7 +7,7 @@
  * linked against libsift3d_amd.so.  Detection, description, matching and the warp run as HIP kernels;
  * RANSAC is host C.  As in the reference, --err_thresh and --num_iter are parsed after the Ransac
  * parameters have been copied into the registration object, so they do not reach the estimator
- * (cli/regSift3D.c:176-178, 222-242).  The drawing outputs (--concat, --keys, --lines) are not offered.
+ * (cli/regSift3D.c:176-178, 222-242).
  */
 #include <getopt.h>
 #include <stdio.h>
@@ -35,6 +35,12 @@ static void usage(void)
            " --transform [filename] - The transformation parameters. \n"
            "       Supported file formats: .csv, .csv.gz \n"
            " --warped [filename] -  The warped source image. \n"
+           "       Supported file formats: .nii, .nii.gz \n"
+           " --concat [filename] - Concatenated images, with source on the left \n"
+           "       Supported file formats: .nii, .nii.gz \n"
+           " --keys [filename] - Keypoints drawn in the concatenated image \n"
+           "       Supported file formats: .nii, .nii.gz \n"
+           " --lines [filename] - Lines drawn between matching keypoints \n"
            "       Supported file formats: .nii, .nii.gz \n"
            "At least one output option must be specified. \n"
            "\n"
@@ -76,10 +82,13 @@ static void complain_path(const char *what, const char *path)
 
 int main(int argc, char *argv[])
 {
-    enum { MATCHES = 'a', TRANSFORM, WARPED, NN_THRESH, ERR_THRESH, NUM_ITER, TYPE, RESAMPLE };
+    enum { MATCHES = 'a', TRANSFORM, WARPED, CONCAT, KEYS, LINES, NN_THRESH, ERR_THRESH, NUM_ITER, TYPE, RESAMPLE };
     static const struct option longopts[] = {{"matches", required_argument, NULL, MATCHES},
                                              {"transform", required_argument, NULL, TRANSFORM},
                                              {"warped", required_argument, NULL, WARPED},
+                                             {"concat", required_argument, NULL, CONCAT},
+                                             {"keys", required_argument, NULL, KEYS},
+                                             {"lines", required_argument, NULL, LINES},
                                              {"nn_thresh", required_argument, NULL, NN_THRESH},
                                              {"err_thresh", required_argument, NULL, ERR_THRESH},
                                              {"num_iter", required_argument, NULL, NUM_ITER},
@@ -92,7 +101,8 @@ int main(int argc, char *argv[])
     Image src, ref;
     Mat_rm match_src, match_ref;
     Affine tform;
-    const char *match_path = NULL, *tform_path = NULL, *warped_path = NULL;
+    const char *match_path = NULL, *tform_path = NULL, *warped_path = NULL, *concat_path = NULL, *keys_path = NULL,
+               *lines_path = NULL;
     int have_match = 0, have_tform = 0, resample = 0;
 
     switch (parse_gnu(argc, argv)) {
@@ -121,6 +131,9 @@ int main(int argc, char *argv[])
         case MATCHES: match_path = optarg; have_match = 1; break;
         case TRANSFORM: tform_path = optarg; have_tform = 1; break;
         case WARPED: warped_path = optarg; have_tform = 1; break;
+        case CONCAT: concat_path = optarg; have_match = 1; break;
+        case KEYS: keys_path = optarg; have_match = 1; break;
+        case LINES: lines_path = optarg; have_match = 1; break;
         case NN_THRESH:
             if (set_nn_thresh_Reg_SIFT3D(&reg, atof(optarg))) { complain("Invalid value for nn_thresh."); return 1; }
             break;
@@ -182,6 +195,32 @@ int main(int argc, char *argv[])
         if (im_inv_transform(&tform, &src, LINEAR, SIFT3D_FALSE, &warped)) { complain_bug("Failed to warp the source image."); return 1; }
         if (im_write(warped_path, &warped)) { complain_path("Failed to write the warped image", warped_path); return 1; }
         im_free(&warped);
+    }
+    if (concat_path != NULL || keys_path != NULL || lines_path != NULL) {
+        Image concat, keys, lines;
+        Mat_rm keys_src, keys_ref;
+        init_im(&concat);
+        init_im(&keys);
+        init_im(&lines);
+        if (init_Mat_rm(&keys_src, 0, 0, SIFT3D_DOUBLE, SIFT3D_FALSE) || init_Mat_rm(&keys_ref, 0, 0, SIFT3D_DOUBLE, SIFT3D_FALSE)) {
+            complain_bug("Failed to initialize keypoint matrices.");
+            return 1;
+        }
+        if (SIFT3D_Descriptor_coords_to_Mat_rm(&reg.desc_src, &keys_src) ||
+            SIFT3D_Descriptor_coords_to_Mat_rm(&reg.desc_ref, &keys_ref)) {
+            complain_bug("Failed to convert the keypoints to matrices.");
+            return 1;
+        }
+        if (draw_matches(&src, &ref, &keys_src, &keys_ref, &match_src, &match_ref, concat_path ? &concat : NULL,
+                         keys_path ? &keys : NULL, lines_path ? &lines : NULL)) {
+            complain_bug("Failed to draw the matches.");
+            return 1;
+        }
+        if (concat_path != NULL && im_write(concat_path, &concat)) { complain_path("Failed to write the concatenated image", concat_path); return 1; }
+        if (keys_path != NULL && im_write(keys_path, &keys)) { complain_path("Failed to write the keypoint image", keys_path); return 1; }
+        if (lines_path != NULL && im_write(lines_path, &lines)) { complain_path("Failed to write the line image", lines_path); return 1; }
+        im_free(&concat); im_free(&keys); im_free(&lines);
+        cleanup_Mat_rm(&keys_src); cleanup_Mat_rm(&keys_ref);
     }
     cleanup_tform(&tform);
     cleanup_Mat_rm(&match_src);

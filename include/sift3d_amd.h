@@ -349,6 +349,16 @@ int register_SIFT3D(Reg_SIFT3D *const reg, void *const tform);           /* reg.
 int register_SIFT3D_resample(Reg_SIFT3D *const reg, const Image *const src, const Image *const ref,
                              const interp_type interp, void *const tform); /* reg.c:366 */
 int get_matches_Reg_SIFT3D(const Reg_SIFT3D *const reg, Mat_rm *const match_src, Mat_rm *const match_ref);
+/* picture outputs of regSift3D (host only) */
+int convert_Mat_rm(const Mat_rm *const in, Mat_rm *const out, const Mat_rm_type type);       /* imutil.c:567 */
+int im_pad(const Image *const im, Image *const pad);                     /* imutil.c:1471 */
+int im_concat(const Image *const src1, const Image *const src2, const int dim, Image *const dst); /* imutil.c:1613 */
+int draw_lines(const Mat_rm *const points1, const Mat_rm *const points2, const int *const dims,
+               Image *const out);                                        /* imutil.c:1063 */
+int SIFT3D_Descriptor_coords_to_Mat_rm(const SIFT3D_Descriptor_store *const store, Mat_rm *const mat); /* sift.c:2628 */
+int draw_matches(const Image *const left, const Image *const right, const Mat_rm *const keys_left,
+                 const Mat_rm *const keys_right, const Mat_rm *const match_left, const Mat_rm *const match_right,
+                 Image *const concat, Image *const keys, Image *const lines);               /* sift.c:2990 */
 
 /* ======================= extensions (not in the reference) ========================================= */
 /* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */

@@ -235,9 +235,14 @@ def _reg_end_to_end(tmp_path, dims, nblobs, shift, env):
         with gzip.open(str(tmp_path / f"{name}.nii.gz"), "wb") as f:
             f.write(nifti1_bytes(np.ascontiguousarray(v.transpose(2, 1, 0)), units))
     mt, tf, wp = (str(tmp_path / "out" / n) for n in ("matches.csv", "tform.csv", "warped.nii.gz"))
-    r = run(os.path.join(BIN, "regSift3D"), "--matches", mt, "--transform", tf, "--warped", wp,
-            str(tmp_path / "src.nii.gz"), str(tmp_path / "ref.nii.gz"), env=env)
+    cc, ky, ln = (str(tmp_path / "out" / n) for n in ("concat.nii.gz", "keys.nii.gz", "lines.nii.gz"))
+    r = run(os.path.join(BIN, "regSift3D"), "--matches", mt, "--transform", tf, "--warped", wp, "--concat", cc, "--keys", ky,
+            "--lines", ln, str(tmp_path / "src.nii.gz"), str(tmp_path / "ref.nii.gz"), env=env)
     assert r.returncode == 0, r.stderr
+    for path in (cc, ky, ln):                                             # source | reference side by side
+        pic, _ = _nii_f32(path)
+        assert pic.shape == (2 * nx, ny, nz) and np.isfinite(pic).all()
+    assert _nii_f32(ky)[0].sum() > 0 and _nii_f32(ln)[0].sum() > 0
     m = np.array(_csv(mt), np.float64)
     assert m.shape[1] == 6 and m.shape[0] >= 5
     d = m[:, 3:] - m[:, :3]                                                # ref - src coordinates of a match
@@ -282,3 +287,32 @@ def test_regSift3D_usage(tmp_path):
                       (["--nn_thresh", "2", "--matches", "m.csv", "a", "b"], "Invalid value for nn_thresh.")):
         r = run(exe, *args)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
+
+
+def test_draw_matches_matches_reference(host, reference):
+    """The picture outputs of regSift3D (host only): concatenated volumes, keypoint cubes, match segments --
+    voxel for voxel the reference's images."""
+    rng = np.random.default_rng(11)
+    left = rng.standard_normal((9, 12, 14)).astype(np.float32)            # [z, y, x]
+    right = rng.standard_normal((11, 10, 13)).astype(np.float32)
+    kl = rng.random((15, 3)) * np.array([14, 12, 9]) * 1.1 - 0.5           # some fall outside
+    kr = rng.random((12, 3)) * np.array([13, 10, 11])
+    ml = rng.random((10, 3)) * np.array([13.9, 11.9, 8.9])
+    mr = rng.random((10, 3)) * np.array([12.9, 9.9, 10.9])
+    ml[0] = mr[0] = (3.2, 4.0, 2.0)                                        # a vertical segment after the shift? no: same x + pad
+    ml[1, 0] = 20.0                                                        # outside the left image but inside the canvas
+    outs = []
+    for L in (host, reference):
+        L.sift.draw_matches.argtypes = [P(abi.Image)] * 2 + [P(abi.Mat_rm)] * 4 + [P(abi.Image)] * 3
+        L.imutil.init_Mat_rm.argtypes = [P(abi.Mat_rm), C.c_int, C.c_int, C.c_int, C.c_int]
+        il, ir = L.image_from_numpy(left, (1, 1, 2)), L.image_from_numpy(right, (1, 1, 1))
+        mats = [_mat(L, a) for a in (kl, kr, ml, mr)]
+        ims = [abi.Image() for _ in range(3)]
+        for im in ims:
+            L.imutil.init_im(C.byref(im))
+        assert L.sift.draw_matches(C.byref(il), C.byref(ir), *[C.byref(m) for m in mats], *[C.byref(im) for im in ims]) == 0
+        outs.append([L.image_to_numpy(im) for im in ims])
+        assert L.sift.draw_matches(C.byref(il), C.byref(ir), None, None, None, None, None, None, None) != 0
+    for a, b in zip(*outs):
+        assert a.shape == b.shape == (11, 12, 27) and np.array_equal(a, b)
+    assert outs[0][1].sum() > 0 and outs[0][2].sum() > 0
