@@ -213,6 +213,12 @@ int s3d_k_inv_affine(const float *d_src, int snx, int sny, int snz, int nc, floa
 int s3d_k_nn_best2(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b,
                    size_t b_stride, uint32_t nb, double *d_best, double *d_second, int *d_idx,
                    s3d_stream stream);
+/* Same outputs (bit for bit) through an f32 screening pass + exact verification of the few columns that can be
+ * the nearest or second-nearest neighbour (see s3d_match.hip).  Returns 1 when it declines (a row with more than
+ * 64 candidates, nb < 2): run s3d_k_nn_best2 instead. */
+int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b,
+                        size_t b_stride, uint32_t nb, double *d_best, double *d_second, int *d_idx,
+                        s3d_stream stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,17 @@ static int s3d_ratio_reject(double ssd_best, double ssd_nearest, float nn_thresh
     return ssd_best / ssd_nearest > nn_thresh * nn_thresh;
 }
 
+/* screened kernel first; the exhaustive one when it declines (or when S3D_NN_EXHAUSTIVE is set: tests, ablation) */
+static int s3d_best2(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b, size_t b_stride,
+                     uint32_t nb, double *d_best, double *d_second, int *d_idx, void *stream)
+{
+    if (getenv("S3D_NN_EXHAUSTIVE") == NULL) {
+        const int rc = s3d_k_nn_best2_fast(d_a, a_stride, d_a_sel, na, d_b, b_stride, nb, d_best, d_second, d_idx, stream);
+        if (rc <= 0) return rc;
+    }
+    return s3d_k_nn_best2(d_a, a_stride, d_a_sel, na, d_b, b_stride, nb, d_best, d_second, d_idx, stream);
+}
+
 /* Device-resident form: d_a / d_b point at `float[768]` rows `stride` floats apart (stride % 4 == 0),
  * matches is a host array of na ints. */
 int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const float *d_b, size_t b_stride,
@@ -102,8 +113,7 @@ int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const fl
         goto done;
 
     /* forward pass: every descriptor of A against all of B */
-    if (s3d_k_nn_best2(d_a, a_stride, NULL, (uint32_t)na, d_b, b_stride, (uint32_t)nb, d_best, d_best + n, d_idx,
-                       stream) ||
+    if (s3d_best2(d_a, a_stride, NULL, (uint32_t)na, d_b, b_stride, (uint32_t)nb, d_best, d_best + n, d_idx, stream) ||
         s3d_rt_d2h(h_best, d_best, 2 * n * sizeof(double), stream) ||
         s3d_rt_d2h(h_idx, d_idx, n * sizeof(int), stream) || s3d_rt_sync(stream))
         goto done;
@@ -117,8 +127,7 @@ int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const fl
     /* backward pass: the matched descriptors of B against all of A (sift.c:2880) */
     if (nsel) {
         if (s3d_rt_h2d(d_sel, h_sel, nsel * sizeof(int), stream) ||
-            s3d_k_nn_best2(d_b, b_stride, d_sel, (uint32_t)nsel, d_a, a_stride, (uint32_t)na, d_best, d_best + n,
-                           d_idx, stream) ||
+            s3d_best2(d_b, b_stride, d_sel, (uint32_t)nsel, d_a, a_stride, (uint32_t)na, d_best, d_best + n, d_idx, stream) ||
             s3d_rt_d2h(h_best, d_best, 2 * n * sizeof(double), stream) ||
             s3d_rt_d2h(h_idx, d_idx, nsel * sizeof(int), stream) || s3d_rt_sync(stream))
             goto done;

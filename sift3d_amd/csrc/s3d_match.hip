@@ -146,3 +146,252 @@ extern "C" int s3d_k_nn_best2(const float* d_a, size_t a_stride, const int* d_a_
                        a_stride, d_a_sel, na, d_b, b_stride, nb, d_best, d_second, d_idx);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+/* ================================================================================================
+ * Fast path: f32 screening + exact verification.
+ *
+ * The exhaustive f64 kernel above spends 3 FP64 flops per pair-element on ~1e9 pairs of which all but
+ * two per query are irrelevant.  Here every pair is first scored approximately, S~ = |a|^2 + |b|^2 - 2 a.b
+ * with the dot product in f32 FMAs (157 TFLOP/s vector rate on MI355X, 4x the non-FMA FP64 rate and one
+ * flop-pair per element instead of three), and only the columns that can possibly be the nearest or second
+ * nearest neighbour are re-evaluated exactly, in f64 and in the reference's summation order.
+ *
+ * Why the result is still bit-identical.  Let d bound |S~ - S| for a row (below).  If m2 is the second
+ * smallest S~ of the row, the true nearest and second-nearest columns (and every column tied with them)
+ * have S <= m2 + d, hence S~ <= m2 + 2d: they are all among {j : S~_j <= m2 + 2d}.  That candidate set is
+ * evaluated exactly and scanned in ascending j with the reference's update rule, which yields the same
+ * (best, second, index) as scanning all columns.  Error bound: an n-term f32 dot product accumulated in any
+ * order with or without FMA is within n 2^-24 |a||b| (1 + o(1)) of the exact one; with n = 768 and the
+ * f32 roundings of the norms and of the final combination, d <= 1e-4 |a||b| + 5e-7 (|a|^2 + |b|^2); twice
+ * that is used.  For unit-norm descriptors the candidate band is 4e-4 wide: 2-3 columns per row.
+ * If a row has more candidates than NN_CAP (e.g. many duplicated descriptors) the caller falls back to the
+ * exhaustive kernel for the whole pass.
+ * ================================================================================================ */
+#define NN_CAP 64                    /* candidates per row verified exactly */
+#define GT 128                       /* GEMM tile edge */
+#define GK 16                        /* k-chunk */
+
+/* row r of the (optionally gathered) store -> column r of the k-major copy; zero padding beyond n */
+__global__ void __launch_bounds__(256)
+k_nn_transpose(const float *__restrict__ src, size_t stride, const int *__restrict__ sel, unsigned n, unsigned npad,
+               float *__restrict__ dstT)
+{
+    __shared__ float tile[32][65];
+    const unsigned r0 = blockIdx.x * 32u, e0 = blockIdx.y * 64u;
+    const int t = threadIdx.x;
+    for (int k = t; k < 32 * 64; k += 256) {
+        const unsigned r = r0 + (unsigned)(k >> 6), e = (unsigned)(k & 63);
+        float v = 0.0f;
+        if (r < n) v = src[(size_t)(sel ? (unsigned)sel[r] : r) * stride + e0 + e];
+        tile[k >> 6][e] = v;
+    }
+    __syncthreads();
+    for (int k = t; k < 32 * 64; k += 256) {
+        const unsigned e = (unsigned)(k >> 5), r = (unsigned)(k & 31);
+        if (r0 + r < npad) dstT[(size_t)(e0 + e) * npad + r0 + r] = tile[r][e];
+    }
+}
+
+/* squared norms in f64 (one wave per row), stored as f64 and f32; padding rows get a huge norm */
+__global__ void __launch_bounds__(64)
+k_nn_norms(const float *__restrict__ src, size_t stride, const int *__restrict__ sel, unsigned n, unsigned npad,
+           double *__restrict__ n2d, float *__restrict__ n2f)
+{
+    const unsigned r = blockIdx.x;
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    if (r < n) {
+        const float *p = src + (size_t)(sel ? (unsigned)sel[r] : r) * stride;
+        for (int e = lane; e < NEL; e += 64) s += (double)p[e] * (double)p[e];
+    }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0 && r < npad) {
+        n2d[r] = r < n ? s : 1e30;
+        n2f[r] = r < n ? (float)s : 1e30f;
+    }
+}
+
+/* S~[i][j] = |a_i|^2 + |b_j|^2 - 2 a_i.b_j for one 128 x 128 tile; operands k-major (AT[e][i], BT[e][j]) */
+__global__ void __launch_bounds__(256)
+k_nn_gemm(const float *__restrict__ AT, unsigned napad, unsigned row_base, const float *__restrict__ BT, unsigned nbpad,
+          const float *__restrict__ a2, const float *__restrict__ b2, float *__restrict__ S /* rows x nbpad */)
+{
+    __shared__ __attribute__((aligned(16))) float As[GK][GT];
+    __shared__ __attribute__((aligned(16))) float Bs[GK][GT];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const unsigned i0 = row_base + blockIdx.y * GT, j0 = blockIdx.x * GT;
+    float acc[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[r][c] = 0.0f;
+    /* staging: GK x GT floats per operand = 512 float4, two per thread */
+    const int sk = t >> 5, sq = (t & 31) * 4;                 /* k in 0..7 (+8), column quad */
+    for (int e0 = 0; e0 < NEL; e0 += GK) {
+        const float4 ga0 = *reinterpret_cast<const float4 *>(AT + (size_t)(e0 + sk) * napad + i0 + sq);
+        const float4 ga1 = *reinterpret_cast<const float4 *>(AT + (size_t)(e0 + sk + 8) * napad + i0 + sq);
+        const float4 gb0 = *reinterpret_cast<const float4 *>(BT + (size_t)(e0 + sk) * nbpad + j0 + sq);
+        const float4 gb1 = *reinterpret_cast<const float4 *>(BT + (size_t)(e0 + sk + 8) * nbpad + j0 + sq);
+        __syncthreads();
+        *reinterpret_cast<float4 *>(&As[sk][sq]) = ga0;
+        *reinterpret_cast<float4 *>(&As[sk + 8][sq]) = ga1;
+        *reinterpret_cast<float4 *>(&Bs[sk][sq]) = gb0;
+        *reinterpret_cast<float4 *>(&Bs[sk + 8][sq]) = gb1;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GK; k++) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(&As[k][ty * 8]);
+            const float4 a1 = *reinterpret_cast<const float4 *>(&As[k][ty * 8 + 4]);
+            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 8]);
+            const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 8 + 4]);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[r][c] = __builtin_fmaf(av[r], bv[c], acc[r][c]);
+        }
+    }
+    const unsigned li = blockIdx.y * GT + ty * 8;             /* row inside this chunk of S */
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float na = a2[i0 + ty * 8 + r];
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) o[c] = (na + b2[j0 + tx * 8 + c]) - 2.0f * acc[r][c];
+        float *dst = S + (size_t)(li + r) * nbpad + j0 + tx * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+/* one wave per query row: the two smallest approximate scores, then every column within the error band of
+ * the second one, in ascending column order */
+__global__ void __launch_bounds__(64)
+k_nn_rowscan(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned row_base, unsigned na,
+             const double *__restrict__ a2d, double b2max, int *__restrict__ cand, int *__restrict__ count)
+{
+    const unsigned li = blockIdx.x, i = row_base + li;
+    if (i >= na) return;
+    const int lane = threadIdx.x;
+    const float *row = S + (size_t)li * nbpad;
+    float m1 = 3.0e38f, m2 = 3.0e38f;
+    for (unsigned j = lane; j < nb; j += 64) {
+        const float v = row[j];
+        if (v < m1) { m2 = m1; m1 = v; } else if (v < m2) m2 = v;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {                       /* merge the lanes' (m1, m2) pairs */
+        const float o1 = __shfl_xor(m1, m), o2 = __shfl_xor(m2, m);
+        const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1;
+        const float s2 = m2 < o2 ? m2 : o2;
+        m1 = lo;
+        m2 = hi < s2 ? hi : s2;
+    }
+    const double an = sqrt(a2d[i]), bn = sqrt(b2max);
+    const double d = 2.0 * (1e-4 * an * bn + 5e-7 * (a2d[i] + b2max));
+    const float thr = (float)((double)m2 + 2.0 * d + 1e-7 * fabs((double)m2));
+    unsigned n = 0;
+    for (unsigned j0 = 0; j0 < nb; j0 += 64) {
+        const unsigned j = j0 + lane;
+        const bool hit = j < nb && row[j] <= thr;
+        const unsigned long long mask = __ballot(hit ? 1 : 0);
+        if (hit) {
+            const unsigned pos = n + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < NN_CAP) cand[(size_t)i * NN_CAP + pos] = (int)j;
+        }
+        n += (unsigned)__popcll(mask);
+    }
+    if (lane == 0) count[i] = (int)n;
+}
+
+/* exact f64 SSD (reference order) of each candidate, then the reference's scan over them in column order */
+__global__ void __launch_bounds__(64)
+k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict__ a_sel, unsigned na,
+            const float *__restrict__ b, size_t b_stride, const int *__restrict__ cand, const int *__restrict__ count,
+            double *__restrict__ o_best, double *__restrict__ o_second, int *__restrict__ o_idx, int *__restrict__ overflow)
+{
+    __shared__ double ssd[NN_CAP];
+    const unsigned i = blockIdx.x;
+    if (i >= na) return;
+    const int lane = threadIdx.x;
+    const int n = count[i];
+    if (n > NN_CAP) {
+        if (lane == 0) atomicAdd(overflow, 1);
+        return;
+    }
+    if (lane < n) {
+        const float *pa = a + (size_t)(a_sel ? (unsigned)a_sel[i] : i) * a_stride;
+        const float *pb = b + (size_t)cand[(size_t)i * NN_CAP + lane] * b_stride;
+        double s = 0.0;
+        for (int e = 0; e < NEL; e++) {
+            const double diff = (double)pa[e] - (double)pb[e];
+            s += diff * diff;
+        }
+        ssd[lane] = s;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        Best2 st;
+        st.best = DBL_MAX; st.second = DBL_MAX; st.idx = -1;
+        for (int k = 0; k < n; k++) best2_push(st, ssd[k], cand[(size_t)i * NN_CAP + k]);
+        o_best[i] = st.best; o_second[i] = st.second; o_idx[i] = st.idx;
+    }
+}
+
+/* Same contract as s3d_k_nn_best2.  Returns 1 (outputs undefined) when a row had more than NN_CAP
+ * candidates or the operands do not qualify: the caller then runs s3d_k_nn_best2. */
+extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b,
+                                   size_t b_stride, uint32_t nb, double *d_best, double *d_second, int *d_idx, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (na == 0) return 0;
+    if (nb < 2 || (a_stride & 3) || (b_stride & 3)) return 1;
+    const unsigned napad = (na + GT - 1) / GT * GT, nbpad = (nb + GT - 1) / GT * GT;
+    size_t rows_chunk = ((size_t)1 << 29) / nbpad / GT * GT;          /* <= 2 GiB of scores at a time */
+    if (rows_chunk < GT) rows_chunk = GT;
+    if (rows_chunk > napad) rows_chunk = napad;
+    float *AT = nullptr, *BT = nullptr, *a2f = nullptr, *b2f = nullptr, *S = nullptr;
+    double *a2d = nullptr, *b2d = nullptr, *h_b2 = nullptr;
+    int *cand = nullptr, *count = nullptr, *ovf = nullptr;
+    int rc = -1, h_ovf = 0;
+    double b2max = 0.0;
+#define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
+    NN_TRY(hipMalloc((void **)&AT, sizeof(float) * (size_t)NEL * napad));
+    NN_TRY(hipMalloc((void **)&BT, sizeof(float) * (size_t)NEL * nbpad));
+    NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
+    NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
+    NN_TRY(hipMalloc((void **)&S, sizeof(float) * rows_chunk * nbpad));
+    NN_TRY(hipMalloc((void **)&cand, sizeof(int) * (size_t)na * NN_CAP)); NN_TRY(hipMalloc((void **)&count, sizeof(int) * na));
+    NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
+    NN_TRY(hipMemsetAsync(ovf, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_nn_transpose, dim3(napad / 32, NEL / 64), dim3(256), 0, st, d_a, a_stride, d_a_sel, na, napad, AT);
+    hipLaunchKernelGGL(k_nn_transpose, dim3(nbpad / 32, NEL / 64), dim3(256), 0, st, d_b, b_stride, (const int *)nullptr, nb,
+                       nbpad, BT);
+    hipLaunchKernelGGL(k_nn_norms, dim3(napad), dim3(64), 0, st, d_a, a_stride, d_a_sel, na, napad, a2d, a2f);
+    hipLaunchKernelGGL(k_nn_norms, dim3(nbpad), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, nbpad, b2d, b2f);
+    if ((h_b2 = (double *)malloc(sizeof(double) * nb)) == nullptr) goto done;
+    NN_TRY(hipMemcpyAsync(h_b2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    NN_TRY(hipStreamSynchronize(st));
+    for (uint32_t j = 0; j < nb; j++) b2max = h_b2[j] > b2max ? h_b2[j] : b2max;
+    for (size_t r0 = 0; r0 < napad; r0 += rows_chunk) {
+        const unsigned rows = (unsigned)(r0 + rows_chunk <= napad ? rows_chunk : napad - r0);
+        hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AT, napad, (unsigned)r0, BT, nbpad, a2f,
+                           b2f, S);
+        const unsigned live = r0 + rows <= na ? rows : (na > r0 ? (unsigned)(na - r0) : 0u);
+        if (live)
+            hipLaunchKernelGGL(k_nn_rowscan, dim3(live), dim3(64), 0, st, S, nbpad, nb, (unsigned)r0, na, a2d, b2max, cand,
+                               count);
+    }
+    hipLaunchKernelGGL(k_nn_verify, dim3(na), dim3(64), 0, st, d_a, a_stride, d_a_sel, na, d_b, b_stride, cand, count, d_best,
+                       d_second, d_idx, ovf);
+    NN_TRY(hipGetLastError());
+    NN_TRY(hipMemcpyAsync(&h_ovf, ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+    NN_TRY(hipStreamSynchronize(st));
+    rc = h_ovf ? 1 : 0;
+done:
+#undef NN_TRY
+    hipFree(AT); hipFree(BT); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S);
+    hipFree(cand); hipFree(count); hipFree(ovf);
+    free(h_b2);
+    return rc;
+}

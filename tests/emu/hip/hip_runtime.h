@@ -176,14 +176,16 @@ inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave, bool want_ballot
     const unsigned t = s.cur->tid;
     const unsigned w0 = t & ~63u;
     const unsigned par = s.wave_op[t] & 1;
-    s.wave_op[t]++;
+    const auto myop = ++s.wave_op[t];
     s.wave_buf[par][t] = v;
     yield_to_sched(2);
     const unsigned nt = s.blockDim.x * s.blockDim.y * s.blockDim.z;
     if (want_ballot) {
+        /* a lane took part in this collective iff its own operation counter has reached ours (lanes that left the
+         * kernel earlier have a smaller one; lanes that leave right after it must still be counted) */
         uint64_t m = 0;
         for (unsigned l = 0; l < 64 && w0 + l < nt; l++)
-            if (s.fib[w0 + l].state != 3 && s.wave_buf[par][w0 + l]) m |= 1ull << l;
+            if (s.wave_op[w0 + l] >= myop && s.wave_buf[par][w0 + l]) m |= 1ull << l;
         *ballot_out = m;
         return 0;
     }

@@ -12,6 +12,7 @@ floats within 1e-4 relative (LDS-atomic accumulation order); dense output bit-ex
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -326,3 +327,21 @@ def check_describe_window(lib, oracle, dims, units, nblobs, seed):
     lib.free_image(im)
     lib.sift.cleanup_SIFT3D(C.byref(s))
     return len(xyzos), int(cnt.sum())
+
+
+def check_nn_match_duplicates(lib, oracle, thr=0.8):
+    """More than 64 exact duplicates of one descriptor in the second set: the screened matcher must hand the pass to
+    the exhaustive kernel (candidate overflow) and still return the oracle's matches."""
+    from tests.util import rand_desc
+    d1 = rand_desc(12, 31)
+    d2 = np.vstack([np.repeat(d1[:1], 80, axis=0), rand_desc(20, 32), d1[3:6]])
+    want = oracle.nn_match(d1, d2, thr)
+    rc, got, _ = nn_match_api(lib, d1, d2, thr)
+    assert rc == 0 and np.array_equal(got, want)
+    os.environ["S3D_NN_EXHAUSTIVE"] = "1"                 # the exhaustive kernel on its own, same answer
+    try:
+        rc, got, _ = nn_match_api(lib, d1, d2, thr)
+    finally:
+        del os.environ["S3D_NN_EXHAUSTIVE"]
+    assert rc == 0 and np.array_equal(got, want)
+    return int((want >= 0).sum())

@@ -99,3 +99,7 @@ def test_describe_window_set(emu, oracle, dims, units, nblobs, seed):
 ])
 def test_sep_fir_multichannel_fast_vs_generic(emu, oracle, dims, sigma, nc, chunks):
     parity.check_sep_fir_paths(emu, oracle, dims, sigma, chunks=chunks, nc=nc)
+
+
+def test_nn_match_candidate_overflow(emu, oracle):
+    assert parity.check_nn_match_duplicates(emu, oracle) >= 3

@@ -196,6 +196,20 @@ def test_nn_match_vs_oracle(lib, oracle, n1, seed, thr):
     assert parity.check_nn_match(lib, oracle, n1, seed, thr) > 0
 
 
+def test_nn_match_candidate_overflow(lib, oracle):
+    assert parity.check_nn_match_duplicates(lib, oracle) >= 3
+
+
+@pytest.mark.parametrize("n1,seed", [(3001, 4), (1000, 3)])
+def test_nn_match_exhaustive_kernel(lib, oracle, n1, seed):
+    """The exhaustive f64 kernel (the fallback of the screened matcher) on its own."""
+    os.environ["S3D_NN_EXHAUSTIVE"] = "1"
+    try:
+        assert parity.check_nn_match(lib, oracle, n1, seed, 0.8) > 0
+    finally:
+        del os.environ["S3D_NN_EXHAUSTIVE"]
+
+
 def test_nn_match_golden(lib):
     from tests.util import match_sets
     g = np.load(os.path.join(GOLDEN, "match.npz"))
