@@ -349,7 +349,7 @@ def main():
         # row f1, outside the timed region: SIFT3D_nn_match of this volume's K descriptors against themselves
         # (device resident; the cost does not depend on the data: 2 exhaustive K x K f64 SSD passes)
         t0 = time.perf_counter()
-        m = dev.nn_match(d_desc.value, K, d_desc.value, K, 0.8)
+        m = dev.nn_match(d_desc.value, K, d_desc.value, K, 0.8, stride=776)   # records laid out like SIFT3D_Descriptor
         t_match = time.perf_counter() - t0
         result["config"]["match"] = {"pairs": K * K, "ms": round(t_match * 1e3, 2), "self_matches": int((m == np.arange(K)).sum()),
                                      "Gpairs_per_s": round(2.0 * K * K / t_match / 1e9, 1),
@@ -403,6 +403,34 @@ def main():
         result["config"]["aniso_1x1x1.5"] = {"detect_ms": round(min(t[0] for t in ta[1:]) * 1e3, 2),
                                              "describe_ms": round(min(t[1] for t in ta[1:]) * 1e3, 2),
                                              "keypoints": int(kp3.slab.num)}
+        # BASELINE configs[4]: two anisotropic 512^3 volumes (the second one the first shifted by (3, -2, 1) voxels),
+        # detect + describe each, then SIFT3D_nn_match of the two descriptor sets -- everything resident in HBM
+        if kp3.slab.num:
+            d_vol2 = dev.upload(np.roll(vol, (1, -2, 3), axis=(0, 1, 2)))
+            s4 = abi.SIFT3D()
+            assert lib.sift.init_SIFT3D(C.byref(s4)) == 0
+            kp4 = abi.Keypoint_store()
+            lib.sift.init_Keypoint_store(C.byref(kp4))
+            d4 = C.c_void_p()
+            best = None
+            for _ in range(2):
+                dev.sync()
+                t0 = time.perf_counter()
+                lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(s3), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.5, C.byref(kp3))
+                lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s3), C.byref(kp3), C.byref(d3))
+                lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(s4), C.c_void_p(d_vol2), n, n, n, 1.0, 1.0, 1.5, C.byref(kp4))
+                lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s4), C.byref(kp4), C.byref(d4))
+                dev.sync()
+                t1 = time.perf_counter()
+                mm = dev.nn_match(d3.value, int(kp3.slab.num), d4.value, int(kp4.slab.num), 0.8, stride=776)
+                t2 = time.perf_counter()
+                if best is None or t2 - t0 < best[0]:
+                    best = (t2 - t0, t1 - t0, t2 - t1, int((mm >= 0).sum()))
+            result["config"]["two_volume_match"] = {"total_ms": round(best[0] * 1e3, 1), "features_ms": round(best[1] * 1e3, 1),
+                                                    "match_ms": round(best[2] * 1e3, 1), "keypoints": [int(kp3.slab.num), int(kp4.slab.num)],
+                                                    "matches": best[3], "Mvox_s": round(2 * n ** 3 / best[0] / 1e6, 1)}
+            dev.free(d_vol2)
+            lib.sift.cleanup_SIFT3D(C.byref(s4))
         lib.sift.cleanup_SIFT3D(C.byref(s3))
     if rank == 0 and not args.no_roofline:
         add_roofline(result, dev, n)

@@ -364,8 +364,9 @@ int draw_matches(const Image *const left, const Image *const right, const Mat_rm
 /* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */
 int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz,
                                     double ux, double uy, double uz, Keypoint_store *const kp);
-/* Descriptors stay in HBM: *d_desc receives a device pointer to num x 768 floats owned by the
- * library (valid until the next call on this SIFT3D); pass the result of detect in kp. */
+/* Descriptors stay in HBM: *d_desc receives a device pointer to num records laid out like SIFT3D_Descriptor
+ * (768 bins followed by xd, yd, zd, sd: 776 floats per record), owned by the library and valid until the next
+ * call on this SIFT3D; pass the result of detect in kp. */
 int sift3d_amd_extract_descriptors_dev(SIFT3D *const sift3d, const Keypoint_store *const kp,
                                        const float **d_desc);
 /* Dense descriptors device to device: d_in nx*ny*nz floats, d_out nx*ny*nz*12 floats.
