@@ -29,11 +29,10 @@ k_dense_bary(const float *__restrict__ sm, int nx, int ny, int nz, float iux, fl
     V3 bary;
     const int face = s3d_icos_bin_fast(mesh, g, &bary);
     if (face < 0) return;
-    const float *m = mesh + face * MESH_STRIDE;
     float *t = out12 + vi * S3D_NVERT;
-    t[__float_as_int(m[13])] = bary.x;
-    t[__float_as_int(m[14])] = bary.y;
-    t[__float_as_int(m[15])] = bary.z;
+    t[__float_as_int(S3D_MESH_AT(mesh, face, 13))] = bary.x;
+    t[__float_as_int(S3D_MESH_AT(mesh, face, 14))] = bary.y;
+    t[__float_as_int(S3D_MESH_AT(mesh, face, 15))] = bary.z;
 }
 
 extern "C" int s3d_k_dense_bary(const float *d_smooth, int nx, int ny, int nz, const float unitsf[3],
@@ -146,10 +145,9 @@ k_dense_rot_hist(const float *__restrict__ sm, int nx, int ny, int nz, float uxf
         const float mag = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
         const float w = expf((float)((double)(-0.5f * sq) / sig2));
         const float mw = mag * w;
-        const float *m = mesh + face * MESH_STRIDE;
-        atomicAdd(&h[__float_as_int(m[13])], (unsigned long long)(long long)(mw * bary.x * fscale));
-        atomicAdd(&h[__float_as_int(m[14])], (unsigned long long)(long long)(mw * bary.y * fscale));
-        atomicAdd(&h[__float_as_int(m[15])], (unsigned long long)(long long)(mw * bary.z * fscale));
+        atomicAdd(&h[__float_as_int(S3D_MESH_AT(mesh, face, 13))], (unsigned long long)(long long)(mw * bary.x * fscale));
+        atomicAdd(&h[__float_as_int(S3D_MESH_AT(mesh, face, 14))], (unsigned long long)(long long)(mw * bary.y * fscale));
+        atomicAdd(&h[__float_as_int(S3D_MESH_AT(mesh, face, 15))], (unsigned long long)(long long)(mw * bary.z * fscale));
     }
     s3d_wave_lds_sync();
     if (lane < S3D_NVERT)

@@ -468,11 +468,10 @@ k_bary_x_mc(const float *__restrict__ sm, float *__restrict__ dst, int nx, int n
             V3 bary;
             const int face = s3d_icos_bin_fast(mesh, g, &bary);
             if (face >= 0) {
-                const float *m = mesh + face * MESH_STRIDE;
                 float *t = st + tid * S3D_NVERT;
-                t[__float_as_int(m[13])] = bary.x;
-                t[__float_as_int(m[14])] = bary.y;
-                t[__float_as_int(m[15])] = bary.z;
+                t[__float_as_int(S3D_MESH_AT(mesh, face, 13))] = bary.x;
+                t[__float_as_int(S3D_MESH_AT(mesh, face, 14))] = bary.y;
+                t[__float_as_int(S3D_MESH_AT(mesh, face, 15))] = bary.z;
             }
         }
     }

@@ -46,15 +46,11 @@ extern "C" void s3d_mesh_table(float *out)
         const V3 e1 = v3_sub(v[1], v[0]), e2 = v3_sub(v[2], v[0]);
         const V3 t = v3(v[0].x * -1.0f, v[0].y * -1.0f, v[0].z * -1.0f);
         const V3 q = v3_cross(t, e1);
-        float *m = out + i * MESH_STRIDE;
-        m[0] = e1.x; m[1] = e1.y; m[2] = e1.z;
-        m[3] = e2.x; m[4] = e2.y; m[5] = e2.z;
-        m[6] = t.x; m[7] = t.y; m[8] = t.z;
-        m[9] = q.x; m[10] = q.y; m[11] = q.z;
-        m[12] = v3_dot(e2, q);
+        const float rec[13] = {e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, t.x, t.y, t.z, q.x, q.y, q.z, v3_dot(e2, q)};
+        for (int k = 0; k < 13; k++) S3D_MESH_AT(out, i, k) = rec[k];
         for (int j = 0; j < 3; j++) {
             const int id = faces[i][j];
-            memcpy(&m[13 + j], &id, sizeof(int));
+            memcpy(&S3D_MESH_AT(out, i, 13 + j), &id, sizeof(int));
         }
         cen[i] = v3(v[0].x + v[1].x + v[2].x, v[0].y + v[1].y + v[2].y, v[0].z + v[1].z + v[2].z);
     }
@@ -638,11 +634,11 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         const float mag = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
         const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
         const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
-        const float *m = mesh + face * MESH_STRIDE;
         /* LDS word offsets of the three vertex bins of the base cell (32-bit index arithmetic only) */
         const unsigned cell0 = hbase + (unsigned)(S3D_NVERT * (ibx + 4 * iby + 16 * ibz));
-        const unsigned o0 = cell0 + (unsigned)__float_as_int(m[13]), o1 = cell0 + (unsigned)__float_as_int(m[14]),
-                       o2 = cell0 + (unsigned)__float_as_int(m[15]);
+        const unsigned o0 = cell0 + (unsigned)__float_as_int(S3D_MESH_AT(mesh, face, 13)),
+                       o1 = cell0 + (unsigned)__float_as_int(S3D_MESH_AT(mesh, face, 14)),
+                       o2 = cell0 + (unsigned)__float_as_int(S3D_MESH_AT(mesh, face, 15));
         /* contribution = (mag*bary_v) * wt, formed exactly in integers: the first factor rounded to 23
          * significant bits at the sample's own exponent (gradients are 100-1000x below the bound, a
          * fixed scale would waste those bits), the trilinear weight to 2^-22, both inside the signed

@@ -21,28 +21,33 @@ __host__ __device__ __forceinline__ float v3_dot(V3 a, V3 b) { return a.x * b.x 
  * rounding reproduces that on the device far more closely than the 1-2 ulp device expf. */
 __device__ __forceinline__ float s3d_expf(float x) { return (float)exp((double)x); }
 
-/* Face table entry layout (16 floats): e1[0..2] e2[3..5] t[6..8] q[9..11] e2q[12] idx[13..15] */
+/* Face table: 16 fields per face -- e1[0..2] e2[3..5] t[6..8] q[9..11] e2q[12] idx[13..15] -- stored field
+ * major, field k of face f at k * S3D_NFACES + f.  The kernels keep the table in LDS and every lane looks up its
+ * own face: with the 20 faces of a field in 20 consecutive words the lookups of a wave fall into 20 distinct
+ * banks (a face-major table with 16-word records put all even and all odd faces on one bank each: a 10-way
+ * conflict on every one of the ~16 reads per voxel -- two thirds of the LDS cycles of the descriptor kernel
+ * were bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE). */
 #define MESH_STRIDE 16
+#define S3D_MESH_AT(mesh, f, k) ((mesh)[(k) * S3D_NFACES + (f)])
 
 /* One face of cart2bary (sift.c:335-394) + the acceptance test of icos_hist_bin (sift.c:1669-1671),
  * on the precomputed face constants (e1, e2, t = -v0, q = t x e1 and e2.q do not depend on the input
  * vector, so hoisting them changes no rounding).  Returns 1 if the reference would accept face i. */
 __device__ __forceinline__ int s3d_face_test(const float *__restrict__ mesh, int i, V3 g, V3 *bary)
 {
-    const float *m = mesh + i * MESH_STRIDE;
-    const V3 e1 = v3(m[0], m[1], m[2]);
-    const V3 e2 = v3(m[3], m[4], m[5]);
+    const V3 e1 = v3(S3D_MESH_AT(mesh, i, 0), S3D_MESH_AT(mesh, i, 1), S3D_MESH_AT(mesh, i, 2));
+    const V3 e2 = v3(S3D_MESH_AT(mesh, i, 3), S3D_MESH_AT(mesh, i, 4), S3D_MESH_AT(mesh, i, 5));
     const V3 p = v3_cross(g, e2);
     const float det = v3_dot(e1, p);
     if ((double)fabsf(det) < S3D_BARY_EPS_D) return 0;
     const float det_inv = 1.0f / det;
-    const V3 t = v3(m[6], m[7], m[8]);
-    const V3 q = v3(m[9], m[10], m[11]);
+    const V3 t = v3(S3D_MESH_AT(mesh, i, 6), S3D_MESH_AT(mesh, i, 7), S3D_MESH_AT(mesh, i, 8));
+    const V3 q = v3(S3D_MESH_AT(mesh, i, 9), S3D_MESH_AT(mesh, i, 10), S3D_MESH_AT(mesh, i, 11));
     V3 b;
     b.y = det_inv * v3_dot(t, p);
     b.z = det_inv * v3_dot(g, q);
     b.x = 1.0f - b.y - b.z;
-    const float k = m[12] * det_inv;
+    const float k = S3D_MESH_AT(mesh, i, 12) * det_inv;
     if ((double)b.x < -S3D_BARY_EPS_D || (double)b.y < -S3D_BARY_EPS_D || (double)b.z < -S3D_BARY_EPS_D || k < 0.0f)
         return 0;
     *bary = b;
