@@ -219,6 +219,13 @@ int s3d_k_nn_best2(const float *d_a, size_t a_stride, const int *d_a_sel, uint32
 int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b,
                         size_t b_stride, uint32_t nb, double *d_best, double *d_second, int *d_idx,
                         s3d_stream stream);
+/* Both directions of SIFT3D_nn_match from one f32 score matrix: best / second / index of every row of A over B
+ * (d_f*) and of every row of B over A (d_b*), bit-identical to s3d_k_nn_best2 run each way.  Declines (returns 1)
+ * when the padded na x nb score matrix would exceed 8 GiB, a side has fewer than two rows, or a row/column has
+ * more than 64 candidates. */
+int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t na, const float *d_b, size_t b_stride, uint32_t nb,
+                         double *d_fbest, double *d_fsecond, int *d_fidx, double *d_bbest, double *d_bsecond, int *d_bidx,
+                         s3d_stream stream);
 
 #ifdef __cplusplus
 }

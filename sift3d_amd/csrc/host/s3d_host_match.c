@@ -112,6 +112,36 @@ int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const fl
         s3d_rt_malloc((void **)&d_sel, n * sizeof(int)))
         goto done;
 
+    /* both directions from one score matrix when it fits (s3d_k_nn_match2_fast); otherwise pass by pass below */
+    if (getenv("S3D_NN_EXHAUSTIVE") == NULL && getenv("S3D_NN_TWO_PASS") == NULL) {
+        const size_t m = (size_t)nb;
+        double *d_b2 = NULL, *h_b2 = (double *)malloc(2 * m * sizeof(double));
+        int *d_bi = NULL, *h_bi = (int *)malloc(m * sizeof(int));
+        int fast = -1;
+        if (h_b2 && h_bi && s3d_rt_malloc((void **)&d_b2, 2 * m * sizeof(double)) == 0 &&
+            s3d_rt_malloc((void **)&d_bi, m * sizeof(int)) == 0) {
+            fast = s3d_k_nn_match2_fast(d_a, a_stride, (uint32_t)na, d_b, b_stride, (uint32_t)nb, d_best, d_best + n, d_idx,
+                                        d_b2, d_b2 + m, d_bi, stream);
+            if (fast == 0 &&
+                (s3d_rt_d2h(h_best, d_best, 2 * n * sizeof(double), stream) || s3d_rt_d2h(h_idx, d_idx, n * sizeof(int), stream) ||
+                 s3d_rt_d2h(h_b2, d_b2, 2 * m * sizeof(double), stream) || s3d_rt_d2h(h_bi, d_bi, m * sizeof(int), stream) ||
+                 s3d_rt_sync(stream)))
+                fast = -1;
+        }
+        if (fast == 0) {
+            for (size_t i = 0; i < n; i++) {
+                const int j = h_idx[i];
+                if (j < 0 || s3d_ratio_reject(h_best[i], h_best[n + i], nn_thresh)) continue;      /* forward (sift.c:2873) */
+                if (h_bi[j] == (int)i && !s3d_ratio_reject(h_b2[j], h_b2[m + (size_t)j], nn_thresh)) matches[i] = j;   /* backward */
+            }
+            rc = SIFT3D_SUCCESS;
+        }
+        s3d_rt_free(d_b2); s3d_rt_free(d_bi);
+        free(h_b2); free(h_bi);
+        if (fast == 0) goto done;
+        if (fast < 0) goto done;                 /* device failure (rc stays FAILURE); 1 = declined: fall through */
+    }
+
     /* forward pass: every descriptor of A against all of B */
     if (s3d_best2(d_a, a_stride, NULL, (uint32_t)na, d_b, b_stride, (uint32_t)nb, d_best, d_best + n, d_idx, stream) ||
         s3d_rt_d2h(h_best, d_best, 2 * n * sizeof(double), stream) ||

@@ -395,3 +395,138 @@ done:
     free(h_b2);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Both directions from ONE score matrix.  SIFT3D_nn_match needs, for every a_i, its two nearest b_j, and for
+ * every matched b_j its two nearest a_i (the backward check): the same pair scores read along rows and along
+ * columns.  When the whole matrix fits the budget it is computed once; rows are scanned by k_nn_rowscan, columns by
+ * the kernels below (one lane per column, rows split into segments so that enough waves are in flight), and both
+ * candidate sets go through k_nn_verify.
+ * ---------------------------------------------------------------------------------------------- */
+#define NN_SEG 32
+
+/* partial (m1, m2) of every column over the rows of one segment */
+__global__ void __launch_bounds__(64)
+k_nn_col_min2(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned na, unsigned seg_rows,
+              float *__restrict__ pm1, float *__restrict__ pm2)
+{
+    const unsigned j = blockIdx.x * 64u + threadIdx.x, seg = blockIdx.y;
+    const unsigned i0 = seg * seg_rows, i1 = i0 + seg_rows < na ? i0 + seg_rows : na;
+    float m1 = 3.0e38f, m2 = 3.0e38f;
+    if (j < nb)
+        for (unsigned i = i0; i < i1; i++) {
+            const float v = S[(size_t)i * nbpad + j];
+            if (v < m1) { m2 = m1; m1 = v; } else if (v < m2) m2 = v;
+        }
+    pm1[(size_t)seg * nbpad + j] = m1;
+    pm2[(size_t)seg * nbpad + j] = m2;
+}
+
+/* threshold of every column: second smallest score over all segments + the error band */
+__global__ void __launch_bounds__(64)
+k_nn_col_thr(const float *__restrict__ pm1, const float *__restrict__ pm2, unsigned nbpad, unsigned nb,
+             const double *__restrict__ b2d, double a2max, float *__restrict__ thr)
+{
+    const unsigned j = blockIdx.x * 64u + threadIdx.x;
+    if (j >= nb) return;
+    float m1 = 3.0e38f, m2 = 3.0e38f;
+    for (unsigned s = 0; s < NN_SEG; s++) {
+        const float o1 = pm1[(size_t)s * nbpad + j], o2 = pm2[(size_t)s * nbpad + j];
+        const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1, s2 = m2 < o2 ? m2 : o2;
+        m1 = lo;
+        m2 = hi < s2 ? hi : s2;
+    }
+    const double d = 2.0 * (1e-4 * sqrt(b2d[j]) * sqrt(a2max) + 5e-7 * (b2d[j] + a2max));
+    thr[j] = (float)((double)m2 + 2.0 * d + 1e-7 * fabs((double)m2));
+}
+
+/* pass 0: count the candidates of every (segment, column); pass 1: write them, in ascending row order */
+__global__ void __launch_bounds__(64)
+k_nn_col_cand(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned na, unsigned seg_rows,
+              const float *__restrict__ thr, int *__restrict__ segcnt, int pass, int *__restrict__ cand,
+              int *__restrict__ count)
+{
+    const unsigned j = blockIdx.x * 64u + threadIdx.x, seg = blockIdx.y;
+    if (j >= nb) return;
+    const unsigned i0 = seg * seg_rows, i1 = i0 + seg_rows < na ? i0 + seg_rows : na;
+    const float t = thr[j];
+    unsigned pos = 0;
+    if (pass == 1)
+        for (unsigned s = 0; s < seg; s++) pos += (unsigned)segcnt[(size_t)s * nbpad + j];
+    unsigned n = 0;
+    for (unsigned i = i0; i < i1; i++)
+        if (S[(size_t)i * nbpad + j] <= t) {
+            if (pass == 1 && pos + n < NN_CAP) cand[(size_t)j * NN_CAP + pos + n] = (int)i;
+            n++;
+        }
+    if (pass == 0) segcnt[(size_t)seg * nbpad + j] = (int)n;
+    else if (seg == NN_SEG - 1) count[j] = (int)(pos + n);
+}
+
+/* Forward (rows of A over B) and backward (rows of B over A) best / second / index in one go.  Returns 1 when it
+ * declines (score matrix over the budget, fewer than two rows on a side, candidate overflow). */
+extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t na, const float *d_b, size_t b_stride,
+                                    uint32_t nb, double *d_fbest, double *d_fsecond, int *d_fidx, double *d_bbest,
+                                    double *d_bsecond, int *d_bidx, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (na < 2 || nb < 2 || (a_stride & 3) || (b_stride & 3)) return 1;
+    const unsigned napad = (na + GT - 1) / GT * GT, nbpad = (nb + GT - 1) / GT * GT;
+    if ((size_t)napad * nbpad > ((size_t)1 << 31)) return 1;              /* 8 GiB of scores at most */
+    const unsigned seg_rows = (na + NN_SEG - 1) / NN_SEG;
+    float *AT = nullptr, *BT = nullptr, *a2f = nullptr, *b2f = nullptr, *S = nullptr, *pm1 = nullptr, *pm2 = nullptr,
+          *thr = nullptr;
+    double *a2d = nullptr, *b2d = nullptr, *h_n2 = nullptr;
+    int *candf = nullptr, *countf = nullptr, *candb = nullptr, *countb = nullptr, *segcnt = nullptr, *ovf = nullptr;
+    int rc = -1, h_ovf = 0;
+    double a2max = 0.0, b2max = 0.0;
+#define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
+    NN_TRY(hipMalloc((void **)&AT, sizeof(float) * (size_t)NEL * napad));
+    NN_TRY(hipMalloc((void **)&BT, sizeof(float) * (size_t)NEL * nbpad));
+    NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
+    NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
+    NN_TRY(hipMalloc((void **)&S, sizeof(float) * (size_t)napad * nbpad));
+    NN_TRY(hipMalloc((void **)&pm1, sizeof(float) * (size_t)NN_SEG * nbpad));
+    NN_TRY(hipMalloc((void **)&pm2, sizeof(float) * (size_t)NN_SEG * nbpad));
+    NN_TRY(hipMalloc((void **)&thr, sizeof(float) * nbpad));
+    NN_TRY(hipMalloc((void **)&segcnt, sizeof(int) * (size_t)NN_SEG * nbpad));
+    NN_TRY(hipMalloc((void **)&candf, sizeof(int) * (size_t)na * NN_CAP)); NN_TRY(hipMalloc((void **)&countf, sizeof(int) * na));
+    NN_TRY(hipMalloc((void **)&candb, sizeof(int) * (size_t)nb * NN_CAP)); NN_TRY(hipMalloc((void **)&countb, sizeof(int) * nb));
+    NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
+    NN_TRY(hipMemsetAsync(ovf, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_nn_transpose, dim3(napad / 32, NEL / 64), dim3(256), 0, st, d_a, a_stride, (const int *)nullptr, na,
+                       napad, AT);
+    hipLaunchKernelGGL(k_nn_transpose, dim3(nbpad / 32, NEL / 64), dim3(256), 0, st, d_b, b_stride, (const int *)nullptr, nb,
+                       nbpad, BT);
+    hipLaunchKernelGGL(k_nn_norms, dim3(napad), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, napad, a2d, a2f);
+    hipLaunchKernelGGL(k_nn_norms, dim3(nbpad), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, nbpad, b2d, b2f);
+    if ((h_n2 = (double *)malloc(sizeof(double) * (na > nb ? na : nb))) == nullptr) goto done;
+    NN_TRY(hipMemcpyAsync(h_n2, a2d, sizeof(double) * na, hipMemcpyDeviceToHost, st));
+    NN_TRY(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < na; i++) a2max = h_n2[i] > a2max ? h_n2[i] : a2max;
+    NN_TRY(hipMemcpyAsync(h_n2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    NN_TRY(hipStreamSynchronize(st));
+    for (uint32_t j = 0; j < nb; j++) b2max = h_n2[j] > b2max ? h_n2[j] : b2max;
+    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AT, napad, 0u, BT, nbpad, a2f, b2f, S);
+    hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
+    hipLaunchKernelGGL(k_nn_col_min2, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, pm1, pm2);
+    hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nbpad, nb, b2d, a2max, thr);
+    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, thr, segcnt, 0,
+                       candb, countb);
+    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, thr, segcnt, 1,
+                       candb, countb);
+    hipLaunchKernelGGL(k_nn_verify, dim3(na), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, d_b, b_stride, candf,
+                       countf, d_fbest, d_fsecond, d_fidx, ovf);
+    hipLaunchKernelGGL(k_nn_verify, dim3(nb), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, d_a, a_stride, candb,
+                       countb, d_bbest, d_bsecond, d_bidx, ovf);
+    NN_TRY(hipGetLastError());
+    NN_TRY(hipMemcpyAsync(&h_ovf, ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+    NN_TRY(hipStreamSynchronize(st));
+    rc = h_ovf ? 1 : 0;
+done:
+#undef NN_TRY
+    hipFree(AT); hipFree(BT); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S); hipFree(pm1); hipFree(pm2);
+    hipFree(thr); hipFree(segcnt); hipFree(candf); hipFree(countf); hipFree(candb); hipFree(countb); hipFree(ovf);
+    free(h_n2);
+    return rc;
+}

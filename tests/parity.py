@@ -338,10 +338,11 @@ def check_nn_match_duplicates(lib, oracle, thr=0.8):
     want = oracle.nn_match(d1, d2, thr)
     rc, got, _ = nn_match_api(lib, d1, d2, thr)
     assert rc == 0 and np.array_equal(got, want)
-    os.environ["S3D_NN_EXHAUSTIVE"] = "1"                 # the exhaustive kernel on its own, same answer
-    try:
-        rc, got, _ = nn_match_api(lib, d1, d2, thr)
-    finally:
-        del os.environ["S3D_NN_EXHAUSTIVE"]
-    assert rc == 0 and np.array_equal(got, want)
+    for knob in ("S3D_NN_EXHAUSTIVE", "S3D_NN_TWO_PASS"):   # the exhaustive kernel / the pass-by-pass screened form
+        os.environ[knob] = "1"
+        try:
+            rc, got, _ = nn_match_api(lib, d1, d2, thr)
+        finally:
+            del os.environ[knob]
+        assert rc == 0 and np.array_equal(got, want), knob
     return int((want >= 0).sum())

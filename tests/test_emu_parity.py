@@ -101,5 +101,13 @@ def test_sep_fir_multichannel_fast_vs_generic(emu, oracle, dims, sigma, nc, chun
     parity.check_sep_fir_paths(emu, oracle, dims, sigma, chunks=chunks, nc=nc)
 
 
+def test_nn_match_pass_by_pass(emu, oracle):
+    os.environ["S3D_NN_TWO_PASS"] = "1"
+    try:
+        assert parity.check_nn_match(emu, oracle, 130, 3, 0.6) > 0
+    finally:
+        del os.environ["S3D_NN_TWO_PASS"]
+
+
 def test_nn_match_candidate_overflow(emu, oracle):
     assert parity.check_nn_match_duplicates(emu, oracle) >= 3

@@ -196,6 +196,15 @@ def test_nn_match_vs_oracle(lib, oracle, n1, seed, thr):
     assert parity.check_nn_match(lib, oracle, n1, seed, thr) > 0
 
 
+def test_nn_match_pass_by_pass(lib, oracle):
+    """The screened matcher in its pass-by-pass form (used when the score matrix exceeds the budget)."""
+    os.environ["S3D_NN_TWO_PASS"] = "1"
+    try:
+        assert parity.check_nn_match(lib, oracle, 3001, 4, 0.7) > 0
+    finally:
+        del os.environ["S3D_NN_TWO_PASS"]
+
+
 def test_nn_match_candidate_overflow(lib, oracle):
     assert parity.check_nn_match_duplicates(lib, oracle) >= 3
 
