@@ -242,8 +242,10 @@ k_nn_gemm(const float *__restrict__ AT, unsigned napad, unsigned row_base, const
         for (int k = 0; k < GK; k++) {
             const float4 a0 = *reinterpret_cast<const float4 *>(&As[k][ty * 8]);
             const float4 a1 = *reinterpret_cast<const float4 *>(&As[k][ty * 8 + 4]);
-            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 8]);
-            const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 8 + 4]);
+            /* the thread's 8 columns are tx*4 .. +3 and 64 + tx*4 .. +3: the 16 lanes of a row of threads read 256
+             * contiguous bytes per b128 (tx*8 would put lanes tx and tx+4 on the same banks: 4-way conflicts) */
+            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 4]);
+            const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[k][64 + tx * 4]);
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -258,10 +260,10 @@ k_nn_gemm(const float *__restrict__ AT, unsigned napad, unsigned row_base, const
         const float na = a2[i0 + ty * 8 + r];
         float o[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) o[c] = (na + b2[j0 + tx * 8 + c]) - 2.0f * acc[r][c];
-        float *dst = S + (size_t)(li + r) * nbpad + j0 + tx * 8;
+        for (int c = 0; c < 8; c++) o[c] = (na + b2[j0 + (c < 4 ? 0 : 60) + tx * 4 + c]) - 2.0f * acc[r][c];
+        float *dst = S + (size_t)(li + r) * nbpad + j0 + tx * 4;
         *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        *reinterpret_cast<float4 *>(dst + 64) = make_float4(o[4], o[5], o[6], o[7]);
     }
 }
 
