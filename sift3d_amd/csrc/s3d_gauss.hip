@@ -173,6 +173,73 @@ k_conv_axis_v4(const float *__restrict__ src, float *__restrict__ dst, size_t i4
     reinterpret_cast<float4 *>(dst)[i4] = acc;
 }
 
+/* k_conv_axis_dyadic for the y and z axes, four x-consecutive elements per thread (float4 loads; the per-tap
+ * offsets and fractions are compile-time constants shared by the four).  Same arithmetic per element. */
+template <int HW, int O>
+__global__ void __launch_bounds__(256)
+k_conv_axis_dyadic_v4(const float *__restrict__ src, float *__restrict__ dst, size_t i4_begin, size_t i4_end, size_t sa4,
+                      int n, S3dTaps taps)
+{
+    constexpr int D = 1 << O;
+    constexpr int UHW = (HW + D - 1) / D;
+    constexpr float UF = 1.0f / (float)D;
+    const size_t i4 = i4_begin + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= i4_end) return;
+    const int p = (int)((i4 / sa4) % (size_t)n);
+    const float4 *s = reinterpret_cast<const float4 *>(src) + (i4 - (size_t)p * sa4);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (p >= UHW && p <= n - 2 - UHW) {
+        float4 v[2 * UHW + 2];
+#pragma unroll
+        for (int m = 0; m < 2 * UHW + 2; m++) v[m] = s[(size_t)(p - UHW + m) * sa4];
+#pragma unroll
+        for (int k = 0; k < 2 * HW + 1; k++) {
+            constexpr int BIAS = 64 * D;
+            const int num = HW - k;
+            const int off = (num + BIAS) / D - 64;
+            const float fr = (float)(num - off * D) * UF;
+            const float4 a = v[off + UHW], b = v[off + UHW + 1];
+            const float t = taps.t[k];
+            acc.x = acc.x + t * ((1.0f - fr) * a.x + fr * b.x);
+            acc.y = acc.y + t * ((1.0f - fr) * a.y + fr * b.y);
+            acc.z = acc.z + t * ((1.0f - fr) * a.z + fr * b.z);
+            acc.w = acc.w + t * ((1.0f - fr) * a.w + fr * b.w);
+        }
+    } else {
+        const int dim_end = n - 1;
+        for (int d = -HW; d <= HW; d++) {
+            const float tap = taps.t[d + HW];
+            const float step = (float)d * UF;
+            float coord = (float)p - step;
+            if ((int)coord < 0)
+                coord = -coord;
+            else if ((int)coord >= dim_end)
+                coord = 2.0f * (float)dim_end - coord - 0.1f;
+            const int lo = (int)coord;
+            const float frac = coord - (float)lo;
+            const float4 a = s[(size_t)lo * sa4], b = s[(size_t)(lo + 1) * sa4];
+            acc.x = acc.x + tap * ((1.0f - frac) * a.x + frac * b.x);
+            acc.y = acc.y + tap * ((1.0f - frac) * a.y + frac * b.y);
+            acc.z = acc.z + tap * ((1.0f - frac) * a.z + frac * b.z);
+            acc.w = acc.w + tap * ((1.0f - frac) * a.w + frac * b.w);
+        }
+    }
+    reinterpret_cast<float4 *>(dst)[i4] = acc;
+}
+
+template <int O>
+static bool launch_dyadic_v4(int hw, const float *src, float *dst, size_t ib4, size_t ie4, size_t sa4, int n,
+                             const S3dTaps &t, hipStream_t st)
+{
+    const dim3 grid(s3d_div_up(ie4 - ib4, 256)), block(256);
+    switch (hw) {
+#define S3D_DY(H) case H: hipLaunchKernelGGL((k_conv_axis_dyadic_v4<H, O>), grid, block, 0, st, src, dst, ib4, ie4, sa4, n, t); return true;
+    S3D_DY(1) S3D_DY(2) S3D_DY(3) S3D_DY(4) S3D_DY(5) S3D_DY(6) S3D_DY(7) S3D_DY(8) S3D_DY(9)
+#undef S3D_DY
+    default: return false;
+    }
+}
+
 template <int O>
 static bool launch_dyadic(int hw, const float *src, float *dst, size_t ib, size_t ie, size_t sa, int n,
                           const S3dTaps &t, hipStream_t st)
@@ -212,6 +279,18 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
     if (uhw >= dims[axis] - 1) S3D_FAIL("image too small for this filter along the axis");
     if (d_src == d_dst) S3D_FAIL("in-place axis pass is not supported");
     const size_t ib = strides[2] * (size_t)z0, ie = strides[2] * (size_t)z1;
+    const bool vec4 = axis != 0 && (strides[1] & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15);
+    if (nc == 1 && !g_no_dyadic && vec4) {
+        bool done = false;
+        const size_t sa4 = strides[axis] / 4;
+        if (uf == 0.5f) done = launch_dyadic_v4<1>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
+        else if (uf == 0.25f) done = launch_dyadic_v4<2>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
+        else if (uf == 0.125f) done = launch_dyadic_v4<3>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
+        if (done) {
+            S3D_CHECK_LAUNCH();
+            return S3D_OK;
+        }
+    }
     if (nc == 1 && !g_no_dyadic) {
         bool done = false;
         if (uf == 0.5f) done = launch_dyadic<1>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
@@ -222,7 +301,7 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
             return S3D_OK;
         }
     }
-    if (axis != 0 && (strides[1] & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15) && !g_no_dyadic) {
+    if (vec4 && !g_no_dyadic) {
         hipLaunchKernelGGL(k_conv_axis_v4, dim3(s3d_div_up((ie - ib) / 4, 256)), dim3(256), 0, (hipStream_t)st, d_src,
                            d_dst, ib / 4, ie / 4, strides[axis] / 4, dims[axis], hw, uf, uhw, t);
         S3D_CHECK_LAUNCH();
