@@ -174,6 +174,10 @@ int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint
 /* Profiling-only ablation switch for k_orient / k_describe (see s3d_keypoint.hip); 0 = normal. */
 void s3d_k_set_variant(int v);
 
+/* Self-test: d_out[i] = the kernels' window-weight exponential of d_in[i] (a restatement of glibc 2.35 expf,
+ * which the reference reaches through expf() at sift.c:1401, 1890, 2333); |d_in[i]| < 80. */
+int s3d_k_expf_selftest(const float *d_in, float *d_out, uint32_t n, s3d_stream stream);
+
 /* Icosahedron table for the kernels (host computation in f32, mirrors init_geometry sift.c:215-326
  * incl. the v[0]<->v[1] swap quirk).  Layout per face (16 floats): e1[3] e2[3] t[3] q[3] e2q
  * idx0 idx1 idx2 (indices stored as float bit patterns of ints), followed by a 32-entry face lookup

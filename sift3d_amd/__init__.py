@@ -14,7 +14,7 @@ import os as _os
 from . import abi  # noqa: F401
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
-LIB_PATH = _os.path.join(_HERE, "lib", "libsift3d_amd.so")
+LIB_PATH = _os.environ.get("SIFT3D_AMD_LIB") or _os.path.join(_HERE, "lib", "libsift3d_amd.so")   # override: A/B runs of two builds
 _cdll = None
 
 

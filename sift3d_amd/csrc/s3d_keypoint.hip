@@ -81,6 +81,20 @@ extern "C" void s3d_mesh_table(float *out)
 static int g_variant = 0;
 extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
 
+/* Self-test hook: d_out[i] = s3d_expf(d_in[i]) (the tests compare it with the host libm bit for bit). */
+__global__ void k_expf_selftest(const float *__restrict__ d_in, float *__restrict__ d_out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d_out[i] = s3d_expf(d_in[i]);
+}
+extern "C" int s3d_k_expf_selftest(const float *d_in, float *d_out, uint32_t n, s3d_stream stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_expf_selftest, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
+    S3D_CHECK_LAUNCH();
+    return 0;
+}
+
 /* ---- small helpers ------------------------------------------------------------------------------- */
 /* exact unsigned division by a small divisor through the f32 reciprocal, with fix-up (a < 2^24) */
 __device__ __forceinline__ int fdiv_small(int a, int d, float inv, int *rem)
@@ -595,7 +609,7 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
     g.r00 = key.R[0]; g.r01 = key.R[3]; g.r02 = key.R[6];
     g.r10 = key.R[1]; g.r11 = key.R[4]; g.r12 = key.R[7];
     g.r20 = key.R[2]; g.r21 = key.R[5]; g.r22 = key.R[8];
-    const float nhalf_inv_sig2 = -0.5f / (key.sigma * key.sigma);
+    const double inv_sig2 = 1.0 / (double)(key.sigma * key.sigma);
     const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
 
     /* Fixed-point format of the histogram: value * 2^(40 - bexp), where 2^bexp exceeds the largest possible
@@ -620,9 +634,11 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         desc_window(g, x, y, z, &sq, &vbx, &vby, &vbz);
         gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
-        /* window weight.  expf (<= 1 ulp), not the v_exp_f32 shortcut __expf: the latter pushed one
-         * keypoint of the 64^3 golden case to 1e-2 relative error on the GPU (debug run, round 1). */
-        const float w = expf(sq * nhalf_inv_sig2);           /* 1 ulp from -0.5f*sq/sig2: far inside 1e-4 */
+        /* window weight, bit for bit the reference's expf(-0.5f * sq / (sigma * sigma)) (sift.c:1890): the
+         * descriptor is discontinuous in it (s3d_math.h, s3d_expf).  The float quotient a / b equals the double
+         * product a * fl(1 / b) rounded to float: a quotient of two 24-bit numbers is never within 2^-49 of a
+         * rounding boundary and the product is within 2^-52 of it. */
+        const float w = s3d_expf((float)((double)(-0.5f * sq) * inv_sig2));
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
         gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;

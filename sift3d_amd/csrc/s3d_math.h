@@ -16,10 +16,45 @@ __host__ __device__ __forceinline__ V3 v3_cross(V3 a, V3 b)
 }
 __host__ __device__ __forceinline__ float v3_dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-/* expf as the reference calls it (glibc expf on a float argument).  glibc's expf is computed in
- * double and is correctly rounded except in extremely rare cases; exp() in double followed by one
- * rounding reproduces that on the device far more closely than the 1-2 ulp device expf. */
-__device__ __forceinline__ float s3d_expf(float x) { return (float)exp((double)x); }
+/* expf as the reference calls it: glibc's expf on a float argument (the reference links the host libm; this
+ * image and the GPU box carry glibc 2.35).  The descriptor is NOT continuous in the window weight -- the
+ * reference hands barycentric weights to permuted vertices per face (sift.c:1669-1690), so a gradient that a
+ * last-bit change of the weight moves across an icosahedron edge redistributes a whole sample -- and a 1-ulp
+ * device expf, or even the correctly rounded exp, flipped ~1 keypoint per 1000 beyond 1e-4 at 256^3.  So the
+ * weight is evaluated by glibc's own published algorithm (sysdeps/ieee754/flt-32/e_expf.c, the Arm
+ * optimized-routines expf: N = 32 table of 2^(i/N), degree-3 polynomial, all in double, one final rounding),
+ * restated here; tests/test_emu_parity.py compares it with the host's expf bit for bit over 1e7 arguments
+ * (0 differences in 2e8 when it was written, with and without FMA contraction of the polynomial).
+ * Domain: |x| < 80 (no overflow/underflow branches; the callers pass -4.5 <= x <= 0).
+ * The table holds bits(2^(i/32)) - (i << 47), generated from 60-digit decimals (scripts/gen_exp2_table.py). */
+__device__ __forceinline__ float s3d_expf(float x)
+{
+    static const unsigned long long tab[32] = {
+        0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+        0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+        0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+        0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+        0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+        0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+        0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+        0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+    const double n = 32.0, inv_ln2_n = 0x1.71547652b82fep+0 * n, shift = 0x1.8p52;
+    const double c0 = 0x1.c6af84b912394p-5 / n / n / n, c1 = 0x1.ebfce50fac4f3p-3 / n / n, c2 = 0x1.62e42ff0c52d6p-1 / n;
+    double z = inv_ln2_n * (double)x;
+    double kd = z + shift;                        /* round to nearest integer, kept in the low mantissa bits */
+    unsigned long long ki;
+    __builtin_memcpy(&ki, &kd, 8);
+    kd -= shift;
+    const double r = z - kd;
+    const unsigned long long t = tab[ki & 31u] + (ki << 47);      /* 2^(k/32) */
+    double s;
+    __builtin_memcpy(&s, &t, 8);
+    z = c0 * r + c1;
+    const double r2 = r * r;
+    double y = c2 * r + 1.0;
+    y = z * r2 + y;
+    return (float)(y * s);
+}
 
 /* Face table: 16 fields per face -- e1[0..2] e2[3..5] t[6..8] q[9..11] e2q[12] idx[13..15] -- stored field
  * major, field k of face f at k * S3D_NFACES + f.  The kernels keep the table in LDS and every lane looks up its

@@ -124,6 +124,6 @@ class DeviceLib:
         return m
 
     def mesh_table(self) -> np.ndarray:
-        out = np.zeros(20 * 16, np.float32)
+        out = np.zeros(20 * 16 + 32, np.float32)      # S3D_MESH_FLOATS: face table + 32-word face LUT
         self.L.s3d_mesh_table(out.ctypes.data_as(_f32p))
         return out

@@ -346,3 +346,31 @@ def check_nn_match_duplicates(lib, oracle, thr=0.8):
             del os.environ[knob]
         assert rc == 0 and np.array_equal(got, want), knob
     return int((want >= 0).sum())
+
+
+def check_expf(lib, n=1 << 22, seed=9):
+    """The kernels' window-weight exponential against the host libm's expf -- the function the reference calls
+    (sift.c:1401, 1890, 2333) -- bit for bit, on n arguments covering the window range [-4.5, 0] densely and
+    [-80, 0] sparsely."""
+    from sift3d_amd.device import DeviceLib
+    rng = np.random.default_rng(seed)
+    x = np.concatenate([-(rng.random(n // 2, dtype=np.float32) * np.float32(4.5)),
+                        -(rng.random(n - n // 2, dtype=np.float32) * np.float32(80.0)),
+                        np.array([0.0, -0.0, -1.0, -2.0, -4.5], np.float32)])
+    libm = C.CDLL("libm.so.6")
+    libm.expf.restype, libm.expf.argtypes = C.c_float, [C.c_float]
+    dev = DeviceLib(lib.sift)
+    lib.sift.s3d_k_expf_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    d_in = dev.upload(x)
+    d_out = dev.malloc(x.nbytes)
+    assert lib.sift.s3d_k_expf_selftest(d_in, d_out, len(x), None) == 0
+    got = dev.download(d_out, x.shape)
+    dev.free(d_in); dev.free(d_out)
+    # host side: numpy has no f32 libm binding with glibc's rounding guaranteed, so call libm on a subsample and
+    # on every argument where a correctly rounded exp disagrees with the device (those are the interesting ones)
+    cr = np.exp(x.astype(np.float64)).astype(np.float32)
+    idx = np.unique(np.concatenate([np.nonzero(cr != got)[0], rng.integers(0, len(x), 20000)]))
+    want = np.array([libm.expf(float(v)) for v in x[idx]], np.float32)
+    assert np.array_equal(got[idx].view(np.uint32), want.view(np.uint32)), \
+        f"{(got[idx] != want).sum()} of {len(idx)} differ from the host expf"
+    return len(idx), int((cr != got).sum())

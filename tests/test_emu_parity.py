@@ -111,3 +111,9 @@ def test_nn_match_pass_by_pass(emu, oracle):
 
 def test_nn_match_candidate_overflow(emu, oracle):
     assert parity.check_nn_match_duplicates(emu, oracle) >= 3
+
+
+def test_window_weight_expf_matches_host_libm(emu):
+    """s3d_expf restates glibc's expf; the descriptor is discontinuous in the window weight (s3d_math.h)."""
+    nchecked, ndiff_cr = parity.check_expf(emu, n=1 << 18)
+    assert nchecked >= 10000

@@ -113,6 +113,8 @@ def test_detect_describe_golden(lib, name):
     ((96, 80, 72), (1, 1, 2), 500, 1),
     ((81, 70, 67), (1, 0.8, 1.7), 400, 3),
     ((128, 128, 128), (1, 1, 1), 2000, 0),      # the survey's 491-keypoint anchor
+    ((256, 256, 256), (1, 1, 1), 16000, 2),     # 4 octaves, ~3900 keypoints: every level bit for bit, all descriptors
+    ((192, 160, 128), (1, 1, 1.5), 6000, 7),    # anisotropic slices: fused in-plane passes + generic z pass
 ])
 def test_detect_describe_vs_oracle(lib, oracle, dims, units, nblobs, seed):
     k = parity.check_detect_describe(lib, oracle, dims, units, nblobs, seed)
@@ -303,3 +305,10 @@ def test_properties_at_benchmark_size(lib):
     os.makedirs(out, exist_ok=True)
     json.dump({"K_512": int(len(xyzos)), "desc_sha256": sha(bins)}, open(os.path.join(out, "props_512.json"), "w"))
     lib.sift.cleanup_SIFT3D(C.byref(s))
+
+
+def test_window_weight_expf_matches_host_libm(lib):
+    """The device's window-weight exponential is the host libm's expf bit for bit (4M arguments; the ones where it
+    is not the correctly rounded value are all checked)."""
+    nchecked, ndiff_cr = parity.check_expf(lib, n=1 << 22)
+    assert nchecked >= 20000 and ndiff_cr > 0      # glibc's expf is not correctly rounded in ~6e-4 of cases
