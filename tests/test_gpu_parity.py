@@ -312,3 +312,44 @@ def test_window_weight_expf_matches_host_libm(lib):
     is not the correctly rounded value are all checked)."""
     nchecked, ndiff_cr = parity.check_expf(lib, n=1 << 22)
     assert nchecked >= 20000 and ndiff_cr > 0      # glibc's expf is not correctly rounded in ~6e-4 of cases
+
+
+def test_benchmark_size_vs_reference_golden(lib):
+    """BASELINE configs[1] end to end against the UNMODIFIED reference's output on the same 512^3 volume
+    (tests/golden/full512.npz, written by tests/golden/make_golden_512.py from oracle/_ref): all 31 207 keypoints and
+    their order bit-exact, R within 1e-5, every 32nd descriptor within 1e-4 relative, and two fixed +-1 projections
+    of EVERY descriptor within the bound the 1e-4 band implies (|sum s_i e_i| <= 1e-4 * ||d||_1 + 768e-7)."""
+    import hashlib
+    gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full512.npz")
+    g = np.load(gpath)
+    n = int(g["n"])
+    vol = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
+    assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).digest() == g["sha256"].tobytes(), "generator drifted"
+    s, im, kp = parity.run_detect(lib, vol, (1, 1, 1))
+    xyzos, sd, R = lib.keypoints_to_numpy(kp)
+    assert np.array_equal(xyzos, g["xyzos"].astype(xyzos.dtype)), f"keypoints differ: {len(xyzos)} vs {len(g['xyzos'])}"
+    assert np.array_equal(sd, g["sd"])
+    assert np.abs(R.reshape(len(R), 9) - g["R"]).max() <= 1e-5
+    d = abi.SIFT3D_Descriptor_store()
+    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    bins, _ = lib.descriptors_to_numpy(d)
+    every = int(g["every"])
+    got, want = bins[::every], g["desc"]
+    ok = rel_close(got, want, rtol=1e-4, atol=1e-7)
+    assert ok.all(), f"{(~ok).sum()} of {ok.size} sampled descriptor floats beyond 1e-4 relative"
+    signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    proj = bins.astype(np.float64) @ signs
+    bound = 1e-4 * np.abs(bins.astype(np.float64)).sum(1, keepdims=True) + 768e-7
+    worst = (np.abs(proj - g["proj"]) / bound).max()
+    assert worst <= 1.0, f"descriptor projection off by {worst:.2f} x the 1e-4 band"
+    # typical agreement is far inside the band: report it for the profile notes
+    rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.maximum(np.abs(got), np.abs(want)), 1e-3)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"K": int(len(xyzos)), "sampled_descriptors": int(len(got)), "max_rel_dev_bins_over_1e-3": float(rel.max()),
+               "worst_projection_over_band": float(worst)}, open(os.path.join(out, "golden_512.json"), "w"))
+    lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+    lib.sift.cleanup_Keypoint_store(C.byref(kp))
+    lib.free_image(im)
+    lib.sift.cleanup_SIFT3D(C.byref(s))

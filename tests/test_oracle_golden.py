@@ -96,3 +96,24 @@ def test_nn_match(oracle):
         assert sha(d2) == str(g[f"d2_sha256_{seed}"]), "match_sets drifted"
         for thr in g["thresholds"]:
             assert np.array_equal(oracle.nn_match(d1, d2, float(thr)), g[f"matches_{seed}_{float(thr):.2f}"])
+
+
+def test_full512_fixture_is_self_consistent():
+    """tests/golden/full512.npz (the unmodified reference's output at BASELINE configs[1], consumed by the GPU suite):
+    the survey's keypoint-count anchor, the reference's scan order, orthonormal R, unit descriptors, and the
+    all-keypoint projections agree with the sampled descriptors they were computed from."""
+    g = np.load(os.path.join(GOLDEN, "full512.npz"))
+    xyzos = g["xyzos"].astype(np.int64)
+    K = len(xyzos)
+    assert K == 31207 and int(g["n"]) == 512
+    order = np.lexsort((xyzos[:, 0], xyzos[:, 1], xyzos[:, 2], xyzos[:, 4], xyzos[:, 3]))
+    assert np.array_equal(order, np.arange(K))
+    assert (g["sd"] > 0).all() and g["R"].shape == (K, 9)
+    R = g["R"].reshape(K, 3, 3).astype(np.float64)
+    assert np.abs(np.einsum("kij,kil->kjl", R, R) - np.eye(3)).max() < 1e-3
+    every = int(g["every"])
+    desc = g["desc"].astype(np.float64)
+    assert desc.shape == ((K + every - 1) // every, 768)
+    assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-5
+    signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    assert np.abs(desc @ signs - g["proj"][::every]).max() < 1e-12
