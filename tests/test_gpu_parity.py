@@ -353,3 +353,54 @@ def test_benchmark_size_vs_reference_golden(lib):
     lib.sift.cleanup_Keypoint_store(C.byref(kp))
     lib.free_image(im)
     lib.sift.cleanup_SIFT3D(C.byref(s))
+
+
+def test_two_volume_config_vs_reference_golden(lib):
+    """BASELINE configs[4] at full size against the UNMODIFIED reference (tests/golden/pair512.npz, written by
+    tests/golden/make_golden_pair512.py): two 512^3 volumes with units (1, 1, 1.5); keypoints of both bit-exact, every
+    descriptor inside the 1e-4 band by its two +-1 projections, and SIFT3D_nn_match of the product's descriptors
+    against the reference's matches.  The matcher is bit-exact on equal descriptors (test_nn_match*); here the two
+    descriptor sets differ by up to 1e-4 relative, which may move a ratio test sitting on the 0.8 threshold:
+    at most 1 decision in 5000 may differ, and a differing decision must involve a rejection (never two different
+    partners)."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pair512.npz"))
+    n = int(g["n"])
+    units = tuple(float(u) for u in g["units"])
+    a = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
+    assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest() == g["sha256"].tobytes(), "generator drifted"
+    signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    sets, worst = [], 0.0
+    for tag, vol in (("a", a), ("b", np.roll(a, tuple(int(r) for r in g["roll"]), axis=(0, 1, 2)).copy())):
+        s, im, kp = parity.run_detect(lib, vol, units)
+        xyzos, sd, R = lib.keypoints_to_numpy(kp)
+        assert np.array_equal(xyzos, g[f"xyzos_{tag}"].astype(xyzos.dtype)), f"volume {tag}: keypoints differ"
+        assert np.array_equal(sd, g[f"sd_{tag}"])
+        assert np.abs(R.reshape(len(R), 9) - g[f"R_{tag}"]).max() <= 1e-5
+        d = abi.SIFT3D_Descriptor_store()
+        lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+        assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        bins, _ = lib.descriptors_to_numpy(d)
+        bound = 1e-4 * np.abs(bins.astype(np.float64)).sum(1, keepdims=True) + 768e-7
+        worst = max(worst, float((np.abs(bins.astype(np.float64) @ signs - g[f"proj_{tag}"]) / bound).max()))
+        sets.append(d)
+        lib.sift.cleanup_Keypoint_store(C.byref(kp))
+        lib.free_image(im)
+        lib.sift.cleanup_SIFT3D(C.byref(s))
+    assert worst <= 1.0, f"descriptor projection off by {worst:.2f} x the 1e-4 band"
+    lib.sift.SIFT3D_nn_match.argtypes = [C.POINTER(abi.SIFT3D_Descriptor_store), C.POINTER(abi.SIFT3D_Descriptor_store),
+                                         C.c_float, C.POINTER(C.POINTER(C.c_int))]
+    m = C.POINTER(C.c_int)()
+    assert lib.sift.SIFT3D_nn_match(C.byref(sets[0]), C.byref(sets[1]), 0.8, C.byref(m)) == 0
+    got = np.ctypeslib.as_array(m, shape=(int(sets[0].num),)).astype(np.int32)
+    want = g["match"]
+    diff = np.nonzero(got != want)[0]
+    assert len(diff) <= len(want) // 5000, f"{len(diff)} of {len(want)} match decisions differ"
+    assert ((got[diff] < 0) | (want[diff] < 0)).all(), "a keypoint matched to a different partner"
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"keypoints": [int(sets[0].num), int(sets[1].num)], "matches": int((got >= 0).sum()),
+               "differing_match_decisions": int(len(diff)), "worst_projection_over_band": worst},
+              open(os.path.join(out, "golden_pair512.json"), "w"))
+    for d in sets:
+        lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))

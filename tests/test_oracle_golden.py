@@ -117,3 +117,18 @@ def test_full512_fixture_is_self_consistent():
     assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-5
     signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
     assert np.abs(desc @ signs - g["proj"][::every]).max() < 1e-12
+
+
+def test_pair512_fixture_is_self_consistent():
+    """tests/golden/pair512.npz (BASELINE configs[4] from the unmodified reference): shapes, scan order, match range,
+    and the forward/backward property of SIFT3D_nn_match -- no two keypoints of A share a partner in B."""
+    g = np.load(os.path.join(GOLDEN, "pair512.npz"))
+    ka, kb = len(g["xyzos_a"]), len(g["xyzos_b"])
+    assert (ka, kb) == (33452, 34889) and g["match"].shape == (ka,)
+    for tag in "ab":
+        x = g[f"xyzos_{tag}"].astype(np.int64)
+        assert np.array_equal(np.lexsort((x[:, 0], x[:, 1], x[:, 2], x[:, 4], x[:, 3])), np.arange(len(x)))
+    m = g["match"]
+    assert m.min() >= -1 and m.max() < kb and (m >= 0).sum() == 17874
+    hit = m[m >= 0]
+    assert len(np.unique(hit)) == len(hit)
