@@ -145,9 +145,13 @@ def check_detect_describe(lib, oracle, dims, units, nblobs, seed=0, check_pyrami
             oracle.set_params()
 
 
-def check_dense(lib, oracle, dims, units, out_units=(1, 1, 1), seed=5):
+def dense_input(dims, seed=5):
     nx, ny, nz = dims
-    vol = (synth.blobs(nx, ny, nz, max(8, nx * ny * nz // 300), seed) * 37.0 + 3.0).astype(np.float32)
+    return (synth.blobs(nx, ny, nz, max(8, nx * ny * nz // 300), seed) * 37.0 + 3.0).astype(np.float32)
+
+
+def run_dense(lib, vol, units, out_units=(1, 1, 1)):
+    """SIFT3D_extract_dense_descriptors through the C API of `lib`; returns the [z, y, x, 12] output."""
     s = abi.SIFT3D()
     assert lib.sift.init_SIFT3D(C.byref(s)) == 0
     im = lib.image_from_numpy(vol, units)
@@ -156,11 +160,17 @@ def check_dense(lib, oracle, dims, units, out_units=(1, 1, 1), seed=5):
     out.ux, out.uy, out.uz = out_units
     assert lib.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out)) == 0
     got = lib.image_to_numpy(out)
-    want = oracle.dense(vol, units, out_units)
-    nd = nbitdiff(got, want)
     lib.free_image(im)
     lib.free_image(out)
     lib.sift.cleanup_SIFT3D(C.byref(s))
+    return got
+
+
+def check_dense(lib, oracle, dims, units, out_units=(1, 1, 1), seed=5):
+    vol = dense_input(dims, seed)
+    got = run_dense(lib, vol, units, out_units)
+    want = oracle.dense(vol, units, out_units)
+    nd = nbitdiff(got, want)
     assert nd == 0, f"dense: {nd} of {got.size} elements differ"
 
 

@@ -404,3 +404,17 @@ def test_two_volume_config_vs_reference_golden(lib):
               open(os.path.join(out, "golden_pair512.json"), "w"))
     for d in sets:
         lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+
+
+def test_dense_config_vs_reference_golden(lib):
+    """BASELINE configs[2] (dense descriptors, 256^3) against the UNMODIFIED reference: the SHA-256 of the full
+    256^3 x 12 float32 output equals the reference's (tests/golden/dense256.json, make_golden_dense256.py)."""
+    import hashlib
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dense256.json")))
+    n = g["n"]
+    vol = parity.dense_input((n, n, n))
+    assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).hexdigest() == g["input_sha256"], "generator drifted"
+    out = parity.run_dense(lib, vol, (1, 1, 1))
+    for smp in g["samples"]:
+        assert [int(b) for b in out[tuple(smp["zyx"])].view(np.uint32)] == smp["hist_bits"], smp["zyx"]
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == g["output_sha256"]
