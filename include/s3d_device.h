@@ -138,10 +138,16 @@ typedef struct {
  * [o*num_levels + k], = 1.5 * level scale), else the float triple d_center[3i..] (raw-image
  * variant, sift.c:1534-1604; d_sigma is then per candidate).
  * Outputs: d_R[9*i] row-major rotation, d_keep[i] = 1 iff not rejected and conf >= corner_thresh,
- * d_conf[i] (optional) = corner score, 0 when rejected. */
+ * d_conf[i] (optional) = corner score, 0 when rejected.  Three launches per chunk: window sums (a wave per
+ * candidate), decisions (a thread per candidate), the ordered sum for the few the bound left undecided. */
 int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                  const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                 float *d_R, uint32_t *d_keep, double *d_conf, s3d_stream stream);
+                 float *d_R, uint32_t *d_keep, double *d_conf,
+                 void *d_scratch /* s3d_k_orient_scratch_bytes(num) bytes */, s3d_stream stream);
+/* Candidates are processed in chunks of S3D_ORIENT_CHUNK; the scratch holds one chunk's window sums. */
+#define S3D_ORIENT_CHUNK (1u << 20)
+#define S3D_ORIENT_SCRATCH_BYTES 128u
+size_t s3d_k_orient_scratch_bytes(uint32_t num);
 /* Stable compaction of kept candidates: for i with keep[i], writes x,y,z,o,s (int32 x5) and R.
  * *d_num_out receives the number kept.  d_scratch: >= num/256 + 2 uint32. */
 int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,

@@ -67,6 +67,7 @@ typedef struct {
     uint32_t cand_cap;
     uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
     float *d_R, *d_Rk;
+    void *d_orient;         /* s3d_k_orient scratch for cand_cap candidates */
     int32_t *d_xyzos;
     double *d_sigma;
     float *d_mesh;
@@ -127,7 +128,7 @@ static void ctx_free_pyramid(s3d_ctx *c)
     for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&c->d_level[i]);
     dfree(&c->d_bits); dfree(&c->d_scratch);
     dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep);
-    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_sigma);
+    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_sigma); dfree(&c->d_orient);
     c->nx = c->ny = c->nz = c->num_octaves = c->num_levels = 0;
     c->cand_cap = 0;
     c->have_pyramid = 0;
@@ -364,7 +365,7 @@ static int ctx_ensure_candidates(s3d_ctx *c, uint32_t cap)
 {
     if (c->cand_cap >= cap) return SIFT3D_SUCCESS;
     dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep);
-    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos);
+    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_orient);
     c->cand_cap = 0;
     DEV(s3d_rt_malloc((void **)&c->d_cand_idx, (size_t)cap * sizeof(uint32_t)));
     DEV(s3d_rt_malloc((void **)&c->d_cand_tag, (size_t)cap * sizeof(uint32_t)));
@@ -372,6 +373,7 @@ static int ctx_ensure_candidates(s3d_ctx *c, uint32_t cap)
     DEV(s3d_rt_malloc((void **)&c->d_R, (size_t)cap * 9 * sizeof(float)));
     DEV(s3d_rt_malloc((void **)&c->d_Rk, (size_t)cap * 9 * sizeof(float)));
     DEV(s3d_rt_malloc((void **)&c->d_xyzos, (size_t)cap * 5 * sizeof(int32_t)));
+    DEV(s3d_rt_malloc(&c->d_orient, s3d_k_orient_scratch_bytes(cap)));
     c->cand_cap = cap;
     return SIFT3D_SUCCESS;
 }
@@ -536,7 +538,7 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
         DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
         DEV(s3d_k_orient(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
-                         c->d_R, c->d_keep, NULL, c->stream));
+                         c->d_R, c->d_keep, NULL, c->d_orient, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
                                c->d_Rk, c->d_count + 1, c->d_scratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));
@@ -910,6 +912,7 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
     float *d_centers = NULL, *d_R = NULL;
     double *d_sig = NULL, *d_conf = NULL;
     uint32_t *d_keep = NULL, *d_tags = NULL;
+    void *d_oscr = NULL;
     int rc = SIFT3D_FAILURE;
     if (verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
     if (!s->kernels.downsample_2 && !(s->kernels.downsample_2 = ctx_new())) API_FAIL("sift3d_amd: out of device contexts");
@@ -931,12 +934,13 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
     }
     if (s3d_rt_malloc((void **)&d_centers, num * 3 * sizeof(float)) || s3d_rt_malloc((void **)&d_sig, num * sizeof(double)) ||
         s3d_rt_malloc((void **)&d_R, num * 9 * sizeof(float)) || s3d_rt_malloc((void **)&d_keep, num * sizeof(uint32_t)) ||
-        s3d_rt_malloc((void **)&d_tags, num * sizeof(uint32_t)) || s3d_rt_malloc((void **)&d_conf, num * sizeof(double)))
+        s3d_rt_malloc((void **)&d_tags, num * sizeof(uint32_t)) || s3d_rt_malloc((void **)&d_conf, num * sizeof(double)) ||
+        s3d_rt_malloc(&d_oscr, s3d_k_orient_scratch_bytes((uint32_t)num)))
         goto done;
     if (s3d_rt_h2d(d_centers, centers, num * 3 * sizeof(float), c->stream) ||
         s3d_rt_h2d(d_sig, sig, num * sizeof(double), c->stream) ||
         s3d_rt_h2d(d_tags, tags, num * sizeof(uint32_t), c->stream) ||
-        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, c->stream) ||
+        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, d_oscr, c->stream) ||
         s3d_rt_d2h(R, d_R, num * 9 * sizeof(float), c->stream) ||
         s3d_rt_d2h(keep, d_keep, num * sizeof(uint32_t), c->stream) ||
         s3d_rt_d2h(*conf, d_conf, num * sizeof(double), c->stream) || s3d_rt_sync(c->stream)) {
@@ -958,7 +962,7 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
 done:
     free(centers); free(sig); free(R); free(keep); free(tags);
     s3d_rt_free(d_centers); s3d_rt_free(d_sig); s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_tags);
-    s3d_rt_free(d_conf);
+    s3d_rt_free(d_conf); s3d_rt_free(d_oscr);
     return rc;
 }
 
@@ -986,6 +990,7 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
         float *d_R = NULL;
         uint32_t *d_keep = NULL;
         double *d_sig = NULL;
+        void *d_oscr = NULL;
         rc = SIFT3D_FAILURE;
         if (n >= 0x7FFFFFFFull) API_FAIL("sift3d_amd: volume too large for dense_rotate");
         if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n)) return SIFT3D_FAILURE;
@@ -998,16 +1003,17 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
         if (s3d_rt_malloc((void **)&d_R, n * 9 * sizeof(float)) == 0 &&
             s3d_rt_malloc((void **)&d_keep, n * sizeof(uint32_t)) == 0 &&
             s3d_rt_malloc((void **)&d_sig, sizeof(double)) == 0 &&
+            s3d_rt_malloc(&d_oscr, s3d_k_orient_scratch_bytes((uint32_t)n)) == 0 &&
             s3d_rt_h2d(d_sig, &ori_sigma, sizeof(double), c->stream) == 0 &&
             s3d_k_orient(&pd, NULL, NULL, NULL, (uint32_t)n, d_sig, sift3d->corner_thresh, d_R, d_keep, NULL,
-                         c->stream) == 0 &&
+                         d_oscr, c->stream) == 0 &&
             s3d_k_dense_rot_hist(c->d_aux[1], nx, ny, nz, unitsf, sigma_win, d_R, d_keep, c->d_mesh, d_out,
                                  c->stream) == 0 &&
             s3d_k_dense_post(d_out, d_in, n, c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
             rc = SIFT3D_SUCCESS;
         else
             S3D_MSG("sift3d_amd: dense_rotate failed: %s\n", s3d_rt_last_error());
-        s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_sig);
+        s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_sig); s3d_rt_free(d_oscr);
         return rc;
     }
     /* aux 1: smoothed input, aux 2: scratch (12 channels), aux 3: 12-channel barycentric image */

@@ -123,18 +123,56 @@ __device__ __forceinline__ void ori_bounds(float vc, double rad, float uf, int n
     *e = (int)(fe < (float)(n - 2) ? fe : (float)(n - 2));
 }
 
+/* The orientation of one candidate is three steps, run as three kernels over a chunk of candidates:
+ *   k_orient_wave<1>  one wave per candidate: window sums (structure tensor, gradient, bound terms) -> scratch
+ *   k_orient_decide   one THREAD per candidate: eigen-decomposition, the reference's tests, R.  (All 64 lanes of
+ *                     the candidate's wave used to evaluate this redundantly -- a third of the kernel's
+ *                     instructions; one lane per candidate costs 1/64 of that.)
+ *   k_orient_wave<2>  one wave per candidate the bound could not decide: the reference's ordered f32 sum.
+ * Scratch per candidate (S3D_ORIENT_SCRATCH_BYTES = 16 doubles): a00 a01 a02 a11 a12 a22 | gd[3] | sa[3] | cnt |
+ * then the two leading eigenvectors as 6 floats.  d_keep[i] == 2 marks "undecided" between the steps. */
+#define ORI_SCR 16
+__device__ __forceinline__ int orient_finish(const float vr[2][3], float gwx, float gwy, float gwz, double corner_thresh,
+                                             float R[9], double *conf)
+{
+    /* R and the corner score from a window gradient (gwx, gwy, gwz), the reference's way (sift.c:1446-1492) */
+    float v[2][3];
+    double score = 1.7976931348623157e308;
+    for (int i = 0; i < 2; i++) {
+        const double d = (double)(gwx * vr[i][0] + gwy * vr[i][1] + gwz * vr[i][2]);
+        const double cos_ang = d / (double)(sqrtf(vr[i][0] * vr[i][0] + vr[i][1] * vr[i][1] + vr[i][2] * vr[i][2]) *
+                                             sqrtf(gwx * gwx + gwy * gwy + gwz * gwz));
+        const double ac = fabs(cos_ang);
+        const float sgn = d > 0.0 ? 1.0f : -1.0f;
+        score = score < ac ? score : ac;
+        for (int c = 0; c < 3; c++) {
+            v[i][c] = vr[i][c] * sgn;
+            R[3 * c + i] = v[i][c];
+        }
+    }
+    R[2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];
+    R[5] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
+    R[8] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
+    *conf = score;
+    return score < corner_thresh ? 0 : 1;
+}
+
+template <int PHASE>
 __global__ void __launch_bounds__(64)
-k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
-         const float *__restrict__ d_center, uint32_t num, const double *__restrict__ d_sigma, double corner_thresh,
-         float *__restrict__ d_R, uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, int variant)
+k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
+              const float *__restrict__ d_center, uint32_t cand0, uint32_t num, const double *__restrict__ d_sigma,
+              double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
+              double *__restrict__ d_conf, int variant)
 {
     __shared__ __attribute__((aligned(16))) float term[3][64];
     __shared__ float gw_s[3];
     __shared__ int row_off[65];
     __shared__ unsigned row_first[64];
-    const unsigned cand = blockIdx.x;
+    const unsigned cand = cand0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (cand >= num) return;
+    if (PHASE == 2 && d_keep[cand] != 2u) return;
+    double *scr = d_scr + (size_t)blockIdx.x * ORI_SCR;
     const unsigned tag = d_tag ? d_tag[cand] : 0u;        /* no tags: every candidate lives in level 0 */
     const int o = (int)(tag >> 8), k = (int)(tag & 255u);
     const int li = o * pyr.num_levels + k;
@@ -155,6 +193,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     const double sigma = d_sigma_sel(d_sigma, d_center != nullptr, cand, li);
     const double rad = sigma * 3.0;                        /* ori_rad_fctr */
     const double rad2 = rad * rad, sig2 = sigma * sigma;
+    const double inv_sig2 = 1.0 / sig2;
 
     int xs, xe, ys, ye, zs, ze;
     ori_bounds(vcx, rad, uxf, nx, &xs, &xe);
@@ -170,7 +209,18 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         const float dz = ((float)z - vcz) * uzf;
         const float sq = dx * dx + dy * dy + dz * dz;
         const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
-        const float wa = (float)(-0.5 * (double)sq / sig2);
+        /* (float)(-0.5 * sq / sigma^2), the quotient in double as the reference forms it (sift.c:1401).  The
+         * product with the reciprocal is within 1 ulp of that quotient, so its rounding to float is the
+         * quotient's own unless it sits within a few ulp of a float rounding boundary (the 29 dropped bits
+         * near 2^28): only then, about once in 1e8 samples, is the division itself evaluated. */
+        const double qd = (-0.5 * (double)sq) * inv_sig2;
+        float wa = (float)qd;
+        {
+            unsigned long long qb;
+            __builtin_memcpy(&qb, &qd, 8);
+            const int low = (int)(qb & 0x1fffffffull) - 0x10000000;
+            if ((low < 0 ? -low : low) <= 4) wa = (float)(-0.5 * (double)sq / sig2);
+        }
         *w = (variant & 2) ? __expf(wa) : s3d_expf(wa);
         *gx = 0.5f * (p[1] - p[-1]) * iux;
         *gy = 0.5f * (p[nx] - p[-nx]) * iuy;
@@ -244,6 +294,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         }
     };
 
+    if (PHASE == 1) {
     /* ---- pass 1 (parallel): f64 structure tensor, and for the window gradient sum(w*grad) both its
      * (to f64 accuracy) exact value gd and sum|term| per component, which bounds how far the
      * reference's sequential f32 accumulation can be from gd ------------------------------------- */
@@ -273,7 +324,74 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         cnt += __shfl_xor(cnt, m);
     }
 
-    /* Everything below is evaluated redundantly by all 64 lanes (identical values, no divergence). */
+    if (lane == 0) {
+        scr[0] = a00; scr[1] = a01; scr[2] = a02; scr[3] = a11; scr[4] = a12; scr[5] = a22;
+        scr[6] = gdx; scr[7] = gdy; scr[8] = gdz; scr[9] = sax; scr[10] = say; scr[11] = saz;
+        scr[12] = (double)cnt;
+    }
+    return;
+    }
+    float R[9];
+    for (int i = 0; i < 9; i++) R[i] = 0.0f;
+    int keep = 0;
+    double conf = 0.0;
+    const float grad_thr = (float)1E-10;                   /* ori_grad_thresh, sift.c:49,1426 */
+    float vr[2][3];
+    {
+        const float *vf = reinterpret_cast<const float *>(scr + 13);
+        for (int i = 0; i < 2; i++)
+            for (int c = 0; c < 3; c++) vr[i][c] = vf[3 * i + c];
+    }
+    /* ---- pass 2 (rare): the reference's own summation order ------------------------------------------ */
+    {
+        float gsum = 0.0f;                                 /* lanes 0..2: running sum of component lane */
+        sweep([&](bool valid, int x, int y, int z) {
+            float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+            if (valid) {
+                float gx, gy, gz, w;
+                sample(x, y, z, &gx, &gy, &gz, &w);
+                tx = gx * w; ty = gy * w; tz = gz * w;
+            }
+            term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
+            s3d_wave_lds_sync();
+            if (lane < 3 && !(variant & 1)) {
+                /* scan order (dense ids ascend in z, y, x); the padding of the last turn adds exact +0.  The
+                 * 64 staged terms are pulled into registers with 16 independent ds_read_b128 so the
+                 * dependent chain is 64 adds. */
+                float4 q[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(&term[lane][4 * i]);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    gsum = gsum + q[i].x; gsum = gsum + q[i].y; gsum = gsum + q[i].z; gsum = gsum + q[i].w;
+                }
+            }
+            s3d_wave_lds_sync();
+        });
+        if (lane < 3) gw_s[lane] = gsum;
+        s3d_wave_lds_sync();
+        const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
+        if (!(gwx * gwx + gwy * gwy + gwz * gwz < grad_thr)) keep = orient_finish(vr, gwx, gwy, gwz, corner_thresh, R, &conf);
+    }
+    if (lane != 0) return;
+    if (!keep)
+        for (int i = 0; i < 9; i++) R[i] = 0.0f;
+    for (int i = 0; i < 9; i++) d_R[(size_t)cand * 9 + i] = R[i];
+    d_keep[cand] = (uint32_t)keep;
+    if (d_conf) d_conf[cand] = keep || conf > 0.0 ? conf : 0.0;
+}
+
+__global__ void __launch_bounds__(64)
+k_orient_decide(uint32_t cand0, uint32_t num, double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R,
+                uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, int variant)
+{
+    const unsigned local = blockIdx.x * 64u + threadIdx.x;
+    const unsigned cand = cand0 + local;
+    if (cand >= num || local >= S3D_ORIENT_CHUNK) return;
+    double *scr = d_scr + (size_t)local * ORI_SCR;
+    const double a00 = scr[0], a01 = scr[1], a02 = scr[2], a11 = scr[3], a12 = scr[4], a22 = scr[5];
+    const double gdx = scr[6], gdy = scr[7], gdz = scr[8], sax = scr[9], say = scr[10], saz = scr[11];
+    const int cnt = (int)scr[12];
     float R[9];
     for (int i = 0; i < 9; i++) R[i] = 0.0f;
     int keep = 0;
@@ -287,29 +405,6 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     float vr[2][3];                                        /* the two leading eigenvectors as f32 */
     for (int i = 0; i < 2; i++)
         for (int c = 0; c < 3; c++) vr[i][c] = (float)Q[c][2 - i];
-
-    /* R and the corner score from a window gradient (gwx, gwy, gwz), the reference's way (sift.c:1446-1492) */
-    auto finish = [&](float gwx, float gwy, float gwz) {
-        float v[2][3];
-        double score = 1.7976931348623157e308;
-        for (int i = 0; i < 2; i++) {
-            const double d = (double)(gwx * vr[i][0] + gwy * vr[i][1] + gwz * vr[i][2]);
-            const double cos_ang = d / (double)(sqrtf(vr[i][0] * vr[i][0] + vr[i][1] * vr[i][1] + vr[i][2] * vr[i][2]) *
-                                                 sqrtf(gwx * gwx + gwy * gwy + gwz * gwz));
-            const double ac = fabs(cos_ang);
-            const float sgn = d > 0.0 ? 1.0f : -1.0f;
-            score = score < ac ? score : ac;
-            for (int c = 0; c < 3; c++) {
-                v[i][c] = vr[i][c] * sgn;
-                R[3 * c + i] = v[i][c];
-            }
-        }
-        R[2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];
-        R[5] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
-        R[8] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
-        conf = score;
-        keep = conf < corner_thresh ? 0 : 1;
-    };
 
     /* ---- decision without the ordered sum when it is provably the same --------------------------------
      * Recursive f32 summation of n terms is within n*2^-24*sum|t| of the exact sum, per component.  If
@@ -345,7 +440,7 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
                 if (cmin + marg < corner_thresh) {
                     decided = 1;                           /* certainly below corner_thresh: REJECT */
                 } else if (cmin - marg >= corner_thresh && dmin > 0.0) {
-                    finish((float)gdx, (float)gdy, (float)gdz);   /* signs are safe: R is the reference's */
+                    (void)orient_finish(vr, (float)gdx, (float)gdy, (float)gdz, corner_thresh, R, &conf);   /* signs are safe: R is the reference's */
                     keep = 1;
                     decided = 1;
                 }
@@ -353,38 +448,13 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
         }
     }
 
-    /* ---- pass 2 (rare): the reference's own summation order ------------------------------------------ */
-    if (!decided) {
-        float gsum = 0.0f;                                 /* lanes 0..2: running sum of component lane */
-        sweep([&](bool valid, int x, int y, int z) {
-            float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-            if (valid) {
-                float gx, gy, gz, w;
-                sample(x, y, z, &gx, &gy, &gz, &w);
-                tx = gx * w; ty = gy * w; tz = gz * w;
-            }
-            term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
-            s3d_wave_lds_sync();
-            if (lane < 3 && !(variant & 1)) {
-                /* scan order (dense ids ascend in z, y, x); the padding of the last turn adds exact +0.  The
-                 * 64 staged terms are pulled into registers with 16 independent ds_read_b128 so the
-                 * dependent chain is 64 adds. */
-                float4 q[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(&term[lane][4 * i]);
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    gsum = gsum + q[i].x; gsum = gsum + q[i].y; gsum = gsum + q[i].z; gsum = gsum + q[i].w;
-                }
-            }
-            s3d_wave_lds_sync();
-        });
-        if (lane < 3) gw_s[lane] = gsum;
-        s3d_wave_lds_sync();
-        const float gwx = gw_s[0], gwy = gw_s[1], gwz = gw_s[2];
-        if (!(gwx * gwx + gwy * gwy + gwz * gwz < grad_thr)) finish(gwx, gwy, gwz);
+    if (!decided) {                                        /* k_orient_wave<2> finishes this one */
+        float *vf = reinterpret_cast<float *>(scr + 13);
+        for (int i = 0; i < 2; i++)
+            for (int c = 0; c < 3; c++) vf[3 * i + c] = vr[i][c];
+        d_keep[cand] = 2u;
+        return;
     }
-    if (lane != 0) return;
     if (!keep)
         for (int i = 0; i < 9; i++) R[i] = 0.0f;
     for (int i = 0; i < 9; i++) d_R[(size_t)cand * 9 + i] = R[i];
@@ -392,14 +462,30 @@ k_orient(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_
     if (d_conf) d_conf[cand] = keep || conf > 0.0 ? conf : 0.0;
 }
 
+extern "C" size_t s3d_k_orient_scratch_bytes(uint32_t num)
+{
+    return (size_t)(num < S3D_ORIENT_CHUNK ? num : S3D_ORIENT_CHUNK) * S3D_ORIENT_SCRATCH_BYTES;
+}
+
 extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                             const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                            float *d_R, uint32_t *d_keep, double *d_conf, s3d_stream st)
+                            float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, s3d_stream st)
 {
     if (num == 0) return S3D_OK;
-    hipLaunchKernelGGL(k_orient, dim3(num), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, num, d_sigma,
-                       corner_thresh, d_R, d_keep, d_conf, g_variant);
-    S3D_CHECK_LAUNCH();
+    if (!d_scratch) return S3D_ERR;
+    double *scr = (double *)d_scratch;
+    for (uint32_t c0 = 0; c0 < num; c0 += S3D_ORIENT_CHUNK) {
+        const uint32_t n = num - c0 < S3D_ORIENT_CHUNK ? num - c0 : S3D_ORIENT_CHUNK;
+        hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, g_variant);
+        S3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, num, corner_thresh, scr,
+                           d_R, d_keep, d_conf, g_variant);
+        S3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, g_variant);
+        S3D_CHECK_LAUNCH();
+    }
     return S3D_OK;
 }
 

@@ -214,6 +214,7 @@ class SlabSift3D:
         self.bits_words = nmax // 64 + 2
         self.bits = torch.zeros(3 * self.bits_words, dtype=torch.int64, device=self.dev)   # one bitmap per keypoint level
         self.scratch = torch.zeros(nmax // 64 // 256 + 4096, dtype=torch.int32, device=self.dev)
+        self.orient_scr = None
         self.red = torch.zeros(8, dtype=torch.float32, device=self.dev)
         self.count = torch.zeros(8, dtype=torch.int32, device=self.dev)
         self.cap = 0
@@ -258,7 +259,9 @@ class SlabSift3D:
                                          _vp, _vp, _vp]
         L.s3d_k_compact_bits_base.argtypes = [_vp, C.c_size_t, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp,
                                               _vp]
-        L.s3d_k_orient.argtypes = [P(PyramidDesc), _vp, _vp, _vp, C.c_uint32, _vp, C.c_double, _vp, _vp, _vp, _vp]
+        L.s3d_k_orient.argtypes = [P(PyramidDesc), _vp, _vp, _vp, C.c_uint32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]
+        L.s3d_k_orient_scratch_bytes.argtypes = [C.c_uint32]
+        L.s3d_k_orient_scratch_bytes.restype = C.c_size_t
         L.s3d_k_compact_keys.argtypes = [P(PyramidDesc), _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]
         L.s3d_k_describe.argtypes = [P(PyramidDesc), _vp, C.c_uint32, _vp, _vp, C.c_size_t, _vp]
         L.s3d_rt_sync.argtypes = [_vp]
@@ -420,9 +423,12 @@ class SlabSift3D:
             self.xyzos = np.zeros((0, 5), np.int32)
             self.R = np.zeros((0, 3, 3), np.float32)
             return 0
+        need = int(L.s3d_k_orient_scratch_bytes(ncand))
+        if self.orient_scr is None or self.orient_scr.numel() < need:
+            self.orient_scr = torch.empty(need, dtype=torch.uint8, device=self.dev)
         self._ck(L.s3d_k_orient(C.byref(self.pd), self.cand_idx.data_ptr(), self.cand_tag.data_ptr(), None, ncand,
                                 self.sigma_tab.data_ptr(), float(self.s.corner_thresh), self.Rc.data_ptr(),
-                                self.keep.data_ptr(), None, None), "orient")
+                                self.keep.data_ptr(), None, self.orient_scr.data_ptr(), None), "orient")
         self._ck(L.s3d_k_compact_keys(C.byref(self.pd), self.cand_idx.data_ptr(), self.cand_tag.data_ptr(),
                                       self.Rc.data_ptr(), self.keep.data_ptr(), ncand, self.kxyzos.data_ptr(),
                                       self.Rk.data_ptr(), self.count[1:].data_ptr(), self.scratch.data_ptr(), None),
