@@ -107,6 +107,14 @@ __device__ __forceinline__ int fdiv_small(int a, int d, float inv, int *rem)
     return q;
 }
 
+#if defined(__clang__)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   /* dword-aligned wide loads */
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#else                                      /* the g++ emulator build of the test suite */
+struct f4u { float x, y, z, w; };
+struct f2u { float x, y; };
+#endif
+
 /* ---- orientation ---------------------------------------------------------------------------------- */
 /* sigma table is per level for detected candidates, per candidate for the raw-image variant */
 __device__ __forceinline__ double d_sigma_sel(const double *d_sigma, bool per_cand, unsigned cand, int li)
@@ -168,6 +176,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     __shared__ float gw_s[3];
     __shared__ int row_off[65];
     __shared__ unsigned row_first[64];
+    __shared__ unsigned short row_len[64];
     const unsigned cand = cand0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (cand >= num) return;
@@ -202,26 +211,27 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
     const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
 
-    /* one window sample: weight and iso gradient exactly as the reference evaluates them */
-    auto sample = [&](int x, int y, int z, float *gx, float *gy, float *gz, float *w) {
-        const float dx = ((float)x - vcx) * uxf;
-        const float dy = ((float)y - vcy) * uyf;
-        const float dz = ((float)z - vcz) * uzf;
-        const float sq = dx * dx + dy * dy + dz * dz;
-        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
+        /* window weight of a squared distance, bit for bit the reference's expf(-0.5 * sq / (sigma * sigma)) */
+    auto weight = [&](float sq) -> float {
         /* (float)(-0.5 * sq / sigma^2), the quotient in double as the reference forms it (sift.c:1401).  The
          * product with the reciprocal is within 1 ulp of that quotient, so its rounding to float is the
          * quotient's own unless it sits within a few ulp of a float rounding boundary (the 29 dropped bits
          * near 2^28): only then, about once in 1e8 samples, is the division itself evaluated. */
         const double qd = (-0.5 * (double)sq) * inv_sig2;
         float wa = (float)qd;
-        {
-            unsigned long long qb;
-            __builtin_memcpy(&qb, &qd, 8);
-            const int low = (int)(qb & 0x1fffffffull) - 0x10000000;
-            if ((low < 0 ? -low : low) <= 4) wa = (float)(-0.5 * (double)sq / sig2);
-        }
-        *w = (variant & 2) ? __expf(wa) : s3d_expf(wa);
+        unsigned long long qb;
+        __builtin_memcpy(&qb, &qd, 8);
+        const int low = (int)(qb & 0x1fffffffull) - 0x10000000;
+        if ((low < 0 ? -low : low) <= 4) wa = (float)(-0.5 * (double)sq / sig2);
+        return (variant & 2) ? __expf(wa) : s3d_expf(wa);
+    };
+    /* one window sample: weight and iso gradient exactly as the reference evaluates them */
+    auto sample = [&](int x, int y, int z, float *gx, float *gy, float *gz, float *w) {
+        const float dx = ((float)x - vcx) * uxf;
+        const float dy = ((float)y - vcy) * uyf;
+        const float dz = ((float)z - vcz) * uzf;
+        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x);
+        *w = weight(dx * dx + dy * dy + dz * dz);
         *gx = 0.5f * (p[1] - p[-1]) * iux;
         *gy = 0.5f * (p[nx] - p[-nx]) * iuy;
         *gz = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]) * iuz;
@@ -231,10 +241,11 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
      * its row's interval from the chord and settles both ends with the reference's own test
      * ((double)sq > rad^2 rejects, sift.c:96-109), a wave scan numbers the accepted voxels, and every
      * lane then takes one voxel per turn (row found by binary search in the LDS prefix array).
-     * body(valid, x, y, z) is called by all 64 lanes the same number of times. */
+     * body(valid, x, y, z, nval) is called by all 64 lanes the same number of times; with per > 1 a lane takes
+     * nval <= per consecutive voxels of one row starting at x (the order-free pass only). */
     const int nrows = (wx > 0 && wy > 0 && wz > 0) ? wy * wz : 0;
     const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
-    auto sweep = [&](auto &&body) {
+    auto sweep = [&](const int per, auto &&body) {
         for (int r0 = 0; r0 < nrows; r0 += 64) {
             int len = 0;
             unsigned first = 0;
@@ -263,32 +274,37 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
                     }
                 }
             }
-            int incl = len;
+            const int units = (len + per - 1) / per;       /* runs of `per` x-consecutive voxels (per is a literal) */
+            int incl = units;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const int up = __shfl(incl, lane >= d ? lane - d : lane);
                 if (lane >= d) incl += up;
             }
-            row_off[lane] = incl - len;
+            row_off[lane] = incl - units;
             row_first[lane] = first;
+            row_len[lane] = (unsigned short)len;
             if (lane == 63) row_off[64] = incl;
             s3d_wave_lds_sync();
             const int total = row_off[64];
             for (int i0 = 0; i0 < total; i0 += 64) {
                 const int id = i0 + lane;
                 const bool valid = id < total;
-                int x = 0, y = 0, z = 0;
+                int x = 0, y = 0, z = 0, nval = 0;
                 if (valid) {
                     int sg = 0;
 #pragma unroll
                     for (int step = 32; step; step >>= 1)
                         if (row_off[sg + step] <= id) sg += step;      /* last row starting at or before id */
                     const unsigned fv = row_first[sg];
-                    x = xs + (int)(fv & 1023u) + (id - row_off[sg]);
+                    const int q = per * (id - row_off[sg]);
+                    const int left = (int)row_len[sg] - q;
+                    nval = left < per ? left : per;
+                    x = xs + (int)(fv & 1023u) + q;
                     y = ys + (int)((fv >> 10) & 1023u);
                     z = zs + (int)(fv >> 20);
                 }
-                body(valid, x, y, z);
+                body(valid, x, y, z, nval);
             }
             s3d_wave_lds_sync();
         }
@@ -301,20 +317,38 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
     double gdx = 0, gdy = 0, gdz = 0, sax = 0, say = 0, saz = 0;
     int cnt = 0;
-    sweep([&](bool valid, int x, int y, int z) {
+    /* four x-consecutive voxels per lane and turn: one row decode and five wide unaligned loads (the level
+     * buffers carry the slack, s3d_device.h) instead of four decodes and 24 dword loads */
+    sweep(4, [&](bool valid, int x0, int y, int z, int nval) {
         if (!valid) return;
-        float gx, gy, gz, w;
-        sample(x, y, z, &gx, &gy, &gz, &w);
-        a00 += (double)gx * (double)gx * (double)w;
-        a01 += (double)gx * (double)gy * (double)w;
-        a02 += (double)gx * (double)gz * (double)w;
-        a11 += (double)gy * (double)gy * (double)w;
-        a12 += (double)gy * (double)gz * (double)w;
-        a22 += (double)gz * (double)gz * (double)w;
-        const float tx = gx * w, ty = gy * w, tz = gz * w;
-        gdx += (double)tx; gdy += (double)ty; gdz += (double)tz;
-        sax += fabs((double)tx); say += fabs((double)ty); saz += fabs((double)tz);
-        cnt++;
+        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
+        const f4u ca = *(const f4u *)(p - 1);
+        const f2u cb = *(const f2u *)(p + 3);
+        const f4u yp = *(const f4u *)(p + nx), ym = *(const f4u *)(p - nx);
+        const f4u zp = *(const f4u *)(p + plane), zm = *(const f4u *)(p - (ptrdiff_t)plane);
+        const float cx[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
+        const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
+        const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
+        const float dy = ((float)y - vcy) * uyf, dz = ((float)z - vcz) * uzf;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j >= nval) break;
+            const float dx = ((float)(x0 + j) - vcx) * uxf;
+            const float w = weight(dx * dx + dy * dy + dz * dz);
+            const float gx = 0.5f * (cx[j + 2] - cx[j]) * iux;
+            const float gy = 0.5f * (ypv[j] - ymv[j]) * iuy;
+            const float gz = 0.5f * (zpv[j] - zmv[j]) * iuz;
+            a00 += (double)gx * (double)gx * (double)w;
+            a01 += (double)gx * (double)gy * (double)w;
+            a02 += (double)gx * (double)gz * (double)w;
+            a11 += (double)gy * (double)gy * (double)w;
+            a12 += (double)gy * (double)gz * (double)w;
+            a22 += (double)gz * (double)gz * (double)w;
+            const float tx = gx * w, ty = gy * w, tz = gz * w;
+            gdx += (double)tx; gdy += (double)ty; gdz += (double)tz;
+            sax += fabs((double)tx); say += fabs((double)ty); saz += fabs((double)tz);
+            cnt++;
+        }
     });
     for (int m = 32; m >= 1; m >>= 1) {                    /* xor butterfly: every lane ends with the totals */
         a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
@@ -345,7 +379,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     /* ---- pass 2 (rare): the reference's own summation order ------------------------------------------ */
     {
         float gsum = 0.0f;                                 /* lanes 0..2: running sum of component lane */
-        sweep([&](bool valid, int x, int y, int z) {
+        sweep(1, [&](bool valid, int x, int y, int z, int) {
             float tx = 0.0f, ty = 0.0f, tz = 0.0f;
             if (valid) {
                 float gx, gy, gz, w;
@@ -579,14 +613,6 @@ extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d
 #define DESC_THREADS 256
 #define DESC_WAVES (DESC_THREADS / 64)
 #define DESC_PER 4                         /* x-consecutive window voxels per chunk (one thread, one turn) */
-#if defined(__clang__)
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   /* dword-aligned wide loads */
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-#else                                      /* the g++ emulator build of the test suite */
-struct f4u { float x, y, z, w; };
-struct f2u { float x, y; };
-#endif
-
 __device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n, int *s, int *e)
 {
     const float fs = floorf(vc - rad / uf);
