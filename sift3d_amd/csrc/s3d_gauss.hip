@@ -227,6 +227,118 @@ k_conv_axis_dyadic_v4(const float *__restrict__ src, float *__restrict__ dst, si
     reinterpret_cast<float4 *>(dst)[i4] = acc;
 }
 
+/* k_conv_axis_dyadic along x.  Main workgroups (64 x 4 threads: one wave per 256-voxel row segment, four rows):
+ * four consecutive interior outputs per thread from a few aligned float4 loads of the row.  Edge workgroups:
+ * one thread per output of the float4 groups at the two row ends (the groups that hold mirrored taps or whose
+ * loads would leave the row), packed densely.  Keeping the edge outputs inside the row waves -- as the
+ * one-output kernel does -- puts ~1400 instructions of mirror arithmetic for 3 active lanes on EVERY wave's path,
+ * because every wave owns a row end: the x pass of octave 1 ran at 1 TB/s, 4x slower than its y and z passes.
+ * Same taps, same order, same expression per element: bit-identical. */
+template <int HW, int O>
+__global__ void __launch_bounds__(256)
+k_conv_x_dyadic_v4(const float *__restrict__ src, float *__restrict__ dst, size_t row_begin, unsigned nrows, int n,
+                   int edge_lo, int hi0, unsigned main_x, S3dTaps taps)
+{
+    constexpr int D = 1 << O;
+    constexpr int UHW = (HW + D - 1) / D;
+    constexpr float UF = 1.0f / (float)D;
+    constexpr int LPAD = (UHW + 3) & ~3;                    /* floats loaded before the first output */
+    constexpr int NV = (LPAD + 4 + UHW + 1 + 3) / 4;        /* float4 loads */
+    if (blockIdx.x < main_x) {
+        const unsigned row = blockIdx.x * 4u + threadIdx.y;
+        const int p0 = 4 * (int)(blockIdx.y * 64u + threadIdx.x);
+        if (row >= nrows || p0 < edge_lo || p0 >= hi0) return;
+        const float *s = src + (row_begin + row) * (size_t)n;
+        float v[4 * NV];
+#pragma unroll
+        for (int m = 0; m < NV; m++) {
+            const float4 q = *reinterpret_cast<const float4 *>(s + p0 - LPAD + 4 * m);
+            v[4 * m] = q.x; v[4 * m + 1] = q.y; v[4 * m + 2] = q.z; v[4 * m + 3] = q.w;
+        }
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2 * HW + 1; k++) {
+                constexpr int BIAS = 64 * D;
+                const int num = HW - k;                            /* -d */
+                const int off = (num + BIAS) / D - 64;             /* floor(num / D) */
+                const float fr = (float)(num - off * D) * UF;
+                acc = acc + taps.t[k] * ((1.0f - fr) * v[LPAD + e + off] + fr * v[LPAD + e + off + 1]);
+            }
+            out[e] = acc;
+        }
+        *reinterpret_cast<float4 *>(dst + (row_begin + row) * (size_t)n + p0) = make_float4(out[0], out[1], out[2], out[3]);
+        return;
+    }
+    if (blockIdx.y != 0) return;
+    const unsigned nedge = (unsigned)(edge_lo + (n - hi0));
+    const unsigned gid = (blockIdx.x - main_x) * 256u + threadIdx.y * 64u + threadIdx.x;
+    const unsigned row = gid / nedge;
+    if (row >= nrows) return;
+    const int j = (int)(gid - row * nedge);
+    const int p = j < edge_lo ? j : hi0 + (j - edge_lo);
+    const float *s = src + (row_begin + row) * (size_t)n;
+    float acc = 0.0f;
+    if (p >= UHW && p <= n - 2 - UHW) {
+#pragma unroll
+        for (int k = 0; k < 2 * HW + 1; k++) {
+            constexpr int BIAS = 64 * D;
+            const int num = HW - k;
+            const int off = (num + BIAS) / D - 64;
+            const float fr = (float)(num - off * D) * UF;
+            acc = acc + taps.t[k] * ((1.0f - fr) * s[p + off] + fr * s[p + off + 1]);
+        }
+    } else {
+        const int dim_end = n - 1;
+        float a[2 * HW + 1], b[2 * HW + 1], fr[2 * HW + 1];
+#pragma unroll
+        for (int d = -HW; d <= HW; d++) {
+            const float step = (float)d * UF;
+            float coord = (float)p - step;
+            if ((int)coord < 0)
+                coord = -coord;
+            else if ((int)coord >= dim_end)
+                coord = 2.0f * (float)dim_end - coord - 0.1f;
+            const int lo = (int)coord;
+            fr[d + HW] = coord - (float)lo;
+            a[d + HW] = s[lo];
+            b[d + HW] = s[lo + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * HW + 1; k++) acc = acc + taps.t[k] * ((1.0f - fr[k]) * a[k] + fr[k] * b[k]);
+    }
+    dst[(row_begin + row) * (size_t)n + p] = acc;
+}
+
+template <int O>
+static bool launch_x_dyadic_v4(int hw, const float *src, float *dst, size_t row_begin, size_t nrows, int n, const S3dTaps &t,
+                               hipStream_t st)
+{
+    if (hw < 1 || hw > 9) return false;
+    constexpr int D = 1 << O;
+    const int uhw = (hw + D - 1) / D, lpad = (uhw + 3) & ~3, nv = (lpad + 4 + uhw + 1 + 3) / 4;
+    /* float4 groups [edge_lo, hi0) take the register path; the rest of each row goes to the edge workgroups */
+    int edge_lo = n, hi0 = n;
+    for (int p0 = 0; p0 + 3 < n; p0 += 4)
+        if (p0 >= lpad && p0 - lpad + 4 * nv <= n && p0 + 3 <= n - 2 - uhw) {
+            if (edge_lo == n) edge_lo = p0;
+            hi0 = p0 + 4;
+        }
+    if (edge_lo == n) hi0 = n;                              /* no register-path group: every output is an edge output */
+    const size_t nedge = (size_t)edge_lo + (size_t)(n - hi0);
+    if (nrows * nedge >= 0xffffffffull) return false;
+    const unsigned main_x = s3d_div_up(nrows, 4), edge_x = s3d_div_up(nrows * nedge, 256);
+    const dim3 grid(main_x + edge_x, s3d_div_up((size_t)n / 4, 64)), block(64, 4);
+    switch (hw) {
+#define S3D_DY(H) case H: hipLaunchKernelGGL((k_conv_x_dyadic_v4<H, O>), grid, block, 0, st, src, dst, row_begin, (unsigned)nrows, n, edge_lo, hi0, main_x, t); return true;
+    S3D_DY(1) S3D_DY(2) S3D_DY(3) S3D_DY(4) S3D_DY(5) S3D_DY(6) S3D_DY(7) S3D_DY(8) S3D_DY(9)
+#undef S3D_DY
+    default: return false;
+    }
+}
+
 template <int O>
 static bool launch_dyadic_v4(int hw, const float *src, float *dst, size_t ib4, size_t ie4, size_t sa4, int n,
                              const S3dTaps &t, hipStream_t st)
@@ -286,6 +398,18 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
         if (uf == 0.5f) done = launch_dyadic_v4<1>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
         else if (uf == 0.25f) done = launch_dyadic_v4<2>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
         else if (uf == 0.125f) done = launch_dyadic_v4<3>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
+        if (done) {
+            S3D_CHECK_LAUNCH();
+            return S3D_OK;
+        }
+    }
+    if (nc == 1 && !g_no_dyadic && axis == 0 && (nx & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15) &&
+        (size_t)ny * (size_t)(z1 - z0) < 0xffffffffull) {
+        bool done = false;
+        const size_t row_begin = (size_t)ny * (size_t)z0, nrows = (size_t)ny * (size_t)(z1 - z0);
+        if (uf == 0.5f) done = launch_x_dyadic_v4<1>(hw, d_src, d_dst, row_begin, nrows, nx, t, (hipStream_t)st);
+        else if (uf == 0.25f) done = launch_x_dyadic_v4<2>(hw, d_src, d_dst, row_begin, nrows, nx, t, (hipStream_t)st);
+        else if (uf == 0.125f) done = launch_x_dyadic_v4<3>(hw, d_src, d_dst, row_begin, nrows, nx, t, (hipStream_t)st);
         if (done) {
             S3D_CHECK_LAUNCH();
             return S3D_OK;
