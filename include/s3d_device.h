@@ -92,6 +92,9 @@ int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, i
 /* ---- DoG + extrema  (build_dog sift3d/sift.c:1052-1071, detect_extrema sift.c:1074-1212) -------- */
 /* *d_max = max |a - b|  : per-level `dogmax` (sift.c:1161-1166) without materialising the DoG. */
 int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float *d_max, s3d_stream stream);
+/* d_max3[k] = max |d_levels4[k] - d_levels4[k+1]|, k = 0..2, in one pass (16-byte aligned levels; the host array
+ * of four device pointers is read at call time). */
+int s3d_k_dogmax3(const float *const *d_levels4, size_t n, float *d_max3, s3d_stream stream);
 /* Extrema of DoG(s) = L1 - L2 against DoG(s-1) = L0 - L1 and DoG(s+1) = L2 - L3 for one level:
  * bit i of d_bits (64-bit words, little-endian bit order) is set iff linear voxel i is a candidate
  * (strict 6-neighbour + prev/next centre test, |v| > (float)(peak_thresh * *d_dogmax)).

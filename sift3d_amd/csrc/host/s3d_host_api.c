@@ -498,9 +498,11 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
             int fused = 1;                               /* all keypoint levels in one pass over the GSS levels */
             if (nkp <= S3D_FUSED_KP_MAX) {
                 unsigned long long *bits[S3D_FUSED_KP_MAX];
-                for (int ks = 1; ks <= nkp; ks++) {
-                    bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
-                    DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + ks, c->stream));
+                for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
+                if (nkp == 3) {
+                    DEV(s3d_k_dogmax3((const float *const *)(lp + 1), n, c->d_red + 1, c->stream));
+                } else {
+                    for (int ks = 1; ks <= nkp; ks++) DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + ks, c->stream));
                 }
                 fused = s3d_k_extrema_fused((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz,
                                             sift3d->peak_thresh, c->d_red + 1, bits, c->stream);

@@ -73,6 +73,53 @@ extern "C" int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float 
     return launch_absmax(d_a, d_b, n, d_max, (hipStream_t)st);
 }
 
+/* The three dogmax values of an octave with num_kp_levels = 3 in ONE pass over the four GSS levels involved
+ * (six level reads as three k_absmax<1> launches): out[k] = max |l[k] - l[k+1]|, k = 0..2. */
+struct DogMax3Args { const float *l[4]; };
+__global__ void __launch_bounds__(RED_BLOCK) k_dogmax3(DogMax3Args a, size_t n, unsigned *out)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * RED_BLOCK;
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    auto upd = [](float m, float x, float y) { const float d = fabsf(x - y); return m > d ? m : d; };
+    for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n4; i += stride) {
+        const float4 p = reinterpret_cast<const float4 *>(a.l[0])[i], q = reinterpret_cast<const float4 *>(a.l[1])[i];
+        const float4 r = reinterpret_cast<const float4 *>(a.l[2])[i], t = reinterpret_cast<const float4 *>(a.l[3])[i];
+        m0 = upd(m0, p.x, q.x); m0 = upd(m0, p.y, q.y); m0 = upd(m0, p.z, q.z); m0 = upd(m0, p.w, q.w);
+        m1 = upd(m1, q.x, r.x); m1 = upd(m1, q.y, r.y); m1 = upd(m1, q.z, r.z); m1 = upd(m1, q.w, r.w);
+        m2 = upd(m2, r.x, t.x); m2 = upd(m2, r.y, t.y); m2 = upd(m2, r.z, t.z); m2 = upd(m2, r.w, t.w);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n; i += stride) {
+        m0 = upd(m0, a.l[0][i], a.l[1][i]); m1 = upd(m1, a.l[1][i], a.l[2][i]); m2 = upd(m2, a.l[2][i], a.l[3][i]);
+    }
+    m0 = block_max(m0);
+    __syncthreads();
+    m1 = block_max(m1);
+    __syncthreads();
+    m2 = block_max(m2);
+    if (threadIdx.x == 0) {
+        atomicMax(out, __float_as_uint(m0));
+        atomicMax(out + 1, __float_as_uint(m1));
+        atomicMax(out + 2, __float_as_uint(m2));
+    }
+}
+
+extern "C" int s3d_k_dogmax3(const float *const *d_levels4, size_t n, float *d_max3, s3d_stream st)
+{
+    S3D_HIP(hipMemsetAsync(d_max3, 0, 3 * sizeof(float), (hipStream_t)st));
+    if (n == 0) return S3D_OK;
+    DogMax3Args a;
+    for (int k = 0; k < 4; k++) {
+        a.l[k] = d_levels4[k];
+        if ((uintptr_t)a.l[k] & 15) S3D_FAIL("s3d_k_dogmax3: levels must be 16-byte aligned");
+    }
+    unsigned blocks = s3d_div_up(n / 4 + 1, RED_BLOCK);
+    if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
+    hipLaunchKernelGGL(k_dogmax3, dim3(blocks), dim3(RED_BLOCK), 0, (hipStream_t)st, a, n, (unsigned *)d_max3);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
 /* v /= max (IEEE division, like the reference -- not a multiply by the reciprocal) */
 __global__ void __launch_bounds__(256) k_scale_div(float *v, size_t n, const float *d_max)
 {

@@ -248,6 +248,7 @@ class SlabSift3D:
         L.s3d_mesh_table.argtypes = [_f32p]
         L.s3d_k_absmax.argtypes = [_vp, C.c_size_t, _vp, _vp]
         L.s3d_k_dogmax.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp]
+        L.s3d_k_dogmax3.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, _vp, _vp]
         L.s3d_k_scale_div.argtypes = [_vp, C.c_size_t, _vp, _vp]
         L.s3d_k_decimate2.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]
         L.s3d_k_sep_fir.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, _vp]
@@ -380,18 +381,21 @@ class SlabSift3D:
                     continue
                 nwords = ((zb - za) * pe + 63) // 64
                 fused = self.nkp == 3 and nxo % 4 == 0          # all keypoint levels in one pass (s3d_k_extrema_fused)
+                if fused:           # the three dogmax values in one pass over GSS levels 1..4 (s3d_k_dogmax3)
+                    l4 = (C.c_void_p * 4)(*[(lev[o][k].ptr(za) if shard_o else lev[o][k].view) for k in range(1, 5)])
+                    self._ck(L.s3d_k_dogmax3(l4, ((zb - za) if shard_o else nzo) * pe, self.red[1:].data_ptr(), None),
+                             "dogmax3")
                 for ks in range(1, self.nkp + 1):
-                    red = self.red[ks:] if fused else self.red[1:]
+                    if fused:
+                        break
+                    red = self.red[1:]
                     if shard_o:     # max |DoG| over my planes, then over the ranks (sift.c:1161-1169)
                         self._ck(L.s3d_k_dogmax(lev[o][ks].ptr(za), lev[o][ks + 1].ptr(za), (zb - za) * pe,
                                                 red.data_ptr(), None), "dogmax")
-                        if not fused:
-                            comm.allreduce_max_(self.red[1:2])
+                        comm.allreduce_max_(self.red[1:2])
                     else:           # replicated octave: every rank sees the whole level
                         self._ck(L.s3d_k_dogmax(lev[o][ks].view, lev[o][ks + 1].view, nzo * pe, red.data_ptr(), None),
                                  "dogmax")
-                    if fused:
-                        continue
                     self._ck(L.s3d_k_extrema_slab(lev[o][ks - 1].view, lev[o][ks].view, lev[o][ks + 1].view,
                                                   lev[o][ks + 2].view, nxo, nyo, nzo, za, zb, float(self.s.peak_thresh),
                                                   self.red[1:].data_ptr(), self.bits.data_ptr(), None), "extrema")
