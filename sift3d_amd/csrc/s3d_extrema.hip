@@ -97,29 +97,41 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
      * Survivors (~1 %) are remembered as bits s*4+j of pmax / pmin. */
     unsigned pmax = 0u, pmin = 0u;
     bool row_ok = false;
+    float d[NKP + 2][4];                                   /* DoG centres, level k: L(k) - L(k+1) */
+#pragma unroll
+    for (int k = 0; k < NKP + 2; k++) d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.0f;
     if (idx < n) {                                         /* n - idx0 is a multiple of 4 (nx % 4 == 0) */
-        const unsigned z = idx / plane;
-        const unsigned rem = idx - z * plane;
-        const unsigned y = rem / nx;
-        const unsigned x = rem - y * nx;
-        row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
         float4 c[NKP + 3];
 #pragma unroll
         for (int k = 0; k < NKP + 3; k++) c[k] = *reinterpret_cast<const float4 *>(a.l[k] + idx);
-        float d[NKP + 2][4];                               /* DoG centres, level k: L(k) - L(k+1) */
 #pragma unroll
         for (int k = 0; k < NKP + 2; k++) {
             d[k][0] = c[k].x - c[k + 1].x; d[k][1] = c[k].y - c[k + 1].y;
             d[k][2] = c[k].z - c[k + 1].z; d[k][3] = c[k].w - c[k + 1].w;
         }
+    }
+    /* x neighbours of the thread's end voxels: the neighbouring lanes hold them as the last / first DoG value of
+     * their float4s; only the two end lanes of a wave load them (12 dword loads per thread used to be a third
+     * of the kernel's memory instructions).  All lanes take part in the exchange. */
+    float from_lo[NKP], from_hi[NKP];
+#pragma unroll
+    for (int s = 0; s < NKP; s++) {
+        from_lo[s] = __shfl_up(d[s + 1][3], 1);
+        from_hi[s] = __shfl_down(d[s + 1][0], 1);
+    }
+    if (idx < n) {
+        const unsigned z = idx / plane;
+        const unsigned rem = idx - z * plane;
+        const unsigned y = rem / nx;
+        const unsigned x = rem - y * nx;
+        row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
 #pragma unroll
         for (int s = 0; s < NKP; s++) {
             const float thr = (float)(peak * (double)d_dogmax[s]);        /* sift.c:1169 */
-            /* x neighbours of the thread's end voxels: one scalar pair each (same cache lines as the
-             * neighbouring threads' float4s); idx-1 / idx+4 stay inside the level for every tested voxel */
             const float *l1 = a.l[s + 1], *l2 = a.l[s + 2];
-            const float left = (row_ok && x >= 1) ? l1[idx - 1] - l2[idx - 1] : 0.0f;
-            const float right = (row_ok && x + 5 <= nx) ? l1[idx + 4] - l2[idx + 4] : 0.0f;
+            float left = 0.0f, right = 0.0f;              /* idx-1 / idx+4 stay inside the level for every tested voxel */
+            if (row_ok && x >= 1) left = lane > 0 ? from_lo[s] : l1[idx - 1] - l2[idx - 1];
+            if (row_ok && x + 5 <= nx) right = lane < 63 ? from_hi[s] : l1[idx + 4] - l2[idx + 4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const unsigned xj = x + (unsigned)j;

@@ -220,6 +220,12 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
     (void)width;
     return __shfl(v, src < 64 ? src : lane);
 }
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    const int lane = (int)(emu::S().cur->tid & 63);
+    const int src = lane - (int)d;
+    (void)width;
+    return __shfl(v, src >= 0 ? src : lane);
+}
 template <class T> static inline T __shfl_xor(T v, int m, int width = 64) {
     const int lane = (int)(emu::S().cur->tid & 63);
     (void)width;
