@@ -231,6 +231,7 @@ template <class T> static inline T __shfl_xor(T v, int m, int width = 64) {
     (void)width;
     return __shfl(v, lane ^ m);
 }
+static inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
 static inline unsigned long long __ballot(int pred) {
     uint64_t m = 0;
     emu::wave_exchange(pred ? 1 : 0, 0, true, &m);
@@ -243,6 +244,7 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }

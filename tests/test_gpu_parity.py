@@ -32,6 +32,9 @@ def lib(hip):
     ((37, 41, 29), (0.5, 1.3, 4), 1, 1.94659, 1.0),
     ((29, 33, 27), (1, 1, 2), 12, 2.8284, 1.0),        # 12-channel (dense blur shape)
     ((29, 33, 27), (1, 1, 2), 3, 1.22627, -1.0),       # unit = -1
+    ((24, 20, 70), (1, 1, 1.5), 1, 2.45255, 1.0),      # LDS-ring z pass (generic spacing), two z chunks, ragged columns
+    ((20, 24, 40), (1, 1, 0.7), 1, 1.54501, 1.0),      # the same with taps 1.43 planes apart (32-row ring)
+    ((256, 128, 200), (1, 1, 1.5), 1, 2.45255, 1.0),   # ... at a size with many waves per plane and four z chunks
 ])
 def test_sep_fir_api(lib, oracle, dims, units, nc, sigma, unit):
     parity.check_sep_fir_api(lib, oracle, dims, units, nc, sigma, unit)
