@@ -151,6 +151,8 @@ int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint3
 #define S3D_ORIENT_CHUNK (1u << 20)
 #define S3D_ORIENT_SCRATCH_BYTES 128u
 size_t s3d_k_orient_scratch_bytes(uint32_t num);
+/* Test knob: candidates per chunk (0 or > S3D_ORIENT_CHUNK restores the default; the scratch size is unaffected). */
+void s3d_k_set_orient_chunk(uint32_t n);
 /* Stable compaction of kept candidates: for i with keep[i], writes x,y,z,o,s (int32 x5) and R.
  * *d_num_out receives the number kept.  d_scratch: >= num/256 + 2 uint32. */
 int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,

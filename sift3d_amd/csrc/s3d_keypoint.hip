@@ -416,12 +416,12 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
 }
 
 __global__ void __launch_bounds__(64)
-k_orient_decide(uint32_t cand0, uint32_t num, double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R,
+k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R,
                 uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, int variant)
 {
     const unsigned local = blockIdx.x * 64u + threadIdx.x;
     const unsigned cand = cand0 + local;
-    if (cand >= num || local >= S3D_ORIENT_CHUNK) return;
+    if (cand >= num || local >= nchunk) return;
     double *scr = d_scr + (size_t)local * ORI_SCR;
     const double a00 = scr[0], a01 = scr[1], a02 = scr[2], a11 = scr[3], a12 = scr[4], a22 = scr[5];
     const double gdx = scr[6], gdy = scr[7], gdz = scr[8], sax = scr[9], say = scr[10], saz = scr[11];
@@ -496,6 +496,13 @@ k_orient_decide(uint32_t cand0, uint32_t num, double corner_thresh, double *__re
     if (d_conf) d_conf[cand] = keep || conf > 0.0 ? conf : 0.0;
 }
 
+/* candidates per chunk of s3d_k_orient (test knob: the suite shrinks it to exercise the chunk loop on small inputs) */
+static uint32_t g_orient_chunk = S3D_ORIENT_CHUNK;
+extern "C" void s3d_k_set_orient_chunk(uint32_t n)
+{
+    g_orient_chunk = n == 0 || n > S3D_ORIENT_CHUNK ? S3D_ORIENT_CHUNK : (n < 64u ? 64u : n);
+}
+
 extern "C" size_t s3d_k_orient_scratch_bytes(uint32_t num)
 {
     return (size_t)(num < S3D_ORIENT_CHUNK ? num : S3D_ORIENT_CHUNK) * S3D_ORIENT_SCRATCH_BYTES;
@@ -508,12 +515,13 @@ extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, 
     if (num == 0) return S3D_OK;
     if (!d_scratch) return S3D_ERR;
     double *scr = (double *)d_scratch;
-    for (uint32_t c0 = 0; c0 < num; c0 += S3D_ORIENT_CHUNK) {
-        const uint32_t n = num - c0 < S3D_ORIENT_CHUNK ? num - c0 : S3D_ORIENT_CHUNK;
+    const uint32_t chunk = g_orient_chunk;
+    for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
+        const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
         hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
                            d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, g_variant);
         S3D_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, num, corner_thresh, scr,
+        hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
                            d_R, d_keep, d_conf, g_variant);
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,

@@ -64,6 +64,19 @@ def test_dense_rotate(emu, oracle):
     parity.check_dense_rotate(emu, oracle, (16, 14, 12), (1, 1, 2))
 
 
+def test_orientation_chunk_loop(emu, oracle):
+    """s3d_k_orient works through its candidates in chunks of 2^20 (one candidate per voxel in the dense_rotate path
+    can exceed that): with the chunk shrunk to 512 and 64 candidates the same results must come out."""
+    emu.sift.s3d_k_set_orient_chunk.argtypes = [C.c_uint32]
+    for chunk in (512, 64):
+        emu.sift.s3d_k_set_orient_chunk(chunk)
+        try:
+            parity.check_dense_rotate(emu, oracle, (16, 14, 12), (1, 1, 2))
+            parity.check_detect_describe(emu, oracle, (40, 36, 32), (1, 1, 1), 120, 4, check_pyramid=False)
+        finally:
+            emu.sift.s3d_k_set_orient_chunk(0)
+
+
 def test_raw_variants(emu, oracle):
     parity.check_raw_variants(emu, oracle, (32, 32, 32), (1, 1, 1), 40)
 
