@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(RED_BLOCK) k_dogmax3(DogMax3Args a, size_t n, 
     const size_t stride = (size_t)gridDim.x * RED_BLOCK;
     float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
     auto upd = [](float m, float x, float y) { const float d = fabsf(x - y); return m > d ? m : d; };
+#pragma unroll 2
     for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n4; i += stride) {
         const float4 p = reinterpret_cast<const float4 *>(a.l[0])[i], q = reinterpret_cast<const float4 *>(a.l[1])[i];
         const float4 r = reinterpret_cast<const float4 *>(a.l[2])[i], t = reinterpret_cast<const float4 *>(a.l[3])[i];
