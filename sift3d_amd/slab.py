@@ -72,10 +72,13 @@ class Comm:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
 
-    def exchange(self, send_lo, send_hi, recv_lo, recv_hi) -> None:
-        """send_lo -> rank-1 (lands in its recv_hi), send_hi -> rank+1 (its recv_lo).  Views of 1-D tensors."""
+    def exchange_async(self, send_lo, send_hi, recv_lo, recv_hi):
+        """send_lo -> rank-1 (lands in its recv_hi), send_hi -> rank+1 (its recv_lo).  Views of 1-D tensors.
+        Posts the transfers and returns a handle for finish(): the receive buffers must not be read (and the send
+        buffers not be overwritten) before that.  With RCCL the transfers run on the communicator's stream next to
+        whatever is launched afterwards."""
         if self.world == 1:
-            return
+            return None
         d, r, w = self.dist, self.rank, self.world
         ops, stage_back = [], []
 
@@ -100,11 +103,20 @@ class Comm:
             rcv(recv_lo, r - 1)
         if r < w - 1 and recv_hi is not None:
             rcv(recv_hi, r + 1)
-        if ops:
-            for q in d.batch_isend_irecv(ops):
-                q.wait()
+        works = d.batch_isend_irecv(ops) if ops else []
+        return works, stage_back, ops          # ops: keeps the (possibly staged) send tensors alive until finish()
+
+    def finish(self, handle) -> None:
+        if handle is None:
+            return
+        works, stage_back, _ = handle
+        for q in works:
+            q.wait()
         for t, h in stage_back:
             t.copy_(h)
+
+    def exchange(self, send_lo, send_hi, recv_lo, recv_hi) -> None:
+        self.finish(self.exchange_async(send_lo, send_hi, recv_lo, recv_hi))
 
     def allgather_cat(self, t: torch.Tensor) -> torch.Tensor:
         """Concatenate equally sized 1-D tensors of all ranks in rank order."""
@@ -215,6 +227,7 @@ class SlabSift3D:
         self.bits = torch.zeros(3 * self.bits_words, dtype=torch.int64, device=self.dev)   # one bitmap per keypoint level
         self.scratch = torch.zeros(nmax // 64 // 256 + 4096, dtype=torch.int32, device=self.dev)
         self.orient_scr = None
+        self._pending = []                       # deferred halo transfers of the current detect()
         self.red = torch.zeros(8, dtype=torch.float32, device=self.dev)
         self.count = torch.zeros(8, dtype=torch.int32, device=self.dev)
         self.cap = 0
@@ -278,12 +291,24 @@ class SlabSift3D:
     def _reach(self, taps, o):                    # planes of z halo one application needs
         return int(math.ceil(np.float32(len(taps) // 2) * self._uf(o)[2]))
 
-    def _exchange(self, lv: _Level, o: int, h: int):
-        """Fill h halo planes on each interior side of a sharded level from the Z-neighbours."""
+    def _exchange(self, lv: _Level, o: int, h: int, now: int | None = None):
+        """Fill h halo planes on each interior side of a sharded level from the Z-neighbours.  now < h: only the
+        `now` planes next to the slab are waited for (what the next Gaussian and the extrema read); the outer
+        h - now planes -- the orientation / descriptor windows, read only in _keypoints() -- travel while the rest of
+        the pyramid is computed and are collected by _finish_halos()."""
         if self.comm.world == 1 or h <= 0:
             return
         z0, z1 = self.part[o]
-        self.comm.exchange(lv.planes(z0, z0 + h), lv.planes(z1 - h, z1), lv.planes(z0 - h, z0), lv.planes(z1, z1 + h))
+        n = h if now is None or now >= h else max(now, 1)
+        self.comm.exchange(lv.planes(z0, z0 + n), lv.planes(z1 - n, z1), lv.planes(z0 - n, z0), lv.planes(z1, z1 + n))
+        if n < h:
+            self._pending.append(self.comm.exchange_async(lv.planes(z0 + n, z0 + h), lv.planes(z1 - h, z1 - n),
+                                                          lv.planes(z0 - h, z0 - n), lv.planes(z1 + n, z1 + h)))
+
+    def _finish_halos(self):
+        for hnd in self._pending:
+            self.comm.finish(hnd)
+        self._pending = []
 
     def _gauss(self, src: _Level, dst: _Level, o: int, taps):
         nxo, nyo, nzo = self.dims[o]
@@ -322,8 +347,9 @@ class SlabSift3D:
         for o in range(self.no):
             shard_o = sharded and o <= self.o_shard
             for k in range(1, self.nl):
-                if shard_o:
-                    self._exchange(lev[o][k - 1], o, self._halo_of_level(o, k - 1))
+                if shard_o:     # the next Gaussian reads `reach` planes, the extrema one; the rest may arrive later
+                    self._exchange(lev[o][k - 1], o, self._halo_of_level(o, k - 1),
+                                   now=max(1, self._reach(self.taps[k - 1], o)))
                 self._gauss(lev[o][k - 1], lev[o][k], o, self.taps[k - 1])
             if shard_o:
                 self._exchange(lev[o][self.nl - 1], o, self._halo_of_level(o, self.nl - 1))
@@ -345,6 +371,7 @@ class SlabSift3D:
                     lev[o + 1][0].t[:full.numel()].copy_(full)
                 else:
                     self._ck(L.s3d_k_decimate2(lev[o][ds].view, nxo, nyo, nzo, lev[o + 1][0].view, None), "decimate2")
+        self._finish_halos()
         return self._keypoints()
 
     def _halo_of_level(self, o: int, k: int) -> int:
