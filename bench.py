@@ -356,6 +356,32 @@ def main():
                                      "method": "f32 screening of all pairs (forward and backward pass) + exact f64 verification "
                                                "of the candidates; indices bit-identical to the exhaustive f64 search"}
     if rank == 0 and not args.no_match:
+        # SURVEY 8(d) "API-to-API", outside the timed region: the same volume through the reference's own entry points
+        # with HOST buffers (pageable Image in, host Keypoint_store / SIFT3D_Descriptor_store out): what a relinked
+        # caller sees, PCIe transfers included.  Never `value`.
+        him = lib.image_from_numpy(vol)
+        hs = abi.SIFT3D()
+        assert lib.sift.init_SIFT3D(C.byref(hs)) == 0
+        hkp = abi.Keypoint_store()
+        lib.sift.init_Keypoint_store(C.byref(hkp))
+        hd = abi.SIFT3D_Descriptor_store()
+        lib.sift.init_SIFT3D_Descriptor_store(C.byref(hd))
+        th = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            assert lib.sift.SIFT3D_detect_keypoints(C.byref(hs), C.byref(him), C.byref(hkp)) == 0
+            t1 = time.perf_counter()
+            assert lib.sift.SIFT3D_extract_descriptors(C.byref(hs), C.byref(hkp), C.byref(hd)) == 0
+            th.append((t1 - t0, time.perf_counter() - t1))
+        hb = min(th[1:], key=lambda t: t[0] + t[1])
+        result["config"]["host_api"] = {"detect_ms": round(hb[0] * 1e3, 1), "describe_ms": round(hb[1] * 1e3, 1),
+                                        "Mvox_s": round(n ** 3 / (hb[0] + hb[1]) / 1e6, 1), "keypoints": int(hkp.slab.num),
+                                        "note": "host Image in, host stores out (512 MiB up, 97 MB down over PCIe)"}
+        lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(hd))
+        lib.sift.cleanup_Keypoint_store(C.byref(hkp))
+        lib.free_image(him)
+        lib.sift.cleanup_SIFT3D(C.byref(hs))
+    if rank == 0 and not args.no_match:
         # BASELINE configs[2], outside the timed region: SIFT3D_extract_dense_descriptors on a 256^3 volume,
         # device to device (12-channel output, 805 MB)
         nd = 256
