@@ -211,7 +211,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
     const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
 
-        /* window weight of a squared distance, bit for bit the reference's expf(-0.5 * sq / (sigma * sigma)) */
+    /* window weight of a squared distance, bit for bit the reference's expf(-0.5 * sq / (sigma * sigma)) */
     auto weight = [&](float sq) -> float {
         /* (float)(-0.5 * sq / sigma^2), the quotient in double as the reference forms it (sift.c:1401).  The
          * product with the reciprocal is within 1 ulp of that quotient, so its rounding to float is the
