@@ -71,7 +71,8 @@ int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny
                   const float uf[3], const float *taps, int width, s3d_stream stream);
 /* Z-slab form: the pointers are VIEWS addressed by global z -- element (x,y,z)
  * at view[(z*ny + y)*nx + x] -- of which only the caller's planes plus halos are backed by memory.
- * Produces dst planes [z0, z1) from src planes [z0-h, z1+h) clamped to [0, nz), h = ceil(hw*uf[2]):
+ * Produces dst planes [z0, z1) from src planes [z0-h, z1+h) clamped to [0, nz), h = ceil(hw*uf[2]) + 1 (the
+ * extra plane: the reference's drifting tap coordinate, see s3d_gauss.hip; fused unit-spacing path: hw):
  * the halo planes come from the Z-neighbours; the global ends use the reference's mirror rule.
  * dst / tmp planes in that range are scratch.  nc == 1. */
 int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0,

@@ -1231,7 +1231,10 @@ extern "C" int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp
     if (nx < 1 || ny < 1 || nz < 1 || z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad dimensions");
     const int hw = width / 2;
     if (fast_eligible(nx, ny, nz, 1, uf, width)) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, hw, t, st);
-    const int h = (int)ceilf((float)hw * uf[2]);
+    /* planes of z halo the z pass reads: ceil(hw * uf) by the tap positions, plus one -- the reference's running
+     * coordinate (coord -= step; ...; coord += step) drifts by an ulp, and where hw * uf is integral the last tap
+     * then lands just below an integer and interpolates with the plane beyond (weight ~1e-6: one ulp of the output) */
+    const int h = (int)ceilf((float)hw * uf[2]) + 1;
     const int za = z0 - h > 0 ? z0 - h : 0, zb = z1 + h < nz ? z1 + h : nz;
     if (fast_xy_eligible(nx, ny, nz, 1, uf, width) && !g_no_dyadic) {
         if (fast_xy_dispatch(d_src, d_tmp, nx, ny, za, zb, hw, t, st)) return S3D_ERR;

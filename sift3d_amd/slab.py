@@ -288,8 +288,11 @@ class SlabSift3D:
         u = self.lunits[o]
         return np.array([np.float32(1.0 / u[0]), np.float32(1.0 / u[1]), np.float32(1.0 / u[2])], np.float32)
 
-    def _reach(self, taps, o):                    # planes of z halo one application needs
-        return int(math.ceil(np.float32(len(taps) // 2) * self._uf(o)[2]))
+    def _reach(self, taps, o):                    # planes of z halo one application needs (s3d_k_sep_fir_slab)
+        hw, uf = len(taps) // 2, self._uf(o)
+        if uf[0] == 1.0 and uf[1] == 1.0 and uf[2] == 1.0:
+            return hw                             # fused unit-spacing path: exact
+        return int(math.ceil(np.float32(hw) * uf[2])) + 1      # + 1: the reference's drifting tap coordinate
 
     def _exchange(self, lv: _Level, o: int, h: int, now: int | None = None):
         """Fill h halo planes on each interior side of a sharded level from the Z-neighbours.  now < h: only the

@@ -384,3 +384,33 @@ def check_expf(lib, n=1 << 22, seed=9):
     assert np.array_equal(got[idx].view(np.uint32), want.view(np.uint32)), \
         f"{(got[idx] != want).sum()} of {len(idx)} differ from the host expf"
     return len(idx), int((cr != got).sum())
+
+
+def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
+    """s3d_k_sep_fir_slab on plane ranges of a fully backed volume against the whole-volume result, with the scratch
+    poisoned (0xFF = NaN) so that any plane the range arithmetic forgets shows up.  Integral hw * uf is the case that
+    needs the extra halo plane (the reference's drifting tap coordinate)."""
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    vol = np.random.default_rng(0).standard_normal((nz, ny, nx)).astype(np.float32)
+    uf = np.array([np.float32(1.0 / u) for u in units], np.float32)
+    L.s3d_k_sep_fir_slab.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    d_src, d_a, d_b, d_t = dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes)
+    try:
+        for sigma in sigmas:
+            taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)
+            dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
+            full = dev.download(d_a, vol.shape)
+            assert nbitdiff(full, oracle.sep_fir(vol, taps, units, 1.0)) == 0
+            for z0, z1 in splits:
+                L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+                L.s3d_rt_memset(C.c_void_p(d_b), 0xFF, vol.nbytes, None)
+                assert L.s3d_k_sep_fir_slab(d_src, d_b, d_t, nx, ny, nz, z0, z1, uf.ctypes.data, taps.ctypes.data,
+                                            taps.size, None) == 0
+                got = dev.download(d_b, vol.shape)[z0:z1]
+                nd = nbitdiff(got, full[z0:z1])
+                assert nd == 0, f"slab [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
+    finally:
+        for p in (d_src, d_a, d_b, d_t):
+            dev.free(p)

@@ -132,3 +132,13 @@ def test_window_weight_expf_matches_host_libm(emu):
     """s3d_expf restates glibc's expf; the descriptor is discontinuous in the window weight (s3d_math.h)."""
     nchecked, ndiff_cr = parity.check_expf(emu, n=1 << 18)
     assert nchecked >= 10000
+
+
+@pytest.mark.parametrize("dims,units", [((32, 32, 64), (1, 1, 1.5)), ((32, 28, 48), (1, 1, 1)), ((24, 24, 40), (2, 2, 2)),
+                                        ((21, 19, 40), (1, 0.7, 1.3))])
+def test_sep_fir_slab_ranges(emu, oracle, dims, units):
+    """Plane ranges of s3d_k_sep_fir_slab (the Z-slab form) equal the whole-volume pass bit for bit; widths 7 and 13
+    at uz = 1.5 have hw * uf integral (the extra halo plane)."""
+    nz = dims[2]
+    parity.check_sep_fir_slab(emu, oracle, dims, units, (0.973294, 1.22627, 1.94659),
+                              ((nz // 2, nz), (0, nz // 2), (nz // 4, nz // 4 + 9)))

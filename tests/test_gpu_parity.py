@@ -421,3 +421,13 @@ def test_dense_config_vs_reference_golden(lib):
     for smp in g["samples"]:
         assert [int(b) for b in out[tuple(smp["zyx"])].view(np.uint32)] == smp["hist_bits"], smp["zyx"]
     assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == g["output_sha256"]
+
+
+@pytest.mark.parametrize("dims,units", [((32, 32, 64), (1, 1, 1.5)), ((32, 28, 48), (1, 1, 1)), ((24, 24, 40), (2, 2, 2)),
+                                        ((21, 19, 40), (1, 0.7, 1.3))])
+def test_sep_fir_slab_ranges(lib, oracle, dims, units):
+    """Plane ranges of s3d_k_sep_fir_slab (the Z-slab form) equal the whole-volume pass bit for bit; widths 7 and 13
+    at uz = 1.5 have hw * uf integral (the extra halo plane)."""
+    nz = dims[2]
+    parity.check_sep_fir_slab(lib, oracle, dims, units, (0.973294, 1.22627, 1.94659),
+                              ((nz // 2, nz), (0, nz // 2), (nz // 4, nz // 4 + 9)))

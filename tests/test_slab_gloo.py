@@ -60,7 +60,8 @@ def test_slab_world1_equals_c_api(emu, oracle):
 
 
 @pytest.mark.parametrize("dims,units,nblobs,seed", [((32, 32, 64), (1.0, 1.0, 1.0), 130, 1),
-                                                    ((36, 28, 64), (1.0, 0.9, 1.0), 130, 2)])
+                                                    ((36, 28, 64), (1.0, 0.9, 1.0), 130, 2),
+                                                    ((32, 32, 64), (1.0, 1.0, 1.5), 130, 3)])   # k_conv_z_ring on slabs
 def test_slab_world2_gloo(emu, tmp_path, dims, units, nblobs, seed):
     nx, ny, nz = dims
     out = str(tmp_path / "slab.npz")
