@@ -63,12 +63,26 @@ def test_slab_world1_equals_c_api(emu, oracle):
                                                     ((36, 28, 64), (1.0, 0.9, 1.0), 130, 2),
                                                     ((32, 32, 64), (1.0, 1.0, 1.5), 130, 3)])   # k_conv_z_ring on slabs
 def test_slab_world2_gloo(emu, tmp_path, dims, units, nblobs, seed):
+    _run_world(emu, tmp_path, dims, units, nblobs, seed, 2)
+
+
+def test_slab_world3_gloo(emu, tmp_path):
+    """Three ranks: the middle one exchanges halos with both neighbours (the N >= 3 pattern of the 8-GPU run)."""
+    _run_world(emu, tmp_path, (32, 32, 96), (1.0, 1.0, 1.0), 200, 6, 3)
+
+
+def test_slab_two_sharded_octaves_gloo(emu, tmp_path):
+    """Slabs thick enough for octave 1 to be sharded as well (slab-local decimation, halos at two octaves)."""
+    _run_world(emu, tmp_path, (24, 24, 128), (1.0, 1.0, 1.0), 260, 8, 2, o_shard=1)
+
+
+def _run_world(emu, tmp_path, dims, units, nblobs, seed, world, o_shard=0):
     nx, ny, nz = dims
     out = str(tmp_path / "slab.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE="2",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE=str(world),
                OMP_NUM_THREADS="2")
     procs = []
-    for r in range(2):
+    for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), out, str(nx),
                                        str(ny), str(nz), str(nblobs), str(seed), json.dumps(PARAMS),
@@ -76,7 +90,7 @@ def test_slab_world2_gloo(emu, tmp_path, dims, units, nblobs, seed):
     logs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     got = np.load(out)
-    assert int(got["o_shard"]) == 0 and int(got["bytes_exchanged"]) > 0     # octave 0 really was sharded
+    assert int(got["o_shard"]) == o_shard and int(got["bytes_exchanged"]) > 0   # the octaves really were sharded
     vol = synth.blobs(nx, ny, nz, nblobs, seed)
     want_x, want_R, want_b = single_process(emu, vol, units)
     assert len(want_x) > 5
