@@ -355,6 +355,25 @@ def main():
                                      "Gpairs_per_s": round(2.0 * K * K / t_match / 1e9, 1),
                                      "method": "f32 screening of all pairs (forward and backward pass) + exact f64 verification "
                                                "of the candidates; indices bit-identical to the exhaustive f64 search"}
+    if rank == 0 and K and not args.no_match:
+        # what the descriptor kernel (70 % of the step) works through, outside the timed region: the test aid of
+        # k_describe (variant bit 4) returns the number of accepted window voxels per keypoint instead of a descriptor
+        lib.sift.s3d_k_set_variant.argtypes = [C.c_int]
+        lib.sift.s3d_k_set_variant(16)
+        try:
+            lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
+            dev.sync()
+            rec = dev.download(d_desc.value, (K, 776))
+        finally:
+            lib.sift.s3d_k_set_variant(0)
+        wv = int(np.ascontiguousarray(rec[:, 0]).view(np.uint32).astype(np.int64).sum())
+        lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))    # restore the records
+        dev.sync()
+        result["config"]["describe_kernel"] = {
+            "window_voxels": wv, "lds_atomics_per_window_voxel": 24,
+            "Gvox_window_per_s": round(wv / t_describe / 1e9, 1),
+            "G_lds_atomic_lane_ops_per_s": round(24.0 * wv / t_describe / 1e9, 1),
+            "bound": "LDS atomic throughput (24 ds_add_u64 to data-dependent bins per window voxel), not HBM or MFMA"}
     if rank == 0 and not args.no_match:
         # SURVEY 8(d) "API-to-API", outside the timed region: the same volume through the reference's own entry points
         # with HOST buffers (pageable Image in, host Keypoint_store / SIFT3D_Descriptor_store out): what a relinked
