@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="volume edge (default 512 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-match", action="store_true", help="skip the (untimed) matcher measurement")
+    ap.add_argument("--no-match", action="store_true", help="skip the untimed extras after the timed steps (matcher, descriptor-kernel statistics, host-buffer API, dense 256^3, anisotropic and two-volume configurations)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one independent volume per rank instead of the Z-slab decomposition")
