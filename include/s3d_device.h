@@ -55,6 +55,8 @@ int s3d_k_absmax(const float *d_v, size_t n, float *d_max, s3d_stream stream);
 int s3d_k_scale_div(float *d_v, size_t n, const float *d_max, s3d_stream stream);
 /* dst(x,y,z) = src(2x,2y,2z), dst dims = floor(n/2)   (im_downsample_2x, imutil/imutil.c:1742-1768) */
 int s3d_k_decimate2(const float *d_src, int nx, int ny, int nz, float *d_dst, s3d_stream stream);
+/* the same for nc interleaved channels (im_downsample_2x on a multi-channel Image) */
+int s3d_k_decimate2_nc(const float *d_src, int nx, int ny, int nz, int nc, float *d_dst, s3d_stream stream);
 /* dst = a - b   (im_subtract, imutil/imutil.c:1997-2017) */
 int s3d_k_subtract(const float *d_a, const float *d_b, float *d_dst, size_t n, s3d_stream stream);
 

@@ -202,6 +202,12 @@ void cleanup_Sep_FIR_filter(Sep_FIR_filter *const f);                           
 /* The north-star "im_Gauss_filter": x, y, z passes on the GPU.  Host images in, host image out. */
 int apply_Sep_FIR_filter(const Image *const src, Image *const dst, Sep_FIR_filter *const f,
                          const double unit);                                             /* imutil.c:3459 */
+/* The element-wise steps of the pyramid build as the reference exports them: host images in and out, the work on
+ * the device (the kernels of rows a2, a7, a8).  im_max_abs returns NaN if the device call fails. */
+float im_max_abs(const Image *const im);                                 /* imutil.c:1959 */
+void im_scale(const Image *const im);                                    /* imutil.c:1977 */
+int im_subtract(Image *src1, Image *src2, Image *dst);                   /* imutil.c:1997 */
+int im_downsample_2x(const Image *const src, Image *const dst);          /* imutil.c:1742 */
 
 void init_GSS_filters(GSS_filters *const gss);                          /* imutil.c:3744 */
 int make_gss(GSS_filters *const gss, const Pyramid *const pyr);         /* imutil.c:3752 */
@@ -216,6 +222,8 @@ void cleanup_Pyramid(Pyramid *const pyr);                               /* imuti
 /* ======================= libsift3D subset (replaces sift3d/sift.h entries) ========================= */
 int init_SIFT3D(SIFT3D *sift3d);                                        /* sift.c:583 */
 void cleanup_SIFT3D(SIFT3D *const sift3d);                              /* sift.c:659 */
+/* Deep copy: parameters, image and pyramids (device to device into a context of dst's own). */
+int copy_SIFT3D(const SIFT3D *const src, SIFT3D *const dst);          /* sift.c:629 */
 int set_peak_thresh_SIFT3D(SIFT3D *const sift3d, const double peak_thresh);       /* sift.c:514 */
 int set_corner_thresh_SIFT3D(SIFT3D *const sift3d, const double corner_thresh);   /* sift.c:527 */
 int set_num_kp_levels_SIFT3D(SIFT3D *const sift3d, const unsigned int num_kp_levels); /* sift.c:542 */

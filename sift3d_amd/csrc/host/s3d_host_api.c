@@ -822,6 +822,194 @@ int apply_Sep_FIR_filter(const Image *const src, Image *const dst, Sep_FIR_filte
     return rc;
 }
 
+/* copy_SIFT3D (sift.c:629-655): parameters, the (scaled) image and both pyramids.  The voxels live on the device
+ * here, so the deep copy is device to device into a context of dst's own; host-side level metadata (dims, units,
+ * scales) is rebuilt by the same calls the reference makes and then aligned with src's (quirk C-12 leaves the
+ * units of octaves >= 1 a function of the struct's history).  The copy can serve SIFT3D_extract_descriptors
+ * without a detect of its own, like the reference's. */
+int copy_SIFT3D(const SIFT3D *const src, SIFT3D *const dst)
+{
+    const s3d_ctx *sc = sift_ctx(src);
+    cleanup_SIFT3D(dst);
+    if (init_SIFT3D(dst)) return SIFT3D_FAILURE;
+    set_sigma_n_SIFT3D(dst, src->gpyr.sigma_n);
+    set_sigma0_SIFT3D(dst, src->gpyr.sigma0);
+    if (set_peak_thresh_SIFT3D(dst, src->peak_thresh) || set_corner_thresh_SIFT3D(dst, src->corner_thresh) ||
+        set_num_kp_levels_SIFT3D(dst, (unsigned)src->gpyr.num_kp_levels))
+        return SIFT3D_FAILURE;
+    dst->dense_rotate = src->dense_rotate;
+    if (sc == NULL || sc->d_im == NULL || src->im.nx <= 0) return SIFT3D_SUCCESS;     /* no image yet */
+    {
+        s3d_ctx *dc;
+        const size_t n0 = (size_t)src->im.nx * src->im.ny * src->im.nz;
+        const int L = src->gpyr.num_levels;
+        if (!(dst->kernels.downsample_2 = ctx_new())) API_FAIL("sift3d_amd: out of device contexts");
+        dc = sift_ctx(dst);
+        dc->stream = sc->stream;
+        if (ctx_base(dc)) return SIFT3D_FAILURE;
+        dst->im.nx = src->im.nx; dst->im.ny = src->im.ny; dst->im.nz = src->im.nz; dst->im.nc = 1;
+        dst->im.ux = src->im.ux; dst->im.uy = src->im.uy; dst->im.uz = src->im.uz;
+        im_default_stride(&dst->im);
+        if (resize_SIFT3D(dst, dst->gpyr.num_kp_levels) || ctx_ensure_pyramid(dst, dc)) return SIFT3D_FAILURE;
+        if (dst->gpyr.num_octaves != src->gpyr.num_octaves || dst->gpyr.num_levels != L ||
+            dst->dog.num_levels != src->dog.num_levels)
+            API_FAIL("sift3d_amd: copy_SIFT3D: pyramid shapes differ");
+        for (int i = 0; i < src->gpyr.num_octaves * L; i++) {
+            dst->gpyr.levels[i].ux = src->gpyr.levels[i].ux; dst->gpyr.levels[i].uy = src->gpyr.levels[i].uy;
+            dst->gpyr.levels[i].uz = src->gpyr.levels[i].uz; dst->gpyr.levels[i].s = src->gpyr.levels[i].s;
+        }
+        for (int i = 0; i < src->dog.num_octaves * src->dog.num_levels; i++) {
+            dst->dog.levels[i].ux = src->dog.levels[i].ux; dst->dog.levels[i].uy = src->dog.levels[i].uy;
+            dst->dog.levels[i].uz = src->dog.levels[i].uz; dst->dog.levels[i].s = src->dog.levels[i].s;
+        }
+        DEV(s3d_rt_d2d(dc->d_im, sc->d_im, n0 * sizeof(float), dc->stream));
+        if (sc->have_pyramid) {
+            for (int o = 0; o < src->gpyr.num_octaves; o++)
+                for (int k = 0; k < L; k++)
+                    DEV(s3d_rt_d2d(dc->d_level[o * L + k], sc->d_level[o * L + k], sc->level_elems[o] * sizeof(float),
+                                   dc->stream));
+            dc->have_pyramid = 1;
+        }
+        DEV(s3d_rt_sync(dc->stream));
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- element-wise image helpers of the path as public entry points (host image in, host image out) ----------
+ * im_max_abs / im_scale (imutil.c:1959-1991, row a2), im_subtract (imutil.c:1997-2017, row a8) and
+ * im_downsample_2x (imutil.c:1742-1768, row a7) run the same kernels the pyramid build uses. */
+static float *dense_view(const Image *im, float **owned)
+{
+    *owned = NULL;
+    if (s3d_im_is_default_stride(im)) return im->data;
+    *owned = (float *)malloc((size_t)im->nx * im->ny * im->nz * im->nc * sizeof(float));
+    if (*owned) s3d_im_gather(im, *owned);
+    return *owned;
+}
+
+/* max |v| of a host image through the device; scale != 0: also divide by it in place (im_scale) */
+static int max_abs_dev(const Image *im, int scale, float *out)
+{
+    const size_t n = (size_t)im->nx * im->ny * im->nz * im->nc;
+    float *owned = NULL, *dense;
+    int rc = SIFT3D_FAILURE;
+    *out = 0.0f;
+    if (im->data == NULL || n == 0) return SIFT3D_SUCCESS;
+    if ((dense = dense_view(im, &owned)) == NULL) return SIFT3D_FAILURE;
+    pthread_mutex_lock(&g_shared_lock);
+    {
+        s3d_ctx *c = &g_shared;
+        if (ctx_base(c) == 0 && ctx_aux(c, 0, n) == 0 &&
+            s3d_rt_h2d(c->d_aux[0], dense, n * sizeof(float), c->stream) == 0 &&
+            s3d_k_absmax(c->d_aux[0], n, c->d_red, c->stream) == 0 &&
+            (!scale || s3d_k_scale_div(c->d_aux[0], n, c->d_red, c->stream) == 0) &&
+            s3d_rt_d2h(out, c->d_red, sizeof(float), c->stream) == 0 &&
+            (!scale || s3d_rt_d2h(dense, c->d_aux[0], n * sizeof(float), c->stream) == 0) &&
+            s3d_rt_sync(c->stream) == 0)
+            rc = SIFT3D_SUCCESS;
+        else
+            S3D_MSG("im_max_abs / im_scale: device error: %s \n", s3d_rt_last_error());
+    }
+    pthread_mutex_unlock(&g_shared_lock);
+    if (rc == SIFT3D_SUCCESS && scale && owned) {          /* strided image: write the scaled values back in place */
+        int x, y, z, k;
+        size_t i = 0;
+        for (z = 0; z < im->nz; z++)
+            for (y = 0; y < im->ny; y++)
+                for (x = 0; x < im->nx; x++)
+                    for (k = 0; k < im->nc; k++) SIFT3D_IM_GET_VOX(im, x, y, z, k) = owned[i++];
+    }
+    free(owned);
+    return rc;
+}
+
+float im_max_abs(const Image *const im) /* imutil.c:1959 */
+{
+    float m;
+    return max_abs_dev(im, 0, &m) == SIFT3D_SUCCESS ? m : NAN;      /* no error channel: NaN + message on device failure */
+}
+
+void im_scale(const Image *const im) /* imutil.c:1977 */
+{
+    float m;
+    (void)max_abs_dev(im, 1, &m);
+}
+
+int im_subtract(Image *src1, Image *src2, Image *dst) /* imutil.c:1997 */
+{
+    const size_t n = (size_t)src1->nx * src1->ny * src1->nz * src1->nc;
+    float *o1 = NULL, *o2 = NULL, *a, *b;
+    int rc = SIFT3D_FAILURE;
+    if (src1->nx != src2->nx || src1->ny != src2->ny || src1->nz != src2->nz || src1->nc != src2->nc) return SIFT3D_FAILURE;
+    if (src1->data == NULL || src2->data == NULL) return SIFT3D_FAILURE;
+    a = dense_view(src1, &o1);
+    b = dense_view(src2, &o2);
+    if (a == NULL || b == NULL || im_copy_dims(src1, dst)) {       /* im_copy_dims: dims, strides, units; resizes dst */
+        free(o1); free(o2);
+        return SIFT3D_FAILURE;
+    }
+    pthread_mutex_lock(&g_shared_lock);
+    {
+        s3d_ctx *c = &g_shared;
+        if (ctx_base(c) == 0 && ctx_aux(c, 0, n) == 0 && ctx_aux(c, 1, n) == 0 && ctx_aux(c, 2, n) == 0 &&
+            s3d_rt_h2d(c->d_aux[0], a, n * sizeof(float), c->stream) == 0 &&
+            s3d_rt_h2d(c->d_aux[1], b, n * sizeof(float), c->stream) == 0 &&
+            s3d_k_subtract(c->d_aux[0], c->d_aux[1], c->d_aux[2], n, c->stream) == 0 && s3d_rt_sync(c->stream) == 0) {
+            if (s3d_im_is_default_stride(dst)) {
+                rc = s3d_rt_d2h(dst->data, c->d_aux[2], n * sizeof(float), c->stream) || s3d_rt_sync(c->stream)
+                         ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
+            } else {                                                /* dst inherited src1's non-default strides */
+                float *tmp = (float *)malloc(n * sizeof(float));
+                if (tmp && s3d_rt_d2h(tmp, c->d_aux[2], n * sizeof(float), c->stream) == 0 && s3d_rt_sync(c->stream) == 0) {
+                    int x, y, z, k;
+                    size_t i = 0;
+                    for (z = 0; z < dst->nz; z++)
+                        for (y = 0; y < dst->ny; y++)
+                            for (x = 0; x < dst->nx; x++)
+                                for (k = 0; k < dst->nc; k++) SIFT3D_IM_GET_VOX(dst, x, y, z, k) = tmp[i++];
+                    rc = SIFT3D_SUCCESS;
+                }
+                free(tmp);
+            }
+        }
+        if (rc != SIFT3D_SUCCESS) S3D_MSG("im_subtract: device error: %s \n", s3d_rt_last_error());
+    }
+    pthread_mutex_unlock(&g_shared_lock);
+    free(o1); free(o2);
+    return rc;
+}
+
+int im_downsample_2x(const Image *const src, Image *const dst) /* imutil.c:1742 */
+{
+    const size_t n = (size_t)src->nx * src->ny * src->nz * src->nc;
+    float *owned = NULL, *dense;
+    size_t m;
+    int rc = SIFT3D_FAILURE;
+    dst->nx = (int)floor((double)src->nx / 2.0);
+    dst->ny = (int)floor((double)src->ny / 2.0);
+    dst->nz = (int)floor((double)src->nz / 2.0);
+    dst->nc = src->nc;
+    im_default_stride(dst);
+    if (im_resize(dst)) return SIFT3D_FAILURE;
+    m = (size_t)dst->nx * dst->ny * dst->nz * dst->nc;
+    if (m == 0) return SIFT3D_SUCCESS;
+    if (src->data == NULL || (dense = dense_view(src, &owned)) == NULL) return SIFT3D_FAILURE;
+    pthread_mutex_lock(&g_shared_lock);
+    {
+        s3d_ctx *c = &g_shared;
+        if (ctx_base(c) == 0 && ctx_aux(c, 0, n) == 0 && ctx_aux(c, 1, m) == 0 &&
+            s3d_rt_h2d(c->d_aux[0], dense, n * sizeof(float), c->stream) == 0 &&
+            s3d_k_decimate2_nc(c->d_aux[0], src->nx, src->ny, src->nz, src->nc, c->d_aux[1], c->stream) == 0 &&
+            s3d_rt_d2h(dst->data, c->d_aux[1], m * sizeof(float), c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
+            rc = SIFT3D_SUCCESS;
+        else
+            S3D_MSG("im_downsample_2x: device error: %s \n", s3d_rt_last_error());
+    }
+    pthread_mutex_unlock(&g_shared_lock);
+    free(owned);
+    return rc;
+}
+
 /* ---- raw-image variants (sift.c:1978-2006, 2131-2195, 1534-1604) --------------------------------------- */
 /* smooth_scale_raw_input on the device: d_out = im_scale(G_{sigma_n -> sigma0}(d_in)) */
 static int smooth_scale_raw_dev(const SIFT3D *sift3d, s3d_ctx *c, const float *d_in, float *d_out, float *d_tmp,

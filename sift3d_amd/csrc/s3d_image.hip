@@ -191,3 +191,26 @@ extern "C" int s3d_k_decimate2(const float *d_src, int nx, int ny, int nz, float
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
+
+/* im_downsample_2x with interleaved channels (imutil.c:1742-1768): a dst row of mx * nc floats per (y, z) */
+__global__ void __launch_bounds__(256) k_decimate2_nc(const float *__restrict__ src, int nx, int ny, int nc, int mx,
+                                                      int my, float *__restrict__ dst)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    if (e >= mx * nc) return;
+    const int x = e / nc, c = e - x * nc;
+    dst[((size_t)z * my + y) * mx * nc + e] = src[(((size_t)(2 * z) * ny + 2 * y) * nx + 2 * x) * nc + c];
+}
+
+extern "C" int s3d_k_decimate2_nc(const float *d_src, int nx, int ny, int nz, int nc, float *d_dst, s3d_stream st)
+{
+    if (nc == 1) return s3d_k_decimate2(d_src, nx, ny, nz, d_dst, st);
+    const int mx = nx / 2, my = ny / 2, mz = nz / 2;
+    if (mx < 1 || my < 1 || mz < 1 || nc < 1) S3D_FAIL("volume too small to decimate");
+    if (my > 65535 || mz > 65535) S3D_FAIL("volume too large for the decimation grid");
+    hipLaunchKernelGGL(k_decimate2_nc, dim3(s3d_div_up((size_t)mx * nc, 256), my, mz), dim3(256), 0, (hipStream_t)st, d_src,
+                       nx, ny, nc, mx, my, d_dst);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
