@@ -23,15 +23,27 @@
 
 #include "s3d_host.h"
 
-/* parameters of the reference, sift.c:34-38, 48-55 */
-static const double peak_thresh_default = 0.1;
-static const int num_kp_levels_default = 3;
-static const double corner_thresh_default = 0.4;
-static const double sigma_n_default = 1.15;
-static const double sigma0_default = 1.6;
-static const double ori_sig_fctr = 1.5;
-static const double desc_sig_fctr = 7.071067812;
-static const double desc_rad_fctr = 2.0;
+/* Parameters of the reference with external linkage, as libsift3D exports them (sift.c:34-58: 19 `const` data
+ * symbols; no header declares them, but `nm -D` of the reference shows them and a caller may). */
+const double peak_thresh_default = 0.1;
+const int num_kp_levels_default = 3;
+const double corner_thresh_default = 0.4;
+const double sigma_n_default = 1.15;
+const double sigma0_default = 1.6;
+const char opt_peak_thresh[] = "peak_thresh";
+const char opt_corner_thresh[] = "corner_thresh";
+const char opt_num_kp_levels[] = "num_kp_levels";
+const char opt_sigma_n[] = "sigma_n";
+const char opt_sigma0[] = "sigma0";
+const double max_eig_ratio = 0.90;
+const double ori_grad_thresh = 1E-10;
+const double bary_eps = FLT_EPSILON * 1E1;
+const double ori_sig_fctr = 1.5;
+const double ori_rad_fctr = 3.0;
+const double desc_sig_fctr = 7.071067812;
+const double desc_rad_fctr = 2.0;
+const double trunc_thresh = 0.2f * 128.0f / DESC_NUMEL;
+const double gr = 1.6180339887;
 
 #define DESC_REC_FLOATS (sizeof(SIFT3D_Descriptor) / sizeof(float)) /* 776 */
 

@@ -88,3 +88,19 @@ def test_gauss_filter_bank_is_the_references(oracle):
         lib.imutil.cleanup_Gauss_filter(C.byref(g))
     g = abi.Gauss_filter()
     assert lib.imutil.init_Gauss_incremental_filter(C.byref(g), 2.0, 1.0, 3) != 0   # s_cur > s_next
+
+
+def test_exported_constants_match_the_reference(reference):
+    """libsift3D exports its 19 parameter constants as data symbols (sift.c:34-58); same names, types and values."""
+    import ctypes as C
+    from sift3d_amd import build as _b
+    mine = C.CDLL(_b.build())
+    for name in ("peak_thresh_default", "corner_thresh_default", "sigma_n_default", "sigma0_default", "max_eig_ratio",
+                 "ori_grad_thresh", "bary_eps", "ori_sig_fctr", "ori_rad_fctr", "desc_sig_fctr", "desc_rad_fctr",
+                 "trunc_thresh", "gr"):
+        assert C.c_double.in_dll(mine, name).value == C.c_double.in_dll(reference.sift, name).value, name
+    assert C.c_int.in_dll(mine, "num_kp_levels_default").value == C.c_int.in_dll(reference.sift, "num_kp_levels_default").value
+    for name in ("opt_peak_thresh", "opt_corner_thresh", "opt_num_kp_levels", "opt_sigma_n", "opt_sigma0"):
+        a = C.string_at(C.addressof(C.c_char.in_dll(mine, name)))
+        b = C.string_at(C.addressof(C.c_char.in_dll(reference.sift, name)))
+        assert a == b == name[4:].encode(), name
