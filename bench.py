@@ -375,6 +375,28 @@ def main():
             "G_lds_atomic_lane_ops_per_s": round(24.0 * wv / t_describe / 1e9, 1),
             "bound": "LDS atomic throughput (24 ds_add_u64 to data-dependent bins per window voxel), not HBM or MFMA"}
     if rank == 0 and not args.no_match:
+        # BASELINE configs[0] flavour, outside the timed region: the kpSift3D program on a 128^3 NIfTI-1 volume
+        # (.nii.gz in, keypoint and descriptor CSVs out) -- process start, HIP initialisation, zlib and CSV
+        # formatting included: plumbing, not throughput.
+        exe = os.path.join(ROOT, "sift3d_amd", "bin", "kpSift3D")
+        if os.path.exists(exe):
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                v128 = synth.blobs(128, 128, 128, synth.default_nblobs(128, 128, 128), 1)
+                him = lib.image_from_numpy(v128)
+                src = os.path.join(td, "vol.nii.gz")
+                lib.imutil.im_write.argtypes = [C.c_char_p, C.POINTER(abi.Image)]
+                if lib.imutil.im_write(src.encode(), C.byref(him)) == 0:
+                    t0 = time.perf_counter()
+                    r = subprocess.run([exe, "--keys", os.path.join(td, "k.csv"), "--desc", os.path.join(td, "d.csv"), src],
+                                       capture_output=True, text=True)
+                    t_cli = time.perf_counter() - t0
+                    nk = sum(1 for _ in open(os.path.join(td, "k.csv"))) if r.returncode == 0 else -1
+                    result["config"]["kpSift3D_128"] = {"wall_ms": round(t_cli * 1e3, 1), "keypoints": nk,
+                                                        "returncode": r.returncode}
+                lib.free_image(him)
+    if rank == 0 and not args.no_match:
         # SURVEY 8(d) "API-to-API", outside the timed region: the same volume through the reference's own entry points
         # with HOST buffers (pageable Image in, host Keypoint_store / SIFT3D_Descriptor_store out): what a relinked
         # caller sees, PCIe transfers included.  Never `value`.
