@@ -78,10 +78,12 @@ typedef struct {
     uint32_t *d_count;      /* [0] candidates, [1] keypoints */
     uint32_t cand_cap;
     uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
+    uint32_t *d_kscratch;   /* block counters of s3d_k_compact_keys: cand_cap/256 + 2 (grows with cand_cap) */
     float *d_R, *d_Rk;
     void *d_orient;         /* s3d_k_orient scratch for cand_cap candidates */
     int32_t *d_xyzos;
     double *d_sigma;
+    double h_sigma[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];   /* staging for the async upload to d_sigma */
     float *d_mesh;
     int have_pyramid;
     long last_num_candidates;
@@ -139,7 +141,7 @@ static void ctx_free_pyramid(s3d_ctx *c)
     dfree(&c->d_im); dfree(&c->d_tmp);
     for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&c->d_level[i]);
     dfree(&c->d_bits); dfree(&c->d_scratch);
-    dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep);
+    dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep); dfree(&c->d_kscratch);
     dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_sigma); dfree(&c->d_orient);
     c->nx = c->ny = c->nz = c->num_octaves = c->num_levels = 0;
     c->cand_cap = 0;
@@ -199,8 +201,18 @@ static s3d_ctx *sift_ctx(const SIFT3D *s) { return ctx_get(s->kernels.downsample
 /* ---- SIFT3D object ------------------------------------------------------------------------------------ */
 static int resize_SIFT3D(SIFT3D *const sift3d, const int num_kp_levels);
 
+/* The host pyramids were re-shaped or re-scaled: what the device holds no longer matches them, so
+ * SIFT3D_have_gpyr() must say no until the next detect (the reference would describe from stale levels;
+ * here the level table itself would be mis-indexed). */
+static void invalidate_device_pyramid(const SIFT3D *sift3d)
+{
+    s3d_ctx *c = sift_ctx(sift3d);
+    if (c) c->have_pyramid = 0;
+}
+
 static int set_scales_SIFT3D(SIFT3D *const sift3d, const double sigma0, const double sigma_n) /* sift.c:916-934 */
 {
+    invalidate_device_pyramid(sift3d);
     if (set_scales_Pyramid(sigma0, sigma_n, &sift3d->gpyr) || set_scales_Pyramid(sigma0, sigma_n, &sift3d->dog))
         return SIFT3D_FAILURE;
     if (sift3d->im.nx <= 0) return SIFT3D_SUCCESS;       /* no image yet */
@@ -323,6 +335,7 @@ static int resize_SIFT3D(SIFT3D *const sift3d, const int num_kp_levels)
     const unsigned num_dog_levels = (unsigned)num_kp_levels + 2;
     const unsigned num_gpyr_levels = num_dog_levels + 1;
     int num_octaves = 0;
+    invalidate_device_pyramid(sift3d);
     if (im->nx > 0) {
         int mind = im->nx < im->ny ? im->nx : im->ny;
         if (im->nz < mind) mind = im->nz;
@@ -365,7 +378,7 @@ static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
     maxwords = (n0 + 63) / 64;
     c->bits_words = maxwords;
     DEV(s3d_rt_malloc((void **)&c->d_bits, S3D_FUSED_KP_MAX * maxwords * sizeof(unsigned long long)));
-    DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 256 + 4096) * sizeof(uint32_t)));   /* bitmap + keypoint block counters */
+    DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 1024 + 8) * sizeof(uint32_t)));     /* bitmap block counters */
     DEV(s3d_rt_malloc((void **)&c->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS));
     c->nx = l0->nx; c->ny = l0->ny; c->nz = l0->nz;
     c->num_octaves = g->num_octaves;
@@ -376,12 +389,13 @@ static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
 static int ctx_ensure_candidates(s3d_ctx *c, uint32_t cap)
 {
     if (c->cand_cap >= cap) return SIFT3D_SUCCESS;
-    dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep);
+    dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep); dfree(&c->d_kscratch);
     dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_orient);
     c->cand_cap = 0;
     DEV(s3d_rt_malloc((void **)&c->d_cand_idx, (size_t)cap * sizeof(uint32_t)));
     DEV(s3d_rt_malloc((void **)&c->d_cand_tag, (size_t)cap * sizeof(uint32_t)));
     DEV(s3d_rt_malloc((void **)&c->d_keep, (size_t)cap * sizeof(uint32_t)));
+    DEV(s3d_rt_malloc((void **)&c->d_kscratch, ((size_t)cap / 256 + 8) * sizeof(uint32_t)));
     DEV(s3d_rt_malloc((void **)&c->d_R, (size_t)cap * 9 * sizeof(float)));
     DEV(s3d_rt_malloc((void **)&c->d_Rk, (size_t)cap * 9 * sizeof(float)));
     DEV(s3d_rt_malloc((void **)&c->d_xyzos, (size_t)cap * 5 * sizeof(int32_t)));
@@ -548,15 +562,15 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
 
     fill_pyr_desc(g, c->d_level, &pd);
     {
-        double sig[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
+        double *const sig = c->h_sigma;                   /* lives in the context: the copy below is asynchronous */
         for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
         DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
         DEV(s3d_k_orient(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
                          c->d_R, c->d_keep, NULL, c->d_orient, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
-                               c->d_Rk, c->d_count + 1, c->d_scratch, c->stream));
+                               c->d_Rk, c->d_count + 1, c->d_kscratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));
-        DEV(s3d_rt_sync(c->stream));                      /* also orders the reads of `sig` */
+        DEV(s3d_rt_sync(c->stream));
     }
     {
         const uint32_t K = counts[1];

@@ -378,7 +378,10 @@ int find_tform_ransac(const Ransac *const ran, const Mat_rm *const src, const Ma
     int *cset = (int *)malloc(sizeof(int) * npts), *best = (int *)malloc(sizeof(int) * npts);
     int *scratch = (int *)malloc(sizeof(int) * npts);
     double *ps = NULL, *pr = NULL;
-    if (init_Affine(&cur, dim)) return SIFT3D_FAILURE;
+    if (init_Affine(&cur, dim)) {
+        free(cset); free(best); free(scratch);
+        return SIFT3D_FAILURE;
+    }
     if (!cset || !best || !scratch) goto done;
     const double thr2 = ran->err_thresh * ran->err_thresh;
     for (int it = 0; it < ran->num_iter; it++) {
