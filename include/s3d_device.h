@@ -46,6 +46,13 @@ int s3d_rt_event_create(void **ev);
 int s3d_rt_event_destroy(void *ev);
 int s3d_rt_event_record(void *ev, s3d_stream stream);
 int s3d_rt_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchronises on ev_stop */
+int s3d_rt_event_sync(void *ev);
+int s3d_rt_stream_wait_event(s3d_stream stream, void *ev);   /* work queued on stream after this waits for ev */
+/* pinned host memory: page-lock a caller's buffer / allocate a page-locked staging buffer */
+int s3d_rt_host_register(void *p, size_t bytes);
+int s3d_rt_host_unregister(void *p);
+int s3d_rt_host_alloc(void **p, size_t bytes);
+int s3d_rt_host_free(void *p);
 const char *s3d_rt_last_error(void);
 
 /* ---- image ops ---------------------------------------------------------------------------------- */

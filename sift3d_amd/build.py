@@ -20,8 +20,8 @@ OBJ = os.path.join(HERE, "lib", "obj")
 INC = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
-               "s3d_dense.hip", "s3d_match.hip", "s3d_resample.hip"]
-C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c", "host/s3d_host_draw.c"]
+               "s3d_dense.hip", "s3d_match.hip", "s3d_resample.hip", "s3d_rccl.hip"]
+C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c", "host/s3d_host_draw.c", "host/s3d_host_slab.c"]
 BIN = os.path.join(HERE, "bin")
 CLI_PROGRAMS = ["kpSift3D", "denseSift3D", "regSift3D"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -72,7 +72,7 @@ def build(verbose: bool = False) -> str:
         # -Bsymbolic: the library's own calls to init_im & co bind to itself even if another libimutil
         # (e.g. the reference oracle in a test process) is loaded.
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", out, *objs, "-lm", "-lz",
-              "-lpthread"])
+              "-lpthread", "-ldl"])
     synth = os.path.join(LIB, "libs3d_synth.so")
     ssrc = os.path.join(CSRC, "synth.c")
     if _newer(ssrc, synth):

@@ -17,4 +17,19 @@ int s3d_resize_pyramid(const Image *const im, const int first_level, const unsig
                        Pyramid *const pyr, const int alloc_host);
 int s3d_resize_descriptor_store(SIFT3D_Descriptor_store *const desc, const long num);
 
+/* verify_keys (sift.c:2050-2091) */
+int s3d_verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz);
+/* scalar set-up of extract_descrip (sift.c:1845-1851) for one keypoint, in the reference's float steps */
+void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave, s3d_desc_key *out);
+
+/* ---- one process, N GPUs behind the reference entry points (s3d_host_slab.c) --------------------------- */
+struct s3d_mgpu;
+int s3d_mgpu_wanted(const struct s3d_mgpu *m);            /* > 1: the multi-GPU path is switched on */
+int s3d_mgpu_configure(struct s3d_mgpu **m, int ngpu, int flags);
+int s3d_mgpu_detect(struct s3d_mgpu **m, const SIFT3D *sift3d, const float *host_dense, int nx, int ny, int nz,
+                    double ux, double uy, double uz, Keypoint_store *kp);
+int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descriptor *out);
+int s3d_mgpu_info(const struct s3d_mgpu *m, int r, void *info);
+void s3d_mgpu_free(struct s3d_mgpu *m);
+
 #endif

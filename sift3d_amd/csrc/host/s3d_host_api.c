@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "s3d_host.h"
+#include "sift3d_amd_slab.h"
 
 /* Parameters of the reference with external linkage, as libsift3D exports them (sift.c:34-58: 19 `const` data
  * symbols; no header declares them, but `nm -D` of the reference shows them and a caller may). */
@@ -94,6 +95,9 @@ typedef struct {
     /* generic scratch for apply_Sep_FIR_filter / dense / raw variants */
     size_t aux_elems[4];
     float *d_aux[4];
+    /* one process, N GPUs (s3d_host_slab.c): when set, detect / describe run on Z-slabs and d_level stays empty */
+    struct s3d_mgpu *mgpu;
+    int mgpu_env_checked, pyramid_on_slabs;
 } s3d_ctx;
 
 #define S3D_MAX_CTX 256
@@ -166,6 +170,7 @@ static void ctx_release(int handle)
     g_ctx[handle - 1] = NULL;
     pthread_mutex_unlock(&g_ctx_lock);
     if (c) {
+        s3d_mgpu_free(c->mgpu);
         ctx_free_all(c);
         free(c);
     }
@@ -429,19 +434,13 @@ static void unit_factors(const double units[3], double unit, float uf[3])
 
 /* set_im_SIFT3D (sift.c:883-913) for an input already on the host or on the device: metadata on the
  * host, voxels into d_im, then im_scale on the device. */
-static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const float *d_vol, int nx, int ny,
-                         int nz, double ux, double uy, double uz)
+/* host half of set_im_SIFT3D: metadata of sift3d->im (im_copy_dims: dims, default strides, nc and units; data stays
+ * NULL) and, when the dims changed, of the pyramids and the filter bank */
+static int set_im_meta(SIFT3D *const sift3d, int nx, int ny, int nz, double ux, double uy, double uz)
 {
     Image *const sim = &sift3d->im;
-    s3d_ctx *c;
     const int had_image = sim->nx > 0;
     const int same_dims = had_image && sim->nx == nx && sim->ny == ny && sim->nz == nz;
-    size_t n;
-    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
-        API_FAIL("sift3d_amd: out of device contexts");
-    c = sift_ctx(sift3d);
-    if (ctx_base(c)) return SIFT3D_FAILURE;
-    /* host metadata of sift3d->im (im_copy_dims: dims, default strides, nc and units); data stays NULL */
     sim->nx = nx; sim->ny = ny; sim->nz = nz; sim->nc = 1;
     sim->ux = ux; sim->uy = uy; sim->uz = uz;
     im_default_stride(sim);
@@ -458,6 +457,20 @@ static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const fl
             lv->ux = ux; lv->uy = uy; lv->uz = uz;
         }
     }
+    return SIFT3D_SUCCESS;
+}
+
+static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const float *d_vol, int nx, int ny,
+                         int nz, double ux, double uy, double uz)
+{
+    s3d_ctx *c;
+    size_t n;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    if (ctx_base(c)) return SIFT3D_FAILURE;
+    if (set_im_meta(sift3d, nx, ny, nz, ux, uy, uz)) return SIFT3D_FAILURE;
+    c->pyramid_on_slabs = 0;
     if (ctx_ensure_pyramid(sift3d, c)) return SIFT3D_FAILURE;
     n = (size_t)nx * ny * nz;
     if (host_dense) DEV(s3d_rt_h2d(c->d_im, host_dense, n * sizeof(float), c->stream));
@@ -602,6 +615,39 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
     return SIFT3D_SUCCESS;
 }
 
+/* Number of GPUs this struct's detect / describe run on: sift3d_amd_set_num_gpus(), else the environment
+ * (SIFT3D_NGPU, SIFT3D_SLAB_LOOPBACK), read once per struct.  Creates the device context on first use. */
+static int mgpu_for(SIFT3D *const sift3d)
+{
+    s3d_ctx *c;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new())) return 0;
+    c = sift_ctx(sift3d);
+    if (!c->mgpu_env_checked) {
+        const char *e = getenv("SIFT3D_NGPU"), *l = getenv("SIFT3D_SLAB_LOOPBACK");
+        c->mgpu_env_checked = 1;
+        if (c->mgpu == NULL && e && atoi(e) > 1)
+            (void)s3d_mgpu_configure(&c->mgpu, atoi(e), l && atoi(l) ? SIFT3D_AMD_SLAB_LOOPBACK : 0);
+    }
+    return s3d_mgpu_wanted(c->mgpu);
+}
+
+int sift3d_amd_set_num_gpus(SIFT3D *const sift3d, int ngpu, int flags)
+{
+    s3d_ctx *c;
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    c = sift_ctx(sift3d);
+    c->mgpu_env_checked = 1;                               /* an explicit call overrides the environment */
+    if (c->pyramid_on_slabs) c->have_pyramid = c->pyramid_on_slabs = 0;
+    return s3d_mgpu_configure(&c->mgpu, ngpu, flags);
+}
+
+int sift3d_amd_get_slab_info(const SIFT3D *const sift3d, int r, sift3d_amd_slab_info *info)
+{
+    const s3d_ctx *c = sift_ctx(sift3d);
+    return c ? s3d_mgpu_info(c->mgpu, r, info) : SIFT3D_FAILURE;
+}
+
 int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoint_store *const kp) /* sift.c:1609 */
 {
     float *dense = NULL;
@@ -618,6 +664,17 @@ int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoin
         if ((dense = (float *)malloc(sizeof(float) * (size_t)im->nx * im->ny * im->nz)) == NULL) return SIFT3D_FAILURE;
         s3d_im_gather(im, dense);
         src = dense;
+    }
+    if (mgpu_for(sift3d) > 1) {                            /* Z-slabs over several GPUs (s3d_host_slab.c) */
+        s3d_ctx *c = sift_ctx(sift3d);
+        c->have_pyramid = 0;
+        rc = set_im_meta(sift3d, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz);
+        if (rc == SIFT3D_SUCCESS)
+            rc = s3d_mgpu_detect(&c->mgpu, sift3d, src, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz, kp);
+        free(dense);
+        if (rc) return SIFT3D_FAILURE;
+        c->have_pyramid = c->pyramid_on_slabs = 1;
+        return SIFT3D_SUCCESS;
     }
     rc = set_im_device(sift3d, src, NULL, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz);
     if (rc == SIFT3D_SUCCESS && dense) rc = s3d_rt_sync(sift_ctx(sift3d)->stream) ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
@@ -663,7 +720,7 @@ int SIFT3D_have_gpyr(const SIFT3D *const sift3d) /* sift.c:1936-1942, plus: the 
 }
 
 /* verify_keys, sift.c:2050-2091 */
-static int verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz)
+int s3d_verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz)
 {
     const long num = (long)kp->slab.num;
     if (num < 1) {
@@ -688,8 +745,8 @@ static int verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz)
 }
 
 /* scalar set-up of extract_descrip (sift.c:1845-1851) in the reference's float arithmetic */
-static void make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave,
-                          s3d_desc_key *out)
+void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave,
+                       s3d_desc_key *out)
 {
     const float sigma = key->sd * desc_sig_fctr;
     const float win_radius = desc_rad_fctr * sigma;
@@ -739,7 +796,7 @@ static int describe_from_gpyr(SIFT3D *const sift3d, const Keypoint_store *const 
     s3d_pyramid_desc pd;
     s3d_desc_key *keys;
     int rc;
-    if (verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
+    if (s3d_verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
     if (!SIFT3D_have_gpyr(sift3d)) {
         S3D_MSG("SIFT3D_extract_descriptors: no Gaussian pyramid is available. Make sure SIFT3D_detect_keypoints "
                 "was called prior to calling this function. \n");
@@ -753,7 +810,7 @@ static int describe_from_gpyr(SIFT3D *const sift3d, const Keypoint_store *const 
             free(keys);
             API_FAIL("SIFT3D_extract_descriptors: keypoint %zu has no pyramid level (o=%d, s=%d)", i, key->o, key->s);
         }
-        make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + i);
+        s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + i);
     }
     fill_pyr_desc(g, c->d_level, &pd);
     rc = describe_dev(sift3d, c, &pd, keys, num, host_out);
@@ -775,7 +832,7 @@ int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const
                                SIFT3D_Descriptor_store *const desc) /* sift.c:2025-2046 */
 {
     const Image *first;
-    if (verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
+    if (s3d_verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
     if (!SIFT3D_have_gpyr(sift3d)) {
         S3D_MSG("SIFT3D_extract_descriptors: no Gaussian pyramid is available. Make sure SIFT3D_detect_keypoints "
                 "was called prior to calling this function. \n");
@@ -784,6 +841,7 @@ int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const
     first = sift3d->gpyr.levels;
     desc->nx = first->nx; desc->ny = first->ny; desc->nz = first->nz;
     if (s3d_resize_descriptor_store(desc, (long)kp->slab.num)) return SIFT3D_FAILURE;
+    if (sift_ctx(sift3d)->pyramid_on_slabs) return s3d_mgpu_describe(sift_ctx(sift3d)->mgpu, kp, desc->buf);
     if (describe_from_gpyr(sift3d, kp, desc->buf)) return SIFT3D_FAILURE;
     fill_desc_coords(kp, desc->buf);
     return SIFT3D_SUCCESS;
@@ -791,6 +849,8 @@ int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const
 
 int sift3d_amd_extract_descriptors_dev(SIFT3D *const sift3d, const Keypoint_store *const kp, const float **d_desc)
 {
+    if (sift_ctx(sift3d) && sift_ctx(sift3d)->pyramid_on_slabs)
+        API_FAIL("sift3d_amd_extract_descriptors_dev: the pyramid is spread over several GPUs; use SIFT3D_extract_descriptors");
     if (describe_from_gpyr(sift3d, kp, NULL)) return SIFT3D_FAILURE;
     if (d_desc) *d_desc = sift_ctx(sift3d)->d_desc;
     return SIFT3D_SUCCESS;
@@ -864,7 +924,8 @@ int copy_SIFT3D(const SIFT3D *const src, SIFT3D *const dst)
         set_num_kp_levels_SIFT3D(dst, (unsigned)src->gpyr.num_kp_levels))
         return SIFT3D_FAILURE;
     dst->dense_rotate = src->dense_rotate;
-    if (sc == NULL || sc->d_im == NULL || src->im.nx <= 0) return SIFT3D_SUCCESS;     /* no image yet */
+    if (sc == NULL || sc->d_im == NULL || src->im.nx <= 0 || sc->pyramid_on_slabs)
+        return SIFT3D_SUCCESS;                            /* no image yet (a multi-GPU pyramid is not copied: parameters only) */
     {
         s3d_ctx *dc;
         const size_t n0 = (size_t)src->im.nx * src->im.ny * src->im.nz;
@@ -1090,7 +1151,7 @@ int SIFT3D_extract_raw_descriptors(SIFT3D *const sift3d, const Image *const im, 
     s3d_desc_key *keys;
     const size_t num = kp->slab.num;
     int rc;
-    if (verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
+    if (s3d_verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
     if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
         API_FAIL("sift3d_amd: out of device contexts");
     c = sift_ctx(sift3d);
@@ -1101,7 +1162,7 @@ int SIFT3D_extract_raw_descriptors(SIFT3D *const sift3d, const Image *const im, 
     for (size_t i = 0; i < num; i++) {                    /* keypoint2base, sift.c:2094-2115 */
         const Keypoint *key = kp->buf + i;
         const double f = ldexp(1.0, key->o);
-        make_desc_key(key, key->xd * f, key->yd * f, key->zd * f, 0, 0, keys + i);
+        s3d_make_desc_key(key, key->xd * f, key->yd * f, key->zd * f, 0, 0, keys + i);
     }
     rc = describe_dev(sift3d, c, &pd, keys, num, desc->buf);
     free(keys);
@@ -1130,7 +1191,7 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
     uint32_t *d_keep = NULL, *d_tags = NULL;
     void *d_oscr = NULL;
     int rc = SIFT3D_FAILURE;
-    if (verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
+    if (s3d_verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
     if (!s->kernels.downsample_2 && !(s->kernels.downsample_2 = ctx_new())) API_FAIL("sift3d_amd: out of device contexts");
     c = sift_ctx(s);
     if ((*conf = (double *)SIFT3D_safe_realloc(*conf, num * sizeof(double))) == NULL) return SIFT3D_FAILURE;
@@ -1296,6 +1357,7 @@ int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog)
     s3d_ctx *c = sift_ctx(sift3d);
     Pyramid *g = &sift3d->gpyr, *d = &sift3d->dog;
     if (!SIFT3D_have_gpyr(sift3d)) API_FAIL("sift3d_amd_download_pyramid: no device pyramid");
+    if (c->pyramid_on_slabs) API_FAIL("sift3d_amd_download_pyramid: the pyramid is spread over several GPUs");
     for (int i = 0; i < g->num_octaves * g->num_levels; i++) {
         Image *lv = g->levels + i;
         if (im_resize(lv)) return SIFT3D_FAILURE;

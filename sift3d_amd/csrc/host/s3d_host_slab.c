@@ -1,0 +1,1128 @@
+/* s3d_host_slab.c -- multi-GPU detect + describe by Z-slab decomposition (include/sift3d_amd_slab.h,
+ * SURVEY.md section 8e).  Host C: this file decides who owns which planes, which planes travel, and in which
+ * order the single-GPU kernels of include/s3d_device.h run on them; it does no arithmetic on voxels.
+ *
+ * What it reproduces is SIFT3D_detect_keypoints (sift3d/sift.c:1609-1641: set_im_SIFT3D 883-913, build_gpyr
+ * 989-1050, detect_extrema 1074-1212, assign_orientations 1264-1325) and SIFT3D_extract_descriptors
+ * (sift.c:2025-2046) for ONE volume spread over several GPUs, bit for bit: every kernel sees the global voxel
+ * indices and the global depth (the reference's mirror rule only applies at the two global ends), keypoints come
+ * out in the reference's (o, s, z, y, x) order per rank and ranks are ordered by z.
+ *
+ * Views.  A sharded GSS level is stored as [slab + 2H halo planes] and handed to the kernels as a pointer
+ * indexed by GLOBAL z (view = base - zlo * plane): the single-GPU kernels run unchanged on it.
+ *
+ * Contents: (1) the rank object sift3d_amd_slab; (2) the in-process loop-back transport; (3) s3d_mgpu: N rank
+ * threads behind the plain SIFT3D entry points.  The RCCL transport lives in csrc/s3d_rccl.hip.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "s3d_host.h"
+#include "sift3d_amd_slab.h"
+
+#define DESC_REC_FLOATS (sizeof(SIFT3D_Descriptor) / sizeof(float)) /* 776 */
+
+static __thread char g_slab_err[512];
+#define SLAB_FAIL(...)                                           \
+    do {                                                         \
+        snprintf(g_slab_err, sizeof(g_slab_err), __VA_ARGS__);   \
+        S3D_MSG("%s\n", g_slab_err);                             \
+        return SIFT3D_FAILURE;                                   \
+    } while (0)
+#define DEV(call)                                                                        \
+    do {                                                                                 \
+        if ((call) != 0) SLAB_FAIL("sift3d_amd slab: %s failed: %s", #call, s3d_rt_last_error()); \
+    } while (0)
+#define COMM(call)                                                                       \
+    do {                                                                                 \
+        if ((call) != 0) SLAB_FAIL("sift3d_amd slab: transport: %s failed", #call);      \
+    } while (0)
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* ---- a GSS level: backing planes [zlo, zlo+n) of a volume indexed by global z ----------------------------- */
+typedef struct {
+    float *base;
+    size_t pe;      /* elements per plane */
+    long zlo, n;
+} s3d_lev;
+
+static float *lev_ptr(const s3d_lev *l, long z)        /* address of global plane z (backed or not) */
+{
+    return (float *)((uintptr_t)l->base + (uintptr_t)((intptr_t)(z - l->zlo) * (intptr_t)l->pe * 4));
+}
+#define lev_view(l) lev_ptr((l), 0)
+
+struct sift3d_amd_slab {
+    sift3d_amd_transport t;
+    s3d_stream cs, ms;              /* compute stream; transfer stream of the deferred halo planes */
+    int own_cs;
+    void *ev_ready, *ev_done;
+    int pending;                    /* deferred halo transfers in flight on ms */
+    SIFT3D plan;                    /* host-side plan: pyramid metadata, filter bank, thresholds */
+    int nx, ny, nz;
+    double units[3];
+    int no, nl, nkp, first_level;
+    int dims[S3D_MAX_OCTAVES][3];
+    double lunits[S3D_MAX_OCTAVES][3];
+    int H, o_shard;
+    int *bounds;                    /* world + 1 base-slice boundaries */
+    int part[S3D_MAX_OCTAVES][2];   /* my planes [z0, z1) of each octave (storage when sharded, work always) */
+    s3d_lev lev[S3D_MAX_OCTAVES * S3D_MAX_LEVELS], im, tmp;
+    float *d_seed;                  /* all-gather staging for the first replicated octave */
+    size_t seed_elems;              /* per rank */
+    unsigned long long *d_bits;
+    size_t bits_words;
+    uint32_t *d_scratch, *d_kscratch, *d_count;
+    float *d_red;
+    uint32_t cap;
+    uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
+    float *d_R, *d_Rk;
+    int32_t *d_xyzos;
+    void *d_orient;
+    size_t orient_bytes;
+    float *d_mesh;
+    double *d_sigma;
+    double h_sigma[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
+    float h_flag;
+    uint32_t h_counts[2];
+    s3d_pyramid_desc pd;
+    size_t desc_cap;
+    s3d_desc_key *d_keys;
+    float *d_desc;
+    long num_candidates, num_keypoints;
+    double halo_bytes, device_bytes, detect_ms, describe_ms;
+};
+
+static int dmalloc(sift3d_amd_slab *sl, void *pp, size_t bytes, int zero)
+{
+    void **p = (void **)pp;
+    DEV(s3d_rt_malloc(p, bytes));
+    if (zero) DEV(s3d_rt_memset(*p, 0, bytes, sl->cs));
+    sl->device_bytes += (double)bytes;
+    return SIFT3D_SUCCESS;
+}
+
+static void dfree(void *pp)
+{
+    void **p = (void **)pp;
+    if (*p) s3d_rt_free(*p);
+    *p = NULL;
+}
+
+static int lev_alloc(sift3d_amd_slab *sl, s3d_lev *l, long zlo, long n, size_t pe)
+{
+    l->zlo = zlo; l->n = n; l->pe = pe;
+    return dmalloc(sl, &l->base, (size_t)n * pe * sizeof(float), 1);   /* zeroed: halo planes outside the volume stay 0 */
+}
+
+/* tap spacing per axis of octave o: (float)(1 / units[axis]) (imutil.c:2286-2287 with unit = 1) */
+static void octave_uf(const sift3d_amd_slab *sl, int o, float uf[3])
+{
+    for (int a = 0; a < 3; a++) uf[a] = (float)(1.0 / sl->lunits[o][a]);
+}
+
+/* planes of z halo one application of `f` needs at octave o (s3d_k_sep_fir_slab) */
+static int filter_reach(const sift3d_amd_slab *sl, const Sep_FIR_filter *f, int o)
+{
+    const int hw = f->width / 2;
+    float uf[3];
+    octave_uf(sl, o, uf);
+    if (uf[0] == 1.0f && uf[1] == 1.0f && uf[2] == 1.0f) return hw;     /* fused unit-spacing path: exact */
+    return (int)ceilf((float)hw * uf[2]) + 1;                           /* + 1: the reference's drifting tap coordinate */
+}
+
+/* base-slice boundaries: the largest number of sharded octaves whose slabs are all >= H planes thick */
+static int plan_partition(sift3d_amd_slab *sl)
+{
+    const int G = sl->t.world, r = sl->t.rank;
+    if ((sl->bounds = (int *)calloc((size_t)G + 1, sizeof(int))) == NULL) SLAB_FAIL("sift3d_amd slab: out of memory");
+    sl->o_shard = -1;
+    if (G == 1) {
+        sl->o_shard = sl->no - 1;
+        sl->bounds[0] = 0; sl->bounds[1] = sl->nz;
+    } else {
+        for (int S = sl->no - 1; S >= 0 && sl->o_shard < 0; S--) {
+            /* boundaries aligned so that 2x decimation stays slab-local down to octave S, and one step further when a
+             * replicated octave follows (its seed planes are then whole per rank) */
+            const int A = 1 << (S + (S + 1 < sl->no ? 1 : 0));
+            int ok = 1;
+            for (int q = 0; q < G; q++) sl->bounds[q] = (int)(((long)q * sl->nz / G) / A * A);
+            sl->bounds[G] = sl->nz;
+            for (int q = 0; q < G && ok; q++)
+                if ((sl->bounds[q + 1] >> S) - (sl->bounds[q] >> S) < sl->H) ok = 0;
+            if (ok) sl->o_shard = S;
+        }
+        if (sl->o_shard < 0)
+            SLAB_FAIL("sift3d_amd slab: %d slices over %d ranks gives slabs thinner than the descriptor halo (%d planes); "
+                      "use fewer ranks or a deeper volume", sl->nz, G, sl->H);
+    }
+    for (int o = 0; o < sl->no; o++) {
+        const int nzo = sl->dims[o][2];
+        if (o <= sl->o_shard) {
+            sl->part[o][0] = sl->bounds[r] >> o;
+            sl->part[o][1] = r == G - 1 ? nzo : sl->bounds[r + 1] >> o;
+        } else {
+            sl->part[o][0] = (int)((long)r * nzo / G);
+            sl->part[o][1] = (int)((long)(r + 1) * nzo / G);
+        }
+    }
+    return SIFT3D_SUCCESS;
+}
+
+void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
+{
+    if (sl == NULL) return;
+    s3d_rt_sync(sl->cs);
+    if (sl->ms) s3d_rt_sync(sl->ms);
+    for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&sl->lev[i].base);
+    dfree(&sl->im.base); dfree(&sl->tmp.base); dfree(&sl->d_seed);
+    dfree(&sl->d_bits); dfree(&sl->d_scratch); dfree(&sl->d_kscratch); dfree(&sl->d_count); dfree(&sl->d_red);
+    dfree(&sl->d_cand_idx); dfree(&sl->d_cand_tag); dfree(&sl->d_keep); dfree(&sl->d_R); dfree(&sl->d_Rk);
+    dfree(&sl->d_xyzos); dfree(&sl->d_orient); dfree(&sl->d_mesh); dfree(&sl->d_sigma);
+    dfree(&sl->d_keys); dfree(&sl->d_desc);
+    if (sl->ev_ready) s3d_rt_event_destroy(sl->ev_ready);
+    if (sl->ev_done) s3d_rt_event_destroy(sl->ev_done);
+    if (sl->ms) s3d_rt_stream_destroy(sl->ms);
+    if (sl->own_cs && sl->cs) s3d_rt_stream_destroy(sl->cs);
+    cleanup_SIFT3D(&sl->plan);
+    free(sl->bounds);
+    free(sl);
+}
+
+static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_stream)
+{
+    const int G = sl->t.world;
+    SIFT3D *p = &sl->plan;
+    const Pyramid *g;
+    if (init_SIFT3D(p)) SLAB_FAIL("sift3d_amd slab: init_SIFT3D failed");
+    if (set_sigma_n_SIFT3D(p, params->gpyr.sigma_n) || set_sigma0_SIFT3D(p, params->gpyr.sigma0) ||
+        set_peak_thresh_SIFT3D(p, params->peak_thresh) || set_corner_thresh_SIFT3D(p, params->corner_thresh) ||
+        set_num_kp_levels_SIFT3D(p, (unsigned)params->gpyr.num_kp_levels))
+        SLAB_FAIL("sift3d_amd slab: invalid parameters");
+    if (sift3d_amd_plan(p, sl->nx, sl->ny, sl->nz, sl->units[0], sl->units[1], sl->units[2])) return SIFT3D_FAILURE;
+    g = &p->gpyr;
+    sl->no = g->num_octaves; sl->nl = g->num_levels; sl->nkp = g->num_kp_levels; sl->first_level = g->first_level;
+    for (int o = 0; o < sl->no; o++) {
+        const Image *lv = g->levels + o * sl->nl;
+        sl->dims[o][0] = lv->nx; sl->dims[o][1] = lv->ny; sl->dims[o][2] = lv->nz;
+        sl->lunits[o][0] = lv->ux; sl->lunits[o][1] = lv->uy; sl->lunits[o][2] = lv->uz;
+    }
+    {   /* H: planes a descriptor window (+ the gradient stencil) reaches beyond its centre, in octave voxels: the
+         * window radius is 2 * 7.0711 * sd physical units (sift.c:1846-1847) with sd <= the scale of the last keypoint level */
+        const double sd_max = g->sigma0 * pow(2.0, (double)(sl->nkp - 1) / sl->nkp);
+        sl->H = (int)ceil(2.0 * 7.071067812 * sd_max / sl->units[2]) + 3;
+    }
+    if (plan_partition(sl)) return SIFT3D_FAILURE;
+
+    if (hip_stream) sl->cs = (s3d_stream)hip_stream;
+    else { DEV(s3d_rt_stream_create(&sl->cs)); sl->own_cs = 1; }
+    DEV(s3d_rt_stream_create(&sl->ms));
+    DEV(s3d_rt_event_create(&sl->ev_ready));
+    DEV(s3d_rt_event_create(&sl->ev_done));
+
+    /* ---- buffers ---- */
+    const int hal = G > 1 ? sl->H : 0;
+    size_t tmp_elems;
+    for (int o = 0; o < sl->no; o++) {
+        const size_t pe = (size_t)sl->dims[o][0] * sl->dims[o][1];
+        for (int k = 0; k < sl->nl; k++) {
+            s3d_lev *l = &sl->lev[o * sl->nl + k];
+            if (o <= sl->o_shard && G > 1) {
+                if (lev_alloc(sl, l, sl->part[o][0] - sl->H, (sl->part[o][1] - sl->part[o][0]) + 2 * sl->H, pe)) return SIFT3D_FAILURE;
+            } else if (lev_alloc(sl, l, 0, sl->dims[o][2], pe)) {
+                return SIFT3D_FAILURE;
+            }
+        }
+    }
+    {
+        const int z0 = sl->part[0][0], z1 = sl->part[0][1];
+        const size_t pe0 = (size_t)sl->nx * sl->ny;
+        if (lev_alloc(sl, &sl->im, z0 - hal, (z1 - z0) + 2 * hal, pe0)) return SIFT3D_FAILURE;
+        /* scratch of the separable filter: my octave-0 slab with halos, or a whole replicated octave */
+        tmp_elems = (size_t)((z1 - z0) + 2 * hal) * pe0;
+        for (int o = sl->o_shard + 1; o < sl->no; o++) {
+            const size_t e = (size_t)sl->dims[o][0] * sl->dims[o][1] * sl->dims[o][2];
+            if (e > tmp_elems) tmp_elems = e;
+        }
+        sl->tmp.zlo = z0 - hal; sl->tmp.n = (long)((tmp_elems + pe0 - 1) / pe0); sl->tmp.pe = pe0;
+        if (dmalloc(sl, &sl->tmp.base, (size_t)sl->tmp.n * pe0 * sizeof(float), 1)) return SIFT3D_FAILURE;
+        sl->bits_words = (size_t)(z1 - z0) * pe0 / 64 + 2;
+    }
+    if (G > 1 && sl->o_shard + 1 < sl->no) {          /* seed of the first replicated octave: equal-size contributions */
+        const int o = sl->o_shard + 1;
+        int maxp = 0;
+        for (int q = 0; q < G; q++) {
+            const int a = sl->bounds[q] >> o, b = q == G - 1 ? sl->dims[o][2] : sl->bounds[q + 1] >> o;
+            if (b - a > maxp) maxp = b - a;
+        }
+        sl->seed_elems = (size_t)maxp * sl->dims[o][0] * sl->dims[o][1];
+        if (dmalloc(sl, &sl->d_seed, (size_t)(G + 1) * sl->seed_elems * sizeof(float), 1)) return SIFT3D_FAILURE;
+    }
+    if (dmalloc(sl, &sl->d_bits, S3D_FUSED_KP_MAX * sl->bits_words * sizeof(unsigned long long), 1) ||
+        dmalloc(sl, &sl->d_scratch, (sl->bits_words / 1024 + 16) * sizeof(uint32_t), 1) ||
+        dmalloc(sl, &sl->d_red, 16 * sizeof(float), 1) || dmalloc(sl, &sl->d_count, 8 * sizeof(uint32_t), 1) ||
+        dmalloc(sl, &sl->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS, 0))
+        return SIFT3D_FAILURE;
+    {
+        float mesh[S3D_MESH_FLOATS];
+        s3d_mesh_table(mesh);
+        if (dmalloc(sl, &sl->d_mesh, sizeof(mesh), 0)) return SIFT3D_FAILURE;
+        DEV(s3d_rt_h2d(sl->d_mesh, mesh, sizeof(mesh), sl->cs));
+        for (int i = 0; i < sl->no * sl->nl; i++) sl->h_sigma[i] = 1.5 * g->levels[i].s;    /* ori_sig_fctr */
+        DEV(s3d_rt_h2d(sl->d_sigma, sl->h_sigma, sizeof(double) * (size_t)sl->no * sl->nl, sl->cs));
+        DEV(s3d_rt_sync(sl->cs));                       /* `mesh` is a stack buffer */
+    }
+    memset(&sl->pd, 0, sizeof(sl->pd));
+    sl->pd.num_octaves = sl->no; sl->pd.num_levels = sl->nl; sl->pd.first_level = sl->first_level;
+    for (int o = 0; o < sl->no; o++) {
+        for (int a = 0; a < 3; a++) {
+            sl->pd.dims[o][a] = sl->dims[o][a];
+            sl->pd.unitsf[o][a] = (float)sl->lunits[o][a];
+        }
+        for (int k = 0; k < sl->nl; k++) sl->pd.d_level[o * sl->nl + k] = lev_view(&sl->lev[o * sl->nl + k]);
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_slab_create(sift3d_amd_slab **out, const SIFT3D *params, const sift3d_amd_transport *t, int nx, int ny,
+                           int nz, double ux, double uy, double uz, void *hip_stream)
+{
+    sift3d_amd_slab *sl;
+    *out = NULL;
+    if (t == NULL || t->world < 1 || t->rank < 0 || t->rank >= t->world) SLAB_FAIL("sift3d_amd_slab_create: bad transport");
+    if (t->world > 1 && (!t->allreduce_max || !t->exchange || !t->allgather || !t->allgather_host))
+        SLAB_FAIL("sift3d_amd_slab_create: incomplete transport");
+    if (nx < 1 || ny < 1 || nz < 1) SLAB_FAIL("sift3d_amd_slab_create: bad dimensions");
+    if ((sl = (sift3d_amd_slab *)calloc(1, sizeof(*sl))) == NULL) SLAB_FAIL("sift3d_amd_slab_create: out of memory");
+    sl->t = *t;
+    sl->nx = nx; sl->ny = ny; sl->nz = nz;
+    sl->units[0] = ux; sl->units[1] = uy; sl->units[2] = uz;
+    if (slab_build(sl, params, hip_stream)) {
+        sift3d_amd_slab_destroy(sl);
+        return SIFT3D_FAILURE;
+    }
+    *out = sl;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_slab_get_info(const sift3d_amd_slab *sl, sift3d_amd_slab_info *info)
+{
+    info->rank = sl->t.rank; info->world = sl->t.world;
+    info->z0 = sl->part[0][0]; info->z1 = sl->part[0][1];
+    info->o_shard = sl->o_shard; info->halo = sl->H;
+    info->num_octaves = sl->no; info->num_levels = sl->nl;
+    info->num_candidates = sl->num_candidates; info->num_keypoints = sl->num_keypoints;
+    info->halo_bytes = sl->halo_bytes; info->device_bytes = sl->device_bytes;
+    info->detect_ms = sl->detect_ms; info->describe_ms = sl->describe_ms;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_slab_owner(const sift3d_amd_slab *sl, const Keypoint *key)
+{
+    const int G = sl->t.world, o = key->o;
+    if (o < 0 || o >= sl->no || key->zd < 0 || key->zd >= sl->dims[o][2]) return -1;
+    const int z = (int)key->zd, nzo = sl->dims[o][2];
+    if (o <= sl->o_shard) {
+        for (int q = 0; q < G; q++) {
+            const int b = q == G - 1 ? nzo : sl->bounds[q + 1] >> o;
+            if (z < b) return q;
+        }
+        return G - 1;
+    }
+    for (int q = 0; q < G; q++)
+        if (z < (int)((long)(q + 1) * nzo / G)) return q;
+    return G - 1;
+}
+
+/* ---- halo traffic -------------------------------------------------------------------------------------------- */
+/* Fill h halo planes on each interior side of a sharded level from the Z-neighbours.  now < h: only the `now`
+ * planes next to the slab are ordered with the compute stream (what the next Gaussian and the extrema read); the
+ * outer h - now planes -- orientation / descriptor windows, read only after finish_halos() -- travel on the transfer
+ * lane while the rest of the pyramid is computed. */
+static int exchange_halo(sift3d_amd_slab *sl, const s3d_lev *lv, int o, int h, int now)
+{
+    if (sl->t.world == 1 || h <= 0) return SIFT3D_SUCCESS;
+    const int z0 = sl->part[o][0], z1 = sl->part[o][1];
+    const int n = (now <= 0 || now >= h) ? h : now;
+    const size_t pb = lv->pe * sizeof(float);
+    const int sides = (sl->t.rank > 0) + (sl->t.rank < sl->t.world - 1);
+    COMM(sl->t.exchange(sl->t.self, lev_ptr(lv, z0), lev_ptr(lv, z0 - n), lev_ptr(lv, z1 - n), lev_ptr(lv, z1),
+                        (size_t)n * pb, 0, sl->cs));
+    sl->halo_bytes += (double)sides * n * pb;
+    if (n < h) {
+        DEV(s3d_rt_event_record(sl->ev_ready, sl->cs));
+        DEV(s3d_rt_stream_wait_event(sl->ms, sl->ev_ready));
+        COMM(sl->t.exchange(sl->t.self, lev_ptr(lv, z0 + n), lev_ptr(lv, z0 - h), lev_ptr(lv, z1 - h), lev_ptr(lv, z1 + n),
+                            (size_t)(h - n) * pb, 1, sl->ms));
+        sl->halo_bytes += (double)sides * (h - n) * pb;
+        sl->pending = 1;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+static int finish_halos(sift3d_amd_slab *sl)
+{
+    if (sl->pending) {
+        DEV(s3d_rt_event_record(sl->ev_done, sl->ms));
+        DEV(s3d_rt_stream_wait_event(sl->cs, sl->ev_done));
+        sl->pending = 0;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* halo planes level k of a sharded octave needs from each neighbour once it is complete */
+static int halo_of_level(const sift3d_amd_slab *sl, int o, int k)
+{
+    int h = 1;                                              /* the extrema look at z +- 1 */
+    if (k + 1 < sl->nl) {
+        const int rch = filter_reach(sl, &sl->plan.gss.gauss_octave[k].f, o);
+        if (rch > h) h = rch;                               /* the next Gaussian's reach */
+    }
+    if (k >= 1 && k <= sl->nkp && sl->H > h) h = sl->H;      /* levels s = 0..nkp-1: orientation + descriptor windows */
+    return h;
+}
+
+static int gauss(sift3d_amd_slab *sl, const s3d_lev *src, const s3d_lev *dst, int o, const Sep_FIR_filter *f)
+{
+    float uf[3];
+    octave_uf(sl, o, uf);
+    if (o <= sl->o_shard && sl->t.world > 1) {
+        const int z0 = sl->part[o][0], z1 = sl->part[o][1];
+        const size_t pe = (size_t)sl->dims[o][0] * sl->dims[o][1];
+        /* the scratch, seen as a view of this octave whose first backed plane is z0 - H */
+        float *tmpv = (float *)((uintptr_t)sl->tmp.base - (uintptr_t)((intptr_t)(z0 - sl->H) * (intptr_t)pe * 4));
+        DEV(s3d_k_sep_fir_slab(lev_view(src), lev_view(dst), tmpv, sl->dims[o][0], sl->dims[o][1], sl->dims[o][2], z0, z1, uf,
+                               f->kernel, f->width, sl->cs));
+    } else {
+        DEV(s3d_k_sep_fir(lev_view(src), lev_view(dst), sl->tmp.base, sl->dims[o][0], sl->dims[o][1], sl->dims[o][2], 1, uf,
+                          f->kernel, f->width, sl->cs));
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- detect ---------------------------------------------------------------------------------------------------- */
+static int ensure_candidates(sift3d_amd_slab *sl, uint32_t cap)
+{
+    if (sl->cap >= cap) return SIFT3D_SUCCESS;
+    dfree(&sl->d_cand_idx); dfree(&sl->d_cand_tag); dfree(&sl->d_keep); dfree(&sl->d_R); dfree(&sl->d_Rk);
+    dfree(&sl->d_xyzos); dfree(&sl->d_kscratch);
+    sl->cap = 0;
+    if (dmalloc(sl, &sl->d_cand_idx, (size_t)cap * sizeof(uint32_t), 0) || dmalloc(sl, &sl->d_cand_tag, (size_t)cap * sizeof(uint32_t), 0) ||
+        dmalloc(sl, &sl->d_keep, (size_t)cap * sizeof(uint32_t), 0) || dmalloc(sl, &sl->d_R, (size_t)cap * 9 * sizeof(float), 0) ||
+        dmalloc(sl, &sl->d_Rk, (size_t)cap * 9 * sizeof(float), 0) || dmalloc(sl, &sl->d_xyzos, (size_t)cap * 5 * sizeof(int32_t), 0) ||
+        dmalloc(sl, &sl->d_kscratch, ((size_t)cap / 256 + 8) * sizeof(uint32_t), 0))
+        return SIFT3D_FAILURE;
+    sl->cap = cap;
+    return SIFT3D_SUCCESS;
+}
+
+static int build_pyramid(sift3d_amd_slab *sl)
+{
+    const int G = sl->t.world, sharded = G > 1, nl = sl->nl;
+    const GSS_filters *gss = &sl->plan.gss;
+    if (exchange_halo(sl, &sl->im, 0, filter_reach(sl, &gss->first_gauss.f, 0), 0)) return SIFT3D_FAILURE;
+    if (gauss(sl, &sl->im, &sl->lev[0], 0, &gss->first_gauss.f)) return SIFT3D_FAILURE;
+    for (int o = 0; o < sl->no; o++) {
+        const int shard_o = sharded && o <= sl->o_shard;
+        s3d_lev *L = &sl->lev[o * nl];
+        for (int k = 1; k < nl; k++) {
+            const Sep_FIR_filter *f = &gss->gauss_octave[k - 1].f;
+            if (shard_o) {      /* the next Gaussian reads `reach` planes, the extrema one; the rest may arrive later */
+                int nowp = filter_reach(sl, f, o);
+                if (nowp < 1) nowp = 1;
+                if (exchange_halo(sl, &L[k - 1], o, halo_of_level(sl, o, k - 1), nowp)) return SIFT3D_FAILURE;
+            }
+            if (gauss(sl, &L[k - 1], &L[k], o, f)) return SIFT3D_FAILURE;
+        }
+        if (shard_o && exchange_halo(sl, &L[nl - 1], o, halo_of_level(sl, o, nl - 1), 0)) return SIFT3D_FAILURE;
+        if (o + 1 < sl->no) {
+            const int ds = nl - 3 > 0 ? nl - 3 : 0;          /* level index of s_end - 2 (sift.c:1036-1045) */
+            const int nxo = sl->dims[o][0], nyo = sl->dims[o][1], nzo = sl->dims[o][2];
+            s3d_lev *N = &sl->lev[(o + 1) * nl];
+            if (sharded && o + 1 <= sl->o_shard) {           /* slab-local decimation */
+                const int a = sl->part[o + 1][0], b = sl->part[o + 1][1];
+                DEV(s3d_k_decimate2(lev_ptr(&L[ds], 2 * a), nxo, nyo, 2 * (b - a), lev_ptr(&N[0], a), sl->cs));
+            } else if (sharded && o == sl->o_shard) {        /* seed the first replicated octave */
+                const size_t pen = (size_t)sl->dims[o + 1][0] * sl->dims[o + 1][1];
+                const int a = sl->bounds[sl->t.rank] >> (o + 1);
+                const int b = sl->t.rank == G - 1 ? sl->dims[o + 1][2] : sl->bounds[sl->t.rank + 1] >> (o + 1);
+                float *mine = sl->d_seed + (size_t)G * sl->seed_elems;
+                if (b > a) DEV(s3d_k_decimate2(lev_ptr(&L[ds], 2 * a), nxo, nyo, 2 * (b - a), mine, sl->cs));
+                COMM(sl->t.allgather(sl->t.self, mine, sl->d_seed, sl->seed_elems * sizeof(float), sl->cs));
+                sl->halo_bytes += (double)(G - 1) * sl->seed_elems * sizeof(float);
+                for (int q = 0; q < G; q++) {
+                    const int qa = sl->bounds[q] >> (o + 1);
+                    const int qb = q == G - 1 ? sl->dims[o + 1][2] : sl->bounds[q + 1] >> (o + 1);
+                    if (qb > qa)
+                        DEV(s3d_rt_d2d(lev_ptr(&N[0], qa), sl->d_seed + (size_t)q * sl->seed_elems,
+                                       (size_t)(qb - qa) * pen * sizeof(float), sl->cs));
+                }
+            } else {
+                DEV(s3d_k_decimate2(lev_view(&L[ds]), nxo, nyo, nzo, lev_view(&N[0]), sl->cs));
+            }
+        }
+    }
+    return finish_halos(sl);
+}
+
+/* detect_extrema over my planes of every octave; the candidate list in the reference's scan order */
+static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
+{
+    const int G = sl->t.world, nl = sl->nl, nkp = sl->nkp;
+    uint32_t cap = sl->cap;
+    if (cap == 0) {
+        size_t nloc = 0;
+        for (int o = 0; o < sl->no; o++) nloc += (size_t)(sl->part[o][1] - sl->part[o][0]) * sl->dims[o][0] * sl->dims[o][1];
+        cap = (uint32_t)(nloc / 128 + 4096);
+    }
+    for (;;) {
+        if (ensure_candidates(sl, cap)) return SIFT3D_FAILURE;
+        DEV(s3d_rt_memset(sl->d_count, 0, 8 * sizeof(uint32_t), sl->cs));
+        for (int o = 0; o < sl->no; o++) {
+            const int nxo = sl->dims[o][0], nyo = sl->dims[o][1], nzo = sl->dims[o][2];
+            const size_t pe = (size_t)nxo * nyo;
+            const int za = sl->part[o][0], zb = sl->part[o][1];
+            const int shard_o = G > 1 && o <= sl->o_shard;
+            const s3d_lev *L = &sl->lev[o * nl];
+            if (zb <= za) continue;          /* only in a replicated octave with fewer planes than ranks: no collectives there */
+            const size_t nwords = ((size_t)(zb - za) * pe + 63) / 64;
+            const int fused = nkp == 3 && (nxo & 3) == 0;   /* all keypoint levels in one pass (s3d_k_extrema_fused) */
+            if (fused) {
+                const float *l4[4], *l6[6];
+                unsigned long long *bits[3];
+                for (int k = 0; k < 4; k++) l4[k] = shard_o ? lev_ptr(&L[k + 1], za) : lev_view(&L[k + 1]);
+                DEV(s3d_k_dogmax3(l4, (size_t)(shard_o ? zb - za : nzo) * pe, sl->d_red + 1, sl->cs));
+                if (shard_o) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 3, sl->cs));   /* the three maxima at once */
+                for (int k = 0; k < 6; k++) l6[k] = lev_view(&L[k]);
+                for (int k = 0; k < 3; k++) bits[k] = sl->d_bits + (size_t)k * sl->bits_words;
+                if (s3d_k_extrema_fused(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
+                    SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                for (int ks = 1; ks <= 3; ks++)
+                    DEV(s3d_k_compact_bits_base(bits[ks - 1], nwords, (uint32_t)((size_t)za * pe), sl->d_cand_idx, sl->d_cand_tag,
+                                                ((uint32_t)o << 8) | (uint32_t)ks, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
+                continue;
+            }
+            for (int ks = 1; ks <= nkp; ks++) {
+                if (shard_o) {      /* max |DoG| over my planes, then over the ranks (sift.c:1161-1169) */
+                    DEV(s3d_k_dogmax(lev_ptr(&L[ks], za), lev_ptr(&L[ks + 1], za), (size_t)(zb - za) * pe, sl->d_red + 1, sl->cs));
+                    COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 1, sl->cs));
+                } else {            /* replicated octave: every rank sees the whole level */
+                    DEV(s3d_k_dogmax(lev_view(&L[ks]), lev_view(&L[ks + 1]), (size_t)nzo * pe, sl->d_red + 1, sl->cs));
+                }
+                DEV(s3d_k_extrema_slab(lev_view(&L[ks - 1]), lev_view(&L[ks]), lev_view(&L[ks + 1]), lev_view(&L[ks + 2]), nxo, nyo,
+                                       nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, sl->d_bits, sl->cs));
+                DEV(s3d_k_compact_bits_base(sl->d_bits, nwords, (uint32_t)((size_t)za * pe), sl->d_cand_idx, sl->d_cand_tag,
+                                            ((uint32_t)o << 8) | (uint32_t)ks, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
+            }
+        }
+        DEV(s3d_rt_d2h(sl->h_counts, sl->d_count, sizeof(uint32_t), sl->cs));
+        DEV(s3d_rt_sync(sl->cs));
+        /* the redo decision must be collective: a rank that looped alone would re-enter the all-reduces */
+        sl->h_flag = sl->h_counts[0] > sl->cap ? 1.0f : 0.0f;
+        if (G > 1) {
+            DEV(s3d_rt_h2d(sl->d_red + 8, &sl->h_flag, sizeof(float), sl->cs));
+            COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 8, 1, sl->cs));
+            DEV(s3d_rt_d2h(&sl->h_flag, sl->d_red + 8, sizeof(float), sl->cs));
+            DEV(s3d_rt_sync(sl->cs));
+        }
+        if (sl->h_flag == 0.0f) break;
+        cap = sl->h_counts[0] + 1024 > sl->cap ? sl->h_counts[0] + 1024 : sl->cap + 1024;
+    }
+    *ncand = sl->h_counts[0];
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp)
+{
+    const int z0 = sl->part[0][0], z1 = sl->part[0][1];
+    const size_t n_local = (size_t)(z1 - z0) * sl->nx * sl->ny;
+    float *own = lev_ptr(&sl->im, z0);
+    uint32_t ncand = 0, K;
+    const double t0 = now_ms();
+    if (vol == NULL) SLAB_FAIL("sift3d_amd_slab_detect: no volume");
+    sl->halo_bytes = 0.0;
+    if (on_device) DEV(s3d_rt_d2d(own, vol, n_local * sizeof(float), sl->cs));
+    else DEV(s3d_rt_h2d(own, vol, n_local * sizeof(float), sl->cs));
+    /* im_scale with the global maximum (sift.c:903, imutil.c:1977-1991) */
+    DEV(s3d_k_absmax(own, n_local, sl->d_red, sl->cs));
+    if (sl->t.world > 1) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red, 1, sl->cs));
+    DEV(s3d_k_scale_div(own, n_local, sl->d_red, sl->cs));
+    if (build_pyramid(sl)) return SIFT3D_FAILURE;
+    if (find_candidates(sl, &ncand)) return SIFT3D_FAILURE;
+    sl->num_candidates = (long)ncand;
+    sl->num_keypoints = 0;
+    kp->nx = sl->nx; kp->ny = sl->ny; kp->nz = sl->nz;
+    if (ncand == 0) return resize_Keypoint_store(kp, 0);
+    {
+        const size_t need = s3d_k_orient_scratch_bytes(ncand);
+        if (need > sl->orient_bytes) {
+            dfree(&sl->d_orient);
+            sl->orient_bytes = 0;
+            if (dmalloc(sl, &sl->d_orient, need, 0)) return SIFT3D_FAILURE;
+            sl->orient_bytes = need;
+        }
+    }
+    DEV(s3d_k_orient(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, NULL, ncand, sl->d_sigma, sl->plan.corner_thresh, sl->d_R,
+                     sl->d_keep, NULL, sl->d_orient, sl->cs));
+    DEV(s3d_k_compact_keys(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, sl->d_R, sl->d_keep, ncand, sl->d_xyzos, sl->d_Rk,
+                           sl->d_count + 1, sl->d_kscratch, sl->cs));
+    DEV(s3d_rt_d2h(sl->h_counts + 1, sl->d_count + 1, sizeof(uint32_t), sl->cs));
+    DEV(s3d_rt_sync(sl->cs));
+    K = sl->h_counts[1];
+    sl->num_keypoints = (long)K;
+    if (resize_Keypoint_store(kp, K)) return SIFT3D_FAILURE;
+    if (K == 0) return SIFT3D_SUCCESS;
+    {
+        int32_t *xyzos = (int32_t *)malloc((size_t)K * 5 * sizeof(int32_t));
+        float *R = (float *)malloc((size_t)K * 9 * sizeof(float));
+        if (!xyzos || !R) { free(xyzos); free(R); SLAB_FAIL("sift3d_amd slab: out of host memory"); }
+        if (s3d_rt_d2h(xyzos, sl->d_xyzos, (size_t)K * 5 * sizeof(int32_t), sl->cs) ||
+            s3d_rt_d2h(R, sl->d_Rk, (size_t)K * 9 * sizeof(float), sl->cs) || s3d_rt_sync(sl->cs)) {
+            free(xyzos); free(R);
+            SLAB_FAIL("sift3d_amd slab: keypoint download failed: %s", s3d_rt_last_error());
+        }
+        for (uint32_t i = 0; i < K; i++) {
+            Keypoint *key = kp->buf + i;
+            init_Keypoint(key);
+            key->xd = (double)xyzos[5 * i + 0]; key->yd = (double)xyzos[5 * i + 1]; key->zd = (double)xyzos[5 * i + 2];
+            key->o = xyzos[5 * i + 3]; key->s = xyzos[5 * i + 4];
+            key->sd = SIFT3D_PYR_IM_GET(&sl->plan.dog, key->o, key->s)->s;
+            memcpy(key->r_data, R + 9 * i, 9 * sizeof(float));
+        }
+        free(xyzos); free(R);
+    }
+    sl->detect_ms = now_ms() - t0;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- describe --------------------------------------------------------------------------------------------------- */
+/* Descriptors of kp->buf[sel[j]], j < nsel (sel == NULL: all of kp), of keypoints this rank owns.  Records go to
+ * sl->d_desc[j]; with `out` they are also copied to out[sel[j]] (runs of consecutive indices in one transfer each),
+ * coordinate fields filled as sift.c:1920-1925. */
+static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const size_t *sel, size_t nsel, SIFT3D_Descriptor *out)
+{
+    const Pyramid *g = &sl->plan.gpyr;
+    s3d_desc_key *keys;
+    if (nsel == 0) return SIFT3D_SUCCESS;
+    if (sl->desc_cap < nsel) {
+        dfree(&sl->d_keys); dfree(&sl->d_desc);
+        sl->desc_cap = 0;
+        if (dmalloc(sl, &sl->d_keys, nsel * sizeof(s3d_desc_key), 0) || dmalloc(sl, &sl->d_desc, nsel * sizeof(SIFT3D_Descriptor), 0))
+            return SIFT3D_FAILURE;
+        sl->desc_cap = nsel;
+    }
+    if ((keys = (s3d_desc_key *)malloc(nsel * sizeof(s3d_desc_key))) == NULL) SLAB_FAIL("sift3d_amd slab: out of host memory");
+    for (size_t j = 0; j < nsel; j++) {
+        const Keypoint *key = kp->buf + (sel ? sel[j] : j);
+        const int oi = key->o - g->first_octave, ki = key->s - g->first_level;
+        if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) {
+            free(keys);
+            SLAB_FAIL("sift3d_amd slab: keypoint %zu has no pyramid level (o=%d, s=%d)", sel ? sel[j] : j, key->o, key->s);
+        }
+        if (sl->t.world > 1 && sift3d_amd_slab_owner(sl, key) != sl->t.rank) {
+            free(keys);
+            SLAB_FAIL("sift3d_amd slab: keypoint %zu (z=%g, octave %d) is not in rank %d's slab", sel ? sel[j] : j, key->zd,
+                      key->o, sl->t.rank);
+        }
+        s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + j);
+    }
+    if (s3d_rt_h2d(sl->d_keys, keys, nsel * sizeof(s3d_desc_key), sl->cs) ||
+        s3d_k_describe(&sl->pd, sl->d_keys, (uint32_t)nsel, sl->d_mesh, sl->d_desc, DESC_REC_FLOATS, sl->cs)) {
+        s3d_rt_sync(sl->cs);
+        free(keys);
+        SLAB_FAIL("sift3d_amd slab: describe failed: %s", s3d_rt_last_error());
+    }
+    if (out) {
+        for (size_t j = 0; j < nsel;) {
+            size_t e = j + 1;
+            while (e < nsel && sel && sel[e] == sel[e - 1] + 1) e++;
+            if (!sel) e = nsel;
+            if (s3d_rt_d2h(out + (sel ? sel[j] : j), sl->d_desc + j * DESC_REC_FLOATS, (e - j) * sizeof(SIFT3D_Descriptor), sl->cs)) {
+                s3d_rt_sync(sl->cs);
+                free(keys);
+                SLAB_FAIL("sift3d_amd slab: descriptor download failed: %s", s3d_rt_last_error());
+            }
+            j = e;
+        }
+    }
+    if (s3d_rt_sync(sl->cs)) { free(keys); SLAB_FAIL("sift3d_amd slab: describe failed: %s", s3d_rt_last_error()); }
+    free(keys);
+    if (out)
+        for (size_t j = 0; j < nsel; j++) {
+            const size_t i = sel ? sel[j] : j;
+            const Keypoint *key = kp->buf + i;
+            const double f = ldexp(1.0, key->o);
+            out[i].xd = key->xd * f; out[i].yd = key->yd * f; out[i].zd = key->zd * f;
+            out[i].sd = key->sd;
+        }
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_slab_describe(sift3d_amd_slab *sl, const Keypoint_store *kp, SIFT3D_Descriptor_store *desc, const float **d_desc)
+{
+    const size_t num = kp->slab.num;
+    const double t0 = now_ms();
+    if (d_desc) *d_desc = NULL;
+    if (desc) { desc->nx = sl->nx; desc->ny = sl->ny; desc->nz = sl->nz; }
+    if (num == 0) {                           /* a rank may own no keypoints: not an error here */
+        if (desc) { free(desc->buf); desc->buf = NULL; desc->num = 0; }
+        return SIFT3D_SUCCESS;
+    }
+    if (s3d_verify_keys(kp, sl->nx, sl->ny, sl->nz)) return SIFT3D_FAILURE;
+    if (desc && s3d_resize_descriptor_store(desc, (long)num)) return SIFT3D_FAILURE;
+    if (describe_sel(sl, kp, NULL, num, desc ? desc->buf : NULL)) return SIFT3D_FAILURE;
+    if (d_desc) *d_desc = sl->d_desc;
+    sl->describe_ms = now_ms() - t0;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- gather ------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t x, y, z, o, s, pad;
+    double sd;
+    float R[9];
+    float pad2;
+} kp_rec;
+
+/* order of the reference: (o, s) groups ascending; inside a group the ranks in z order, each rank's list as it is */
+static void merge_order(const kp_rec *const *lists, const long *counts, int G, long *rank_of, long *idx_of)
+{
+    long *cur = (long *)calloc((size_t)G, sizeof(long));
+    long n = 0, total = 0;
+    for (int q = 0; q < G; q++) total += counts[q];
+    while (n < total) {
+        int bo = 0x7fffffff, bs = 0x7fffffff;
+        for (int q = 0; q < G; q++)
+            if (cur[q] < counts[q]) {
+                const kp_rec *k = lists[q] + cur[q];
+                if (k->o < bo || (k->o == bo && k->s < bs)) { bo = k->o; bs = k->s; }
+            }
+        for (int q = 0; q < G; q++)
+            while (cur[q] < counts[q] && lists[q][cur[q]].o == bo && lists[q][cur[q]].s == bs) {
+                rank_of[n] = q; idx_of[n] = cur[q];
+                n++; cur[q]++;
+            }
+    }
+    free(cur);
+}
+
+int sift3d_amd_slab_gather(sift3d_amd_slab *sl, const Keypoint_store *kp, const SIFT3D_Descriptor_store *desc,
+                           Keypoint_store *kp_all, SIFT3D_Descriptor_store *desc_all)
+{
+    const int G = sl->t.world;
+    const long K = (long)kp->slab.num;
+    long *counts = (long *)calloc((size_t)G, sizeof(long)), maxk = 0, total = 0;
+    long *rank_of = NULL, *idx_of = NULL;
+    kp_rec *mine = NULL, *all = NULL;
+    const kp_rec **lists = NULL;
+    SIFT3D_Descriptor *dall = NULL, *dmine = NULL;
+    int rc = SIFT3D_FAILURE;
+    const int want_desc = desc != NULL && desc_all != NULL;
+    if (!counts) goto done;
+    if (G == 1) counts[0] = K;
+    else if (sl->t.allgather_host(sl->t.self, &K, counts, sizeof(long))) goto done;
+    for (int q = 0; q < G; q++) { if (counts[q] > maxk) maxk = counts[q]; total += counts[q]; }
+    kp_all->nx = sl->nx; kp_all->ny = sl->ny; kp_all->nz = sl->nz;
+    if (desc_all) { desc_all->nx = sl->nx; desc_all->ny = sl->ny; desc_all->nz = sl->nz; }
+    if (total == 0) { rc = resize_Keypoint_store(kp_all, 0); goto done; }
+    mine = (kp_rec *)calloc((size_t)maxk, sizeof(kp_rec));
+    all = (kp_rec *)calloc((size_t)maxk * G, sizeof(kp_rec));
+    lists = (const kp_rec **)calloc((size_t)G, sizeof(*lists));
+    rank_of = (long *)calloc((size_t)total, sizeof(long));
+    idx_of = (long *)calloc((size_t)total, sizeof(long));
+    if (!mine || !all || !lists || !rank_of || !idx_of) goto done;
+    for (long i = 0; i < K; i++) {
+        const Keypoint *key = kp->buf + i;
+        kp_rec *r = mine + i;
+        r->x = (int32_t)key->xd; r->y = (int32_t)key->yd; r->z = (int32_t)key->zd; r->o = key->o; r->s = key->s;
+        r->sd = key->sd;
+        memcpy(r->R, key->R.u.data_float ? key->R.u.data_float : key->r_data, sizeof(r->R));
+    }
+    if (G == 1) memcpy(all, mine, (size_t)K * sizeof(kp_rec));
+    else if (sl->t.allgather_host(sl->t.self, mine, all, (size_t)maxk * sizeof(kp_rec))) goto done;
+    for (int q = 0; q < G; q++) lists[q] = all + (size_t)q * maxk;
+    merge_order(lists, counts, G, rank_of, idx_of);
+    if (resize_Keypoint_store(kp_all, (size_t)total)) goto done;
+    for (long i = 0; i < total; i++) {
+        const kp_rec *r = lists[rank_of[i]] + idx_of[i];
+        Keypoint *key = kp_all->buf + i;
+        init_Keypoint(key);
+        key->xd = r->x; key->yd = r->y; key->zd = r->z; key->o = r->o; key->s = r->s; key->sd = r->sd;
+        memcpy(key->r_data, r->R, sizeof(r->R));
+    }
+    if (want_desc) {
+        if (s3d_resize_descriptor_store(desc_all, total)) goto done;
+        if (G == 1) {
+            memcpy(desc_all->buf, desc->buf, (size_t)K * sizeof(SIFT3D_Descriptor));
+        } else {
+            dmine = (SIFT3D_Descriptor *)calloc((size_t)maxk, sizeof(SIFT3D_Descriptor));
+            dall = (SIFT3D_Descriptor *)malloc((size_t)maxk * G * sizeof(SIFT3D_Descriptor));
+            if (!dmine || !dall) goto done;
+            if (K) memcpy(dmine, desc->buf, (size_t)K * sizeof(SIFT3D_Descriptor));
+            if (sl->t.allgather_host(sl->t.self, dmine, dall, (size_t)maxk * sizeof(SIFT3D_Descriptor))) goto done;
+            for (long i = 0; i < total; i++)
+                desc_all->buf[i] = dall[(size_t)rank_of[i] * maxk + idx_of[i]];
+        }
+    }
+    rc = SIFT3D_SUCCESS;
+done:
+    free(counts); free(mine); free(all); free(lists); free(rank_of); free(idx_of); free(dall); free(dmine);
+    if (rc) S3D_MSG("sift3d_amd_slab_gather failed\n");
+    return rc;
+}
+
+/* ====================================================================================================================
+ * Loop-back transport: `world` ranks are host threads of this process.  Every operation is
+ *      synchronise my stream (my data is complete) | barrier | pull from the peers, device to device | synchronise |
+ *      barrier (peers may overwrite what I read).
+ * No overlap, by design: it exists so that the multi-rank driver above can be exercised -- bit for bit -- on a box
+ * with a single GPU (all ranks on one device) and under the CPU emulator. */
+typedef struct {
+    int world, alive;
+    pthread_barrier_t bar;
+    pthread_mutex_t lock;
+    const void *slot[2][256];          /* published pointers: [0] lo / generic, [1] hi */
+    float red[256][16];
+} lb_group;
+
+typedef struct {
+    lb_group *g;
+    int rank;
+} lb_rank;
+
+static int lb_allreduce_max(void *self, float *d_buf, int n, void *stream)
+{
+    lb_rank *me = (lb_rank *)self;
+    lb_group *g = me->g;
+    float v[16];
+    if (n > 16) return -1;
+    if (s3d_rt_d2h(g->red[me->rank], d_buf, (size_t)n * sizeof(float), stream) || s3d_rt_sync(stream)) return -1;
+    pthread_barrier_wait(&g->bar);
+    for (int i = 0; i < n; i++) {
+        v[i] = g->red[0][i];
+        for (int q = 1; q < g->world; q++)
+            if (g->red[q][i] > v[i]) v[i] = g->red[q][i];
+    }
+    pthread_barrier_wait(&g->bar);
+    if (s3d_rt_h2d(d_buf, v, (size_t)n * sizeof(float), stream) || s3d_rt_sync(stream)) return -1;
+    return 0;
+}
+
+static int lb_exchange(void *self, const void *d_send_lo, void *d_recv_lo, const void *d_send_hi, void *d_recv_hi, size_t bytes,
+                       int lane, void *stream)
+{
+    lb_rank *me = (lb_rank *)self;
+    lb_group *g = me->g;
+    int rc = 0;
+    (void)lane;
+    if (s3d_rt_sync(stream)) rc = -1;
+    g->slot[0][me->rank] = d_send_lo;
+    g->slot[1][me->rank] = d_send_hi;
+    pthread_barrier_wait(&g->bar);
+    if (me->rank > 0 && s3d_rt_d2d(d_recv_lo, g->slot[1][me->rank - 1], bytes, stream)) rc = -1;
+    if (me->rank < g->world - 1 && s3d_rt_d2d(d_recv_hi, g->slot[0][me->rank + 1], bytes, stream)) rc = -1;
+    if (s3d_rt_sync(stream)) rc = -1;
+    pthread_barrier_wait(&g->bar);
+    return rc;
+}
+
+static int lb_allgather(void *self, const void *d_send, void *d_recv, size_t bytes, void *stream)
+{
+    lb_rank *me = (lb_rank *)self;
+    lb_group *g = me->g;
+    int rc = 0;
+    if (s3d_rt_sync(stream)) rc = -1;
+    g->slot[0][me->rank] = d_send;
+    pthread_barrier_wait(&g->bar);
+    for (int q = 0; q < g->world; q++)
+        if (s3d_rt_d2d((char *)d_recv + (size_t)q * bytes, g->slot[0][q], bytes, stream)) rc = -1;
+    if (s3d_rt_sync(stream)) rc = -1;
+    pthread_barrier_wait(&g->bar);
+    return rc;
+}
+
+static int lb_allgather_host(void *self, const void *send, void *recv, size_t bytes)
+{
+    lb_rank *me = (lb_rank *)self;
+    lb_group *g = me->g;
+    g->slot[0][me->rank] = send;
+    pthread_barrier_wait(&g->bar);
+    for (int q = 0; q < g->world; q++) memcpy((char *)recv + (size_t)q * bytes, g->slot[0][q], bytes);
+    pthread_barrier_wait(&g->bar);
+    return 0;
+}
+
+static void lb_destroy(void *self)
+{
+    lb_rank *me = (lb_rank *)self;
+    lb_group *g = me->g;
+    int last;
+    pthread_mutex_lock(&g->lock);
+    last = --g->alive == 0;
+    pthread_mutex_unlock(&g->lock);
+    free(me);
+    if (last) {
+        pthread_barrier_destroy(&g->bar);
+        pthread_mutex_destroy(&g->lock);
+        free(g);
+    }
+}
+
+int sift3d_amd_loopback_create(int world, sift3d_amd_transport *t)
+{
+    lb_group *g;
+    if (world < 1 || world > 256) SLAB_FAIL("sift3d_amd_loopback_create: world must be in [1, 256]");
+    if ((g = (lb_group *)calloc(1, sizeof(*g))) == NULL) SLAB_FAIL("sift3d_amd_loopback_create: out of memory");
+    g->world = g->alive = world;
+    pthread_barrier_init(&g->bar, NULL, (unsigned)world);
+    pthread_mutex_init(&g->lock, NULL);
+    for (int r = 0; r < world; r++) {
+        lb_rank *me = (lb_rank *)calloc(1, sizeof(*me));
+        if (!me) SLAB_FAIL("sift3d_amd_loopback_create: out of memory");
+        me->g = g; me->rank = r;
+        t[r].rank = r; t[r].world = world; t[r].self = me;
+        t[r].allreduce_max = lb_allreduce_max;
+        t[r].exchange = lb_exchange;
+        t[r].allgather = lb_allgather;
+        t[r].allgather_host = lb_allgather_host;
+        t[r].destroy = lb_destroy;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* ====================================================================================================================
+ * s3d_mgpu: one process, N GPUs, behind SIFT3D_detect_keypoints / SIFT3D_extract_descriptors.  One host thread per
+ * rank for the duration of a call (thread r: device dev[r]); the caller's host Image is uploaded slab by slab by the
+ * rank threads themselves (N concurrent PCIe streams), results land directly in the caller's stores. */
+struct s3d_mgpu {
+    int ngpu, flags;
+    int built;                       /* slabs exist for (nx, ny, nz, units, params) below */
+    int nx, ny, nz;
+    double units[3];
+    double sigma_n, sigma0, peak_thresh, corner_thresh;
+    int num_kp_levels;
+    int dev[256];
+    sift3d_amd_transport t[256];
+    sift3d_amd_slab *sl[256];
+    Keypoint_store kp[256];
+};
+
+/* optional: only present when the RCCL transport is linked in (it is not in the CPU emulator build) */
+extern int sift3d_amd_rccl_create_all(int world, const int *devices, sift3d_amd_transport *t) __attribute__((weak));
+
+int s3d_mgpu_wanted(const struct s3d_mgpu *m) { return m ? m->ngpu : 0; }
+
+static void mgpu_teardown(struct s3d_mgpu *m)
+{
+    int cur = 0;
+    s3d_rt_get_device(&cur);
+    for (int r = 0; r < m->ngpu; r++) {
+        if (m->sl[r]) { s3d_rt_set_device(m->dev[r]); sift3d_amd_slab_destroy(m->sl[r]); m->sl[r] = NULL; }
+        if (m->t[r].destroy) { m->t[r].destroy(m->t[r].self); memset(&m->t[r], 0, sizeof(m->t[r])); }
+    }
+    s3d_rt_set_device(cur);
+    m->built = 0;
+}
+
+void s3d_mgpu_free(struct s3d_mgpu *m)
+{
+    if (!m) return;
+    mgpu_teardown(m);
+    for (int r = 0; r < 256; r++) cleanup_Keypoint_store(&m->kp[r]);
+    free(m);
+}
+
+int s3d_mgpu_configure(struct s3d_mgpu **pm, int ngpu, int flags)
+{
+    struct s3d_mgpu *m = *pm;
+    if (ngpu > 256) SLAB_FAIL("sift3d_amd_set_num_gpus: at most 256 ranks");
+    if (m && (m->ngpu != ngpu || m->flags != flags)) { s3d_mgpu_free(m); m = *pm = NULL; }
+    if (ngpu <= 1) {
+        if (m) s3d_mgpu_free(m);
+        *pm = NULL;
+        return SIFT3D_SUCCESS;
+    }
+    if (m) return SIFT3D_SUCCESS;
+    if ((m = (struct s3d_mgpu *)calloc(1, sizeof(*m))) == NULL) SLAB_FAIL("sift3d_amd: out of memory");
+    m->ngpu = ngpu; m->flags = flags;
+    for (int r = 0; r < 256; r++) init_Keypoint_store(&m->kp[r]);
+    *pm = m;
+    return SIFT3D_SUCCESS;
+}
+
+typedef struct {
+    struct s3d_mgpu *m;
+    int r, op, rc;                    /* op 0: create, 1: detect, 2: describe */
+    const SIFT3D *params;
+    const float *host;                /* whole host volume (detect) */
+    const Keypoint_store *kp;         /* global list (describe) */
+    const size_t *sel; size_t nsel;
+    SIFT3D_Descriptor *out;
+    char err[256];
+} mgpu_job;
+
+static void *mgpu_thread(void *arg)
+{
+    mgpu_job *j = (mgpu_job *)arg;
+    struct s3d_mgpu *m = j->m;
+    const int r = j->r;
+    j->rc = SIFT3D_FAILURE;
+    if (s3d_rt_set_device(m->dev[r])) { snprintf(j->err, sizeof(j->err), "%s", s3d_rt_last_error()); return NULL; }
+    switch (j->op) {
+    case 0:
+        j->rc = sift3d_amd_slab_create(&m->sl[r], j->params, &m->t[r], m->nx, m->ny, m->nz, m->units[0], m->units[1], m->units[2], NULL);
+        break;
+    case 1: {
+        sift3d_amd_slab_info inf;
+        sift3d_amd_slab_get_info(m->sl[r], &inf);
+        j->rc = sift3d_amd_slab_detect(m->sl[r], j->host + (size_t)inf.z0 * m->nx * m->ny, 0, &m->kp[r]);
+        break;
+    }
+    default:
+        j->rc = describe_sel(m->sl[r], j->kp, j->sel, j->nsel, j->out);
+    }
+    if (j->rc) snprintf(j->err, sizeof(j->err), "%.250s", g_slab_err);
+    return NULL;
+}
+
+static int mgpu_run(struct s3d_mgpu *m, mgpu_job *jobs)
+{
+    pthread_t th[256];
+    int started[256] = {0}, rc = SIFT3D_SUCCESS;
+    for (int r = 0; r < m->ngpu; r++) started[r] = pthread_create(&th[r], NULL, mgpu_thread, &jobs[r]) == 0;
+    for (int r = 0; r < m->ngpu; r++) {
+        if (started[r]) pthread_join(th[r], NULL);
+        else jobs[r].rc = SIFT3D_FAILURE;
+    }
+    for (int r = 0; r < m->ngpu; r++)
+        if (jobs[r].rc) {
+            snprintf(g_slab_err, sizeof(g_slab_err), "rank %d: %.250s", r, started[r] ? jobs[r].err : "thread creation failed");
+            rc = SIFT3D_FAILURE;
+        }
+    return rc;
+}
+
+static int mgpu_build(struct s3d_mgpu *m, const SIFT3D *p, int nx, int ny, int nz, double ux, double uy, double uz)
+{
+    mgpu_job jobs[256];
+    int cur = 0, ndev = 0;
+    mgpu_teardown(m);
+    DEV(s3d_rt_get_device(&cur));
+    DEV(s3d_rt_device_count(&ndev));
+    if (m->flags & SIFT3D_AMD_SLAB_LOOPBACK) {
+        for (int r = 0; r < m->ngpu; r++) m->dev[r] = cur;
+        if (sift3d_amd_loopback_create(m->ngpu, m->t)) return SIFT3D_FAILURE;
+    } else {
+        if (ndev < m->ngpu) SLAB_FAIL("sift3d_amd: %d GPUs requested (SIFT3D_NGPU / sift3d_amd_set_num_gpus), %d visible", m->ngpu, ndev);
+        for (int r = 0; r < m->ngpu; r++) m->dev[r] = r;
+        if (sift3d_amd_rccl_create_all == NULL) SLAB_FAIL("sift3d_amd: this build has no RCCL transport");
+        if (sift3d_amd_rccl_create_all(m->ngpu, m->dev, m->t)) SLAB_FAIL("sift3d_amd: RCCL initialisation failed: %s", s3d_rt_last_error());
+    }
+    m->nx = nx; m->ny = ny; m->nz = nz;
+    m->units[0] = ux; m->units[1] = uy; m->units[2] = uz;
+    m->sigma_n = p->gpyr.sigma_n; m->sigma0 = p->gpyr.sigma0; m->peak_thresh = p->peak_thresh;
+    m->corner_thresh = p->corner_thresh; m->num_kp_levels = p->gpyr.num_kp_levels;
+    memset(jobs, 0, sizeof(mgpu_job) * (size_t)m->ngpu);
+    for (int r = 0; r < m->ngpu; r++) { jobs[r].m = m; jobs[r].r = r; jobs[r].op = 0; jobs[r].params = p; }
+    if (mgpu_run(m, jobs)) {
+        S3D_MSG("sift3d_amd: multi-GPU set-up failed: %s\n", g_slab_err);
+        mgpu_teardown(m);
+        s3d_rt_set_device(cur);
+        return SIFT3D_FAILURE;
+    }
+    s3d_rt_set_device(cur);
+    m->built = 1;
+    return SIFT3D_SUCCESS;
+}
+
+int s3d_mgpu_detect(struct s3d_mgpu **pm, const SIFT3D *p, const float *host_dense, int nx, int ny, int nz, double ux,
+                    double uy, double uz, Keypoint_store *kp)
+{
+    struct s3d_mgpu *m = *pm;
+    mgpu_job jobs[256];
+    const int same = m->built && m->nx == nx && m->ny == ny && m->nz == nz && m->units[0] == ux && m->units[1] == uy &&
+                     m->units[2] == uz && m->sigma_n == p->gpyr.sigma_n && m->sigma0 == p->gpyr.sigma0 &&
+                     m->num_kp_levels == p->gpyr.num_kp_levels;
+    if (!same && mgpu_build(m, p, nx, ny, nz, ux, uy, uz)) return SIFT3D_FAILURE;
+    for (int r = 0; r < m->ngpu; r++) {              /* thresholds may change between calls without a rebuild */
+        m->sl[r]->plan.peak_thresh = p->peak_thresh;
+        m->sl[r]->plan.corner_thresh = p->corner_thresh;
+    }
+    memset(jobs, 0, sizeof(mgpu_job) * (size_t)m->ngpu);
+    for (int r = 0; r < m->ngpu; r++) { jobs[r].m = m; jobs[r].r = r; jobs[r].op = 1; jobs[r].host = host_dense; }
+    if (mgpu_run(m, jobs)) {
+        S3D_MSG("sift3d_amd: multi-GPU detect failed: %s\n", g_slab_err);
+        return SIFT3D_FAILURE;
+    }
+    {   /* global list in the reference order */
+        const int G = m->ngpu;
+        size_t total = 0, n = 0;
+        size_t cur[256] = {0};
+        for (int r = 0; r < G; r++) total += m->kp[r].slab.num;
+        kp->nx = nx; kp->ny = ny; kp->nz = nz;
+        if (resize_Keypoint_store(kp, total)) return SIFT3D_FAILURE;
+        while (n < total) {
+            int bo = 0x7fffffff, bs = 0x7fffffff;
+            for (int r = 0; r < G; r++)
+                if (cur[r] < m->kp[r].slab.num) {
+                    const Keypoint *k = m->kp[r].buf + cur[r];
+                    if (k->o < bo || (k->o == bo && k->s < bs)) { bo = k->o; bs = k->s; }
+                }
+            for (int r = 0; r < G; r++)
+                while (cur[r] < m->kp[r].slab.num && m->kp[r].buf[cur[r]].o == bo && m->kp[r].buf[cur[r]].s == bs)
+                    copy_Keypoint(m->kp[r].buf + cur[r]++, kp->buf + n++);
+        }
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descriptor *out)
+{
+    const size_t num = kp->slab.num;
+    const int G = m->ngpu;
+    mgpu_job jobs[256];
+    size_t *sel, *fill, cnt[256] = {0};
+    int *owner, rc;
+    if (!m->built) SLAB_FAIL("sift3d_amd: no multi-GPU pyramid: call SIFT3D_detect_keypoints first");
+    if ((owner = (int *)malloc(num * sizeof(int))) == NULL) SLAB_FAIL("sift3d_amd: out of memory");
+    for (size_t i = 0; i < num; i++) {
+        owner[i] = sift3d_amd_slab_owner(m->sl[0], kp->buf + i);
+        if (owner[i] < 0) { free(owner); SLAB_FAIL("sift3d_amd: keypoint %zu lies outside the volume", i); }
+        cnt[owner[i]]++;
+    }
+    sel = (size_t *)malloc((num + 1) * sizeof(size_t));
+    fill = (size_t *)calloc(256, sizeof(size_t));
+    if (!sel || !fill) { free(owner); free(sel); free(fill); SLAB_FAIL("sift3d_amd: out of memory"); }
+    memset(jobs, 0, sizeof(mgpu_job) * (size_t)G);
+    {
+        size_t off = 0;
+        for (int r = 0; r < G; r++) {
+            jobs[r].m = m; jobs[r].r = r; jobs[r].op = 2; jobs[r].kp = kp; jobs[r].out = out;
+            jobs[r].sel = sel + off; jobs[r].nsel = cnt[r];
+            fill[r] = off;
+            off += cnt[r];
+        }
+        for (size_t i = 0; i < num; i++) sel[fill[owner[i]]++] = i;
+    }
+    rc = mgpu_run(m, jobs);
+    if (rc) S3D_MSG("sift3d_amd: multi-GPU describe failed: %s\n", g_slab_err);
+    free(owner); free(sel); free(fill);
+    return rc;
+}
+
+int s3d_mgpu_info(const struct s3d_mgpu *m, int r, void *info)
+{
+    if (!m || !m->built || r < 0 || r >= m->ngpu) return SIFT3D_FAILURE;
+    return sift3d_amd_slab_get_info(m->sl[r], (sift3d_amd_slab_info *)info);
+}

@@ -74,6 +74,30 @@ extern "C" int s3d_rt_event_record(void *ev, s3d_stream st)
     S3D_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)st));
     return S3D_OK;
 }
+extern "C" int s3d_rt_stream_wait_event(s3d_stream st, void *ev)
+{
+    S3D_HIP(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ev, 0));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_event_sync(void *ev) { S3D_HIP(hipEventSynchronize((hipEvent_t)ev)); return S3D_OK; }
+/* page-lock / release a caller's host buffer so that copies from / to it run at full PCIe rate and asynchronously */
+extern "C" int s3d_rt_host_register(void *p, size_t bytes)
+{
+    S3D_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_host_unregister(void *p) { S3D_HIP(hipHostUnregister(p)); return S3D_OK; }
+extern "C" int s3d_rt_host_alloc(void **p, size_t bytes)
+{
+    *p = NULL;
+    S3D_HIP(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    return S3D_OK;
+}
+extern "C" int s3d_rt_host_free(void *p)
+{
+    if (p) S3D_HIP(hipHostFree(p));
+    return S3D_OK;
+}
 extern "C" int s3d_rt_event_elapsed_ms(void *a, void *b, float *ms)
 {
     S3D_HIP(hipEventSynchronize((hipEvent_t)b));

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define __global__
@@ -157,7 +158,12 @@ inline void run_block() {
     }
 }
 
+/* one kernel at a time: the emulator state and the `static` LDS are process-wide, and the loop-back ranks of the
+ * multi-GPU tests are host threads of one process */
+inline std::recursive_mutex &launch_lock() { static std::recursive_mutex m; return m; }
+
 template <class F> inline void launch(dim3 grid, dim3 block, F f) {
+    std::lock_guard<std::recursive_mutex> guard(launch_lock());
     State &s = S();
     s.gridDim = grid;
     s.blockDim = block;
@@ -271,6 +277,13 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0;
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+#define hipHostRegisterDefault 0
+#define hipHostMallocDefault 0
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return 0; }
+static inline hipError_t hipHostUnregister(void *) { return 0; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \

@@ -1,5 +1,8 @@
-"""CPU, world_size 2 over gloo: the Z-slab sharded path (sift3d_amd/slab.py) must reproduce the
-single-process result bit for bit -- same keypoints in the reference order, same R, same descriptors.
+"""CPU: the C Z-slab driver (csrc/host/s3d_host_slab.c, include/sift3d_amd_slab.h) must reproduce the
+single-process result bit for bit -- same keypoints in the reference order, same R, same descriptors --
+  * over its in-process loop-back transport (ranks = host threads; 2, 3 and 4 ranks, uneven slabs),
+  * over gloo with world_size 2 and 3 (one process per rank, a callback transport over torch.distributed),
+  * behind the plain SIFT3D_detect_keypoints / SIFT3D_extract_descriptors (sift3d_amd_set_num_gpus).
 Compute = the product's kernels under the SIMT emulator; comparison partner = the same emulated library
 driven through the reference C API in one process, itself checked against the oracle."""
 import ctypes as C
@@ -10,11 +13,10 @@ import sys
 
 import numpy as np
 import pytest
-import torch
 
 from sift3d_amd import abi, synth
+from sift3d_amd import slab as slabmod
 from sift3d_amd.device import bind_extensions
-from sift3d_amd.slab import Comm, SlabSift3D
 from tests import parity
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,29 +30,53 @@ def emu():
     L = C.CDLL(os.path.join(EMU_DIR, "libsift3d_emu.so"))
     lib = abi.Sift3dLib(L, None, "emulated")
     bind_extensions(L)
+    slabmod.bind(L)
     return lib
 
 
-def single_process(lib, vol, units):
-    s, im, kp = parity.run_detect(lib, vol, units, PARAMS)
+def single_process(lib, vol, units, params=PARAMS):
+    s, im, kp = parity.run_detect(lib, vol, units, params)
     xyzos, sd, R = lib.keypoints_to_numpy(kp)
     d = abi.SIFT3D_Descriptor_store()
     lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
     assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
-    bins, _ = lib.descriptors_to_numpy(d)
-    return xyzos, R, bins
+    bins, xyzs = lib.descriptors_to_numpy(d)
+    return xyzos, sd, R, bins, xyzs
+
+
+def run_loopback(L, world, dims, units, nblobs, seed, params=PARAMS):
+    """`world` rank threads over the library's loop-back transport; returns rank 0's gathered result + infos."""
+    nx, ny, nz = dims
+    tr = slabmod.loopback_transports(L, world)
+
+    def rank(r):
+        sl = slabmod.Slab(L, tr[r], nx, ny, nz, units=units, params=params)
+        inf = sl.info()
+        vol = synth.blobs(nx, ny, nz, nblobs, seed, z0=inf.z0, z1=inf.z1)
+        k = sl.detect(vol, on_device=False)
+        sl.describe()
+        kp_all, d_all = sl.gather()
+        inf = sl.info()
+        res = (abi.Sift3dLib.keypoints_to_numpy(kp_all), abi.Sift3dLib.descriptors_to_numpy(d_all), k,
+               (inf.z0, inf.z1, inf.o_shard, inf.halo, inf.halo_bytes))
+        sl.close()
+        return res
+
+    out = slabmod.run_ranks(world, rank)
+    for r in range(world):
+        tr[r].destroy(tr[r].self)
+    return out
 
 
 def test_slab_world1_equals_c_api(emu, oracle):
     """One rank: the slab driver is just another host of the same kernels."""
     nx, ny, nz = 32, 32, 40
     vol = synth.blobs(nx, ny, nz, 80, 4)
-    want_x, want_R, want_b = single_process(emu, vol, (1, 1, 1))
-    sl = SlabSift3D(emu.sift, "cpu", Comm(None), nx, ny, nz, params=PARAMS)
-    k = sl.detect(torch.from_numpy(vol))
+    want_x, want_sd, want_R, want_b, want_c = single_process(emu, vol, (1, 1, 1))
+    (kp, (bins, xyzs), k, inf), = run_loopback(emu.sift, 1, (nx, ny, nz), (1, 1, 1), 80, 4)
     assert k == len(want_x) > 0
-    assert np.array_equal(sl.xyzos, want_x) and np.array_equal(sl.R, want_R)
-    assert np.array_equal(sl.describe()[:, :768].numpy(), want_b)
+    assert np.array_equal(kp[0], want_x) and np.array_equal(kp[1], want_sd) and np.array_equal(kp[2], want_R)
+    assert np.array_equal(bins, want_b) and np.array_equal(xyzs, want_c)
     oracle.set_params(sigma_n=0.8, sigma0=1.2)
     try:
         ox, _, _ = oracle.detect(vol)
@@ -59,24 +85,88 @@ def test_slab_world1_equals_c_api(emu, oracle):
         oracle.set_params()
 
 
-@pytest.mark.parametrize("dims,units,nblobs,seed", [((32, 32, 64), (1.0, 1.0, 1.0), 130, 1),
-                                                    ((36, 28, 64), (1.0, 0.9, 1.0), 130, 2),
-                                                    ((32, 32, 64), (1.0, 1.0, 1.5), 130, 3)])   # k_conv_z_ring on slabs
-def test_slab_world2_gloo(emu, tmp_path, dims, units, nblobs, seed):
-    _run_world(emu, tmp_path, dims, units, nblobs, seed, 2)
+@pytest.mark.parametrize("world,dims,units,nblobs,seed,o_shard", [
+    (2, (32, 32, 64), (1.0, 1.0, 1.0), 130, 1, 0),
+    (3, (32, 32, 96), (1.0, 1.0, 1.0), 200, 6, 0),        # an interior rank with two neighbours
+    (3, (28, 36, 100), (1.0, 1.0, 1.0), 200, 7, 0),       # nz not divisible by the ranks: uneven slabs
+    (2, (32, 32, 64), (1.0, 1.0, 1.5), 130, 3, 0),        # anisotropic slices: k_conv_z_ring on slabs
+    (2, (24, 24, 128), (1.0, 1.0, 1.0), 260, 8, 1),       # two sharded octaves + replicated ones
+    (4, (16, 16, 256), (1.0, 1.0, 1.0), 300, 9, 1),       # four ranks, octaves 0-1 sharded, seed all-gather of 4
+])
+def test_slab_loopback(emu, world, dims, units, nblobs, seed, o_shard):
+    vol = synth.blobs(*dims, nblobs, seed)
+    want_x, want_sd, want_R, want_b, want_c = single_process(emu, vol, units)
+    assert len(want_x) > 5
+    out = run_loopback(emu.sift, world, dims, units, nblobs, seed)
+    ks = [o[2] for o in out]
+    assert sum(ks) == len(want_x) and sum(1 for k in ks if k > 0) >= 2          # the work really was split
+    for (kp, (bins, xyzs), _, inf) in out:                                       # every rank holds the global result
+        assert inf[2] == o_shard and inf[4] > 0
+        assert np.array_equal(kp[0], want_x) and np.array_equal(kp[1], want_sd) and np.array_equal(kp[2], want_R)
+        assert np.array_equal(bins, want_b) and np.array_equal(xyzs, want_c)
+    z = [o[3][:2] for o in out]
+    assert z[0][0] == 0 and z[-1][1] == dims[2] and all(z[i][1] == z[i + 1][0] for i in range(world - 1))
 
 
-def test_slab_world3_gloo(emu, tmp_path):
-    """Three ranks: the middle one exchanges halos with both neighbours (the N >= 3 pattern of the 8-GPU run)."""
-    _run_world(emu, tmp_path, (32, 32, 96), (1.0, 1.0, 1.0), 200, 6, 3)
+def test_slab_too_thin_is_refused(emu):
+    tr = slabmod.loopback_transports(emu.sift, 2)
+    with pytest.raises(ValueError):
+        slabmod.Slab(emu.sift, tr[0], 32, 32, 40)        # default parameters: H = 39 > 20-slice slabs
+    for r in range(2):
+        tr[r].destroy(tr[r].self)
 
 
-def test_slab_two_sharded_octaves_gloo(emu, tmp_path):
-    """Slabs thick enough for octave 1 to be sharded as well (slab-local decimation, halos at two octaves)."""
-    _run_world(emu, tmp_path, (24, 24, 128), (1.0, 1.0, 1.0), 260, 8, 2, o_shard=1)
+@pytest.mark.parametrize("ngpu,dims,seed", [(2, (32, 32, 64), 11), (3, (24, 40, 99), 12)])
+def test_plain_api_on_loopback_ranks(emu, ngpu, dims, seed):
+    """sift3d_amd_set_num_gpus(.., LOOPBACK): the reference entry points themselves run N rank threads and hand back
+    the global stores; a caller that filters the keypoint list before describing is served as well."""
+    L = emu.sift
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, 150, seed)
+    want_x, want_sd, want_R, want_b, want_c = single_process(emu, vol, (1, 1, 1))
+    s = slabmod.make_params(L, PARAMS)
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), ngpu, slabmod.SLAB_LOOPBACK) == 0
+    im = emu.image_from_numpy(vol)
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    d = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d))
+    for _ in range(2):                                   # the second call reuses the slabs
+        assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        assert L.SIFT3D_have_gpyr(C.byref(s))
+        assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        x, sd, R = emu.keypoints_to_numpy(kp)
+        bins, xyzs = emu.descriptors_to_numpy(d)
+        assert np.array_equal(x, want_x) and np.array_equal(sd, want_sd) and np.array_equal(R, want_R)
+        assert np.array_equal(bins, want_b) and np.array_equal(xyzs, want_c)
+    inf = slabmod.SlabInfo()
+    assert L.sift3d_amd_get_slab_info(C.byref(s), ngpu - 1, C.byref(inf)) == 0 and inf.z1 == nz and inf.world == ngpu
+    # every third keypoint only, as a caller may do between the two calls
+    sub = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(sub))
+    idx = list(range(0, len(want_x), 3))
+    assert L.resize_Keypoint_store(C.byref(sub), len(idx)) == 0
+    L.copy_Keypoint.argtypes = [C.POINTER(abi.Keypoint), C.POINTER(abi.Keypoint)]
+    for j, i in enumerate(idx):
+        assert L.copy_Keypoint(C.byref(kp.buf[i]), C.byref(sub.buf[j])) == 0
+    assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(sub), C.byref(d)) == 0
+    bins, _ = emu.descriptors_to_numpy(d)
+    assert np.array_equal(bins, want_b[idx])
+    # back to one GPU: the same struct detects on the single-device path again
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 1, 0) == 0
+    assert not L.SIFT3D_have_gpyr(C.byref(s))
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+    assert np.array_equal(emu.keypoints_to_numpy(kp)[0], want_x)
+    L.cleanup_SIFT3D(C.byref(s))
 
 
-def _run_world(emu, tmp_path, dims, units, nblobs, seed, world, o_shard=0):
+@pytest.mark.parametrize("world,dims,units,nblobs,seed,o_shard", [
+    (2, (36, 28, 64), (1.0, 0.9, 1.0), 130, 2, 0),
+    (3, (32, 32, 96), (1.0, 1.0, 1.0), 200, 6, 0),
+    (2, (24, 24, 128), (1.0, 1.0, 1.0), 260, 8, 1),
+])
+def test_slab_gloo(emu, tmp_path, world, dims, units, nblobs, seed, o_shard):
+    """One process per rank over gloo: what `torchrun bench.py --gpus N` does with RCCL, on the CPU."""
     nx, ny, nz = dims
     out = str(tmp_path / "slab.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE=str(world),
@@ -91,10 +181,11 @@ def _run_world(emu, tmp_path, dims, units, nblobs, seed, world, o_shard=0):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     got = np.load(out)
     assert int(got["o_shard"]) == o_shard and int(got["bytes_exchanged"]) > 0   # the octaves really were sharded
+    assert int(got["bytes_exchanged"]) == int(got["halo_bytes"])                # the driver's own count of what it sent
     vol = synth.blobs(nx, ny, nz, nblobs, seed)
-    want_x, want_R, want_b = single_process(emu, vol, units)
+    want_x, want_sd, want_R, want_b, want_c = single_process(emu, vol, units)
     assert len(want_x) > 5
-    assert 0 < int(got["local_k"]) < len(want_x)                             # both ranks own keypoints
-    assert np.array_equal(got["xyzos"], want_x)
+    assert 0 < int(got["local_k"]) < len(want_x)                             # rank 0 owns some, not all
+    assert np.array_equal(got["xyzos"], want_x) and np.array_equal(got["sd"], want_sd)
     assert np.array_equal(got["R"], want_R)
-    assert np.array_equal(got["desc"], want_b)
+    assert np.array_equal(got["desc"], want_b) and np.array_equal(got["dxyzs"], want_c)
