@@ -8,10 +8,12 @@ SIFT3D_detect_keypoints (copy + scale + 36 Gaussian applications + extrema + ori
 keypoint list is downloaded because the API returns it) followed by SIFT3D_extract_descriptors for
 every keypoint with the descriptors left in HBM.  At N = 1 the workload is BASELINE.json configs[1]:
 512^3 float32, "blobs+noise" generator, 128 000 blobs (31 207 keypoints).  At N > 1 the workload is ONE
-512 x 512 x (512*N) volume sharded by Z-slab over the N GPUs (sift3d_amd/slab.py): 512 slices per GPU
-(weak scaling), halo planes exchanged with RCCL send/recv between Z-neighbours, all_reduce(max) for the
-scale and peak thresholds, all_gather for the replicated coarse octaves.
-`--replicas` runs one independent volume per rank instead.
+512 x 512 x (512*N) volume sharded by Z-slab over the N GPUs by the host-C driver of
+include/sift3d_amd_slab.h (csrc/host/s3d_host_slab.c): 512 slices per GPU (weak scaling), halo planes exchanged
+with ncclSend/ncclRecv between Z-neighbours, ncclAllReduce(max) for the scale and peak thresholds, ncclAllGather
+for the seed of the replicated coarse octaves; BASELINE configs[3] (one 1024^3 volume in
+nz/N-slice slabs) rides along untimed as config.strong_1024, or is the timed workload with --strong.
+`--replicas` runs one independent volume per rank instead; `--loopback R` runs R slab ranks on ONE GPU (diagnostic).
 
 One JSON line on stdout (rank 0).  Besides the driver's contract it carries
   roofline      the fused X+Y Gaussian kernel at 512^3 (dominant kernel of the north-star Gaussian),
@@ -139,73 +141,157 @@ def cpu_baseline(sample_n=160):
     raise RuntimeError(f"cpu baseline worker failed (rc {r.returncode}): {r.stderr[-300:]}")
 
 
-def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
-    """N > 1: ONE volume of n x n x (n*N) voxels, Z-slab sharded over the N GPUs (sift3d_amd/slab.py):
-    per-GPU work is fixed (weak scaling), halos travel by RCCL send/recv between Z-neighbours."""
-    import torch
-    from sift3d_amd.slab import Comm, SlabSift3D
-    n = args.size
-    nz = n * world
-    comm = Comm(dist, stage_via_host=bool(os.environ.get("S3D_BENCH_SAME_GPU")))
-    sl = SlabSift3D(sift3d_amd.cdll(), f"cuda:{local_rank}", comm, n, n, nz)
-    z0, z1 = sl.part[0]
-    nblobs = synth.default_nblobs(n, n, nz)
+METRIC = "Mvoxels/s detect+describe on 512^3 float32; 3D Gaussian achieved HBM GB/s vs roofline"
+
+
+def slab_job(L, dev, transport, dims, steps, warmup, sync_all, tag):
+    """One rank's share of a Z-slab job on an nx x ny x nz volume through the C driver (include/sift3d_amd_slab.h):
+    synthesise + upload my slab, `warmup` untimed steps, one split step, `steps` timed steps.  sync_all(): barrier
+    over the ranks with this rank's stream drained.  Returns this rank's measurements."""
+    from sift3d_amd import slab as S
+    nx, ny, nz = dims
+    sl = S.Slab(L, transport, nx, ny, nz)
+    inf = sl.info()
+    nblobs = synth.default_nblobs(nx, ny, nz)
     t0 = time.perf_counter()
-    vol = torch.from_numpy(synth.blobs(n, n, nz, nblobs, seed=0, z0=z0, z1=z1)).to(f"cuda:{local_rank}")
-    log(f"[rank {rank}] slab z=[{z0},{z1}) of {n}x{n}x{nz} synthesised in {time.perf_counter() - t0:.1f} s")
+    vol = synth.blobs(nx, ny, nz, nblobs, seed=0, z0=inf.z0, z1=inf.z1)
+    d_vol = dev.upload(vol)
+    del vol
+    log(f"[{tag} rank {inf.rank}] slab z=[{inf.z0},{inf.z1}) of {nx}x{ny}x{nz} synthesised + uploaded in "
+        f"{time.perf_counter() - t0:.1f} s; {inf.device_bytes / 2**30:.1f} GiB of HBM")
 
     def step():
-        sl.detect(vol)
-        return sl.describe()
+        sl.detect(d_vol, on_device=True)
+        sl.describe(to_host=False)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    full_sync()
+    sync_all()
     t0 = time.perf_counter()
-    sl.detect(vol)
-    torch.cuda.synchronize()
+    sl.detect(d_vol, on_device=True)
     t_detect = time.perf_counter() - t0
     t0 = time.perf_counter()
-    sl.describe()
-    torch.cuda.synchronize()
+    sl.describe(to_host=False)
     t_describe = time.perf_counter() - t0
-    comm.bytes_exchanged = 0
-    full_sync()
+    sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    full_sync()
+    sync_all()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed, float(len(sl.xyzos)), float(sl.num_candidates), float(comm.bytes_exchanged)],
-                     device="cuda", dtype=torch.float64)
-    tmax = t.clone()
-    if comm.stage:
-        tmax, t = tmax.cpu(), t.cpu()
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax[0].item())
+    inf = sl.info()
+    out = {"elapsed": elapsed, "detect_ms": t_detect * 1e3, "describe_ms": t_describe * 1e3, "keypoints": int(inf.num_keypoints),
+           "candidates": int(inf.num_candidates), "halo_bytes": float(inf.halo_bytes), "o_shard": int(inf.o_shard),
+           "halo": int(inf.halo), "slices": int(inf.z1 - inf.z0), "device_GiB": inf.device_bytes / 2**30, "nblobs": nblobs}
+    dev.free(d_vol)
+    sl.close()
+    return out
+
+
+def slab_summary(per_rank, dims, steps, world, transport_name):
+    nx, ny, nz = dims
+    elapsed = max(r["elapsed"] for r in per_rank)
+    r0 = per_rank[0]
+    return elapsed, {
+        "keypoints": sum(r["keypoints"] for r in per_rank), "extrema_candidates": sum(r["candidates"] for r in per_rank),
+        "detect_ms": round(max(r["detect_ms"] for r in per_rank), 3), "describe_ms": round(max(r["describe_ms"] for r in per_rank), 3),
+        "keypoints_per_rank": [r["keypoints"] for r in per_rank], "slices_per_rank": [r["slices"] for r in per_rank],
+        "sharded_octaves": r0["o_shard"] + 1, "halo_planes": r0["halo"],
+        "halo_MB_per_step_all_ranks": round(sum(r["halo_bytes"] for r in per_rank) / 1e6, 1),
+        "HBM_GiB_per_rank": round(max(r["device_GiB"] for r in per_rank), 2),
+        "Mvox_s": round(float(nx) * ny * nz * steps / elapsed / 1e6, 1), "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "parallelism": f"Z-slab x{world}, host C driver (csrc/host/s3d_host_slab.c), transport: {transport_name}; halos between "
+                       f"Z-neighbours, max all-reduce for the scale / peak thresholds, all-gather of the coarse-octave seed"}
+
+
+def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
+    """N > 1 under torchrun: one rank per GPU, the C Z-slab driver over RCCL (ncclSend/ncclRecv halos).  Timed
+    workload: ONE n x n x (n*N) volume, n slices per GPU (weak scaling; --strong: one --strong-size^3 volume, nz/N
+    slices per GPU).  After the timed region, unless --no-match: BASELINE configs[3] as named -- one 1024^3 volume in
+    nz/N-slice slabs (config.strong_1024)."""
+    import torch
+    from sift3d_amd import slab as S
+    L = sift3d_amd.cdll()
+    same_gpu = bool(os.environ.get("S3D_BENCH_SAME_GPU"))
+    tname, tr, keep = "RCCL (ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip)", None, None
+    ok = 0.0
+    if not same_gpu:
+        try:
+            tr = S.rccl_transport(L, dist, rank, world)
+            ok = 1.0
+        except Exception as e:              # the decision to fall back must be collective
+            log(f"[rank {rank}] RCCL transport unavailable: {e}")
+    flag = torch.tensor([ok], device="cpu" if same_gpu else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag.item()) == 0.0:
+        keep = S.DistTransport(L, dist, device=f"cuda:{local_rank}", stage_via_host=same_gpu)
+        tr = keep.struct
+        tname = "torch.distributed callbacks (" + ("gloo, staged through the host" if same_gpu else "nccl") + ")"
+
+    def gather(m):
+        box = [None] * world
+        dist.all_gather_object(box, m)
+        return box
+
+    n = args.size
+    dims = (args.strong_size,) * 3 if args.strong else (n, n, n * world)
+    per_rank = gather(slab_job(L, dev, tr, dims, args.steps, args.warmup, full_sync, "timed"))
+    extra = None
+    if not args.no_match and not args.strong and world in (2, 4, 8, 16):
+        extra = gather(slab_job(L, dev, tr, (1024, 1024, 1024), 2, 1, full_sync, "configs[3]"))
     if rank == 0:
-        nvox = float(n) * n * nz
-        result = {
-            "metric": "Mvoxels/s detect+describe on 512^3 float32; 3D Gaussian achieved HBM GB/s vs roofline",
-            "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"one {n}x{n}x{nz} float32 blobs+noise volume ({nblobs} blobs), unit voxels, default "
-                                   f"SIFT3D parameters, Z-slab sharded: {n} slices per GPU; detect + describe all "
-                                   f"keypoints, slabs and descriptors resident in HBM",
-                       "keypoints": int(t[1].item()), "extrema_candidates": int(t[2].item()),
-                       "detect_ms": round(t_detect * 1e3, 3), "describe_ms": round(t_describe * 1e3, 3),
-                       "sharded_octaves": sl.o_shard + 1, "halo_planes": sl.H,
-                       "halo_MB_per_step_all_ranks": round(float(t[3].item()) / args.steps / 1e6, 1),
-                       "parallelism": f"Z-slab x{world}: RCCL send/recv halos between Z-neighbours, all_reduce(max) "
-                                      f"for the scale/peak thresholds, all_gather of the coarse-octave seed"},
-        }
+        elapsed, cfg = slab_summary(per_rank, dims, args.steps, world, tname)
+        nvox = float(dims[0]) * dims[1] * dims[2]
+        cfg["workload"] = (f"one {dims[0]}x{dims[1]}x{dims[2]} float32 blobs+noise volume ({per_rank[0]['nblobs']} blobs), unit voxels, "
+                           f"default SIFT3D parameters, Z-slab sharded: {per_rank[0]['slices']} slices per GPU; detect + describe "
+                           f"all keypoints, slabs and descriptors resident in HBM")
+        result = {"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                  "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                  "dtype": "f32", "data": "synthetic", "config": cfg}
+        if extra is not None:
+            _, c3 = slab_summary(extra, (1024, 1024, 1024), 2, world, tname)
+            c3["workload"] = f"BASELINE configs[3]: one 1024^3 volume, Z-slabs of {extra[0]['slices']} slices on {world} GPUs"
+            result["config"]["strong_1024"] = c3
         if not args.no_roofline:
             add_roofline(result, dev, n)
         print(json.dumps(result), flush=True)
     dist.barrier()
+    if keep is None and tr is not None and tr.destroy:
+        tr.destroy(tr.self)
     dist.destroy_process_group()
+
+
+def run_loopback(args, dev):
+    """Diagnostic on ONE GPU: --loopback R runs R ranks as host threads that share the device (the library's
+    loop-back transport) -- the multi-rank code path with its slab geometry, halos and orderings, minus xGMI.  What it
+    measures is the decomposition's overhead (halo recomputation, replicated octaves, synchronous hand-offs), not
+    scaling."""
+    import threading
+    from sift3d_amd import slab as S
+    L = sift3d_amd.cdll()
+    R = args.loopback
+    n = args.size
+    dims = (args.strong_size,) * 3 if args.strong else (n, n, n * R)
+    tr = S.loopback_transports(L, R)
+    bar = threading.Barrier(R)
+
+    def body(r):
+        def sync_all():
+            dev.sync()
+            bar.wait()
+        return slab_job(L, dev, tr[r], dims, args.steps, args.warmup, sync_all, "loopback")
+
+    per_rank = S.run_ranks(R, body)
+    for r in range(R):
+        tr[r].destroy(tr[r].self)
+    elapsed, cfg = slab_summary(per_rank, dims, args.steps, R, "in-process loop-back, all ranks on one GPU")
+    cfg["workload"] = f"one {dims[0]}x{dims[1]}x{dims[2]} volume in {R} Z-slabs on ONE GPU (diagnostic, not a scaling number)"
+    nvox = float(dims[0]) * dims[1] * dims[2]
+    print(json.dumps({"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                      "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                      "dtype": "f32", "data": "synthetic", "config": cfg}), flush=True)
 
 
 def add_roofline(result, dev, n):
@@ -242,6 +328,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="skip the untimed extras after the timed steps (matcher, descriptor-kernel statistics, host-buffer API, dense 256^3, anisotropic and two-volume configurations)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1 (or --loopback): one --strong-size^3 volume split into nz/N-slice slabs instead of n slices per GPU")
+    ap.add_argument("--strong-size", type=int, default=1024, help="edge of the --strong volume (1024 = BASELINE configs[3])")
+    ap.add_argument("--loopback", type=int, default=0,
+                    help="diagnostic on one GPU: R Z-slab ranks as host threads sharing the device (loop-back transport)")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one independent volume per rank instead of the Z-slab decomposition")
     args = ap.parse_args()
@@ -278,6 +369,9 @@ def main():
         dev.check(dev.L.s3d_rt_sync(None))
 
     n = args.size
+    if world == 1 and args.loopback > 1:
+        run_loopback(args, dev)
+        return
     if world > 1 and not args.replicas:
         run_slab(args, dist, dev, rank, local_rank, world, full_sync)
         return
@@ -335,7 +429,7 @@ def main():
         nvox = float(n) ** 3
         value = world * nvox * args.steps / elapsed / 1e6
         result = {
-            "metric": "Mvoxels/s detect+describe on 512^3 float32; 3D Gaussian achieved HBM GB/s vs roofline",
+            "metric": METRIC,
             "value": round(value, 2), "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -1,8 +1,12 @@
-"""GPU (-m gpu): the Z-slab path on real hardware.  The box has ONE GPU, so the two ranks share it and the
-collectives are staged through gloo (Comm(stage_via_host=True)); kernels, views, halos and the global
-ordering are exactly those of the multi-GPU run, only the transport differs (RCCL there)."""
+"""GPU (-m gpu): the multi-GPU Z-slab path (include/sift3d_amd_slab.h, csrc/host/s3d_host_slab.c) on real hardware.
+
+The test box has ONE GPU, so the ranks are host threads that share it (the library's loop-back transport): kernels,
+views, halo schedule, partition and global ordering are exactly those of the multi-GPU run; only the transport differs
+(RCCL there -- exercised here as far as one device allows: library load, communicator creation, the collectives with a
+world of one).  Every result must equal the single-GPU entry points bit for bit, including BASELINE configs[3]'s
+geometry (1024 slices over 8 ranks: 128-slice slabs, octaves 0-1 sharded, octaves >= 2 replicated) and, with
+S3D_TEST_1024=0 not set, configs[3] itself: one 1024^3 volume, 8 slabs."""
 import ctypes as C
-import json
 import os
 import subprocess
 import sys
@@ -11,37 +15,173 @@ import numpy as np
 import pytest
 
 from sift3d_amd import abi, synth
+from sift3d_amd import slab as S
 from tests import parity
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def single_gpu(hip, vol, units=(1, 1, 1)):
+    s, im, kp = parity.run_detect(hip, vol, units)
+    xyzos, sd, R = hip.keypoints_to_numpy(kp)
+    d = abi.SIFT3D_Descriptor_store()
+    hip.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert hip.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    bins, xyzs = hip.descriptors_to_numpy(d)
+    hip.sift.cleanup_SIFT3D(C.byref(s))
+    hip.free_image(im)
+    return xyzos, sd, R, bins, xyzs
+
+
+def loopback(L, world, vol, units=(1, 1, 1)):
+    nz, ny, nx = vol.shape
+    tr = S.loopback_transports(L, world)
+
+    def rank(r):
+        sl = S.Slab(L, tr[r], nx, ny, nz, units=units)
+        inf = sl.info()
+        k = sl.detect(np.ascontiguousarray(vol[inf.z0:inf.z1]), on_device=False)
+        sl.describe()
+        kp_all, d_all = sl.gather()
+        inf = sl.info()
+        out = (abi.Sift3dLib.keypoints_to_numpy(kp_all), abi.Sift3dLib.descriptors_to_numpy(d_all), k, inf.o_shard,
+               inf.halo_bytes, (inf.z0, inf.z1))
+        sl.close()
+        return out
+
+    out = S.run_ranks(world, rank)
+    for r in range(world):
+        tr[r].destroy(tr[r].self)
+    return out
+
+
+@pytest.mark.parametrize("world,dims,nblobs,seed,o_shard", [
+    (2, (96, 80, 192), 1400, 5, 1),        # 96-slice slabs: octaves 0 and 1 sharded (H = 39)
+    (3, (96, 80, 240), 1750, 6, 1),        # an interior rank; 80-slice slabs
+    (3, (64, 72, 250), 1100, 7, 1),        # nz not divisible by the ranks: uneven slabs (80/84/86), both octaves sharded
+    (3, (64, 72, 200), 900, 10, 0),        # uneven slabs (66/66/68), one sharded octave + replicated ones
+    (8, (64, 64, 1024), 4000, 8, 1),       # BASELINE configs[3]'s slab geometry: 128 slices per rank
+])
+def test_loopback_ranks_equal_single_gpu(hip, world, dims, nblobs, seed, o_shard):
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    want = single_gpu(hip, vol)
+    assert len(want[0]) > 100
+    out = loopback(hip.sift, world, vol)
+    ks = [o[2] for o in out]
+    assert sum(ks) == len(want[0]) and all(k > 0 for k in ks)
+    for (kp, (bins, xyzs), _, osh, hb, _) in (out[0], out[-1]):
+        assert osh == o_shard and hb > 0
+        assert np.array_equal(kp[0], want[0]) and np.array_equal(kp[1], want[1])     # keypoints, order, scales
+        assert np.array_equal(kp[2], want[2])                                        # R
+        assert np.array_equal(bins, want[3]) and np.array_equal(xyzs, want[4])       # integer histograms: bitwise equal
+
+
+def test_loopback_anisotropic_slices(hip):
+    """units (1, 1, 1.5): the z pass of the slabs runs on k_conv_z_ring with fractional taps and a wider halo."""
+    vol = synth.blobs(80, 72, 256, 1500, 9)
+    want = single_gpu(hip, vol, (1, 1, 1.5))
+    out = loopback(hip.sift, 2, vol, (1, 1, 1.5))
+    kp, (bins, xyzs) = out[0][0], out[0][1]
+    assert len(want[0]) > 50
+    assert np.array_equal(kp[0], want[0]) and np.array_equal(kp[2], want[2]) and np.array_equal(bins, want[3])
+
+
+def test_plain_entry_points_on_eight_slabs(hip):
+    """sift3d_amd_set_num_gpus(&sift3d, 8, LOOPBACK): SIFT3D_detect_keypoints / SIFT3D_extract_descriptors themselves
+    run eight rank threads on 128-slice slabs and return the global stores (what SIFT3D_NGPU=8 does for a relinked
+    caller on an 8-GPU node, there over RCCL)."""
+    L = hip.sift
+    S.bind(L)
+    vol = synth.blobs(64, 64, 1024, 4000, 8)
+    want = single_gpu(hip, vol)
+    s = S.make_params(L)
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 8, S.SLAB_LOOPBACK) == 0
+    im = hip.image_from_numpy(vol)
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    d = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d))
+    for _ in range(2):
+        assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        x, sd, R = hip.keypoints_to_numpy(kp)
+        bins, xyzs = hip.descriptors_to_numpy(d)
+        assert np.array_equal(x, want[0]) and np.array_equal(sd, want[1]) and np.array_equal(R, want[2])
+        assert np.array_equal(bins, want[3]) and np.array_equal(xyzs, want[4])
+    inf = S.SlabInfo()
+    assert L.sift3d_amd_get_slab_info(C.byref(s), 3, C.byref(inf)) == 0
+    assert (inf.z0, inf.z1, inf.o_shard, inf.world) == (384, 512, 1, 8)
+    L.cleanup_SIFT3D(C.byref(s))
+    hip.free_image(im)
+
+
+def test_rccl_transport_with_a_world_of_one(hip):
+    """What one GPU can check of csrc/s3d_rccl.hip: librccl opens, both communicators initialise, and the collectives
+    run on the device (max all-reduce, all-gather, host all-gather: identities for one rank); a slab over that
+    transport equals the plain path."""
+    import sift3d_amd
+    L = S.bind(hip.sift)
+    dev = sift3d_amd.load_device()
+    idb = C.create_string_buffer(S.RCCL_ID_BYTES)
+    assert L.sift3d_amd_rccl_unique_id(idb) == 0, dev.err()
+    t = S.Transport()
+    assert L.sift3d_amd_rccl_create(idb.raw, 0, 1, C.byref(t)) == 0, dev.err()
+    a = np.array([3.0, -1.0, 7.5], np.float32)
+    d_a = dev.upload(a)
+    assert t.allreduce_max(t.self, d_a, 3, None) == 0, dev.err()
+    d_b = dev.malloc(12)
+    assert t.allgather(t.self, d_a, d_b, 12, None) == 0, dev.err()
+    dev.sync()
+    assert np.array_equal(dev.download(d_b, (3,)), a)
+    h = np.arange(5, dtype=np.int64)
+    g = np.zeros(5, np.int64)
+    assert t.allgather_host(t.self, h.ctypes.data, g.ctypes.data, h.nbytes) == 0 and np.array_equal(g, h)
+    assert t.exchange(t.self, d_a, d_b, d_a, d_b, 12, 1, None) == 0          # no neighbours: nothing moves
+    vol = synth.blobs(64, 64, 64, 250, 3)
+    want = single_gpu(hip, vol)
+    sl = S.Slab(L, t, 64, 64, 64)
+    assert sl.detect(vol, on_device=False) == len(want[0])
+    sl.describe()
+    assert np.array_equal(abi.Sift3dLib.keypoints_to_numpy(sl.kp)[0], want[0])
+    assert np.array_equal(abi.Sift3dLib.descriptors_to_numpy(sl.desc)[0], want[3])
+    sl.close()
+    t.destroy(t.self)
+    dev.free(d_a)
+    dev.free(d_b)
+
+
 WORKER = r'''
-import ctypes as C, json, os, sys
+import ctypes as C, os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 import sift3d_amd
-from sift3d_amd import synth
-from sift3d_amd.slab import Comm, SlabSift3D
+from sift3d_amd import abi, synth
+from sift3d_amd.slab import DistTransport, Slab
 out, nx, ny, nz, nblobs, seed = sys.argv[2], *(int(v) for v in sys.argv[3:8])
 dist.init_process_group("gloo")
 torch.cuda.set_device(0)
-comm = Comm(dist, stage_via_host=True)
-sl = SlabSift3D(sift3d_amd.cdll(), "cuda:0", comm, nx, ny, nz)
-z0, z1 = sl.part[0]
-vol = torch.from_numpy(synth.blobs(nx, ny, nz, nblobs, seed, z0=z0, z1=z1)).cuda()
-k = sl.detect(vol)
-desc = sl.describe()
-xyzos, R, d = sl.gather_keypoints(desc)
+L = sift3d_amd.cdll()
+tr = DistTransport(L, dist, device="cuda:0", stage_via_host=True)
+sl = Slab(L, tr.struct, nx, ny, nz)
+inf = sl.info()
+k = sl.detect(synth.blobs(nx, ny, nz, nblobs, seed, z0=inf.z0, z1=inf.z1), on_device=False)
+sl.describe()
+kp_all, d_all = sl.gather()
 if dist.get_rank() == 0:
-    np.savez(out, xyzos=xyzos, R=R, desc=d, o_shard=sl.o_shard, local_k=k)
+    xyzos, sd, R = abi.Sift3dLib.keypoints_to_numpy(kp_all)
+    np.savez(out, xyzos=xyzos, R=R, desc=abi.Sift3dLib.descriptors_to_numpy(d_all)[0], o_shard=sl.info().o_shard, local_k=k)
 dist.barrier()
+sl.close()
 dist.destroy_process_group()
 '''
 
 
-def test_slab_two_ranks_share_one_gpu(hip, tmp_path):
-    nx, ny, nz, nblobs, seed = 96, 80, 192, 1400, 5          # slab 96 slices: octaves 0 and 1 are sharded (H = 40)
+def test_two_processes_share_one_gpu(hip, tmp_path):
+    """One process per rank, as under torchrun: here two processes on the one GPU with the collectives staged through
+    gloo (a callback transport); the C driver, kernels and orderings are the multi-GPU ones."""
+    nx, ny, nz, nblobs, seed = 96, 80, 192, 1400, 5
     out = str(tmp_path / "slab.npz")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -53,14 +193,75 @@ def test_slab_two_ranks_share_one_gpu(hip, tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
     got = np.load(out)
     assert int(got["o_shard"]) == 1
-    vol = synth.blobs(nx, ny, nz, nblobs, seed)
-    s, im, kp = parity.run_detect(hip, vol, (1, 1, 1))
-    xyzos, sd, R = hip.keypoints_to_numpy(kp)
+    want = single_gpu(hip, synth.blobs(nx, ny, nz, nblobs, seed))
+    assert len(want[0]) > 100 and 0 < int(got["local_k"]) < len(want[0])
+    assert np.array_equal(got["xyzos"], want[0]) and np.array_equal(got["R"], want[2]) and np.array_equal(got["desc"], want[3])
+
+
+@pytest.mark.skipif(os.environ.get("S3D_TEST_1024") == "0", reason="S3D_TEST_1024=0")
+def test_config3_1024_cubed(hip):
+    """BASELINE configs[3]: one 1024^3 float32 volume (4 GiB).  (a) single GPU: the keypoint count of the reference
+    generator's volume (246 249, profiles/README.md), reference order, orthonormal R, unit-norm descriptors;
+    (b) the same volume as eight 128-slice Z-slabs (loop-back ranks on this GPU): keypoints, R and descriptors
+    bit-identical to (a)."""
+    import hashlib
+    import sift3d_amd
+    L = S.bind(hip.sift)
+    dev = sift3d_amd.load_device()
+    n = 1024
+    vol = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
+    # (a) device-resident single-GPU run
+    d_vol = dev.upload(vol)
+    s = S.make_params(L)
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    assert L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp)) == 0
     d = abi.SIFT3D_Descriptor_store()
-    hip.sift.init_SIFT3D_Descriptor_store(C.byref(d))
-    assert hip.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
-    bins, _ = hip.descriptors_to_numpy(d)
-    assert len(xyzos) > 100 and 0 < int(got["local_k"]) < len(xyzos)
-    assert np.array_equal(got["xyzos"], xyzos)              # same keypoints, same (o, s, z, y, x) order
-    assert np.array_equal(got["R"], R)
-    assert np.array_equal(got["desc"], bins)                # integer histogram: bitwise reproducible
+    L.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    K = int(kp.slab.num)
+    raw = np.ctypeslib.as_array(C.cast(kp.buf, C.POINTER(C.c_uint8)), shape=(K, C.sizeof(abi.Keypoint)))
+    xyz = raw[:, 72:96].copy().view(np.float64).reshape(K, 3)
+    os_ = raw[:, 104:112].copy().view(np.int32).reshape(K, 2)
+    R = raw[:, 0:36].copy().view(np.float32).reshape(K, 3, 3)
+    assert K == 246249
+    key = ((os_[:, 0].astype(np.int64) * 8 + os_[:, 1]) << 40) | (xyz[:, 2].astype(np.int64) << 26) | \
+          (xyz[:, 1].astype(np.int64) << 13) | xyz[:, 0].astype(np.int64)
+    assert np.all(np.diff(key) > 0)                                            # reference order, no duplicates
+    RtR = np.einsum("kij,kil->kjl", R.astype(np.float64), R.astype(np.float64))
+    assert np.abs(RtR - np.eye(3)).max() < 1e-4 and np.abs(np.linalg.det(R.astype(np.float64)) - 1).max() < 1e-4
+    draw = np.ctypeslib.as_array(C.cast(d.buf, C.POINTER(C.c_uint8)), shape=(K, C.sizeof(abi.SIFT3D_Descriptor)))
+    bins = draw[:, :3072].view(np.float32)
+    nrm = np.sqrt((bins.astype(np.float64) ** 2).sum(1))
+    assert np.abs(nrm - 1).max() < 1e-5 and bins.min() >= 0
+    want_kp = hashlib.sha256(np.ascontiguousarray(raw[:, 72:112]).tobytes() + np.ascontiguousarray(raw[:, 0:36]).tobytes()).hexdigest()
+    want_desc = hashlib.sha256(np.ascontiguousarray(bins).tobytes()).hexdigest()
+    L.cleanup_SIFT3D(C.byref(s))                                               # frees the 37 GB single-GPU pyramid
+    dev.free(d_vol)
+    # (b) eight slabs behind the plain entry points
+    s8 = S.make_params(L)
+    assert L.sift3d_amd_set_num_gpus(C.byref(s8), 8, S.SLAB_LOOPBACK) == 0
+    im = abi.Image()
+    hip.imutil.init_im(C.byref(im))
+    im.nx = im.ny = im.nz = n
+    im.nc = 1
+    im.ux = im.uy = im.uz = 1.0
+    hip.imutil.im_default_stride(C.byref(im))
+    im.data = vol.ctypes.data_as(C.POINTER(C.c_float))                          # the numpy array is the voxel buffer
+    kp8 = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp8))
+    d8 = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d8))
+    assert L.SIFT3D_detect_keypoints(C.byref(s8), C.byref(im), C.byref(kp8)) == 0
+    assert int(kp8.slab.num) == K
+    assert L.SIFT3D_extract_descriptors(C.byref(s8), C.byref(kp8), C.byref(d8)) == 0
+    raw8 = np.ctypeslib.as_array(C.cast(kp8.buf, C.POINTER(C.c_uint8)), shape=(K, C.sizeof(abi.Keypoint)))
+    got_kp = hashlib.sha256(np.ascontiguousarray(raw8[:, 72:112]).tobytes() + np.ascontiguousarray(raw8[:, 0:36]).tobytes()).hexdigest()
+    draw8 = np.ctypeslib.as_array(C.cast(d8.buf, C.POINTER(C.c_uint8)), shape=(K, C.sizeof(abi.SIFT3D_Descriptor)))
+    got_desc = hashlib.sha256(np.ascontiguousarray(draw8[:, :3072]).tobytes()).hexdigest()
+    inf = S.SlabInfo()
+    assert L.sift3d_amd_get_slab_info(C.byref(s8), 7, C.byref(inf)) == 0
+    assert (inf.z0, inf.z1, inf.o_shard) == (896, 1024, 1)                      # 128-slice slabs, octaves 0-1 sharded
+    assert got_kp == want_kp and got_desc == want_desc
+    assert np.array_equal(draw8[:, 3072:], draw[:, 3072:])                      # descriptor coordinates and scales
+    L.cleanup_SIFT3D(C.byref(s8))
