@@ -452,17 +452,11 @@ def main():
     if rank == 0 and K and not args.no_match:
         # what the descriptor kernel (70 % of the step) works through, outside the timed region: the test aid of
         # k_describe (variant bit 4) returns the number of accepted window voxels per keypoint instead of a descriptor
-        lib.sift.s3d_k_set_variant.argtypes = [C.c_int]
-        lib.sift.s3d_k_set_variant(16)
-        try:
-            lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
-            dev.sync()
-            rec = dev.download(d_desc.value, (K, 776))
-        finally:
-            lib.sift.s3d_k_set_variant(0)
-        wv = int(np.ascontiguousarray(rec[:, 0]).view(np.uint32).astype(np.int64).sum())
-        lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))    # restore the records
-        dev.sync()
+        lib.sift.sift3d_amd_describe_window_stats.argtypes = [C.POINTER(abi.SIFT3D), C.POINTER(abi.Keypoint_store),
+                                                              C.POINTER(C.c_uint)]
+        st = np.zeros((K, 2), np.uint32)
+        assert lib.sift.sift3d_amd_describe_window_stats(C.byref(s), C.byref(kp), st.ctypes.data_as(C.POINTER(C.c_uint))) == 0
+        wv = int(st[:, 0].astype(np.int64).sum())
         result["config"]["describe_kernel"] = {
             "window_voxels": wv, "lds_atomics_per_window_voxel": 24,
             "Gvox_window_per_s": round(wv / t_describe / 1e9, 1),

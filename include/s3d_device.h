@@ -192,6 +192,11 @@ int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint
                    const float *d_mesh, float *d_out, size_t out_stride /* floats, >= 768 */,
                    s3d_stream stream);
 
+/* Test / diagnostics aid: d_stats[2i] = number of voxels the descriptor window of keypoint i accepts, d_stats[2i+1] = a
+ * checksum of their coordinates, produced by the descriptor kernel's own window enumeration. */
+int s3d_k_describe_window_stats(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
+                                uint32_t *d_stats, s3d_stream stream);
+
 /* Profiling-only ablation switch for k_orient / k_describe (see s3d_keypoint.hip); 0 = normal. */
 void s3d_k_set_variant(int v);
 

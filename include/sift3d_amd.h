@@ -394,6 +394,9 @@ int sift3d_amd_plan(SIFT3D *const sift3d, int nx, int ny, int nz, double ux, dou
  * 768 floats `stride` floats apart (multiple of 4); matches: host array of na ints. */
 int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const float *d_b, size_t b_stride,
                             long nb, float nn_thresh, int *matches, void *hip_stream);
+/* Diagnostics: for each keypoint of kp (detected on this SIFT3D) the number of voxels its descriptor window accepts
+ * (stats[2i]) and a checksum of their coordinates (stats[2i+1]); stats: host array of 2 * kp->slab.num. */
+int sift3d_amd_describe_window_stats(SIFT3D *const sift3d, const Keypoint_store *const kp, unsigned int *stats);
 /* Number of extrema candidates before orientation rejection in the last detect (diagnostics). */
 long sift3d_amd_last_num_candidates(const SIFT3D *const sift3d);
 /* Stream on which this SIFT3D's kernels run (opaque hipStream_t); set before the first detect. */

@@ -24,6 +24,10 @@ HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip"
 C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c", "host/s3d_host_draw.c", "host/s3d_host_slab.c"]
 BIN = os.path.join(HERE, "bin")
 CLI_PROGRAMS = ["kpSift3D", "denseSift3D", "regSift3D"]
+# Per-file extra flags.  s3d_keypoint.hip: the SLP vectoriser pairs scalar f32 operations into v_pk_* instructions, which on
+# gfx950 cost 4.4 cycles per wave64 against 2.8 for a scalar f32 op (scripts/ubench_valu.hip) and need register shuffles
+# and s_nops around them: a net loss for the VALU-bound descriptor kernel.
+EXTRA_HIP_FLAGS = {"s3d_keypoint.hip": ["-fno-slp-vectorize"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]
@@ -57,7 +61,7 @@ def build(verbose: bool = False) -> str:
         if _newer(src, o, headers):
             if verbose:
                 print("hipcc", s)
-            _run([HIPCC, *HIP_FLAGS, "-c", src, "-o", o])
+            _run([HIPCC, *HIP_FLAGS, *EXTRA_HIP_FLAGS.get(s, []), "-c", src, "-o", o])
         objs.append(o)
     for s in C_SOURCES:
         src = os.path.join(CSRC, s)

@@ -818,6 +818,38 @@ static int describe_from_gpyr(SIFT3D *const sift3d, const Keypoint_store *const 
     return rc;
 }
 
+int sift3d_amd_describe_window_stats(SIFT3D *const sift3d, const Keypoint_store *const kp, unsigned int *stats)
+{
+    const Pyramid *g = &sift3d->gpyr;
+    s3d_ctx *c = sift_ctx(sift3d);
+    const size_t num = kp->slab.num;
+    s3d_pyramid_desc pd;
+    s3d_desc_key *keys;
+    uint32_t *d_stats = NULL;
+    int rc = SIFT3D_FAILURE;
+    if (s3d_verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
+    if (!SIFT3D_have_gpyr(sift3d) || c->pyramid_on_slabs) API_FAIL("sift3d_amd_describe_window_stats: no single-GPU pyramid");
+    if (ctx_ensure_desc(c, num)) return SIFT3D_FAILURE;
+    if ((keys = (s3d_desc_key *)malloc(num * sizeof(s3d_desc_key))) == NULL) return SIFT3D_FAILURE;
+    for (size_t i = 0; i < num; i++) {
+        const Keypoint *key = kp->buf + i;
+        const int oi = key->o - g->first_octave, ki = key->s - g->first_level;
+        if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) { free(keys); return SIFT3D_FAILURE; }
+        s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + i);
+    }
+    fill_pyr_desc(g, c->d_level, &pd);
+    if (s3d_rt_malloc((void **)&d_stats, num * 2 * sizeof(uint32_t)) == 0 &&
+        s3d_rt_h2d(c->d_keys, keys, num * sizeof(s3d_desc_key), c->stream) == 0 &&
+        s3d_k_describe_window_stats(&pd, c->d_keys, (uint32_t)num, d_stats, c->stream) == 0 &&
+        s3d_rt_d2h(stats, d_stats, num * 2 * sizeof(uint32_t), c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
+        rc = SIFT3D_SUCCESS;
+    else
+        S3D_MSG("sift3d_amd_describe_window_stats: %s\n", s3d_rt_last_error());
+    s3d_rt_free(d_stats);
+    free(keys);
+    return rc;
+}
+
 static void fill_desc_coords(const Keypoint_store *kp, SIFT3D_Descriptor *buf)
 {
     for (size_t i = 0; i < kp->slab.num; i++) {           /* sift.c:1920-1925 */

@@ -942,12 +942,456 @@ k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t
         out[(size_t)kid * out_stride + tid + j * DESC_THREADS] = v[j] * inv;
 }
 
+
+/* ==== the descriptor kernel, second form: one 1024-thread workgroup per keypoint ==========================================
+ *
+ * Same window enumeration as above (A1 closed-form row intervals settled by the reference's own test, A2 block scan,
+ * B one 4-voxel chunk per thread and turn) and the same bit-faithful per-voxel front end (window weight, rotation,
+ * icosahedron face through the reference's ray-triangle test).  What changed is everything around the LDS atomics,
+ * which with the VALU work were the two saturated resources of the kernel (rocprofv3 + scripts/ubench_lds2/3.hip):
+ *
+ *  (1) Bank-private histogram copies.  A ds_add_u64 costs the LDS pipe 6.4 clk per wave when the lanes hit distinct
+ *      banks and 11.9 clk with data-dependent addresses (64 lanes x 2 dwords over 64 banks, processed 16 lanes at
+ *      a time).  With 16 copies laid out copy-minor -- word (bin, copy) at bin*16 + copy, copy = lane & 15 -- the 16 lanes
+ *      of a pass always sit in 16 different bank pairs whatever their bins are: conflict free by construction.  16 x 768
+ *      x 8 B = 96 KB of LDS is what a CU has room for once, hence ONE workgroup of 16 waves per CU (4 per SIMD, 128
+ *      VGPRs each) instead of five of 4 waves.
+ *  (2) One VALU instruction per contribution.  A contribution (mag * bary_v) * (wx * wy * wz) is formed as
+ *      fma(m_v, w_c, M) in f64 with M = 1.5 * 2^(52 - f): the product of two f32-derived doubles is exact, the single
+ *      rounding of the fma lands on the fixed-point grid 2^-f, and the low 48 bits of the result's bit pattern ARE that
+ *      fixed-point number (the exponent field and bit 51 are the same for every contribution and fall outside the low
+ *      48 bits), so the raw 64-bit pattern goes straight into ds_add_u64 and the sums of the low 48 bits are exact
+ *      integers: order free, bitwise reproducible, rounded to nearest instead of truncated.  f is chosen per keypoint so
+ *      that a copy's bin cannot leave 47 bits: (window voxels / 16) * gradient bound * 2^f < 2^47.  (Was: two 24-bit
+ *      integer multiplies + a 64-bit shift per contribution and the integer conversion of every weight.)
+ *  (3) The window weight expf(-sq / 2 sigma^2) comes from a per-keypoint table indexed by the integer squared distance
+ *      when that is exact (integer centre, equal power-of-two units: every octave of a unit-voxel volume); the table
+ *      entries are produced by the same restated glibc expf on the same float argument, so nothing changes bit-wise.
+ *      Otherwise the weight is computed per voxel as before, with the exp2 table in LDS instead of global memory.
+ *  (4) The four voxels of a chunk are straight-line code (no per-voxel select chains over the loaded neighbours).
+ */
+#define DW_THREADS 1024
+#define DW_WAVES (DW_THREADS / 64)
+#define DW_NCOPY 16
+#define DW_TMAX 2048                      /* entries of the weight table (squared voxel distances 0 .. DW_TMAX-1) */
+#define DW_HIST_WORDS (S3D_DESC_NUMEL * DW_NCOPY)
+
+struct DwShared {
+    unsigned long long hist[DW_HIST_WORDS];
+    unsigned long long etab[32];
+    double part[DW_WAVES];
+    float mesh[S3D_MESH_FLOATS];
+    float fcn[9 * S3D_NFACES];            /* per face, field major: N = e2 x e1, C = e2 x t, q  (dw_face_fast) */
+    int vofs[S3D_NFACES * 3];             /* byte offset of vertex bin idx[face][j] inside a cell: idx * DW_NCOPY * 8 */
+    float wtab[DW_TMAX];
+    unsigned seg_first[DW_THREADS];
+    int seg_off[DW_THREADS + 1];
+    unsigned short seg_len[DW_THREADS];
+    int wave_tot[DW_WAVES];
+    unsigned win_chk, win_vox;
+};
+
+#if defined(S3D_EMU)
+#define DW_SHARED_DECL static DwShared dw_smem_obj; DwShared &sm = dw_smem_obj
+#else
+#define DW_SHARED_DECL extern __shared__ unsigned long long dw_smem_raw[]; DwShared &sm = *reinterpret_cast<DwShared *>(dw_smem_raw)
+#endif
+
+/* s3d_expf with the exp2 table passed in (LDS) */
+__device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long *__restrict__ tab)
+{
+    const double n = 32.0, inv_ln2_n = 0x1.71547652b82fep+0 * n, shift = 0x1.8p52;
+    const double c0 = 0x1.c6af84b912394p-5 / n / n / n, c1 = 0x1.ebfce50fac4f3p-3 / n / n, c2 = 0x1.62e42ff0c52d6p-1 / n;
+    double z = inv_ln2_n * (double)x;
+    double kd = z + shift;
+    unsigned long long ki;
+    __builtin_memcpy(&ki, &kd, 8);
+    kd -= shift;
+    const double r = z - kd;
+    const unsigned long long t = tab[ki & 31u] + (ki << 47);
+    double s;
+    __builtin_memcpy(&s, &t, 8);
+    z = c0 * r + c1;
+    const double r2 = r * r;
+    double y = c2 * r + 1.0;
+    y = z * r2 + y;
+    return (float)(y * s);
+}
+
+#if defined(S3D_EMU)
+#define DW_RCP(x) (1.0f / (x))
+#define DW_SQRT(x) sqrtf(x)
+#else
+#define DW_RCP(x) __builtin_amdgcn_rcpf(x)
+#define DW_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#endif
+
+/* Face + barycentric weights of a gradient direction for the descriptor kernel.  Same decision procedure as
+ * s3d_icos_bin_fast -- the face of the octant/type lookup is taken only if the vector lies at least 2e-5 (in barycentric
+ * units) inside it, anything closer to an edge goes through the reference's sequential search with the reference's
+ * arithmetic -- but the inside test and the weights of the (99.99 %) safe samples come from three dot products with
+ * per-face constants, det = g.(e2 x e1), b.y det = g.(e2 x t), b.z det = g.q (the triple products of cart2bary,
+ * sift.c:335-394, with the constant factors pulled together), and a 1-ulp reciprocal: the weights then differ from the
+ * reference's by ~1e-6 relative -- they are continuous quantities, the tolerance is 1e-4 -- while the DECISION which
+ * face (the discontinuous part, see s3d_math.h) is unchanged: a 1e-6 error cannot carry a sample across the 2e-5 margin. */
+__device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, const float *__restrict__ fcn, V3 g, float gg, V3 *bary)
+{
+    if ((double)gg < S3D_BARY_EPS_D) return -1;
+    const float ax = fabsf(g.x), ay = fabsf(g.y), az = fabsf(g.z);
+    const float c0 = 0.57735027f, c1 = 0.35682209f, c2 = 0.93417236f;
+    const float s0 = c0 * (ax + ay + az);
+    const float s1 = c1 * ax + c2 * az;
+    const float s2 = c2 * ax + c1 * ay;
+    const float s3 = c2 * ay + c1 * az;
+    int t = 0;
+    float best = s0;
+    if (s1 > best) { best = s1; t = 1; }
+    if (s2 > best) { best = s2; t = 2; }
+    if (s3 > best) { best = s3; t = 3; }
+    const int key = (g.x < 0.0f ? 1 : 0) | (g.y < 0.0f ? 2 : 0) | (g.z < 0.0f ? 4 : 0) | (t << 3);
+    const int face = __float_as_int(mesh[S3D_LUT_OFFSET + key]);
+    const float *f = fcn + face;
+    const float det = f[0 * S3D_NFACES] * g.x + f[1 * S3D_NFACES] * g.y + f[2 * S3D_NFACES] * g.z;
+    const float ny = f[3 * S3D_NFACES] * g.x + f[4 * S3D_NFACES] * g.y + f[5 * S3D_NFACES] * g.z;
+    const float nz = f[6 * S3D_NFACES] * g.x + f[7 * S3D_NFACES] * g.y + f[8 * S3D_NFACES] * g.z;
+    const float inv = DW_RCP(det);
+    V3 b;
+    b.y = ny * inv;
+    b.z = nz * inv;
+    b.x = 1.0f - b.y - b.z;
+    /* the ray hits the plane of the face in front of the origin iff k = (e2.q) / det > 0 (e2.q: field 12) */
+    if (fabsf(det) > 1e-5f && mesh[12 * S3D_NFACES + face] * inv > 0.0f && b.x >= 2e-5f && b.y >= 2e-5f && b.z >= 2e-5f) {
+        *bary = b;
+        return face;
+    }
+    return s3d_icos_bin(mesh, g, bary);
+}
+
+__device__ __forceinline__ double dw_block_sum(double v, double *part)
+{
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < DW_WAVES; w++) r += part[w];
+    __syncthreads();
+    return r;
+}
+
+template <bool COUNT_ONLY>
+__global__ void __launch_bounds__(DW_THREADS)
+k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num, const float *__restrict__ d_mesh,
+              float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ stats)
+{
+    DW_SHARED_DECL;
+    const unsigned kid = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (kid >= num) return;
+    const s3d_desc_key key = keys[kid];
+    const int o = key.octave;
+    const float *__restrict__ im = pyr.d_level[key.level];
+    const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
+    const size_t plane = (size_t)nx * ny;
+    DescGeom g;
+    g.cx = key.cx; g.cy = key.cy; g.cz = key.cz;
+    g.uxf = pyr.unitsf[o][0]; g.uyf = pyr.unitsf[o][1]; g.uzf = pyr.unitsf[o][2];
+    g.rad2 = key.rad * key.rad; g.half = key.half; g.binf = key.binf;
+    g.r00 = key.R[0]; g.r01 = key.R[3]; g.r02 = key.R[6];
+    g.r10 = key.R[1]; g.r11 = key.R[4]; g.r12 = key.R[7];
+    g.r20 = key.R[2]; g.r21 = key.R[5]; g.r22 = key.R[8];
+    const double inv_sig2 = 1.0 / (double)(key.sigma * key.sigma);
+    const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
+    int xe, ye, ze;
+    desc_bounds(key.cx, key.rad, g.uxf, nx, &g.xs, &xe);
+    desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
+    desc_bounds(key.cz, key.rad, g.uzf, nz, &g.zs, &ze);
+    const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
+    const int nrows = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wy * wz : 0;
+
+    /* weight table: usable when squared distances are exact integers times u^2 */
+    int ipow;
+    const float um = frexpf(g.uxf, &ipow);
+    const int cxi = (int)key.cx, cyi = (int)key.cy, czi = (int)key.cz;
+    const float u2 = g.uxf * g.uxf;
+    const bool use_tab = !COUNT_ONLY && g.uxf == g.uyf && g.uxf == g.uzf && um == 0.5f && (float)cxi == key.cx &&
+                         (float)cyi == key.cy && (float)czi == key.cz && g.rad2 / u2 < 1700.0f;   /* + 6 r + 9 for the chunk's last voxel stays below DW_TMAX */
+
+    /* fixed-point grid 2^-f of the histogram (see (2) above): a contribution is bounded by the gradient bound 2^bexp
+     * (level voxels are bounded by 1 -- scaled input, convex filters -- so a central difference is <= 1/u per axis) */
+    int bexp;
+    (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);
+    int head = 1;
+    {
+        const unsigned long long per_copy = (unsigned long long)(wx > 0 ? wx : 1) * (unsigned)(wy > 0 ? wy : 1) * (unsigned)(wz > 0 ? wz : 1) / DW_NCOPY + 4096ull;
+        while ((1ull << head) < per_copy) head++;
+    }
+    const int fbits = 47 - bexp - head;
+    const double Mfix = ldexp(1.5, 52 - fbits);
+    const double unscale = ldexp(1.0, -fbits);
+
+    for (int i = tid; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
+    if (!COUNT_ONLY)
+        for (int i = tid; i < S3D_MESH_FLOATS; i += DW_THREADS) sm.mesh[i] = d_mesh[i];
+    if (!COUNT_ONLY && tid >= 64 && tid < 64 + S3D_NFACES) {
+        const int fc = tid - 64;
+        const float *m = d_mesh;
+        const V3 e1 = v3(S3D_MESH_AT(m, fc, 0), S3D_MESH_AT(m, fc, 1), S3D_MESH_AT(m, fc, 2));
+        const V3 e2 = v3(S3D_MESH_AT(m, fc, 3), S3D_MESH_AT(m, fc, 4), S3D_MESH_AT(m, fc, 5));
+        const V3 tt = v3(S3D_MESH_AT(m, fc, 6), S3D_MESH_AT(m, fc, 7), S3D_MESH_AT(m, fc, 8));
+        const V3 nn = v3_cross(e2, e1), cc = v3_cross(e2, tt);
+        const float rec[9] = {nn.x, nn.y, nn.z, cc.x, cc.y, cc.z, S3D_MESH_AT(m, fc, 9), S3D_MESH_AT(m, fc, 10), S3D_MESH_AT(m, fc, 11)};
+        for (int k = 0; k < 9; k++) sm.fcn[k * S3D_NFACES + fc] = rec[k];
+    }
+    if (!COUNT_ONLY && tid < S3D_NFACES * 3)
+        sm.vofs[tid] = __float_as_int(d_mesh[(13 + tid / S3D_NFACES) * S3D_NFACES + tid % S3D_NFACES]) * (DW_NCOPY * 8);
+    if (tid < 32) {
+        static const unsigned long long tab[32] = {
+            0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+            0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+            0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+            0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+            0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+            0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+            0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+            0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+        sm.etab[tid] = tab[tid];
+    }
+    if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; }
+    __syncthreads();
+    if (use_tab) {
+        /* entry i: the weight of a voxel at squared distance i * u^2, through the very float steps of sift.c:1890 */
+        const int nent = (int)(g.rad2 / u2) + 2;
+        for (int i = tid; i < nent; i += DW_THREADS) {
+            const float sq = (float)i * u2;
+            sm.wtab[i] = s3d_expf_tab((float)((double)(-0.5f * sq) * inv_sig2), sm.etab);
+        }
+        __syncthreads();
+    }
+
+    const unsigned copy8 = (unsigned)(lane & (DW_NCOPY - 1)) * 8u;
+    char *const hbase = reinterpret_cast<char *>(sm.hist);
+
+    /* cell coordinates advance linearly along x: vb(x + 1) = vb(x) + (R^T e_x) ux binf.  They only feed the trilinear
+     * weights (continuous); whether a voxel belongs to the window was settled exactly in A1. */
+    const float svx = g.r00 * g.uxf * g.binf, svy = g.r10 * g.uxf * g.binf, svz = g.r20 * g.uxf * g.binf;
+
+    /* one accepted voxel: cell coordinates vb, window weight w, central differences (x2) */
+    auto accumulate = [&](float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
+        gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
+        gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
+        gx = gx * w; gy = gy * w; gz = gz * w;
+        V3 gr;
+        gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
+        gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
+        gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
+        const float gg = gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
+        V3 bary;
+        const int face = dw_face_fast(sm.mesh, sm.fcn, gr, gg, &bary);
+        if (face < 0) return;
+        const float mag = DW_SQRT(gg);
+        /* base cell and offsets inside it; the clamps only matter for the last-bit slack of the stepped coordinates */
+        int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
+        ibx = ibx > 3 ? 3 : ibx; iby = iby > 3 ? 3 : iby; ibz = ibz > 3 ? 3 : ibz;
+        const double dvx = (double)(vbx - (float)ibx), dvy = (double)(vby - (float)iby), dvz = (double)(vbz - (float)ibz);
+        const double m0 = (double)(mag * bary.x), m1 = (double)(mag * bary.y), m2 = (double)(mag * bary.z);
+        const unsigned cellb = (unsigned)(ibx + 4 * iby + 16 * ibz) * (unsigned)(S3D_NVERT * DW_NCOPY * 8) + copy8;
+        char *const p0 = hbase + cellb + (unsigned)sm.vofs[face];
+        char *const p1 = hbase + cellb + (unsigned)sm.vofs[S3D_NFACES + face];
+        char *const p2 = hbase + cellb + (unsigned)sm.vofs[2 * S3D_NFACES + face];
+        const double wxs[2] = {1.0 - dvx, dvx}, wys[2] = {1.0 - dvy, dvy}, wzs[2] = {1.0 - dvz, dvz};
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+            for (int iy = 0; iy < 2; iy++) {
+                const double wxy = wxs[ix] * wys[iy];
+#pragma unroll
+                for (int iz = 0; iz < 2; iz++) {
+                    if (ibx + ix >= 4 || iby + iy >= 4 || ibz + iz >= 4) continue;        /* vb >= 0 holds */
+                    const double wc = wxy * wzs[iz];
+                    constexpr int DCB = S3D_NVERT * DW_NCOPY * 8;
+                    const int dc = (ix + 4 * iy + 16 * iz) * DCB;                          /* compile-time byte offset */
+                    atomicAdd(reinterpret_cast<unsigned long long *>(p0 + dc), (unsigned long long)__double_as_longlong(fma(m0, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(p1 + dc), (unsigned long long)__double_as_longlong(fma(m1, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(p2 + dc), (unsigned long long)__double_as_longlong(fma(m2, wc, Mfix)));
+                }
+            }
+    };
+
+    /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
+    const float slab_hi = 4.0f / g.binf - g.half;
+    const float a0 = g.r00 * g.uxf, a1 = g.r10 * g.uxf, a2 = g.r20 * g.uxf;
+    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
+    for (int r0 = 0; r0 < nrows; r0 += DW_THREADS) {
+        /* ---- A1: this thread's row ---- */
+        int len = 0;
+        unsigned first = 0;
+        if (r0 + tid < nrows) {
+            int by;
+            const int bz = fdiv_small(r0 + tid, wy, inv_wy, &by);
+            const int y = g.ys + by, z = g.zs + bz;
+            const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
+            const float s2 = g.rad2 - dy * dy - dz * dz;
+            const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) / g.uxf;
+            float lo_f = s2 < -1e-3f * g.rad2 ? 1.0f : -chord, hi_f = s2 < -1e-3f * g.rad2 ? -1.0f : chord;
+            const float c0 = g.r01 * dy + g.r02 * dz, c1 = g.r11 * dy + g.r12 * dz, c2 = g.r21 * dy + g.r22 * dz;
+            const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2};
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if (fabsf(av[i]) > 1e-6f) {                      /* else: left to the exact tests below */
+                    const float t0 = (-g.half - cv[i]) / av[i], t1 = (slab_hi - cv[i]) / av[i];
+                    lo_f = fmaxf(lo_f, fminf(t0, t1));
+                    hi_f = fminf(hi_f, fmaxf(t0, t1));
+                }
+            int lo = (int)ceilf(g.cx + lo_f - 1e-3f), hi = (int)floorf(g.cx + hi_f + 1e-3f);
+            lo = lo > g.xs ? lo : g.xs;
+            hi = hi < xe ? hi : xe;
+            auto inside = [&](int x) {
+                float sq, vx, vy, vz;
+                return desc_window(g, x, y, z, &sq, &vx, &vy, &vz);
+            };
+            while (lo <= hi && !inside(lo)) lo++;
+            while (lo <= hi && !inside(hi)) hi--;
+            if (lo <= hi) {
+                while (lo > g.xs && inside(lo - 1)) lo--;
+                while (hi < xe && inside(hi + 1)) hi++;
+                len = hi - lo + 1;
+                first = (unsigned)(lo - g.xs) | ((unsigned)by << 10) | ((unsigned)bz << 20);
+            }
+        }
+        /* ---- A2: exclusive scan of the chunk counts over the block ---- */
+        const int nchunk = (len + DESC_PER - 1) / DESC_PER;
+        int incl = nchunk;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl(incl, lane >= d ? lane - d : lane);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) sm.wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < (tid >> 6); w++) before += sm.wave_tot[w];
+        sm.seg_first[tid] = first;
+        sm.seg_len[tid] = (unsigned short)len;
+        sm.seg_off[tid] = before + incl - nchunk;
+        if (tid == DW_THREADS - 1) sm.seg_off[DW_THREADS] = before + incl;
+        __syncthreads();
+        const int total = sm.seg_off[DW_THREADS];
+        /* ---- B: one chunk per thread and turn ---- */
+        for (int c = tid; c < total; c += DW_THREADS) {
+            int sg = 0;
+#pragma unroll
+            for (int step = DW_THREADS / 2; step; step >>= 1)
+                if (sm.seg_off[sg + step] <= c) sg += step;         /* last row starting at or before chunk c */
+            const unsigned fv = sm.seg_first[sg];
+            const int q = c - sm.seg_off[sg];
+            const int rest = (int)sm.seg_len[sg] - DESC_PER * q;
+            const int nval = rest < DESC_PER ? rest : DESC_PER;
+            const int x0 = g.xs + (int)(fv & 1023u) + DESC_PER * q, y = g.ys + (int)((fv >> 10) & 1023u),
+                      z = g.zs + (int)(fv >> 20);
+            if (COUNT_ONLY) {                                       /* test aid: count + checksum of the window set */
+                for (int j = 0; j < nval; j++)
+                    atomicAdd(&sm.win_chk, ((unsigned)(x0 + j - g.xs) | (fv & ~1023u)) * 2654435761u);
+                atomicAdd(&sm.win_vox, (unsigned)nval);
+                continue;
+            }
+            const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
+            /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
+             * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
+            const f2u xa = *(const f2u *)(p - 1);
+            const f4u xb = *(const f4u *)(p + 1);
+            const f4u ym = *(const f4u *)(p - nx), yp = *(const f4u *)(p + nx);
+            const f4u zm = *(const f4u *)(p - (ptrdiff_t)plane), zp = *(const f4u *)(p + plane);
+            /* cell coordinates of the chunk's first voxel exactly as the reference forms them; the next three by stepping */
+            float sq0, vbx, vby, vbz;
+            desc_window(g, x0, y, z, &sq0, &vbx, &vby, &vbz);
+            vbx = vbx > 0.0f ? vbx : 0.0f; vby = vby > 0.0f ? vby : 0.0f; vbz = vbz > 0.0f ? vbz : 0.0f;
+            float w0, w1, w2, w3;
+            if (use_tab) {              /* squared voxel distance: d2(x + 1) = d2(x) + 2 dx + 1 */
+                const int dxi = x0 - cxi, dyi = y - cyi, dzi = z - czi;
+                const int d2 = dxi * dxi + dyi * dyi + dzi * dzi;
+                w0 = sm.wtab[d2];
+                w1 = sm.wtab[d2 + 2 * dxi + 1];
+                w2 = sm.wtab[d2 + 4 * dxi + 4];
+                w3 = sm.wtab[d2 + 6 * dxi + 9];
+            } else {
+                const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
+                auto wexact = [&](int x) {
+                    const float dx = ((float)x - g.cx) * g.uxf;
+                    const float sq = dx * dx + dy * dy + dz * dz;
+                    return s3d_expf_tab((float)((double)(-0.5f * sq) * inv_sig2), sm.etab);
+                };
+                w0 = wexact(x0); w1 = wexact(x0 + 1); w2 = wexact(x0 + 2); w3 = wexact(x0 + 3);
+            }
+            accumulate(vbx, vby, vbz, w0, xb.x - xa.x, yp.x - ym.x, zp.x - zm.x);
+            if (nval > 1) accumulate(fmaxf(vbx + svx, 0.0f), fmaxf(vby + svy, 0.0f), fmaxf(vbz + svz, 0.0f), w1, xb.y - xa.y, yp.y - ym.y, zp.y - zm.y);
+            if (nval > 2) accumulate(fmaxf(vbx + 2.0f * svx, 0.0f), fmaxf(vby + 2.0f * svy, 0.0f), fmaxf(vbz + 2.0f * svz, 0.0f), w2, xb.z - xb.x, yp.z - ym.z, zp.z - zm.z);
+            if (nval > 3) accumulate(fmaxf(vbx + 3.0f * svx, 0.0f), fmaxf(vby + 3.0f * svy, 0.0f), fmaxf(vbz + 3.0f * svz, 0.0f), w3, xb.w - xb.y, yp.w - ym.w, zp.w - zm.w);
+        }
+        __syncthreads();                                      /* seg_* are rewritten by the next round */
+    }
+    if (COUNT_ONLY) {
+        if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
+        return;
+    }
+    /* merge the copies (48-bit two's complement integers: order free), then normalise / clamp / normalise */
+    double ss = 0.0;
+    float v = 0.0f;
+    if (tid < S3D_DESC_NUMEL) {
+        long long acc = 0;
+        for (int w = 0; w < DW_NCOPY; w++) {
+            const unsigned long long raw = sm.hist[tid * DW_NCOPY + ((w + tid) & (DW_NCOPY - 1))];
+            acc += (long long)(raw << 16) >> 16;                      /* sign-extend the low 48 bits */
+        }
+        v = (float)((double)acc * unscale);
+        ss = (double)v * (double)v;
+    }
+    const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
+    double norm = sqrt(dw_block_sum(ss, sm.part)) + 2.220446049250313e-16; /* + DBL_EPSILON */
+    float inv = (float)(1.0 / norm);
+    v = v * inv;
+    v = v < trunc ? v : trunc;
+    ss = tid < S3D_DESC_NUMEL ? (double)v * (double)v : 0.0;
+    norm = sqrt(dw_block_sum(ss, sm.part)) + 2.220446049250313e-16;
+    inv = (float)(1.0 / norm);
+    if (tid < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tid] = v * inv;
+}
+
+static int dw_prepare(void)
+{
+#if !defined(S3D_EMU)
+    static int done = 0;
+    if (!done) {
+        S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
+        S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
+        done = 1;
+    }
+#endif
+    return S3D_OK;
+}
+
+/* Test / diagnostics aid: per keypoint the number of voxels the descriptor window accepts and a checksum of their
+ * coordinates (d_stats[2i], d_stats[2i+1]), from the very enumeration the descriptor kernel uses. */
+extern "C" int s3d_k_describe_window_stats(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
+                                           uint32_t *d_stats, s3d_stream st)
+{
+    if (num == 0) return S3D_OK;
+    if (dw_prepare()) return S3D_ERR;
+    hipLaunchKernelGGL((k_describe_wg<true>), dim3(num), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
+                       (const float *)nullptr, (float *)nullptr, (size_t)0, d_stats);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
 extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
                               const float *d_mesh, float *d_out, size_t out_stride, s3d_stream st)
 {
     if (num == 0) return S3D_OK;
     if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
-    if (g_variant & 128)
+    if (!(g_variant & 512)) {
+        if (dw_prepare()) return S3D_ERR;
+        hipLaunchKernelGGL((k_describe_wg<false>), dim3(num), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys,
+                           num, d_mesh, d_out, out_stride, (uint32_t *)nullptr);
+    } else if (g_variant & 128)
         hipLaunchKernelGGL((k_describe<2>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
                            d_mesh, d_out, out_stride, g_variant);
     else if (g_variant & 256)

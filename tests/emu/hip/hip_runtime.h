@@ -25,6 +25,7 @@
 #include <mutex>
 #include <vector>
 
+#define S3D_EMU 1
 #define __global__
 #define __device__
 #define __host__
@@ -249,6 +250,7 @@ static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 

@@ -318,21 +318,13 @@ def check_describe_window(lib, oracle, dims, units, nblobs, seed):
     s, im, kp = run_detect(lib, vol, units)
     xyzos, sd, R = lib.keypoints_to_numpy(kp)
     assert len(xyzos) > 0
-    lib.sift.s3d_k_set_variant.argtypes = [C.c_int]
-    lib.sift.s3d_k_set_variant.restype = None
-    d = abi.SIFT3D_Descriptor_store()
-    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
-    lib.sift.s3d_k_set_variant(16)
-    try:
-        assert lib.sift.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
-    finally:
-        lib.sift.s3d_k_set_variant(0)
-    bins, _ = lib.descriptors_to_numpy(d)
-    got = np.ascontiguousarray(bins[:, :2]).view(np.uint32)
+    lib.sift.sift3d_amd_describe_window_stats.argtypes = [C.POINTER(abi.SIFT3D), C.POINTER(abi.Keypoint_store),
+                                                          C.POINTER(C.c_uint)]
+    got = np.zeros((len(xyzos), 2), np.uint32)
+    assert lib.sift.sift3d_amd_describe_window_stats(C.byref(s), C.byref(kp), got.ctypes.data_as(C.POINTER(C.c_uint))) == 0
     cnt, chk = oracle.describe_window_stats(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
     assert np.array_equal(got[:, 0].astype(np.int64), cnt), np.nonzero(got[:, 0] != cnt)[0][:5]
     assert np.array_equal(got[:, 1], chk)
-    lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
     lib.sift.cleanup_Keypoint_store(C.byref(kp))
     lib.free_image(im)
     lib.sift.cleanup_SIFT3D(C.byref(s))
