@@ -618,8 +618,6 @@ extern "C" int s3d_k_compact_keys(const s3d_pyramid_desc *pyr, const uint32_t *d
 }
 
 /* ---- descriptor ------------------------------------------------------------------------------------ */
-#define DESC_THREADS 256
-#define DESC_WAVES (DESC_THREADS / 64)
 #define DESC_PER 4                         /* x-consecutive window voxels per chunk (one thread, one turn) */
 __device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n, int *s, int *e)
 {
@@ -628,23 +626,6 @@ __device__ __forceinline__ void desc_bounds(float vc, float rad, float uf, int n
     *s = (int)(fs > 1.0f ? fs : 1.0f);
     *e = (int)(fe < (float)(n - 2) ? fe : (float)(n - 2));
 }
-
-/* sum over the block of a double; result valid in every thread */
-__device__ __forceinline__ double block_sum_f64(double v)
-{
-    __shared__ double part[DESC_WAVES];
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = 0.0;
-    for (int w = 0; w < DESC_WAVES; w++) r += part[w];
-    __syncthreads();
-    return r;
-}
-
-/* value of the low 24 bits as a signed number: tells the compiler both factors of a product fit
- * v_mul_i32_i24 / v_mul_hi_i32_i24 (the shifts themselves fold away) */
-__device__ __forceinline__ int sext24(int v) { return (int)((unsigned)v << 8) >> 8; }
 
 /* Per-keypoint geometry shared by the two phases */
 struct DescGeom {
@@ -670,305 +651,48 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
     return !(*vbx < 0 || *vby < 0 || *vbz < 0 || *vbx >= 4.0f || *vby >= 4.0f || *vbz >= 4.0f);
 }
 
-/* One workgroup per keypoint.  The window (sphere of radius rad intersected with the rotated 4x4x4 cell
- * cube, sift.c:1869-1884) is convex, so along every x-row of the bounding box the accepted voxels form ONE
- * interval.  Rounds of 256 rows:
- *   A1  one thread per row: the interval from the closed form (sphere chord, three slab constraints),
- *       then trimmed / extended by the reference's own float test at its two ends -- the accepted set is
- *       exactly the reference's, but only ~4 voxels per row are tested instead of the whole row (the
- *       per-voxel test of all 1.9e5-7.5e5 box voxels was a third of this kernel);
+/* ==== the descriptor kernel: one 1024-thread workgroup per keypoint ========================================================
+ *
+ * extract_descrip (sift.c:1834-1928).  The window (sphere of radius rad intersected with the rotated 4x4x4 cell cube,
+ * sift.c:1869-1884) is convex, so along every x-row of the bounding box the accepted voxels form ONE interval.  Rounds
+ * of 1024 rows:
+ *   A1  one thread per row: the interval from the closed form (sphere chord, three slab constraints), then trimmed /
+ *       extended by the reference's own float test at its two ends -- the accepted set is exactly the reference's
+ *       (tests: count + coordinate checksum per keypoint), at ~4 voxel tests per row instead of 57-91;
  *   A2  block scan of the intervals' chunk counts (a chunk = 4 x-consecutive voxels of one row);
- *   B   every thread takes whole chunks (row found by binary search in the LDS prefix array): lanes sit
- *       16 bytes apart along x, so the six neighbour gathers of 4 voxels are five dwordx4 + one dwordx2 per
- *       lane over contiguous memory; then per voxel: Gaussian weight, rotation, icosahedron face +
- *       barycentric weights, trilinear spread over 8 cells x 3 vertices into the LDS histograms.  With
- *       lanes 4 voxels apart a wave's 64 voxels straddle many cells, which also thins the same-address
- *       collisions of the atomics (x-neighbours share cell and face).
- * There is no voxel queue and no block barrier inside B: waves drift apart freely within a round.
+ *   B   every thread takes whole chunks (row found by binary search in the LDS prefix array): lanes sit 16 bytes apart
+ *       along x, so the six neighbour gathers of 4 voxels are five dwordx4 + one dwordx2 per lane over contiguous memory;
+ *       per voxel: Gaussian window weight, rotation into the keypoint frame, icosahedron face + barycentric weights,
+ *       trilinear spread over 8 cells x 3 vertices into the LDS histograms.
  *
- * Histogram arithmetic.  ds_add_f32 runs at ~0.33 lane-ops/clk/CU on gfx950 whatever the address
- * pattern (measured, scripts/ubench_lds.hip) -- it was 88 % of this kernel -- while the integer LDS
- * atomics run 9-20x faster.  Bins are therefore accumulated in 64-bit fixed point (scale 2^40:
- * range +-8.4e6, resolution 9e-13; a contribution c*2^40 converts exactly unless c < 7.6e-6) with
- * ds_add_u64 and converted to f32 once at the end.  Integer addition is associative, so -- unlike the
- * f32 atomics -- the result is bitwise reproducible from run to run, and it is closer to the exact sum
- * than the reference's sequential f32 accumulation (difference to the reference ~1e-6 relative).
- * The block keeps NCOPY histograms (lane l adds into copy l % NCOPY, row stride 769) to thin out the
- * same-address collisions of x-neighbouring voxels, which share cell and icosahedron face. */
-template <int NCOPY>
-__global__ void __launch_bounds__(DESC_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
-k_describe(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num,
-           const float *__restrict__ d_mesh, float *__restrict__ out, size_t out_stride, int variant)
-{
-    constexpr int HSTRIDE = S3D_DESC_NUMEL + 1;
-    __shared__ unsigned long long hist[NCOPY * HSTRIDE];
-    __shared__ float mesh[S3D_MESH_FLOATS];
-    __shared__ unsigned seg_first[DESC_THREADS];
-    __shared__ unsigned short seg_len[DESC_THREADS];
-    __shared__ int seg_off[DESC_THREADS + 1];
-    __shared__ int wave_tot[DESC_WAVES];
-    __shared__ unsigned win_chk, win_vox;
-    unsigned win_count = 0;
-    const unsigned kid = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (kid >= num) return;
-    const s3d_desc_key key = keys[kid];
-    for (int i = tid; i < NCOPY * HSTRIDE; i += DESC_THREADS) hist[i] = 0ull;
-    for (int i = tid; i < S3D_MESH_FLOATS; i += DESC_THREADS) mesh[i] = d_mesh[i];
-    if (tid == 0) { win_chk = 0; win_vox = 0; }
-    __syncthreads();
-
-    const int o = key.octave;
-    const float *__restrict__ im = pyr.d_level[key.level];
-    const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
-    const size_t plane = (size_t)nx * ny;
-    DescGeom g;
-    g.cx = key.cx; g.cy = key.cy; g.cz = key.cz;
-    g.uxf = pyr.unitsf[o][0]; g.uyf = pyr.unitsf[o][1]; g.uzf = pyr.unitsf[o][2];
-    g.rad2 = key.rad * key.rad; g.half = key.half; g.binf = key.binf;
-    g.r00 = key.R[0]; g.r01 = key.R[3]; g.r02 = key.R[6];
-    g.r10 = key.R[1]; g.r11 = key.R[4]; g.r12 = key.R[7];
-    g.r20 = key.R[2]; g.r21 = key.R[5]; g.r22 = key.R[8];
-    const double inv_sig2 = 1.0 / (double)(key.sigma * key.sigma);
-    const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
-
-    /* Fixed-point format of the histogram: value * 2^(40 - bexp), where 2^bexp exceeds the largest possible
-     * contribution.  (Level voxels are bounded by 1 -- scaled input, convex filters -- so a central
-     * difference is <= 1/u per axis and a contribution mag*wt*bary <= |grad| <= bound.)  Each bin can
-     * absorb 2^23 maximal contributions before overflowing 63 bits; it receives < 2.5e4. */
-    int bexp;
-    (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);   /* bound < 2^bexp */
-    const double unscale = ldexp(1.0, bexp - 40);
-
-    int xe, ye, ze;
-    desc_bounds(key.cx, key.rad, g.uxf, nx, &g.xs, &xe);
-    desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
-    desc_bounds(key.cz, key.rad, g.uzf, nz, &g.zs, &ze);
-    const int wx = xe - g.xs + 1, wy = ye - g.ys + 1, wz = ze - g.zs + 1;
-    const unsigned hbase = (unsigned)(lane & (NCOPY - 1)) * HSTRIDE;
-
-    /* phase B body: one accepted voxel, its central differences already in registers (single call site:
-     * this is the bulk of the kernel's code) */
-    auto accumulate = [&](int x, int y, int z, float gx, float gy, float gz) {
-        float sq, vbx, vby, vbz;
-        desc_window(g, x, y, z, &sq, &vbx, &vby, &vbz);
-        gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
-        gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
-        /* window weight, bit for bit the reference's expf(-0.5f * sq / (sigma * sigma)) (sift.c:1890): the
-         * descriptor is discontinuous in it (s3d_math.h, s3d_expf).  The float quotient a / b equals the double
-         * product a * fl(1 / b) rounded to float: a quotient of two 24-bit numbers is never within 2^-49 of a
-         * rounding boundary and the product is within 2^-52 of it. */
-        const float w = s3d_expf((float)((double)(-0.5f * sq) * inv_sig2));
-        gx = gx * w; gy = gy * w; gz = gz * w;
-        V3 gr;
-        gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
-        gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
-        gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
-        V3 bary;
-        const int face = s3d_icos_bin_fast(mesh, gr, &bary);
-        if (face < 0) return;
-        const float mag = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
-        const float dvx = vbx - floorf(vbx), dvy = vby - floorf(vby), dvz = vbz - floorf(vbz);
-        const int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
-        /* LDS word offsets of the three vertex bins of the base cell (32-bit index arithmetic only) */
-        const unsigned cell0 = hbase + (unsigned)(S3D_NVERT * (ibx + 4 * iby + 16 * ibz));
-        const unsigned o0 = cell0 + (unsigned)__float_as_int(S3D_MESH_AT(mesh, face, 13)),
-                       o1 = cell0 + (unsigned)__float_as_int(S3D_MESH_AT(mesh, face, 14)),
-                       o2 = cell0 + (unsigned)__float_as_int(S3D_MESH_AT(mesh, face, 15));
-        /* contribution = (mag*bary_v) * wt, formed exactly in integers: the first factor rounded to 23
-         * significant bits at the sample's own exponent (gradients are 100-1000x below the bound, a
-         * fixed scale would waste those bits), the trilinear weight to 2^-22, both inside the signed
-         * 24-bit range so that the 46-bit product is two full-rate instructions (v_mul_i32_i24 /
-         * v_mul_hi_i32_i24; a general 64-bit multiply is quarter rate), then shifted to the common
-         * format.  mag >= 1.09e-3 (icos_bin's floor), so 4 <= shift <= 15 + bexp. */
-        int em;
-        (void)frexpf(mag, &em);                                       /* mag < 2^em <= 2^bexp */
-        const float mscale = ldexpf(1.0f, 22 - em);
-        const int shift = 4 - em + bexp;
-        const int m0 = sext24(__float2int_rn(mag * bary.x * mscale));
-        const int m1 = sext24(__float2int_rn(mag * bary.y * mscale));
-        const int m2 = sext24(__float2int_rn(mag * bary.z * mscale));
-        const float wxs[2] = {1.0f - dvx, dvx}, wys[2] = {1.0f - dvy, dvy}, wzs[2] = {1.0f - dvz, dvz};
-        /* (a branch-free variant -- zero weight on a clamped bin -- measured 10 % slower: the skipped cells
-         * are worth more than the divergence costs) */
-#pragma unroll
-        for (int ix = 0; ix < 2; ix++)
-#pragma unroll
-            for (int iy = 0; iy < 2; iy++)
-#pragma unroll
-                for (int iz = 0; iz < 2; iz++) {
-                    if (ibx + ix >= 4 || iby + iy >= 4 || ibz + iz >= 4 || (variant & 4)) continue;   /* vb >= 0 holds */
-                    /* w in [0,1]: the mantissa of w + 2 is round(w * 2^22) (bit 23 of the pattern is 0) */
-                    const int wt = sext24(__float_as_int(wxs[ix] * wys[iy] * wzs[iz] + 2.0f));
-                    const unsigned dc = (unsigned)(S3D_NVERT * (ix + 4 * iy + 16 * iz));      /* compile-time */
-                    atomicAdd(&hist[o0 + dc], (unsigned long long)(((long long)m0 * (long long)wt) >> shift));
-                    atomicAdd(&hist[o1 + dc], (unsigned long long)(((long long)m1 * (long long)wt) >> shift));
-                    atomicAdd(&hist[o2 + dc], (unsigned long long)(((long long)m2 * (long long)wt) >> shift));
-                }
-    };
-
-    /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
-    const float slab_hi = 4.0f / g.binf - g.half;
-    const float a0 = g.r00 * g.uxf, a1 = g.r10 * g.uxf, a2 = g.r20 * g.uxf;
-    const int nrows = (wx > 0 && wy > 0 && wz > 0 && wx < 1024 && wy < 1024 && wz < 1024) ? wy * wz : 0;
-    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
-    for (int r0 = 0; r0 < nrows; r0 += DESC_THREADS) {
-        /* ---- A1: this thread's row ---- */
-        int len = 0;
-        unsigned first = 0;
-        if (r0 + tid < nrows) {
-            int by;
-            const int bz = fdiv_small(r0 + tid, wy, inv_wy, &by);
-            const int y = g.ys + by, z = g.zs + bz;
-            const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
-            const float s2 = g.rad2 - dy * dy - dz * dz;
-            const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) / g.uxf;
-            float lo_f = s2 < -1e-3f * g.rad2 ? 1.0f : -chord, hi_f = s2 < -1e-3f * g.rad2 ? -1.0f : chord;
-            const float c0 = g.r01 * dy + g.r02 * dz, c1 = g.r11 * dy + g.r12 * dz, c2 = g.r21 * dy + g.r22 * dz;
-            const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2};
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-                if (fabsf(av[i]) > 1e-6f) {                      /* else: left to the exact tests below */
-                    const float t0 = (-g.half - cv[i]) / av[i], t1 = (slab_hi - cv[i]) / av[i];
-                    lo_f = fmaxf(lo_f, fminf(t0, t1));
-                    hi_f = fminf(hi_f, fmaxf(t0, t1));
-                }
-            int lo = (int)ceilf(g.cx + lo_f - 1e-3f), hi = (int)floorf(g.cx + hi_f + 1e-3f);
-            lo = lo > g.xs ? lo : g.xs;
-            hi = hi < xe ? hi : xe;
-            auto inside = [&](int x) {
-                float sq, vx, vy, vz;
-                return desc_window(g, x, y, z, &sq, &vx, &vy, &vz);
-            };
-            while (lo <= hi && !inside(lo)) lo++;
-            while (lo <= hi && !inside(hi)) hi--;
-            if (lo <= hi) {
-                while (lo > g.xs && inside(lo - 1)) lo--;
-                while (hi < xe && inside(hi + 1)) hi++;
-                len = hi - lo + 1;
-                first = (unsigned)(lo - g.xs) | ((unsigned)by << 10) | ((unsigned)bz << 20);
-            }
-        }
-        /* ---- A2: exclusive scan of the chunk counts (4 voxels per chunk) over the block ---- */
-        const int nchunk = (len + DESC_PER - 1) / DESC_PER;
-        int incl = nchunk;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl(incl, lane >= d ? lane - d : lane);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) wave_tot[tid >> 6] = incl;
-        __syncthreads();
-        int before = 0;
-        for (int w = 0; w < (tid >> 6); w++) before += wave_tot[w];
-        seg_first[tid] = first;
-        seg_len[tid] = (unsigned short)len;
-        seg_off[tid] = before + incl - nchunk;
-        if (tid == DESC_THREADS - 1) seg_off[DESC_THREADS] = before + incl;
-        __syncthreads();
-        const int total = seg_off[DESC_THREADS];
-        win_count += (unsigned)total;                         /* (chunks; the test aid counts voxels below) */
-        /* ---- B: one chunk (<= 4 x-consecutive voxels of one row) per thread and turn.  Lanes are 16 bytes
-         * apart along x, so the wave's gathers are five dwordx4 and one dwordx2 over contiguous memory. ---- */
-        for (int c = tid; c < total; c += DESC_THREADS) {
-            int sg = 0;
-#pragma unroll
-            for (int step = DESC_THREADS / 2; step; step >>= 1)
-                if (seg_off[sg + step] <= c) sg += step;            /* last row starting at or before chunk c */
-            const unsigned fv = seg_first[sg];
-            const int q = c - seg_off[sg];
-            const int nval = (int)seg_len[sg] - DESC_PER * q < DESC_PER ? (int)seg_len[sg] - DESC_PER * q : DESC_PER;
-            const int x0 = g.xs + (int)(fv & 1023u) + DESC_PER * q, y = g.ys + (int)((fv >> 10) & 1023u),
-                      z = g.zs + (int)(fv >> 20);
-            if (variant & 16) {                                       /* test aid: count + checksum of the set */
-                for (int j = 0; j < nval; j++)
-                    atomicAdd(&win_chk, ((unsigned)(x0 + j - g.xs) | (fv & ~1023u)) * 2654435761u);
-                atomicAdd(&win_vox, (unsigned)nval);
-                continue;
-            }
-            if (variant & 8) continue;
-            const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
-            /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
-             * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
-            const f2u xa = *(const f2u *)(p - 1);
-            const f4u xb = *(const f4u *)(p + 1);
-            const f4u ym = *(const f4u *)(p - nx), yp = *(const f4u *)(p + nx);
-            const f4u zm = *(const f4u *)(p - (ptrdiff_t)plane), zp = *(const f4u *)(p + plane);
-            const float xr[6] = {xa.x, xa.y, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll 1
-            for (int j = 0; j < nval; j++) {
-                const float xl = j == 0 ? xr[0] : j == 1 ? xr[1] : j == 2 ? xr[2] : xr[3];
-                const float xh = j == 0 ? xr[2] : j == 1 ? xr[3] : j == 2 ? xr[4] : xr[5];
-                const float yl = j == 0 ? ym.x : j == 1 ? ym.y : j == 2 ? ym.z : ym.w;
-                const float yh = j == 0 ? yp.x : j == 1 ? yp.y : j == 2 ? yp.z : yp.w;
-                const float zl = j == 0 ? zm.x : j == 1 ? zm.y : j == 2 ? zm.z : zm.w;
-                const float zh = j == 0 ? zp.x : j == 1 ? zp.y : j == 2 ? zp.z : zp.w;
-                accumulate(x0 + j, y, z, xh - xl, yh - yl, zh - zl);
-            }
-        }
-        __syncthreads();                                      /* seg_* are rewritten by the next round */
-    }
-    if (variant & 16) {              /* bit 4: out[0..1] = bit patterns of (count, checksum) of the window set */
-        if (tid == 0) {
-            out[(size_t)kid * out_stride] = __uint_as_float(win_vox + 0u * win_count);
-            out[(size_t)kid * out_stride + 1] = __uint_as_float(win_chk);
-        }
-        return;
-    }
-    /* merge the histogram copies (integers: order free), then normalise / clamp / normalise */
-    float v[S3D_DESC_NUMEL / DESC_THREADS];
-    double ss = 0.0;
-    for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
-        const int i = tid + j * DESC_THREADS;
-        unsigned long long acc64 = hist[i];
-        for (int w = 1; w < NCOPY; w++) acc64 += hist[w * HSTRIDE + i];
-        const float a = (float)((double)(long long)acc64 * unscale);
-        v[j] = a;
-        ss += (double)a * (double)a;
-    }
-    const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
-    double norm = sqrt(block_sum_f64(ss)) + 2.220446049250313e-16;         /* + DBL_EPSILON */
-    float inv = (float)(1.0 / norm);
-    ss = 0.0;
-    for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++) {
-        float a = v[j] * inv;
-        a = a < trunc ? a : trunc;
-        v[j] = a;
-        ss += (double)a * (double)a;
-    }
-    norm = sqrt(block_sum_f64(ss)) + 2.220446049250313e-16;
-    inv = (float)(1.0 / norm);
-    for (int j = 0; j < S3D_DESC_NUMEL / DESC_THREADS; j++)
-        out[(size_t)kid * out_stride + tid + j * DESC_THREADS] = v[j] * inv;
-}
-
-
-/* ==== the descriptor kernel, second form: one 1024-thread workgroup per keypoint ==========================================
- *
- * Same window enumeration as above (A1 closed-form row intervals settled by the reference's own test, A2 block scan,
- * B one 4-voxel chunk per thread and turn) and the same bit-faithful per-voxel front end (window weight, rotation,
- * icosahedron face through the reference's ray-triangle test).  What changed is everything around the LDS atomics,
- * which with the VALU work were the two saturated resources of the kernel (rocprofv3 + scripts/ubench_lds2/3.hip):
+ * What the kernel is made of was decided by measurements on MI355X (rocprofv3 SQ counters, scripts/ubench_lds2/3.hip,
+ * scripts/ubench_valu.hip): it is bound by VALU issue first (a wave64 f32 op costs the SIMD 2.8 cycles, every f64, packed,
+ * conversion or 24-bit-multiply instruction 4.4, rcp/sqrt 8.4) and by the in-order LDS queue second (a table read
+ * queued behind atomics waits for all of them).
  *
  *  (1) Bank-private histogram copies.  A ds_add_u64 costs the LDS pipe 6.4 clk per wave when the lanes hit distinct
  *      banks and 11.9 clk with data-dependent addresses (64 lanes x 2 dwords over 64 banks, processed 16 lanes at
  *      a time).  With 16 copies laid out copy-minor -- word (bin, copy) at bin*16 + copy, copy = lane & 15 -- the 16 lanes
- *      of a pass always sit in 16 different bank pairs whatever their bins are: conflict free by construction.  16 x 768
- *      x 8 B = 96 KB of LDS is what a CU has room for once, hence ONE workgroup of 16 waves per CU (4 per SIMD, 128
- *      VGPRs each) instead of five of 4 waves.
+ *      of a pass always sit in 16 different bank pairs whatever their bins are: conflict free by construction
+ *      (SQ_LDS_BANK_CONFLICT 1.3e10 -> 8.5e8).  16 x 768 x 8 B = 96 KB of LDS is what a CU has room for once, hence ONE
+ *      workgroup of 16 waves per CU (4 per SIMD, 128 VGPRs each).
  *  (2) One VALU instruction per contribution.  A contribution (mag * bary_v) * (wx * wy * wz) is formed as
  *      fma(m_v, w_c, M) in f64 with M = 1.5 * 2^(52 - f): the product of two f32-derived doubles is exact, the single
  *      rounding of the fma lands on the fixed-point grid 2^-f, and the low 48 bits of the result's bit pattern ARE that
  *      fixed-point number (the exponent field and bit 51 are the same for every contribution and fall outside the low
  *      48 bits), so the raw 64-bit pattern goes straight into ds_add_u64 and the sums of the low 48 bits are exact
- *      integers: order free, bitwise reproducible, rounded to nearest instead of truncated.  f is chosen per keypoint so
- *      that a copy's bin cannot leave 47 bits: (window voxels / 16) * gradient bound * 2^f < 2^47.  (Was: two 24-bit
- *      integer multiplies + a 64-bit shift per contribution and the integer conversion of every weight.)
+ *      integers: order free, bitwise reproducible, rounded to nearest.  f is chosen per keypoint so that a copy's bin
+ *      cannot leave 47 bits: (window voxels / 16) * gradient bound * 2^f < 2^47.
  *  (3) The window weight expf(-sq / 2 sigma^2) comes from a per-keypoint table indexed by the integer squared distance
  *      when that is exact (integer centre, equal power-of-two units: every octave of a unit-voxel volume); the table
  *      entries are produced by the same restated glibc expf on the same float argument, so nothing changes bit-wise.
- *      Otherwise the weight is computed per voxel as before, with the exp2 table in LDS instead of global memory.
- *  (4) The four voxels of a chunk are straight-line code (no per-voxel select chains over the loaded neighbours).
+ *      Otherwise the weight is computed per voxel, with the exp2 table in LDS.
+ *  (4) Continuous quantities are not recomputed bit for bit: cell coordinates are stepped along x from the chunk's first
+ *      voxel, the barycentric weights of samples safely inside a face come from three dot products and a 1-ulp
+ *      reciprocal (dw_face_fast), |grad| from a 1-ulp sqrt: ~1e-6 relative against a 1e-4 contract.  Everything that
+ *      DECIDES something -- window membership, the window weight that scales the gradient, the rotated gradient, the
+ *      face near an edge -- stays on the reference's arithmetic.
+ *  (5) A chunk's LDS reads (tables, the next chunk's look-up) are issued before its 96 atomics.
  */
 #define DW_THREADS 1024
 #define DW_WAVES (DW_THREADS / 64)
@@ -1168,6 +892,9 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         __syncthreads();
     }
 
+#if defined(DW_ABLATE)
+    unsigned long long ablate_acc = 0;
+#endif
     const unsigned copy8 = (unsigned)(lane & (DW_NCOPY - 1)) * 8u;
     char *const hbase = reinterpret_cast<char *>(sm.hist);
 
@@ -1175,8 +902,12 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
      * weights (continuous); whether a voxel belongs to the window was settled exactly in A1. */
     const float svx = g.r00 * g.uxf * g.binf, svy = g.r10 * g.uxf * g.binf, svz = g.r20 * g.uxf * g.binf;
 
-    /* one accepted voxel: cell coordinates vb, window weight w, central differences (x2) */
-    auto accumulate = [&](float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
+    /* One accepted voxel in two halves, so that a chunk's LDS READS (tables) all come before its LDS ATOMICS: LDS
+     * operations of a wave complete in order, and a table read queued behind 24 atomics waits for all of them.
+     * front: cell coordinates vb, window weight w, central differences (x2) -> face and the three vertex magnitudes. */
+    struct DwVox { float m0, m1, m2, vbx, vby, vbz; int face; };
+    auto front = [&](float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
+        DwVox v;
         gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
         gx = gx * w; gy = gy * w; gz = gz * w;
@@ -1185,19 +916,29 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
         gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
         const float gg = gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
-        V3 bary;
-        const int face = dw_face_fast(sm.mesh, sm.fcn, gr, gg, &bary);
-        if (face < 0) return;
+        V3 bary = v3(0.0f, 0.0f, 0.0f);
+        v.face = dw_face_fast(sm.mesh, sm.fcn, gr, gg, &bary);
         const float mag = DW_SQRT(gg);
+        v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
+        v.vbx = vbx; v.vby = vby; v.vbz = vbz;
+        return v;
+    };
+    /* back: the trilinear spread over 8 cells x 3 vertices */
+    auto back = [&](const DwVox &v) {
+        if (v.face < 0) return;
+#if defined(DW_ABLATE) && DW_ABLATE == 3          /* profiling build: no back end at all */
+        if (v.m0 == 123.456f) sm.hist[0] = 1ull;
+        return;
+#endif
         /* base cell and offsets inside it; the clamps only matter for the last-bit slack of the stepped coordinates */
-        int ibx = (int)vbx, iby = (int)vby, ibz = (int)vbz;
+        int ibx = (int)v.vbx, iby = (int)v.vby, ibz = (int)v.vbz;
         ibx = ibx > 3 ? 3 : ibx; iby = iby > 3 ? 3 : iby; ibz = ibz > 3 ? 3 : ibz;
-        const double dvx = (double)(vbx - (float)ibx), dvy = (double)(vby - (float)iby), dvz = (double)(vbz - (float)ibz);
-        const double m0 = (double)(mag * bary.x), m1 = (double)(mag * bary.y), m2 = (double)(mag * bary.z);
+        const double dvx = (double)(v.vbx - (float)ibx), dvy = (double)(v.vby - (float)iby), dvz = (double)(v.vbz - (float)ibz);
+        const double m0 = (double)v.m0, m1 = (double)v.m1, m2 = (double)v.m2;
         const unsigned cellb = (unsigned)(ibx + 4 * iby + 16 * ibz) * (unsigned)(S3D_NVERT * DW_NCOPY * 8) + copy8;
-        char *const p0 = hbase + cellb + (unsigned)sm.vofs[face];
-        char *const p1 = hbase + cellb + (unsigned)sm.vofs[S3D_NFACES + face];
-        char *const p2 = hbase + cellb + (unsigned)sm.vofs[2 * S3D_NFACES + face];
+        char *const p0 = hbase + cellb + (unsigned)sm.vofs[v.face];
+        char *const p1 = hbase + cellb + (unsigned)sm.vofs[S3D_NFACES + v.face];
+        char *const p2 = hbase + cellb + (unsigned)sm.vofs[2 * S3D_NFACES + v.face];
         const double wxs[2] = {1.0 - dvx, dvx}, wys[2] = {1.0 - dvy, dvy}, wzs[2] = {1.0 - dvz, dvz};
 #pragma unroll
         for (int ix = 0; ix < 2; ix++)
@@ -1210,11 +951,64 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                     const double wc = wxy * wzs[iz];
                     constexpr int DCB = S3D_NVERT * DW_NCOPY * 8;
                     const int dc = (ix + 4 * iy + 16 * iz) * DCB;                          /* compile-time byte offset */
+#if defined(DW_ABLATE) && DW_ABLATE == 2          /* profiling build: the arithmetic without the LDS atomics */
+                    ablate_acc ^= (unsigned long long)__double_as_longlong(fma(m0, wc, Mfix)) + (unsigned long long)(p0 + dc - hbase);
+                    ablate_acc ^= (unsigned long long)__double_as_longlong(fma(m1, wc, Mfix)) + (unsigned long long)(p1 + dc - hbase);
+                    ablate_acc ^= (unsigned long long)__double_as_longlong(fma(m2, wc, Mfix)) + (unsigned long long)(p2 + dc - hbase);
+#else
                     atomicAdd(reinterpret_cast<unsigned long long *>(p0 + dc), (unsigned long long)__double_as_longlong(fma(m0, wc, Mfix)));
                     atomicAdd(reinterpret_cast<unsigned long long *>(p1 + dc), (unsigned long long)__double_as_longlong(fma(m1, wc, Mfix)));
                     atomicAdd(reinterpret_cast<unsigned long long *>(p2 + dc), (unsigned long long)__double_as_longlong(fma(m2, wc, Mfix)));
+#endif
                 }
             }
+    };
+    /* chunk c of the current round -> its first voxel and length (binary search in the LDS prefix array) */
+    struct DwChunk { int x0, y, z, nval; unsigned fv; };
+    auto lookup = [&](int c) {
+        DwChunk ch;
+        int sg = 0;
+#pragma unroll
+        for (int step = DW_THREADS / 2; step; step >>= 1)
+            if (sm.seg_off[sg + step] <= c) sg += step;             /* last row starting at or before chunk c */
+        ch.fv = sm.seg_first[sg];
+        const int q = c - sm.seg_off[sg];
+        const int rest = (int)sm.seg_len[sg] - DESC_PER * q;
+        ch.nval = rest < DESC_PER ? rest : DESC_PER;
+        ch.x0 = g.xs + (int)(ch.fv & 1023u) + DESC_PER * q;
+        ch.y = g.ys + (int)((ch.fv >> 10) & 1023u);
+        ch.z = g.zs + (int)(ch.fv >> 20);
+        return ch;
+    };
+    /* everything a chunk needs from memory: the six neighbour runs (global) and the four window weights (LDS table, or
+     * computed) */
+    struct DwLoads { f2u xa; f4u xb, ym, yp, zm, zp; float w0, w1, w2, w3; };
+    auto gather = [&](const DwChunk &ch) {
+        DwLoads L;
+        const float *p = im + ((size_t)ch.z * plane + (size_t)ch.y * nx + ch.x0);
+        /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
+         * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
+        L.xa = *(const f2u *)(p - 1);
+        L.xb = *(const f4u *)(p + 1);
+        L.ym = *(const f4u *)(p - nx); L.yp = *(const f4u *)(p + nx);
+        L.zm = *(const f4u *)(p - (ptrdiff_t)plane); L.zp = *(const f4u *)(p + plane);
+        if (use_tab) {                  /* squared voxel distance: d2(x + 1) = d2(x) + 2 dx + 1 */
+            const int dxi = ch.x0 - cxi, dyi = ch.y - cyi, dzi = ch.z - czi;
+            const int d2 = dxi * dxi + dyi * dyi + dzi * dzi;
+            L.w0 = sm.wtab[d2];
+            L.w1 = sm.wtab[d2 + 2 * dxi + 1];
+            L.w2 = sm.wtab[d2 + 4 * dxi + 4];
+            L.w3 = sm.wtab[d2 + 6 * dxi + 9];
+        } else {
+            const float dy = ((float)ch.y - g.cy) * g.uyf, dz = ((float)ch.z - g.cz) * g.uzf;
+            auto wexact = [&](int x) {
+                const float dx = ((float)x - g.cx) * g.uxf;
+                const float sq = dx * dx + dy * dy + dz * dz;
+                return s3d_expf_tab((float)((double)(-0.5f * sq) * inv_sig2), sm.etab);
+            };
+            L.w0 = wexact(ch.x0); L.w1 = wexact(ch.x0 + 1); L.w2 = wexact(ch.x0 + 2); L.w3 = wexact(ch.x0 + 3);
+        }
+        return L;
     };
 
     /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
@@ -1276,56 +1070,47 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         if (tid == DW_THREADS - 1) sm.seg_off[DW_THREADS] = before + incl;
         __syncthreads();
         const int total = sm.seg_off[DW_THREADS];
-        /* ---- B: one chunk per thread and turn ---- */
-        for (int c = tid; c < total; c += DW_THREADS) {
-            int sg = 0;
-#pragma unroll
-            for (int step = DW_THREADS / 2; step; step >>= 1)
-                if (sm.seg_off[sg + step] <= c) sg += step;         /* last row starting at or before chunk c */
-            const unsigned fv = sm.seg_first[sg];
-            const int q = c - sm.seg_off[sg];
-            const int rest = (int)sm.seg_len[sg] - DESC_PER * q;
-            const int nval = rest < DESC_PER ? rest : DESC_PER;
-            const int x0 = g.xs + (int)(fv & 1023u) + DESC_PER * q, y = g.ys + (int)((fv >> 10) & 1023u),
-                      z = g.zs + (int)(fv >> 20);
-            if (COUNT_ONLY) {                                       /* test aid: count + checksum of the window set */
-                for (int j = 0; j < nval; j++)
-                    atomicAdd(&sm.win_chk, ((unsigned)(x0 + j - g.xs) | (fv & ~1023u)) * 2654435761u);
-                atomicAdd(&sm.win_vox, (unsigned)nval);
-                continue;
+        /* ---- B: one chunk per thread and turn; the next chunk's look-up and loads are issued before this chunk's
+         * atomics (they would otherwise queue behind them) ---- */
+        if (COUNT_ONLY) {                                           /* test aid: count + checksum of the window set */
+            for (int c = tid; c < total; c += DW_THREADS) {
+                const DwChunk ch = lookup(c);
+                for (int j = 0; j < ch.nval; j++)
+                    atomicAdd(&sm.win_chk, ((unsigned)(ch.x0 + j - g.xs) | (ch.fv & ~1023u)) * 2654435761u);
+                atomicAdd(&sm.win_vox, (unsigned)ch.nval);
             }
-            const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
-            /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
-             * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
-            const f2u xa = *(const f2u *)(p - 1);
-            const f4u xb = *(const f4u *)(p + 1);
-            const f4u ym = *(const f4u *)(p - nx), yp = *(const f4u *)(p + nx);
-            const f4u zm = *(const f4u *)(p - (ptrdiff_t)plane), zp = *(const f4u *)(p + plane);
-            /* cell coordinates of the chunk's first voxel exactly as the reference forms them; the next three by stepping */
-            float sq0, vbx, vby, vbz;
-            desc_window(g, x0, y, z, &sq0, &vbx, &vby, &vbz);
-            vbx = vbx > 0.0f ? vbx : 0.0f; vby = vby > 0.0f ? vby : 0.0f; vbz = vbz > 0.0f ? vbz : 0.0f;
-            float w0, w1, w2, w3;
-            if (use_tab) {              /* squared voxel distance: d2(x + 1) = d2(x) + 2 dx + 1 */
-                const int dxi = x0 - cxi, dyi = y - cyi, dzi = z - czi;
-                const int d2 = dxi * dxi + dyi * dyi + dzi * dzi;
-                w0 = sm.wtab[d2];
-                w1 = sm.wtab[d2 + 2 * dxi + 1];
-                w2 = sm.wtab[d2 + 4 * dxi + 4];
-                w3 = sm.wtab[d2 + 6 * dxi + 9];
-            } else {
-                const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
-                auto wexact = [&](int x) {
-                    const float dx = ((float)x - g.cx) * g.uxf;
-                    const float sq = dx * dx + dy * dy + dz * dz;
-                    return s3d_expf_tab((float)((double)(-0.5f * sq) * inv_sig2), sm.etab);
-                };
-                w0 = wexact(x0); w1 = wexact(x0 + 1); w2 = wexact(x0 + 2); w3 = wexact(x0 + 3);
+#if defined(DW_ABLATE) && DW_ABLATE == 1          /* profiling build: rows + scan only */
+        } else if (tid < total && tid > 4096) {
+#else
+        } else if (tid < total) {
+#endif
+            int c = tid;
+            DwChunk ch = lookup(c);
+            DwLoads L = gather(ch);
+            for (;;) {
+                /* cell coordinates of the chunk's first voxel exactly as the reference forms them; the next three by
+                 * stepping */
+                float sq0, vbx, vby, vbz;
+                desc_window(g, ch.x0, ch.y, ch.z, &sq0, &vbx, &vby, &vbz);
+                vbx = vbx > 0.0f ? vbx : 0.0f; vby = vby > 0.0f ? vby : 0.0f; vbz = vbz > 0.0f ? vbz : 0.0f;
+                DwVox v0, v1, v2, v3;
+                v1.face = v2.face = v3.face = -1;
+                v0 = front(vbx, vby, vbz, L.w0, L.xb.x - L.xa.x, L.yp.x - L.ym.x, L.zp.x - L.zm.x);
+                if (ch.nval > 1)
+                    v1 = front(fmaxf(vbx + svx, 0.0f), fmaxf(vby + svy, 0.0f), fmaxf(vbz + svz, 0.0f), L.w1, L.xb.y - L.xa.y,
+                               L.yp.y - L.ym.y, L.zp.y - L.zm.y);
+                if (ch.nval > 2)
+                    v2 = front(fmaxf(vbx + 2.0f * svx, 0.0f), fmaxf(vby + 2.0f * svy, 0.0f), fmaxf(vbz + 2.0f * svz, 0.0f), L.w2,
+                               L.xb.z - L.xb.x, L.yp.z - L.ym.z, L.zp.z - L.zm.z);
+                if (ch.nval > 3)
+                    v3 = front(fmaxf(vbx + 3.0f * svx, 0.0f), fmaxf(vby + 3.0f * svy, 0.0f), fmaxf(vbz + 3.0f * svz, 0.0f), L.w3,
+                               L.xb.w - L.xb.y, L.yp.w - L.ym.w, L.zp.w - L.zm.w);
+                c += DW_THREADS;
+                const bool more = c < total;
+                if (more) { ch = lookup(c); L = gather(ch); }
+                back(v0); back(v1); back(v2); back(v3);
+                if (!more) break;
             }
-            accumulate(vbx, vby, vbz, w0, xb.x - xa.x, yp.x - ym.x, zp.x - zm.x);
-            if (nval > 1) accumulate(fmaxf(vbx + svx, 0.0f), fmaxf(vby + svy, 0.0f), fmaxf(vbz + svz, 0.0f), w1, xb.y - xa.y, yp.y - ym.y, zp.y - zm.y);
-            if (nval > 2) accumulate(fmaxf(vbx + 2.0f * svx, 0.0f), fmaxf(vby + 2.0f * svy, 0.0f), fmaxf(vbz + 2.0f * svz, 0.0f), w2, xb.z - xb.x, yp.z - ym.z, zp.z - zm.z);
-            if (nval > 3) accumulate(fmaxf(vbx + 3.0f * svx, 0.0f), fmaxf(vby + 3.0f * svy, 0.0f), fmaxf(vbz + 3.0f * svz, 0.0f), w3, xb.w - xb.y, yp.w - ym.w, zp.w - zm.w);
         }
         __syncthreads();                                      /* seg_* are rewritten by the next round */
     }
@@ -1333,6 +1118,9 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
         return;
     }
+#if defined(DW_ABLATE)
+    if (ablate_acc == 0x1234567ull) sm.hist[1] = 1ull;
+#endif
     /* merge the copies (48-bit two's complement integers: order free), then normalise / clamp / normalise */
     double ss = 0.0;
     float v = 0.0f;
@@ -1387,19 +1175,9 @@ extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d
 {
     if (num == 0) return S3D_OK;
     if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
-    if (!(g_variant & 512)) {
-        if (dw_prepare()) return S3D_ERR;
-        hipLaunchKernelGGL((k_describe_wg<false>), dim3(num), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys,
-                           num, d_mesh, d_out, out_stride, (uint32_t *)nullptr);
-    } else if (g_variant & 128)
-        hipLaunchKernelGGL((k_describe<2>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
-                           d_mesh, d_out, out_stride, g_variant);
-    else if (g_variant & 256)
-        hipLaunchKernelGGL((k_describe<8>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
-                           d_mesh, d_out, out_stride, g_variant);
-    else
-        hipLaunchKernelGGL((k_describe<4>), dim3(num), dim3(DESC_THREADS), 0, (hipStream_t)st, *pyr, d_keys, num,
-                           d_mesh, d_out, out_stride, g_variant);
+    if (dw_prepare()) return S3D_ERR;
+    hipLaunchKernelGGL((k_describe_wg<false>), dim3(num), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
+                       d_mesh, d_out, out_stride, (uint32_t *)nullptr);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
