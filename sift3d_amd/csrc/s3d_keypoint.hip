@@ -699,6 +699,7 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
 #define DW_NCOPY 16
 #define DW_TMAX 2048                      /* entries of the weight table (squared voxel distances 0 .. DW_TMAX-1) */
 #define DW_HIST_WORDS (S3D_DESC_NUMEL * DW_NCOPY)
+#define DW_CMAP 16384                     /* chunks of a round that get a direct chunk -> row entry (the rest: binary search) */
 
 struct DwShared {
     unsigned long long hist[DW_HIST_WORDS];
@@ -711,6 +712,7 @@ struct DwShared {
     unsigned seg_first[DW_THREADS];
     int seg_off[DW_THREADS + 1];
     unsigned short seg_len[DW_THREADS];
+    unsigned short chunk_row[DW_CMAP];    /* row (thread index of the round) that chunk c belongs to */
     int wave_tot[DW_WAVES];
     unsigned win_chk, win_vox;
 };
@@ -757,10 +759,11 @@ __device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long 
  * per-face constants, det = g.(e2 x e1), b.y det = g.(e2 x t), b.z det = g.q (the triple products of cart2bary,
  * sift.c:335-394, with the constant factors pulled together), and a 1-ulp reciprocal: the weights then differ from the
  * reference's by ~1e-6 relative -- they are continuous quantities, the tolerance is 1e-4 -- while the DECISION which
- * face (the discontinuous part, see s3d_math.h) is unchanged: a 1e-6 error cannot carry a sample across the 2e-5 margin. */
-__device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, const float *__restrict__ fcn, V3 g, float gg, V3 *bary)
+ * face (the discontinuous part, see s3d_math.h) is unchanged: a 1e-6 error cannot carry a sample across the 2e-5 margin.
+ * Straight-line code: *safe tells the caller whether the result stands or the sequential search has to decide (the four
+ * voxels of a chunk run this back to back so that the scheduler can interleave them; the rare searches follow). */
+__device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, const float *__restrict__ fcn, V3 g, V3 *bary, bool *safe)
 {
-    if ((double)gg < S3D_BARY_EPS_D) return -1;
     const float ax = fabsf(g.x), ay = fabsf(g.y), az = fabsf(g.z);
     const float c0 = 0.57735027f, c1 = 0.35682209f, c2 = 0.93417236f;
     const float s0 = c0 * (ax + ay + az);
@@ -783,12 +786,10 @@ __device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, cons
     b.y = ny * inv;
     b.z = nz * inv;
     b.x = 1.0f - b.y - b.z;
+    *bary = b;
     /* the ray hits the plane of the face in front of the origin iff k = (e2.q) / det > 0 (e2.q: field 12) */
-    if (fabsf(det) > 1e-5f && mesh[12 * S3D_NFACES + face] * inv > 0.0f && b.x >= 2e-5f && b.y >= 2e-5f && b.z >= 2e-5f) {
-        *bary = b;
-        return face;
-    }
-    return s3d_icos_bin(mesh, g, bary);
+    *safe = fabsf(det) > 1e-5f && mesh[12 * S3D_NFACES + face] * inv > 0.0f && b.x >= 2e-5f && b.y >= 2e-5f && b.z >= 2e-5f;
+    return face;
 }
 
 __device__ __forceinline__ double dw_block_sum(double v, double *part)
@@ -905,8 +906,8 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     /* One accepted voxel in two halves, so that a chunk's LDS READS (tables) all come before its LDS ATOMICS: LDS
      * operations of a wave complete in order, and a table read queued behind 24 atomics waits for all of them.
      * front: cell coordinates vb, window weight w, central differences (x2) -> face and the three vertex magnitudes. */
-    struct DwVox { float m0, m1, m2, vbx, vby, vbz; int face; };
-    auto front = [&](float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
+    struct DwVox { float m0, m1, m2, vbx, vby, vbz, gx, gy, gz; int face; bool safe; };
+    auto front = [&](bool valid, float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
         DwVox v;
         gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
@@ -916,12 +917,25 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
         gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
         const float gg = gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
-        V3 bary = v3(0.0f, 0.0f, 0.0f);
-        v.face = dw_face_fast(sm.mesh, sm.fcn, gr, gg, &bary);
+        V3 bary;
+        bool safe;
+        const int face = dw_face_fast(sm.mesh, sm.fcn, gr, &bary, &safe);
+        const bool live = valid && !((double)gg < S3D_BARY_EPS_D);       /* icos_hist_bin's floor on |grad|^2, sift.c:1655 */
         const float mag = DW_SQRT(gg);
+        v.face = live ? face : -1;
+        v.safe = safe || !live;
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
         v.vbx = vbx; v.vby = vby; v.vbz = vbz;
+        v.gx = gr.x; v.gy = gr.y; v.gz = gr.z;
         return v;
+    };
+    /* the sample lies within 2e-5 of a face edge (or the look-up missed): the reference's sequential search decides */
+    auto resolve = [&](DwVox &v) {
+        if (v.safe) return;
+        V3 bary = v3(0.0f, 0.0f, 0.0f);
+        v.face = s3d_icos_bin(sm.mesh, v3(v.gx, v.gy, v.gz), &bary);
+        const float mag = DW_SQRT(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
+        v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
     };
     /* back: the trilinear spread over 8 cells x 3 vertices */
     auto back = [&](const DwVox &v) {
@@ -963,14 +977,18 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                 }
             }
     };
-    /* chunk c of the current round -> its first voxel and length (binary search in the LDS prefix array) */
+    /* chunk c of the current round -> its first voxel and length */
     struct DwChunk { int x0, y, z, nval; unsigned fv; };
     auto lookup = [&](int c) {
         DwChunk ch;
         int sg = 0;
-#pragma unroll
-        for (int step = DW_THREADS / 2; step; step >>= 1)
-            if (sm.seg_off[sg + step] <= c) sg += step;             /* last row starting at or before chunk c */
+        if (c < DW_CMAP) {
+            sg = (int)sm.chunk_row[c];
+        } else {                                                    /* very long rows only */
+#pragma unroll 1
+            for (int step = DW_THREADS / 2; step; step >>= 1)
+                if (sm.seg_off[sg + step] <= c) sg += step;         /* last row starting at or before chunk c */
+        }
         ch.fv = sm.seg_first[sg];
         const int q = c - sm.seg_off[sg];
         const int rest = (int)sm.seg_len[sg] - DESC_PER * q;
@@ -988,10 +1006,20 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const float *p = im + ((size_t)ch.z * plane + (size_t)ch.y * nx + ch.x0);
         /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
          * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
+#if defined(DW_ABLATE) && DW_ABLATE == 4          /* profiling build: no global loads (synthetic neighbours) */
+        {
+            const float a = (float)(ch.x0 & 7) * 1e-2f, b = (float)(ch.y & 7) * 1e-2f, cc = (float)(ch.z & 7) * 1e-2f;
+            L.xa.x = a; L.xa.y = b; L.xb.x = cc; L.xb.y = a + b; L.xb.z = b + cc; L.xb.w = a - cc;
+            L.ym.x = a; L.ym.y = b; L.ym.z = cc; L.ym.w = a; L.yp.x = b + 0.01f; L.yp.y = cc; L.yp.z = a; L.yp.w = b;
+            L.zm.x = cc; L.zm.y = a; L.zm.z = b; L.zm.w = cc; L.zp.x = a; L.zp.y = b + 0.02f; L.zp.z = cc; L.zp.w = a;
+            if (p == nullptr) L.xa.x = 1.0f;
+        }
+#else
         L.xa = *(const f2u *)(p - 1);
         L.xb = *(const f4u *)(p + 1);
         L.ym = *(const f4u *)(p - nx); L.yp = *(const f4u *)(p + nx);
         L.zm = *(const f4u *)(p - (ptrdiff_t)plane); L.zp = *(const f4u *)(p + plane);
+#endif
         if (use_tab) {                  /* squared voxel distance: d2(x + 1) = d2(x) + 2 dx + 1 */
             const int dxi = ch.x0 - cxi, dyi = ch.y - cyi, dzi = ch.z - czi;
             const int d2 = dxi * dxi + dyi * dyi + dzi * dzi;
@@ -1068,6 +1096,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         sm.seg_len[tid] = (unsigned short)len;
         sm.seg_off[tid] = before + incl - nchunk;
         if (tid == DW_THREADS - 1) sm.seg_off[DW_THREADS] = before + incl;
+        {   /* chunk -> row map: every row enters itself for its own chunks (ten dependent LDS reads of a binary search per
+             * chunk become one) */
+            const int c0 = before + incl - nchunk;
+            for (int q = 0; q < nchunk && c0 + q < DW_CMAP; q++) sm.chunk_row[c0 + q] = (unsigned short)tid;
+        }
         __syncthreads();
         const int total = sm.seg_off[DW_THREADS];
         /* ---- B: one chunk per thread and turn; the next chunk's look-up and loads are issued before this chunk's
@@ -1094,17 +1127,23 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                 desc_window(g, ch.x0, ch.y, ch.z, &sq0, &vbx, &vby, &vbz);
                 vbx = vbx > 0.0f ? vbx : 0.0f; vby = vby > 0.0f ? vby : 0.0f; vbz = vbz > 0.0f ? vbz : 0.0f;
                 DwVox v0, v1, v2, v3;
-                v1.face = v2.face = v3.face = -1;
-                v0 = front(vbx, vby, vbz, L.w0, L.xb.x - L.xa.x, L.yp.x - L.ym.x, L.zp.x - L.zm.x);
-                if (ch.nval > 1)
-                    v1 = front(fmaxf(vbx + svx, 0.0f), fmaxf(vby + svy, 0.0f), fmaxf(vbz + svz, 0.0f), L.w1, L.xb.y - L.xa.y,
-                               L.yp.y - L.ym.y, L.zp.y - L.zm.y);
-                if (ch.nval > 2)
-                    v2 = front(fmaxf(vbx + 2.0f * svx, 0.0f), fmaxf(vby + 2.0f * svy, 0.0f), fmaxf(vbz + 2.0f * svz, 0.0f), L.w2,
-                               L.xb.z - L.xb.x, L.yp.z - L.ym.z, L.zp.z - L.zm.z);
-                if (ch.nval > 3)
-                    v3 = front(fmaxf(vbx + 3.0f * svx, 0.0f), fmaxf(vby + 3.0f * svy, 0.0f), fmaxf(vbz + 3.0f * svz, 0.0f), L.w3,
-                               L.xb.w - L.xb.y, L.yp.w - L.ym.w, L.zp.w - L.zm.w);
+#if defined(DW_ABLATE) && DW_ABLATE == 5          /* profiling build: look-ups and loads only */
+                ablate_acc += (unsigned long long)(L.xa.x + L.xb.w + L.ym.x + L.yp.y + L.zm.z + L.zp.w + L.w0 + L.w3 + vbx);
+                c += DW_THREADS;
+                if (c >= total) break;
+                ch = lookup(c); L = gather(ch);
+                continue;
+#endif
+                /* all four unconditionally (lanes past the end of their row compute on the slack they loaded and are
+                 * marked dead): one straight-line block the scheduler can interleave */
+                v0 = front(true, vbx, vby, vbz, L.w0, L.xb.x - L.xa.x, L.yp.x - L.ym.x, L.zp.x - L.zm.x);
+                v1 = front(ch.nval > 1, fmaxf(vbx + svx, 0.0f), fmaxf(vby + svy, 0.0f), fmaxf(vbz + svz, 0.0f), L.w1,
+                           L.xb.y - L.xa.y, L.yp.y - L.ym.y, L.zp.y - L.zm.y);
+                v2 = front(ch.nval > 2, fmaxf(vbx + 2.0f * svx, 0.0f), fmaxf(vby + 2.0f * svy, 0.0f), fmaxf(vbz + 2.0f * svz, 0.0f),
+                           L.w2, L.xb.z - L.xb.x, L.yp.z - L.ym.z, L.zp.z - L.zm.z);
+                v3 = front(ch.nval > 3, fmaxf(vbx + 3.0f * svx, 0.0f), fmaxf(vby + 3.0f * svy, 0.0f), fmaxf(vbz + 3.0f * svz, 0.0f),
+                           L.w3, L.xb.w - L.xb.y, L.yp.w - L.ym.w, L.zp.w - L.zm.w);
+                if (!(v0.safe && v1.safe && v2.safe && v3.safe)) { resolve(v0); resolve(v1); resolve(v2); resolve(v3); }
                 c += DW_THREADS;
                 const bool more = c < total;
                 if (more) { ch = lookup(c); L = gather(ch); }
