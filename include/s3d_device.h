@@ -88,6 +88,8 @@ int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp, int nx, i
                        int z1, const float uf[3], const float *taps, int width, s3d_stream stream);
 /* Force a code path (tests / profiling): 0 = auto, 1 = generic per-axis passes, 2 = fused fast path
  * (fails if the configuration is not eligible). */
+/* The three knobs below are per calling thread (thread_local): tests and bench.py set them on the thread that then
+ * makes the calls; other threads' SIFT3D objects are not affected. */
 /* rows (planes) per marching chunk of the fused kernels: occupancy vs warm-up re-reads */
 void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z);
 /* record HIP events (from s3d_rt_event_create) before k_gauss_xy, between, and after k_gauss_z of the
@@ -161,7 +163,8 @@ int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint3
 #define S3D_ORIENT_CHUNK (1u << 20)
 #define S3D_ORIENT_SCRATCH_BYTES 128u
 size_t s3d_k_orient_scratch_bytes(uint32_t num);
-/* Test knob: candidates per chunk (0 or > S3D_ORIENT_CHUNK restores the default; the scratch size is unaffected). */
+/* Test knob of the calling thread: candidates per chunk (0 or > S3D_ORIENT_CHUNK restores the default; the scratch
+ * size is unaffected). */
 void s3d_k_set_orient_chunk(uint32_t n);
 /* Stable compaction of kept candidates: for i with keep[i], writes x,y,z,o,s (int32 x5) and R.
  * *d_num_out receives the number kept.  d_scratch: >= num/256 + 2 uint32. */
@@ -196,9 +199,6 @@ int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint
  * checksum of their coordinates, produced by the descriptor kernel's own window enumeration. */
 int s3d_k_describe_window_stats(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
                                 uint32_t *d_stats, s3d_stream stream);
-
-/* Profiling-only ablation switch for k_orient / k_describe (see s3d_keypoint.hip); 0 = normal. */
-void s3d_k_set_variant(int v);
 
 /* Self-test: d_out[i] = the kernels' window-weight exponential of d_in[i] (a restatement of glibc 2.35 expf,
  * which the reference reaches through expf() at sift.c:1401, 1890, 2333); |d_in[i]| < 80. */

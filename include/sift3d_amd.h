@@ -368,6 +368,17 @@ int draw_matches(const Image *const left, const Image *const right, const Mat_rm
                  const Mat_rm *const keys_right, const Mat_rm *const match_left, const Mat_rm *const match_right,
                  Image *const concat, Image *const keys, Image *const lines);               /* sift.c:2990 */
 
+/* small host-side exports a relinked caller may reach */
+void init_Mesh(Mesh *const mesh);                                        /* imutil.c:549 */
+void cleanup_Mesh(Mesh *const mesh);                                     /* imutil.c:557 */
+void init_Slab(Slab *const slab);                                        /* imutil.c:4071 */
+void cleanup_Slab(Slab *const slab);                                     /* imutil.c:4078 */
+int init_Mat_rm_p(Mat_rm *const mat, const void *const p, const int num_rows, const int num_cols,
+                  const Mat_rm_type type, const int set_zero);           /* imutil.c:655 */
+int eigen_Mat_rm(Mat_rm *A, Mat_rm *Q, Mat_rm *L);                       /* imutil.c:2992 (Jacobi instead of LAPACK dsyevd) */
+int copy_Pyramid(const Pyramid *const src, Pyramid *const dst);          /* imutil.c:3995 */
+int write_pyramid(const char *path, Pyramid *pyr);                       /* imutil.c:4093 (after sift3d_amd_download_pyramid) */
+
 /* ======================= extensions (not in the reference) ========================================= */
 /* Device-resident variants: `d_vol` is a float32 volume already in HBM (x fastest, nx*ny*nz). */
 int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling helper run on the GPU box: (1) sweep of the marching-chunk sizes of the fused Gaussian
-kernels at 512^3, (2) ablations of k_orient / k_describe through s3d_k_set_variant.  Prints tables."""
+kernels at 512^3, (2) -- ablations of the descriptor kernel moved to scripts/build_ablate.py + scripts/describe_ab.py.  Prints tables."""
 import ctypes as C
 import json
 import os
@@ -65,46 +65,7 @@ def gauss_sweep():
         dev.free(p)
 
 
-def ablate():
-    vol = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
-    d_vol = dev.upload(vol)
-    s = abi.SIFT3D()
-    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
-    kp = abi.Keypoint_store()
-    lib.sift.init_Keypoint_store(C.byref(kp))
-    d_desc = C.c_void_p()
-    L = lib.sift
-    L.s3d_k_set_variant.argtypes = [C.c_int]
-    res = {}
-    for name, v in (("normal", 0), ("orient_no_ordered_sum", 1), ("orient_fast_exp", 2), ("orient_both", 3)):
-        L.s3d_k_set_variant(v)
-        L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
-        dev.sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
-        dev.sync()
-        res["detect_" + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
-        print("detect", name, res["detect_" + name], "ms  K =", kp.slab.num, flush=True)
-    L.s3d_k_set_variant(0)
-    L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), n, n, n, 1.0, 1.0, 1.0, C.byref(kp))
-    for name, v in (("normal4", 0), ("copies2", 128), ("describe_no_atomics", 4), ("describe_no_phaseB", 8)):
-        L.s3d_k_set_variant(v)
-        L.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
-        dev.sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            L.sift3d_amd_extract_descriptors_dev(C.byref(s), C.byref(kp), C.byref(d_desc))
-        dev.sync()
-        res["describe_" + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
-        print("describe", name, res["describe_" + name], "ms", flush=True)
-    L.s3d_k_set_variant(0)
-    out["ablation"] = res
-
-
 if "gauss" in sys.argv or len(sys.argv) == 1:
     gauss_sweep()
-if "ablate" in sys.argv or len(sys.argv) == 1:
-    ablate()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "tune.json"), "w"))

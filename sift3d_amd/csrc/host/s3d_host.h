@@ -22,6 +22,9 @@ int s3d_verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz);
 /* scalar set-up of extract_descrip (sift.c:1845-1851) for one keypoint, in the reference's float steps */
 void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave, s3d_desc_key *out);
 
+/* fails (with a message) when a descriptor window is too wide for the kernel's row enumeration */
+int s3d_check_desc_windows(const s3d_desc_key *keys, size_t num, const s3d_pyramid_desc *pd);
+
 /* ---- one process, N GPUs behind the reference entry points (s3d_host_slab.c) --------------------------- */
 struct s3d_mgpu;
 int s3d_mgpu_wanted(const struct s3d_mgpu *m);            /* > 1: the multi-GPU path is switched on */

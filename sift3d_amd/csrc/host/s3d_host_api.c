@@ -763,6 +763,30 @@ void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int
     memcpy(out->R, key->R.u.data_float ? key->R.u.data_float : key->r_data, 9 * sizeof(float));
 }
 
+/* The descriptor kernel enumerates a keypoint's window row by row with 10-bit coordinates: a window of 1024 or more
+ * voxels along an axis (voxel spacings ~50 times smaller than the keypoint scale, on volumes wider than 1024) is
+ * beyond it.  Refuse loudly rather than return an empty histogram. */
+int s3d_check_desc_windows(const s3d_desc_key *keys, size_t num, const s3d_pyramid_desc *pd)
+{
+    for (size_t i = 0; i < num; i++) {
+        const s3d_desc_key *k = keys + i;
+        const float c[3] = {k->cx, k->cy, k->cz};
+        for (int a = 0; a < 3; a++) {
+            const float u = pd->unitsf[k->octave][a];
+            const int n = pd->dims[k->octave][a];
+            float lo = floorf(c[a] - k->rad / u), hi = ceilf(c[a] + k->rad / u);
+            if (lo < 1.0f) lo = 1.0f;
+            if (hi > (float)(n - 2)) hi = (float)(n - 2);
+            if (hi - lo + 1.0f >= 1024.0f) {
+                S3D_MSG("sift3d_amd: the descriptor window of keypoint %zu spans %.0f voxels along axis %d (units %g); at most "
+                        "1023 are supported \n", i, (double)(hi - lo + 1.0f), a, (double)u);
+                return SIFT3D_FAILURE;
+            }
+        }
+    }
+    return SIFT3D_SUCCESS;
+}
+
 static int ctx_ensure_desc(s3d_ctx *c, size_t num)
 {
     if (c->desc_cap >= num) return SIFT3D_SUCCESS;
@@ -780,6 +804,7 @@ static int describe_dev(SIFT3D *const sift3d, s3d_ctx *c, const s3d_pyramid_desc
                         size_t num, SIFT3D_Descriptor *host_out)
 {
     (void)sift3d;
+    if (s3d_check_desc_windows(keys, num, pd)) return SIFT3D_FAILURE;
     if (ctx_base(c) || ctx_ensure_desc(c, num)) return SIFT3D_FAILURE;
     DEV(s3d_rt_h2d(c->d_keys, keys, num * sizeof(s3d_desc_key), c->stream));
     DEV(s3d_k_describe(pd, c->d_keys, (uint32_t)num, c->d_mesh, c->d_desc, DESC_REC_FLOATS, c->stream));

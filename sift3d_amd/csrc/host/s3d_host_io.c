@@ -487,3 +487,164 @@ int draw_points(const Mat_rm *const in, const int *const dims, int radius, Image
     }
     return SIFT3D_SUCCESS;
 }
+
+/* ---- remaining exports of SURVEY section 2 rows 5-7: small host-side pieces a relinked caller may reach, so that an
+ * LD_PRELOAD deployment never resolves them to the reference while the pyramids' voxels live in HBM ------------------ */
+void init_Mesh(Mesh *const mesh) /* imutil.c:549-553 */
+{
+    mesh->tri = NULL;
+    mesh->num = -1;
+}
+
+void cleanup_Mesh(Mesh *const mesh) /* imutil.c:557-560 */
+{
+    free(mesh->tri);
+}
+
+void init_Slab(Slab *const slab) /* imutil.c:4071-4074 */
+{
+    slab->buf_size = slab->num = 0;
+    slab->buf = NULL;
+}
+
+void cleanup_Slab(Slab *const slab) /* imutil.c:4078-4082 */
+{
+    if (slab->buf != NULL) free(slab->buf);
+}
+
+/* init_Mat_rm with caller-owned storage (imutil.c:655-676): static_mem is set, resizing to another size fails */
+int init_Mat_rm_p(Mat_rm *const mat, const void *const p, const int num_rows, const int num_cols, const Mat_rm_type type,
+                  const int set_zero)
+{
+    if (init_Mat_rm(mat, num_rows, num_cols, type, set_zero)) return SIFT3D_FAILURE;
+    cleanup_Mat_rm(mat);
+    mat->u.data_double = (double *)p;
+    mat->static_mem = SIFT3D_TRUE;
+    if (set_zero && zero_Mat_rm(mat)) return SIFT3D_FAILURE;
+    return SIFT3D_SUCCESS;
+}
+
+/* Eigen-decomposition of a symmetric matrix (imutil.c:2992-3075: LAPACK dsyevd, all eigenvalues ascending in the
+ * n x 1 matrix L, eigenvectors in the COLUMNS of Q; Q may be NULL).  LAPACK is not linked into this library: cyclic
+ * Jacobi in double, which for symmetric input is accurate to the last few ulps like dsyevd; eigenvector signs are as
+ * arbitrary here as there (callers fix them: sift.c:1467-1471). */
+int eigen_Mat_rm(Mat_rm *A, Mat_rm *Q, Mat_rm *L)
+{
+    const int n = A->num_cols;
+    double *a, *q;
+    if (A->num_rows != n) {
+        puts("eigen_Mat_rm: A be square \n");
+        return SIFT3D_FAILURE;
+    }
+    if (A->type != SIFT3D_DOUBLE) {
+        puts("eigen_Mat_rm: A must have type double \n");
+        return SIFT3D_FAILURE;
+    }
+    L->num_rows = n; L->num_cols = 1; L->type = SIFT3D_DOUBLE;
+    if (resize_Mat_rm(L)) return SIFT3D_FAILURE;
+    if (Q != NULL) {
+        Q->num_rows = Q->num_cols = n; Q->type = SIFT3D_DOUBLE;
+        if (resize_Mat_rm(Q)) return SIFT3D_FAILURE;
+    }
+    if (n == 0) return SIFT3D_SUCCESS;
+    a = (double *)malloc(sizeof(double) * (size_t)n * n);
+    q = (double *)malloc(sizeof(double) * (size_t)n * n);
+    if (!a || !q) { free(a); free(q); return SIFT3D_FAILURE; }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            /* dsyevd with uplo = 'U' on the transposed copy reads one triangle only: the lower one of the row-major A */
+            a[i * n + j] = i >= j ? A->u.data_double[i * n + j] : A->u.data_double[j * n + i];
+            q[i * n + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++) off += a[i * n + j] * a[i * n + j];
+        if (off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int r = p + 1; r < n; r++) {
+                const double apr = a[p * n + r];
+                if (apr == 0.0) continue;
+                const double theta = (a[r * n + r] - a[p * n + p]) / (2.0 * apr);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = a[k * n + p], akr = a[k * n + r];
+                    a[k * n + p] = c * akp - s * akr;
+                    a[k * n + r] = s * akp + c * akr;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = a[p * n + k], ark = a[r * n + k];
+                    a[p * n + k] = c * apk - s * ark;
+                    a[r * n + k] = s * apk + c * ark;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double qkp = q[k * n + p], qkr = q[k * n + r];
+                    q[k * n + p] = c * qkp - s * qkr;
+                    q[k * n + r] = s * qkp + c * qkr;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) L->u.data_double[i] = a[i * n + i];
+    for (int i = 0; i < n - 1; i++)                         /* ascending, eigenvectors along */
+        for (int j = 0; j < n - 1 - i; j++)
+            if (L->u.data_double[j] > L->u.data_double[j + 1]) {
+                const double tl = L->u.data_double[j];
+                L->u.data_double[j] = L->u.data_double[j + 1];
+                L->u.data_double[j + 1] = tl;
+                for (int k = 0; k < n; k++) {
+                    const double tq = q[k * n + j];
+                    q[k * n + j] = q[k * n + j + 1];
+                    q[k * n + j + 1] = tq;
+                }
+            }
+    if (Q != NULL) memcpy(Q->u.data_double, q, sizeof(double) * (size_t)n * n);
+    free(a); free(q);
+    return SIFT3D_SUCCESS;
+}
+
+/* Deep copy of a pyramid (imutil.c:3995-4048): scales, shape, and the voxels of every level that has any on the host.
+ * Levels whose data is NULL -- all of them after a detect here, until sift3d_amd_download_pyramid() -- copy as metadata,
+ * exactly what the reference does with a NULL level. */
+int copy_Pyramid(const Pyramid *const src, Pyramid *const dst)
+{
+    Image dummy;
+    const Image *base = &dummy;
+    int have_levels = 0, rc = SIFT3D_FAILURE;
+    init_im(&dummy);
+    if (set_scales_Pyramid(src->sigma0, src->sigma_n, dst)) return SIFT3D_FAILURE;
+    if (src->levels != NULL && src->num_octaves > 0 && src->num_levels > 0) {
+        base = src->levels;
+        have_levels = 1;
+    }
+    if (resize_Pyramid(base, src->first_level, (unsigned)src->num_kp_levels, (unsigned)src->num_levels, src->first_octave,
+                       (unsigned)src->num_octaves, dst))
+        goto done;
+    if (have_levels)
+        for (int i = 0; i < src->num_octaves * src->num_levels; i++)
+            if (src->levels[i].data != NULL && im_copy_data(src->levels + i, dst->levels + i)) goto done;
+    rc = SIFT3D_SUCCESS;
+done:
+    im_free(&dummy);
+    return rc;
+}
+
+/* One NIfTI file per level, "<path>_o<octave>_s<level>" (imutil.c:4093-4111).  The levels must hold voxels on the host:
+ * after a detect call sift3d_amd_download_pyramid() first. */
+int write_pyramid(const char *path, Pyramid *pyr)
+{
+    char appended[1024];
+    if (s3d_make_parent_dirs(path)) return SIFT3D_FAILURE;
+    for (int o = pyr->first_octave; o < pyr->first_octave + pyr->num_octaves; o++)
+        for (int s = pyr->first_level; s < pyr->first_level + pyr->num_levels; s++) {
+            const Image *lv = SIFT3D_PYR_IM_GET(pyr, o, s);
+            snprintf(appended, sizeof(appended), "%s_o%i_s%i", path, o, s);
+            if (lv->data == NULL) {
+                S3D_MSG("write_pyramid: level (o=%d, s=%d) has no voxels on the host: call sift3d_amd_download_pyramid() "
+                        "after SIFT3D_detect_keypoints \n", o, s);
+                return SIFT3D_FAILURE;
+            }
+            if (write_nii(appended, lv)) return SIFT3D_FAILURE;
+        }
+    return SIFT3D_SUCCESS;
+}

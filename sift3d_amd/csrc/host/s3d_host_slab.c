@@ -637,6 +637,7 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
         }
         s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + j);
     }
+    if (s3d_check_desc_windows(keys, nsel, &sl->pd)) { free(keys); return SIFT3D_FAILURE; }
     if (s3d_rt_h2d(sl->d_keys, keys, nsel * sizeof(s3d_desc_key), sl->cs) ||
         s3d_k_describe(&sl->pd, sl->d_keys, (uint32_t)nsel, sl->d_mesh, sl->d_desc, DESC_REC_FLOATS, sl->cs)) {
         s3d_rt_sync(sl->cs);

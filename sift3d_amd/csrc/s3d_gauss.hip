@@ -465,7 +465,7 @@ static bool launch_z_ring(int hw, const float *src, float *dst, size_t plane4, i
     }
 }
 
-static int g_no_dyadic = 0;      /* profiling / test knob: force the generic kernel */
+static thread_local int g_no_dyadic = 0;      /* profiling / test knob of the calling thread: force the generic kernel */
 
 static int check_taps(const float *taps, int width, S3dTaps *out)
 {
@@ -1007,7 +1007,7 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
     return 1;
 }
 
-static int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk() */
+static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk().  Per calling thread. */
 
 /* profiling knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
  * bit 1 = no dyadic-spacing specialisation of the generic axis pass */
@@ -1021,7 +1021,7 @@ extern "C" void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z)
 }
 
 /* optional HIP events around the two fused kernels (bench.py times the dominant kernel with them) */
-static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static thread_local hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 extern "C" void s3d_k_gauss_set_events(void *before_xy, void *between, void *after_z)
 {
     g_ev[0] = (hipEvent_t)before_xy; g_ev[1] = (hipEvent_t)between; g_ev[2] = (hipEvent_t)after_z;

@@ -71,16 +71,6 @@ extern "C" void s3d_mesh_table(float *out)
     }
 }
 
-/* Ablation knob for profiling runs ONLY (results are wrong for any value but 0):
- *   bit 0: k_orient skips the ordered f32 window-gradient accumulation
- *   bit 1: k_orient uses the fast f32 exp      bit 2: k_describe skips the LDS atomics
- *   bit 3: k_describe skips phase B entirely (row intervals + scan only)
- *   bit 4: k_describe returns (count, checksum) of the accepted window voxels instead of a descriptor
- *   bit 4: k_orient always takes the ordered-sum pass (timing of the bound-based shortcut)
- *   bit 7 / bit 8: 2 / 8 histogram copies per block instead of 4 */
-static int g_variant = 0;
-extern "C" void s3d_k_set_variant(int v) { g_variant = v; }
-
 /* Self-test hook: d_out[i] = s3d_expf(d_in[i]) (the tests compare it with the host libm bit for bit). */
 __global__ void k_expf_selftest(const float *__restrict__ d_in, float *__restrict__ d_out, uint32_t n)
 {
@@ -170,7 +160,7 @@ __global__ void __launch_bounds__(64)
 k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
               const float *__restrict__ d_center, uint32_t cand0, uint32_t num, const double *__restrict__ d_sigma,
               double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
-              double *__restrict__ d_conf, int variant)
+              double *__restrict__ d_conf)
 {
     __shared__ __attribute__((aligned(16))) float term[3][64];
     __shared__ float gw_s[3];
@@ -223,7 +213,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
         __builtin_memcpy(&qb, &qd, 8);
         const int low = (int)(qb & 0x1fffffffull) - 0x10000000;
         if ((low < 0 ? -low : low) <= 4) wa = (float)(-0.5 * (double)sq / sig2);
-        return (variant & 2) ? __expf(wa) : s3d_expf(wa);
+        return s3d_expf(wa);
     };
     /* one window sample: weight and iso gradient exactly as the reference evaluates them */
     auto sample = [&](int x, int y, int z, float *gx, float *gy, float *gz, float *w) {
@@ -388,7 +378,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
             }
             term[0][lane] = tx; term[1][lane] = ty; term[2][lane] = tz;
             s3d_wave_lds_sync();
-            if (lane < 3 && !(variant & 1)) {
+            if (lane < 3) {
                 /* scan order (dense ids ascend in z, y, x); the padding of the last turn adds exact +0.  The
                  * 64 staged terms are pulled into registers with 16 independent ds_read_b128 so the
                  * dependent chain is 64 adds. */
@@ -417,7 +407,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
 
 __global__ void __launch_bounds__(64)
 k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R,
-                uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, int variant)
+                uint32_t *__restrict__ d_keep, double *__restrict__ d_conf)
 {
     const unsigned local = blockIdx.x * 64u + threadIdx.x;
     const unsigned cand = cand0 + local;
@@ -450,7 +440,7 @@ k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thr
     int decided = 0;
     if (ratio_reject) {
         decided = 1;                                       /* REJECT whatever the gradient is */
-    } else if (d_conf == nullptr && !(variant & 16)) {
+    } else if (d_conf == nullptr) {
         const double gam = ((double)cnt + 3.0) * 5.9604644775390625e-08 * 1.001;
         const double ex = gam * sax, ey = gam * say, ez = gam * saz;
         const double del = sqrt(ex * ex + ey * ey + ez * ez);
@@ -497,7 +487,7 @@ k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thr
 }
 
 /* candidates per chunk of s3d_k_orient (test knob: the suite shrinks it to exercise the chunk loop on small inputs) */
-static uint32_t g_orient_chunk = S3D_ORIENT_CHUNK;
+static thread_local uint32_t g_orient_chunk = S3D_ORIENT_CHUNK;   /* test knob of the calling thread */
 extern "C" void s3d_k_set_orient_chunk(uint32_t n)
 {
     g_orient_chunk = n == 0 || n > S3D_ORIENT_CHUNK ? S3D_ORIENT_CHUNK : (n < 64u ? 64u : n);
@@ -519,13 +509,13 @@ extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, 
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
         hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
-                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, g_variant);
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
-                           d_R, d_keep, d_conf, g_variant);
+                           d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
-                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, g_variant);
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
     }
     return S3D_OK;

@@ -1,0 +1,177 @@
+"""CPU: the small host-side exports of SURVEY section 2 rows 5-7 (init_Mat_rm_p, eigen_Mat_rm, copy_Pyramid,
+write_pyramid, init/cleanup_Mesh, init/cleanup_Slab) against the unmodified reference under oracle/_ref -- the symbols
+an LD_PRELOAD deployment would otherwise resolve to the reference while the pyramids' voxels live in HBM."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import sift3d_amd
+from sift3d_amd import abi
+
+P = C.POINTER
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return sift3d_amd.load()
+
+
+def _bind(u):
+    u.init_Mat_rm.argtypes = [P(abi.Mat_rm), C.c_int, C.c_int, C.c_int, C.c_int]
+    u.init_Mat_rm_p.argtypes = [P(abi.Mat_rm), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    u.resize_Mat_rm.argtypes = [P(abi.Mat_rm)]
+    u.cleanup_Mat_rm.argtypes = [P(abi.Mat_rm)]
+    u.cleanup_Mat_rm.restype = None
+    u.eigen_Mat_rm.argtypes = [P(abi.Mat_rm), P(abi.Mat_rm), P(abi.Mat_rm)]
+    u.init_Pyramid.argtypes = [P(abi.Pyramid)]
+    u.init_Pyramid.restype = None
+    u.cleanup_Pyramid.argtypes = [P(abi.Pyramid)]
+    u.cleanup_Pyramid.restype = None
+    u.set_scales_Pyramid.argtypes = [C.c_double, C.c_double, P(abi.Pyramid)]
+    u.resize_Pyramid.argtypes = [P(abi.Image), C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_uint, P(abi.Pyramid)]
+    u.copy_Pyramid.argtypes = [P(abi.Pyramid), P(abi.Pyramid)]
+    u.init_Mesh.argtypes = [P(abi.Mesh)]
+    u.init_Mesh.restype = None
+    u.cleanup_Mesh.argtypes = [P(abi.Mesh)]
+    u.cleanup_Mesh.restype = None
+    u.init_Slab.argtypes = [P(abi.Slab)]
+    u.init_Slab.restype = None
+    u.cleanup_Slab.argtypes = [P(abi.Slab)]
+    u.cleanup_Slab.restype = None
+    return u
+
+
+def _eig(u, a):
+    n = a.shape[0]
+    A, Q, L = abi.Mat_rm(), abi.Mat_rm(), abi.Mat_rm()
+    for m in (A, Q, L):
+        assert u.init_Mat_rm(C.byref(m), n, n, 0, 0) == 0
+    C.memmove(A.data, np.ascontiguousarray(a, np.float64).ctypes.data, a.nbytes)
+    rc = u.eigen_Mat_rm(C.byref(A), C.byref(Q), C.byref(L))
+    lam = np.ctypeslib.as_array(C.cast(L.data, P(C.c_double)), shape=(n,)).copy() if rc == 0 else None
+    vec = np.ctypeslib.as_array(C.cast(Q.data, P(C.c_double)), shape=(n, n)).copy() if rc == 0 else None
+    shape = (L.num_rows, L.num_cols, L.type)
+    for m in (A, Q, L):
+        u.cleanup_Mat_rm(C.byref(m))
+    return rc, lam, vec, shape
+
+
+@pytest.mark.parametrize("n,seed", [(3, 0), (3, 1), (5, 2), (8, 3)])
+def test_eigen_Mat_rm_matches_lapack(lib, reference, n, seed):
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal((n, n))
+    a = b + b.T + np.diag(np.arange(n) * 0.5)              # symmetric, well separated spectrum
+    mine, ref = _bind(lib.imutil), _bind(reference.imutil)
+    rc, lam, vec, shape = _eig(mine, a)
+    rrc, rlam, rvec, rshape = _eig(ref, a)
+    assert rc == rrc == 0 and shape == rshape == (n, 1, 0)
+    assert np.allclose(lam, rlam, rtol=0, atol=1e-12 * np.abs(rlam).max()) and np.all(np.diff(lam) >= 0)
+    for j in range(n):                                      # eigenvectors in the columns, up to sign
+        s = 1.0 if np.dot(vec[:, j], rvec[:, j]) > 0 else -1.0
+        assert np.allclose(vec[:, j], s * rvec[:, j], atol=1e-10)
+    assert np.allclose(a @ vec, vec * lam, atol=1e-11 * np.abs(lam).max())
+    # not square / not double: refused like the reference
+    A, L = abi.Mat_rm(), abi.Mat_rm()
+    assert mine.init_Mat_rm(C.byref(A), 2, 3, 0, 1) == 0 and mine.init_Mat_rm(C.byref(L), 0, 0, 0, 0) == 0
+    assert mine.eigen_Mat_rm(C.byref(A), None, C.byref(L)) != 0
+    mine.cleanup_Mat_rm(C.byref(A))
+
+
+def test_init_Mat_rm_p_aliases_caller_memory(lib, reference):
+    for u in (_bind(lib.imutil), _bind(reference.imutil)):
+        buf = np.arange(12, dtype=np.float64)
+        m = abi.Mat_rm()
+        assert u.init_Mat_rm_p(C.byref(m), buf.ctypes.data, 3, 4, 0, 0) == 0
+        assert m.data == buf.ctypes.data and m.static_mem == 1 and (m.num_rows, m.num_cols, m.type) == (3, 4, 0)
+        assert m.size == 12 * 8
+        assert u.resize_Mat_rm(C.byref(m)) == 0            # same size: fine
+        m.num_cols = 5
+        assert u.resize_Mat_rm(C.byref(m)) != 0            # static memory cannot grow
+        m2 = abi.Mat_rm()
+        assert u.init_Mat_rm_p(C.byref(m2), buf.ctypes.data, 3, 4, 0, 1) == 0 and not buf.any()   # set_zero wipes the caller's buffer
+
+
+def _pyramid(lib_, u, vol):
+    im = lib_.image_from_numpy(vol, units=(1.0, 0.5, 2.0))
+    pyr = abi.Pyramid()
+    u.init_Pyramid(C.byref(pyr))
+    assert u.set_scales_Pyramid(1.6, 1.15, C.byref(pyr)) == 0
+    assert u.resize_Pyramid(C.byref(im), -1, 3, 6, 0, 2, C.byref(pyr)) == 0
+    rng = np.random.default_rng(5)
+    for i in range(pyr.num_octaves * pyr.num_levels):
+        lv = pyr.levels[i]
+        n = lv.nx * lv.ny * lv.nz
+        np.ctypeslib.as_array(lv.data, shape=(n,))[:] = rng.random(n, dtype=np.float32)
+    return im, pyr
+
+
+def _levels(pyr):
+    out = []
+    for i in range(pyr.num_octaves * pyr.num_levels):
+        lv = pyr.levels[i]
+        n = lv.nx * lv.ny * lv.nz
+        out.append(((lv.nx, lv.ny, lv.nz, lv.nc), (lv.ux, lv.uy, lv.uz), lv.s,
+                    None if not lv.data else np.ctypeslib.as_array(lv.data, shape=(n,)).copy()))
+    return out
+
+
+def test_copy_Pyramid_like_the_reference(lib, reference):
+    vol = np.zeros((12, 10, 16), np.float32)
+    results = []
+    for L_ in (lib, reference):
+        u = _bind(L_.imutil)
+        im, pyr = _pyramid(L_, u, vol)
+        dst = abi.Pyramid()
+        u.init_Pyramid(C.byref(dst))
+        assert u.copy_Pyramid(C.byref(pyr), C.byref(dst)) == 0
+        assert (dst.num_octaves, dst.num_levels, dst.first_level, dst.num_kp_levels, dst.sigma0, dst.sigma_n) == \
+               (pyr.num_octaves, pyr.num_levels, pyr.first_level, pyr.num_kp_levels, pyr.sigma0, pyr.sigma_n)
+        a, b = _levels(pyr), _levels(dst)
+        for x, y in zip(a, b):
+            assert x[0] == y[0] and x[1] == y[1] and x[2] == y[2] and np.array_equal(x[3], y[3])
+        assert dst.levels[0].data and C.addressof(dst.levels[0].data.contents) != C.addressof(pyr.levels[0].data.contents)
+        results.append([(x[0], x[1], x[2]) for x in b])
+        # an empty pyramid copies as an empty pyramid
+        e1, e2 = abi.Pyramid(), abi.Pyramid()
+        u.init_Pyramid(C.byref(e1)); u.init_Pyramid(C.byref(e2))
+        assert u.copy_Pyramid(C.byref(e1), C.byref(e2)) == 0 and e2.num_levels == e1.num_levels
+        u.cleanup_Pyramid(C.byref(dst)); u.cleanup_Pyramid(C.byref(pyr))
+        L_.free_image(im)
+    assert results[0] == results[1]                         # level geometry, units and scales as the reference's
+
+
+def test_write_pyramid_one_nifti_per_level(lib, tmp_path):
+    u = _bind(lib.imutil)
+    u.write_pyramid.argtypes = [C.c_char_p, P(abi.Pyramid)]
+    u.read_nii.argtypes = [C.c_char_p, P(abi.Image)]
+    im, pyr = _pyramid(lib, u, np.zeros((12, 10, 16), np.float32))
+    base = str(tmp_path / "sub" / "dir" / "pyr.nii.gz")     # the directories are created (mkpath, imutil.c:4145)
+    assert u.write_pyramid(base.encode(), C.byref(pyr)) == 0
+    lv = _levels(pyr)
+    k = 0
+    for o in range(pyr.first_octave, pyr.first_octave + pyr.num_octaves):
+        for s in range(pyr.first_level, pyr.first_level + pyr.num_levels):
+            path = f"{base}_o{o}_s{s}"
+            assert os.path.exists(path), path
+            k += 1
+    assert k == len(lv) == 12
+    # a level without host voxels (the state after a detect, before sift3d_amd_download_pyramid) is refused
+    lib.imutil.im_free(C.byref(pyr.levels[3]))
+    assert u.write_pyramid(str(tmp_path / "x.nii").encode(), C.byref(pyr)) != 0
+    u.cleanup_Pyramid(C.byref(pyr))
+    lib.free_image(im)
+
+
+def test_mesh_and_slab_lifecycle(lib, reference):
+    for u in (_bind(lib.imutil), _bind(reference.imutil)):
+        m = abi.Mesh()
+        u.init_Mesh(C.byref(m))
+        assert not m.tri and m.num == -1
+        u.cleanup_Mesh(C.byref(m))
+        s = abi.Slab()
+        s.num, s.buf_size = 7, 9
+        u.init_Slab(C.byref(s))
+        assert not s.buf and s.num == 0 and s.buf_size == 0
+        u.cleanup_Slab(C.byref(s))

@@ -264,6 +264,82 @@ def test_errors_like_the_reference(lib):
     lib.sift.cleanup_SIFT3D(C.byref(s))
 
 
+def test_descriptor_window_wider_than_the_kernel_supports_fails_loudly(lib):
+    """Voxel spacing 0.02 along x on a 1100-voxel axis: a descriptor window spans the whole axis (> 1023 voxels), which the
+    kernel's 10-bit row coordinates cannot enumerate.  The call must say no (SIFT3D_FAILURE + message), not hand back an
+    all-zero histogram; the same keypoint with an ordinary spacing is served."""
+    L = lib.sift
+    rng = np.random.default_rng(3)
+    vol = rng.random((16, 16, 1100), dtype=np.float32)
+    s = abi.SIFT3D()
+    assert L.init_SIFT3D(C.byref(s)) == 0
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    assert L.resize_Keypoint_store(C.byref(kp), 1) == 0
+    L.init_Keypoint.argtypes = [C.POINTER(abi.Keypoint)]
+    k = kp.buf[0]
+    L.init_Keypoint(C.byref(k))
+    k.xd, k.yd, k.zd, k.sd, k.o, k.s = 550.0, 8.0, 8.0, 1.6, 0, 0
+    for i, v in enumerate((1, 0, 0, 0, 1, 0, 0, 0, 1)):
+        k.r_data[i] = float(v)
+    d = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d))
+    narrow = lib.image_from_numpy(vol, units=(0.02, 1.0, 1.0))
+    assert L.SIFT3D_extract_raw_descriptors(C.byref(s), C.byref(narrow), C.byref(kp), C.byref(d)) != 0
+    normal = lib.image_from_numpy(vol, units=(1.0, 1.0, 1.0))
+    assert L.SIFT3D_extract_raw_descriptors(C.byref(s), C.byref(normal), C.byref(kp), C.byref(d)) == 0
+    bins, _ = lib.descriptors_to_numpy(d)
+    assert abs(float(np.sqrt((bins.astype(np.float64) ** 2).sum())) - 1.0) < 1e-5
+    lib.free_image(narrow)
+    lib.free_image(normal)
+    L.cleanup_SIFT3D(C.byref(s))
+
+
+def test_two_sift3d_objects_on_two_threads(lib, oracle):
+    """SURVEY 8b threading contract: distinct SIFT3D objects on distinct threads are safe.  Two host threads, each with
+    its own struct (hence its own device context and stream) and its own volume, detect + describe concurrently, five
+    times; every result must equal the single-threaded one bit for bit."""
+    import threading
+    L = lib.sift
+    vols = [synth.blobs(96, 80, 72, 900, 21), synth.blobs(72, 96, 88, 900, 22)]
+
+    def run(vol):
+        s, im, kp = parity.run_detect(lib, vol, (1, 1, 1))
+        d = abi.SIFT3D_Descriptor_store()
+        L.init_SIFT3D_Descriptor_store(C.byref(d))
+        assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        out = (lib.keypoints_to_numpy(kp), lib.descriptors_to_numpy(d)[0])
+        L.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+        L.cleanup_Keypoint_store(C.byref(kp))
+        lib.free_image(im)
+        L.cleanup_SIFT3D(C.byref(s))
+        return out
+
+    want = [run(v) for v in vols]
+    assert all(len(w[0][0]) > 50 for w in want)
+    ox, _, _ = oracle.detect(vols[0])
+    assert np.array_equal(ox, want[0][0][0])
+    got, err = [[], []], []
+
+    def body(i):
+        try:
+            for _ in range(5):
+                got[i].append(run(vols[i]))
+        except BaseException as e:           # noqa: BLE001
+            err.append(e)
+
+    th = [threading.Thread(target=body, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for i in range(2):
+        for (kp, bins) in got[i]:
+            assert np.array_equal(kp[0], want[i][0][0]) and np.array_equal(kp[2], want[i][0][2])
+            assert np.array_equal(bins, want[i][1])
+
+
 def test_properties_at_benchmark_size(lib):
     """512^3 (BASELINE config 2): properties that need no CPU run of that size.
     (1) fused fast path == generic per-axis path bit for bit on the full volume (checksum),
