@@ -64,6 +64,7 @@ static __thread char g_api_err[512];
 const char *sift3d_amd_last_error(void) { return g_api_err; }
 
 /* ---- device context registry ------------------------------------------------------------------------ */
+#define S3D_DESC_BATCHES 8
 typedef struct {
     int in_use;
     s3d_stream stream;
@@ -98,6 +99,9 @@ typedef struct {
     /* one process, N GPUs (s3d_host_slab.c): when set, detect / describe run on Z-slabs and d_level stays empty */
     struct s3d_mgpu *mgpu;
     int mgpu_env_checked, pyramid_on_slabs;
+    /* descriptor download beside the descriptor kernel: a copy stream and one event per batch */
+    s3d_stream copy_stream;
+    void *batch_ev[S3D_DESC_BATCHES];
 } s3d_ctx;
 
 #define S3D_MAX_CTX 256
@@ -159,6 +163,9 @@ static void ctx_free_all(s3d_ctx *c)
     dfree(&c->d_keys); dfree(&c->d_desc);
     c->desc_cap = 0;
     for (int i = 0; i < 4; i++) { dfree(&c->d_aux[i]); c->aux_elems[i] = 0; }
+    for (int i = 0; i < S3D_DESC_BATCHES; i++)
+        if (c->batch_ev[i]) { s3d_rt_event_destroy(c->batch_ev[i]); c->batch_ev[i] = NULL; }
+    if (c->copy_stream) { s3d_rt_stream_destroy(c->copy_stream); c->copy_stream = NULL; }
 }
 
 static void ctx_release(int handle)
@@ -807,6 +814,28 @@ static int describe_dev(SIFT3D *const sift3d, s3d_ctx *c, const s3d_pyramid_desc
     if (s3d_check_desc_windows(keys, num, pd)) return SIFT3D_FAILURE;
     if (ctx_base(c) || ctx_ensure_desc(c, num)) return SIFT3D_FAILURE;
     DEV(s3d_rt_h2d(c->d_keys, keys, num * sizeof(s3d_desc_key), c->stream));
+    if (host_out && num >= 4096) {
+        /* The records (3104 B per keypoint: 97 MB at 512^3) go home batch by batch while the kernel works on the next
+         * batch: all launches are queued first, then each batch is copied as soon as its event fires. */
+        const size_t per = (num + S3D_DESC_BATCHES - 1) / S3D_DESC_BATCHES;
+        if (!c->copy_stream) DEV(s3d_rt_stream_create_nonblocking(&c->copy_stream));
+        for (int b = 0; b < S3D_DESC_BATCHES; b++) {
+            const size_t i0 = (size_t)b * per, n = i0 >= num ? 0 : (num - i0 < per ? num - i0 : per);
+            if (!c->batch_ev[b]) DEV(s3d_rt_event_create(&c->batch_ev[b]));
+            if (n) DEV(s3d_k_describe(pd, c->d_keys + i0, (uint32_t)n, c->d_mesh, c->d_desc + i0 * DESC_REC_FLOATS,
+                                      DESC_REC_FLOATS, c->stream));
+            DEV(s3d_rt_event_record(c->batch_ev[b], c->stream));
+        }
+        for (int b = 0; b < S3D_DESC_BATCHES; b++) {
+            const size_t i0 = (size_t)b * per, n = i0 >= num ? 0 : (num - i0 < per ? num - i0 : per);
+            if (!n) continue;
+            DEV(s3d_rt_stream_wait_event(c->copy_stream, c->batch_ev[b]));
+            DEV(s3d_rt_d2h(host_out + i0, c->d_desc + i0 * DESC_REC_FLOATS, n * sizeof(SIFT3D_Descriptor), c->copy_stream));
+        }
+        DEV(s3d_rt_sync(c->copy_stream));
+        DEV(s3d_rt_sync(c->stream));
+        return SIFT3D_SUCCESS;
+    }
     DEV(s3d_k_describe(pd, c->d_keys, (uint32_t)num, c->d_mesh, c->d_desc, DESC_REC_FLOATS, c->stream));
     if (host_out) DEV(s3d_rt_d2h(host_out, c->d_desc, num * sizeof(SIFT3D_Descriptor), c->stream));
     DEV(s3d_rt_sync(c->stream));

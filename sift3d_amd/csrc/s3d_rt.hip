@@ -60,6 +60,14 @@ extern "C" int s3d_rt_stream_create(s3d_stream *st)
     *st = (s3d_stream)s;
     return S3D_OK;
 }
+/* a stream that does not synchronise with the default (NULL) stream: work on it overlaps kernels queued there */
+extern "C" int s3d_rt_stream_create_nonblocking(s3d_stream *st)
+{
+    hipStream_t s;
+    S3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *st = (s3d_stream)s;
+    return S3D_OK;
+}
 extern "C" int s3d_rt_stream_destroy(s3d_stream st) { S3D_HIP(hipStreamDestroy((hipStream_t)st)); return S3D_OK; }
 extern "C" int s3d_rt_event_create(void **ev)
 {

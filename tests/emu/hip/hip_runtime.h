@@ -269,6 +269,8 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
+#define hipStreamNonBlocking 1
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
