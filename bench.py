@@ -300,17 +300,24 @@ def add_roofline(result, dev, n):
     worst = max(apps, key=lambda a: a["xy_ms"])                       # widest filter = slowest fused kernel
     nv = float(512 if n >= 512 else n) ** 3
     ach = GAUSS_XY_BYTES_PER_VOXEL * nv / (worst["xy_ms"] * 1e-3) / 1e9
-    # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE doubled per the
-    # gfx950 correction + WRITE_SIZE; profiles/pmc_gauss.json), valid for the 512^3 launch only
-    traffic = None
+    # HBM bytes per launch of that kernel from PMC passes (scripts/pmc_hbm.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    # FETCH_SIZE doubled per the gfx950 correction).  A rocprofv3 counter pass cannot run inside this process, so the figure
+    # is read from profiles/pmc_gauss.json -- and used ONLY if that file was measured on this very kernel source (SHA-256 of
+    # csrc/s3d_gauss.hip) at 512^3; otherwise traffic is null.  traffic_source says which run and commit measured it.
+    traffic, traffic_source = None, None
     try:
+        import hashlib
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_gauss.json")))
-        if int(nv) == int(pmc["voxels"]):
+        sha = hashlib.sha256(open(os.path.join(ROOT, "sift3d_amd", "csrc", "s3d_gauss.hip"), "rb").read()).hexdigest()
+        if int(nv) == int(pmc["voxels"]) and pmc.get("gauss_source_sha256") == sha:
             traffic = pmc["kernels"][f"k_gauss_xy<{worst['width'] // 2}>"]["hbm_bytes_per_launch"]
+            traffic_source = f"profiles/pmc_gauss.json: run {pmc.get('run')}, commit {pmc.get('commit')}, same s3d_gauss.hip"
+        else:
+            traffic_source = "profiles/pmc_gauss.json was measured on a different s3d_gauss.hip: not used"
     except Exception:
         traffic = None
     result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                           "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
                                     f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
     result["config"]["gauss_apps"] = apps
