@@ -29,8 +29,20 @@ static inline double u01(uint64_t *s) { return (double)(xs64(s) >> 11) * (1.0 / 
 
 /* z0,z1: only slices [z0,z1) of the full nz-slice volume are produced into out (which holds
  * (z1-z0)*ny*nx floats); lets a rank of a Z-slab-sharded run build just its slab (+halo). */
+/* tform: NULL, or a 3 x 4 row-major affine map applied to every blob centre after it is drawn (c' = A c + t): the same
+ * scene seen through a known transform, without any resampling.  Everything else -- the order
+ * of the draws, the noise -- is unchanged, so tform == identity reproduces the plain volume bit for bit. */
+int s3d_synth_blobs_slab_tform(float *out, int nx, int ny, int nz, int z0, int z1, long nblobs, uint64_t seed,
+                               const double *tform);
+
 int s3d_synth_blobs_slab(float *out, int nx, int ny, int nz, int z0, int z1,
                          long nblobs, uint64_t seed)
+{
+    return s3d_synth_blobs_slab_tform(out, nx, ny, nz, z0, z1, nblobs, seed, NULL);
+}
+
+int s3d_synth_blobs_slab_tform(float *out, int nx, int ny, int nz, int z0, int z1, long nblobs, uint64_t seed,
+                               const double *tform)
 {
     uint64_t st = 88172645463325252ULL ^ (seed * 0x9E3779B97F4A7C15ULL);
     if (st == 0) st = 88172645463325252ULL;
@@ -41,6 +53,12 @@ int s3d_synth_blobs_slab(float *out, int nx, int ny, int nz, int z0, int z1,
         b[i].cx = u01(&st) * nx; b[i].cy = u01(&st) * ny; b[i].cz = u01(&st) * nz;
         b[i].sigma = 1.5 + 4.0 * u01(&st);
         b[i].amp = 2.0 * u01(&st) - 1.0;
+        if (tform) {
+            const double x = b[i].cx, y = b[i].cy, z = b[i].cz;
+            b[i].cx = tform[0] * x + tform[1] * y + tform[2] * z + tform[3];
+            b[i].cy = tform[4] * x + tform[5] * y + tform[6] * z + tform[7];
+            b[i].cz = tform[8] * x + tform[9] * y + tform[10] * z + tform[11];
+        }
     }
     const size_t plane = (size_t)nx * ny;
     #pragma omp parallel

@@ -20,6 +20,8 @@ def _lib() -> C.CDLL:
         _LIB = C.CDLL(path)
         _LIB.s3d_synth_blobs_slab.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_long, C.c_uint64]
+        _LIB.s3d_synth_blobs_slab_tform.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_long, C.c_uint64, C.c_void_p]
     return _LIB
 
 
@@ -30,14 +32,20 @@ def default_nblobs(nx: int, ny: int, nz: int) -> int:
 
 
 def blobs(nx: int, ny: int, nz: int, nblobs: int | None = None, seed: int = 0,
-          z0: int = 0, z1: int | None = None) -> np.ndarray:
-    """float32 volume [z1-z0, ny, nx] (x fastest).  seed=0 is the survey probe's exact RNG stream."""
+          z0: int = 0, z1: int | None = None, tform=None) -> np.ndarray:
+    """float32 volume [z1-z0, ny, nx] (x fastest).  seed=0 is the survey probe's exact RNG stream.
+    tform: optional 3 x 4 affine map applied to the blob centres (voxel coordinates x, y, z) -- the same scene through a
+    known transform, with no resampling involved."""
     if nblobs is None:
         nblobs = default_nblobs(nx, ny, nz)
     if z1 is None:
         z1 = nz
     out = np.empty((z1 - z0, ny, nx), dtype=np.float32)
-    rc = _lib().s3d_synth_blobs_slab(out.ctypes.data, nx, ny, nz, z0, z1, nblobs, seed)
+    if tform is not None:
+        t = np.ascontiguousarray(tform, np.float64).reshape(12)
+        rc = _lib().s3d_synth_blobs_slab_tform(out.ctypes.data, nx, ny, nz, z0, z1, nblobs, seed, t.ctypes.data)
+    else:
+        rc = _lib().s3d_synth_blobs_slab(out.ctypes.data, nx, ny, nz, z0, z1, nblobs, seed)
     if rc != 0:
         raise ValueError("s3d_synth_blobs_slab: bad arguments")
     return out

@@ -9,7 +9,9 @@ Contents (data only):
   xyzos   int16 [K,5]   every keypoint (x, y, z, octave, level) in the reference's order
   sd      float64 [K]   keypoint scales
   R       float32 [K,9] orientation matrices
-  proj    float64 [K,2] two fixed +-1 projections of every 768-float descriptor (signs from a seeded generator)
+  proj    float64 [K,16] sixteen fixed +-1 projections of every 768-float descriptor (signs from a seeded generator; the
+                         first two columns are those of the first version of this fixture)
+  gss_sha / dog_sha  uint8 [levels,32]  SHA-256 of every GSS / DoG level of the reference's pyramids (octave-major)
   every   int           descriptor sampling stride
   desc    float32 [ceil(K/every),768]  the descriptors of keypoints 0, every, 2*every, ...
   sha256  of the float32 input volume (so the test knows it regenerated the same input)
@@ -32,8 +34,22 @@ EVERY = 32
 N = int(os.environ.get("S3D_GOLDEN_N", "512"))
 
 
+NPROJ = 16
+
+
 def projection_signs():
-    return np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    first = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    more = np.random.default_rng(20260928).integers(0, 2, size=(768, NPROJ - 2)).astype(np.float64) * 2.0 - 1.0
+    return np.concatenate([first, more], axis=1)
+
+
+def level_hashes(pyr):
+    out = []
+    for i in range(pyr.num_octaves * pyr.num_levels):
+        lv = pyr.levels[i]
+        a = np.ctypeslib.as_array(lv.data, shape=(lv.nx * lv.ny * lv.nz,))
+        out.append(np.frombuffer(hashlib.sha256(a.tobytes()).digest(), np.uint8))
+    return np.stack(out)
 
 
 def main():
@@ -43,6 +59,7 @@ def main():
     s, im, kp = parity.run_detect(ref, vol, (1, 1, 1))
     xyzos, sd, R = ref.keypoints_to_numpy(kp)
     print(f"reference detect: {len(xyzos)} keypoints in {time.time() - t0:.0f} s", flush=True)
+    gss_sha, dog_sha = level_hashes(s.gpyr), level_hashes(s.dog)
     t0 = time.time()
     d = abi.SIFT3D_Descriptor_store()
     ref.sift.init_SIFT3D_Descriptor_store(C.byref(d))
@@ -54,7 +71,7 @@ def main():
     np.savez_compressed(out, xyzos=xyzos.astype(np.int16), sd=sd.astype(np.float64),
                         R=R.reshape(len(R), 9).astype(np.float32),
                         proj=bins.astype(np.float64) @ projection_signs(), every=np.int64(EVERY),
-                        desc=bins[::EVERY].astype(np.float32), n=np.int64(N),
+                        desc=bins[::EVERY].astype(np.float32), n=np.int64(N), gss_sha=gss_sha, dog_sha=dog_sha,
                         sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(vol).tobytes()).digest(), np.uint8))
     print("wrote", out, os.path.getsize(out), "bytes")
 

@@ -396,8 +396,9 @@ def test_window_weight_expf_matches_host_libm(lib):
 def test_benchmark_size_vs_reference_golden(lib):
     """BASELINE configs[1] end to end against the UNMODIFIED reference's output on the same 512^3 volume
     (tests/golden/full512.npz, written by tests/golden/make_golden_512.py from oracle/_ref): all 31 207 keypoints and
-    their order bit-exact, R within 1e-5, every 32nd descriptor within 1e-4 relative, and two fixed +-1 projections
-    of EVERY descriptor within the bound the 1e-4 band implies (|sum s_i e_i| <= 1e-4 * ||d||_1 + 768e-7)."""
+    their order bit-exact, R within 1e-5, every 32nd descriptor within 1e-4 relative, sixteen fixed +-1 projections
+    of EVERY descriptor within the bound the 1e-4 band implies (|sum s_i e_i| <= 1e-4 * ||d||_1 + 768e-7), and every one of
+    the 42 GSS and 35 DoG levels equal to the reference's by SHA-256."""
     import hashlib
     gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full512.npz")
     g = np.load(gpath)
@@ -418,10 +419,24 @@ def test_benchmark_size_vs_reference_golden(lib):
     ok = rel_close(got, want, rtol=1e-4, atol=1e-7)
     assert ok.all(), f"{(~ok).sum()} of {ok.size} sampled descriptor floats beyond 1e-4 relative"
     signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    nproj = g["proj"].shape[1]                    # 16 independent +-1 projections of EVERY descriptor
+    if nproj > 2:
+        signs = np.concatenate([signs, np.random.default_rng(20260928).integers(0, 2, size=(768, nproj - 2)).astype(np.float64)
+                                * 2.0 - 1.0], axis=1)
     proj = bins.astype(np.float64) @ signs
     bound = 1e-4 * np.abs(bins.astype(np.float64)).sum(1, keepdims=True) + 768e-7
     worst = (np.abs(proj - g["proj"]) / bound).max()
     assert worst <= 1.0, f"descriptor projection off by {worst:.2f} x the 1e-4 band"
+    # every GSS and DoG level of the 512^3 pyramids, by SHA-256 against the reference's
+    assert "gss_sha" in g.files, "tests/golden/full512.npz predates the level hashes: re-run make_golden_512.py"
+    assert lib.sift.sift3d_amd_download_pyramid(C.byref(s), 1) == 0
+    for name, pyr in (("gss_sha", s.gpyr), ("dog_sha", s.dog)):
+        want_sha = g[name]
+        assert len(want_sha) == pyr.num_octaves * pyr.num_levels
+        for i in range(len(want_sha)):
+            lv = pyr.levels[i]
+            a = np.ctypeslib.as_array(lv.data, shape=(lv.nx * lv.ny * lv.nz,))
+            assert hashlib.sha256(a.tobytes()).digest() == want_sha[i].tobytes(), f"{name} level {i} differs from the reference"
     # typical agreement is far inside the band: report it for the profile notes
     rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.maximum(np.abs(got), np.abs(want)), 1e-3)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -434,8 +449,11 @@ def test_benchmark_size_vs_reference_golden(lib):
     lib.sift.cleanup_SIFT3D(C.byref(s))
 
 
-def test_two_volume_config_vs_reference_golden(lib):
-    """BASELINE configs[4] at full size against the UNMODIFIED reference (tests/golden/pair512.npz, written by
+@pytest.mark.parametrize("fixture", ["pair512.npz", "pair512_affine.npz"])
+def test_two_volume_config_vs_reference_golden(lib, fixture):
+    """(pair512_affine.npz: SURVEY 8d's form -- units (1, 1, 2), i.e. half-voxel taps along z at octave 0, and volume B =
+    the scene of A through a known affine map applied to the blob centres in the generator.)
+    BASELINE configs[4] at full size against the UNMODIFIED reference (tests/golden/pair512.npz, written by
     tests/golden/make_golden_pair512.py): two 512^3 volumes with units (1, 1, 1.5); keypoints of both bit-exact, every
     descriptor inside the 1e-4 band by its two +-1 projections, and SIFT3D_nn_match of the product's descriptors
     against the reference's matches.  The matcher is bit-exact on equal descriptors (test_nn_match*); here the two
@@ -443,14 +461,21 @@ def test_two_volume_config_vs_reference_golden(lib):
     at most 1 decision in 5000 may differ, and a differing decision must involve a rejection (never two different
     partners)."""
     import hashlib
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pair512.npz"))
+    gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture)
+    if not os.path.exists(gpath):
+        pytest.skip(f"{fixture} not generated (tests/golden/make_golden_pair512.py)")
+    g = np.load(gpath)
     n = int(g["n"])
     units = tuple(float(u) for u in g["units"])
     a = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
     assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest() == g["sha256"].tobytes(), "generator drifted"
     signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
     sets, worst = [], 0.0
-    for tag, vol in (("a", a), ("b", np.roll(a, tuple(int(r) for r in g["roll"]), axis=(0, 1, 2)).copy())):
+    if "variant" in g.files and str(g["variant"]) == "affine":
+        b = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0, tform=g["tform"])
+    else:
+        b = np.roll(a, tuple(int(r) for r in g["roll"]), axis=(0, 1, 2)).copy()
+    for tag, vol in (("a", a), ("b", b)):
         s, im, kp = parity.run_detect(lib, vol, units)
         xyzos, sd, R = lib.keypoints_to_numpy(kp)
         assert np.array_equal(xyzos, g[f"xyzos_{tag}"].astype(xyzos.dtype)), f"volume {tag}: keypoints differ"
@@ -480,7 +505,7 @@ def test_two_volume_config_vs_reference_golden(lib):
     os.makedirs(out, exist_ok=True)
     json.dump({"keypoints": [int(sets[0].num), int(sets[1].num)], "matches": int((got >= 0).sum()),
                "differing_match_decisions": int(len(diff)), "worst_projection_over_band": worst},
-              open(os.path.join(out, "golden_pair512.json"), "w"))
+              open(os.path.join(out, "golden_" + fixture.replace(".npz", ".json")), "w"))
     for d in sets:
         lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
 
