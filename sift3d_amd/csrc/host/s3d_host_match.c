@@ -122,6 +122,7 @@ int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const fl
             s3d_rt_malloc((void **)&d_bi, m * sizeof(int)) == 0) {
             fast = s3d_k_nn_match2_fast(d_a, a_stride, (uint32_t)na, d_b, b_stride, (uint32_t)nb, d_best, d_best + n, d_idx,
                                         d_b2, d_b2 + m, d_bi, stream);
+            if (getenv("S3D_NN_DEBUG")) S3D_MSG("SIFT3D_nn_match: one-matrix screening returned %d (%s)\n", fast, s3d_rt_last_error());
             if (fast == 0 &&
                 (s3d_rt_d2h(h_best, d_best, 2 * n * sizeof(double), stream) || s3d_rt_d2h(h_idx, d_idx, n * sizeof(int), stream) ||
                  s3d_rt_d2h(h_b2, d_b2, 2 * m * sizeof(double), stream) || s3d_rt_d2h(h_bi, d_bi, m * sizeof(int), stream) ||

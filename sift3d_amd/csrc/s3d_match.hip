@@ -169,27 +169,93 @@ extern "C" int s3d_k_nn_best2(const float* d_a, size_t a_stride, const int* d_a_
  * ================================================================================================ */
 #define NN_CAP 64                    /* candidates per row verified exactly */
 #define GT 128                       /* GEMM tile edge */
-#define GK 16                        /* k-chunk */
 
-/* row r of the (optionally gathered) store -> column r of the k-major copy; zero padding beyond n */
-__global__ void __launch_bounds__(256)
-k_nn_transpose(const float *__restrict__ src, size_t stride, const int *__restrict__ sel, unsigned n, unsigned npad,
-               float *__restrict__ dstT)
+/* ---- f16 split operands for the matrix cores ---------------------------------------------------------------------------
+ * The screening scores only have to be inside the error band d (above), so the 1.5 Tflop of dot products run on the MFMA
+ * units: every descriptor element x (times 2^8: the elements of unit-norm descriptors are <= 0.2, the scaling keeps the
+ * low parts out of f16's subnormal range and is exact) is split into two halves, x = hi + lo + e with hi = f16(x),
+ * lo = f16(x - hi), |e| <= 2^-22 |x|, and a.b = hi.hi + hi.lo + lo.hi + O(2^-22): three v_mfma_f32_32x32x16_f16 per tile
+ * and k-step, products exact in f32, f32 accumulation.  Error against the exact dot product: the f32 accumulation of 768
+ * terms (<= 768 2^-24 |a||b| = 4.6e-5 |a||b|, the same bound as an f32 FMA chain) plus 2^-21 |a||b| from the split: inside
+ * d = 1e-4 |a||b| + ... , so the candidate sets -- and with the exact f64 verification every result bit -- are unchanged. */
+#define NN_SCALE 256.0f
+#if defined(S3D_EMU)
+typedef unsigned short nn_half;
+struct nn_h8 { nn_half v[8]; };
+struct nn_acc16 { float v[16]; };
+static inline nn_half nn_f2h(float f)
+{   /* round to nearest even, subnormals included (what v_cvt_f16_f32 does) */
+    unsigned x;
+    memcpy(&x, &f, 4);
+    const unsigned sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (nn_half)(sign | 0x7c00u);            /* overflow -> inf (not reached here) */
+    if (x < 0x38800000u) {                                               /* subnormal half or zero */
+        if (x < 0x33000000u) return (nn_half)sign;
+        const int e = (int)(x >> 23);
+        unsigned m = (x & 0x7fffffu) | 0x800000u;
+        const int sh = 126 - e;                                          /* 14 .. 24 */
+        const unsigned q = m >> sh, rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        return (nn_half)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const unsigned m = x & 0x7fffffu, e = (x >> 23) - 112u;
+    unsigned h = (e << 10) | (m >> 13);
+    const unsigned rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (nn_half)(sign | h);
+}
+static inline float nn_h2f(nn_half h)
 {
-    __shared__ float tile[32][65];
-    const unsigned r0 = blockIdx.x * 32u, e0 = blockIdx.y * 64u;
-    const int t = threadIdx.x;
-    for (int k = t; k < 32 * 64; k += 256) {
-        const unsigned r = r0 + (unsigned)(k >> 6), e = (unsigned)(k & 63);
-        float v = 0.0f;
-        if (r < n) v = src[(size_t)(sel ? (unsigned)sel[r] : r) * stride + e0 + e];
-        tile[k >> 6][e] = v;
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float f;
+    if (e == 0) f = ldexpf((float)m, -24);
+    else { const unsigned x = ((e + 112u) << 23) | (m << 13); memcpy(&f, &x, 4); }
+    return sign ? -f : f;
+}
+/* v_mfma_f32_32x32x16_f16 for the emulator: A row / B column = lane & 31, k = 8 * (lane >> 5) + i; D register r of a
+ * lane is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 */
+static inline void nn_mfma(nn_acc16 &acc, const nn_h8 &a, const nn_h8 &b)
+{
+    nn_h8 A[64], B[64];
+    emu::wave_gather(&a, sizeof(a), A);
+    emu::wave_gather(&b, sizeof(b), B);
+    const int lane = (int)(emu::S().cur->tid & 63);
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        float sum = acc.v[r];
+        for (int k = 0; k < 16; k++)
+            sum += nn_h2f(A[row + 32 * (k >> 3)].v[k & 7]) * nn_h2f(B[col + 32 * (k >> 3)].v[k & 7]);
+        acc.v[r] = sum;
     }
-    __syncthreads();
-    for (int k = t; k < 32 * 64; k += 256) {
-        const unsigned e = (unsigned)(k >> 5), r = (unsigned)(k & 31);
-        if (r0 + r < npad) dstT[(size_t)(e0 + e) * npad + r0 + r] = tile[r][e];
-    }
+}
+#define NN_ACC_GET(acc, r) ((acc).v[r])
+#else
+typedef _Float16 nn_half;
+typedef _Float16 nn_h8 __attribute__((ext_vector_type(8)));
+typedef float nn_acc16 __attribute__((ext_vector_type(16)));
+#define nn_f2h(f) ((_Float16)(f))
+#define nn_h2f(h) ((float)(h))
+__device__ __forceinline__ void nn_mfma(nn_acc16 &acc, const nn_h8 &a, const nn_h8 &b)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+#define NN_ACC_GET(acc, r) ((acc)[r])
+#endif
+
+/* row r of the (optionally gathered) store -> rows r of the hi / lo f16 copies (row-major, 768 halves per row); zero
+ * padding beyond n */
+__global__ void __launch_bounds__(256)
+k_nn_split(const float *__restrict__ src, size_t stride, const int *__restrict__ sel, unsigned n, unsigned npad,
+           nn_half *__restrict__ hi, nn_half *__restrict__ lo)
+{
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;          /* one element per thread */
+    if (idx >= (size_t)npad * NEL) return;
+    const unsigned r = (unsigned)(idx / NEL), e = (unsigned)(idx % NEL);
+    float x = 0.0f;
+    if (r < n) x = src[(size_t)(sel ? (unsigned)sel[r] : r) * stride + e] * NN_SCALE;
+    const nn_half h = nn_f2h(x);
+    hi[idx] = h;
+    lo[idx] = nn_f2h(x - nn_h2f(h));
 }
 
 /* squared norms in f64 (one wave per row), stored as f64 and f32; padding rows get a huge norm */
@@ -211,60 +277,84 @@ k_nn_norms(const float *__restrict__ src, size_t stride, const int *__restrict__
     }
 }
 
-/* S~[i][j] = |a_i|^2 + |b_j|^2 - 2 a_i.b_j for one 128 x 128 tile; operands k-major (AT[e][i], BT[e][j]) */
+/* S~[i][j] = |a_i|^2 + |b_j|^2 - 2 a_i.b_j for one 128 x 128 tile on the matrix cores.  256 threads = 2 x 2 waves of 64 x 64
+ * (2 x 2 MFMA tiles of 32 x 32 each); k advances 32 halves per step: the four operand panels (A hi/lo, B hi/lo, 128 rows x
+ * 32 halves) go through LDS with a row pitch of 40 halves (conflict-free ds_read_b128 of the fragments: lane l reads row
+ * l & 31 at halves 8 (l >> 5) ..), the next step's global loads are in flight while the current one multiplies. */
+#define GKH 32                       /* halves of k per step */
+#define GLD 40                       /* LDS row pitch in halves */
 __global__ void __launch_bounds__(256)
-k_nn_gemm(const float *__restrict__ AT, unsigned napad, unsigned row_base, const float *__restrict__ BT, unsigned nbpad,
-          const float *__restrict__ a2, const float *__restrict__ b2, float *__restrict__ S /* rows x nbpad */)
+k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsigned row_base, const nn_half *__restrict__ Bh,
+          const nn_half *__restrict__ Bl, unsigned nbpad, const float *__restrict__ a2, const float *__restrict__ b2,
+          float *__restrict__ S /* rows x nbpad */)
 {
-    __shared__ __attribute__((aligned(16))) float As[GK][GT];
-    __shared__ __attribute__((aligned(16))) float Bs[GK][GT];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    __shared__ __attribute__((aligned(16))) nn_half sm[4][GT][GLD];      /* A hi, A lo, B hi, B lo */
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     const unsigned i0 = row_base + blockIdx.y * GT, j0 = blockIdx.x * GT;
-    float acc[8][8];
+    nn_acc16 acc[2][2];
+    for (int tm = 0; tm < 2; tm++)
+        for (int tn = 0; tn < 2; tn++)
+            for (int r = 0; r < 16; r++) NN_ACC_GET(acc[tm][tn], r) = 0.0f;
+    /* staging: per panel 128 rows x 4 quarters of 8 halves = 512 16-byte pieces, two per thread */
+    const nn_half *gsrc[4] = {Ah + (size_t)i0 * NEL, Al + (size_t)i0 * NEL, Bh + (size_t)j0 * NEL, Bl + (size_t)j0 * NEL};
+    nn_h8 stage[4][2];
+    auto fetch = [&](int e0) {
 #pragma unroll
-    for (int r = 0; r < 8; r++)
+        for (int p = 0; p < 4; p++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) acc[r][c] = 0.0f;
-    /* staging: GK x GT floats per operand = 512 float4, two per thread */
-    const int sk = t >> 5, sq = (t & 31) * 4;                 /* k in 0..7 (+8), column quad */
-    for (int e0 = 0; e0 < NEL; e0 += GK) {
-        const float4 ga0 = *reinterpret_cast<const float4 *>(AT + (size_t)(e0 + sk) * napad + i0 + sq);
-        const float4 ga1 = *reinterpret_cast<const float4 *>(AT + (size_t)(e0 + sk + 8) * napad + i0 + sq);
-        const float4 gb0 = *reinterpret_cast<const float4 *>(BT + (size_t)(e0 + sk) * nbpad + j0 + sq);
-        const float4 gb1 = *reinterpret_cast<const float4 *>(BT + (size_t)(e0 + sk + 8) * nbpad + j0 + sq);
+            for (int u = 0; u < 2; u++) {
+                const int c = t + 256 * u, row = c >> 2, q = c & 3;
+                stage[p][u] = *reinterpret_cast<const nn_h8 *>(gsrc[p] + (size_t)row * NEL + e0 + 8 * q);
+            }
+    };
+    fetch(0);
+    for (int e0 = 0; e0 < NEL; e0 += GKH) {
         __syncthreads();
-        *reinterpret_cast<float4 *>(&As[sk][sq]) = ga0;
-        *reinterpret_cast<float4 *>(&As[sk + 8][sq]) = ga1;
-        *reinterpret_cast<float4 *>(&Bs[sk][sq]) = gb0;
-        *reinterpret_cast<float4 *>(&Bs[sk + 8][sq]) = gb1;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int c = t + 256 * u, row = c >> 2, q = c & 3;
+                *reinterpret_cast<nn_h8 *>(&sm[p][row][8 * q]) = stage[p][u];
+            }
         __syncthreads();
+        if (e0 + GKH < NEL) fetch(e0 + GKH);
 #pragma unroll
-        for (int k = 0; k < GK; k++) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(&As[k][ty * 8]);
-            const float4 a1 = *reinterpret_cast<const float4 *>(&As[k][ty * 8 + 4]);
-            /* the thread's 8 columns are tx*4 .. +3 and 64 + tx*4 .. +3: the 16 lanes of a row of threads read 256
-             * contiguous bytes per b128 (tx*8 would put lanes tx and tx+4 on the same banks: 4-way conflicts) */
-            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 4]);
-            const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[k][64 + tx * 4]);
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        for (int kk = 0; kk < GKH; kk += 16) {
+            nn_h8 ah[2], al[2], bh[2], bl[2];
+            const int ko = kk + 8 * (lane >> 5), rl = lane & 31;
 #pragma unroll
-            for (int r = 0; r < 8; r++)
+            for (int tt = 0; tt < 2; tt++) {
+                ah[tt] = *reinterpret_cast<const nn_h8 *>(&sm[0][wm * 64 + tt * 32 + rl][ko]);
+                al[tt] = *reinterpret_cast<const nn_h8 *>(&sm[1][wm * 64 + tt * 32 + rl][ko]);
+                bh[tt] = *reinterpret_cast<const nn_h8 *>(&sm[2][wn * 64 + tt * 32 + rl][ko]);
+                bl[tt] = *reinterpret_cast<const nn_h8 *>(&sm[3][wn * 64 + tt * 32 + rl][ko]);
+            }
 #pragma unroll
-                for (int c = 0; c < 8; c++) acc[r][c] = __builtin_fmaf(av[r], bv[c], acc[r][c]);
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) {
+                    nn_mfma(acc[tm][tn], ah[tm], bh[tn]);
+                    nn_mfma(acc[tm][tn], ah[tm], bl[tn]);
+                    nn_mfma(acc[tm][tn], al[tm], bh[tn]);
+                }
         }
     }
-    const unsigned li = blockIdx.y * GT + ty * 8;             /* row inside this chunk of S */
+    /* D register r of a lane: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of its 32 x 32 tile */
+    const float unscale = 2.0f / (NN_SCALE * NN_SCALE);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const float na = a2[i0 + ty * 8 + r];
-        float o[8];
+    for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) o[c] = (na + b2[j0 + (c < 4 ? 0 : 60) + tx * 4 + c]) - 2.0f * acc[r][c];
-        float *dst = S + (size_t)(li + r) * nbpad + j0 + tx * 4;
-        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4 *>(dst + 64) = make_float4(o[4], o[5], o[6], o[7]);
-    }
+        for (int tn = 0; tn < 2; tn++) {
+            const unsigned col = j0 + wn * 64 + tn * 32 + (lane & 31);
+            const float nb = b2[col];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned lrow = blockIdx.y * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float na = a2[row_base + lrow];
+                S[(size_t)lrow * nbpad + col] = (na + nb) - unscale * NN_ACC_GET(acc[tm][tn], r);
+            }
+        }
 }
 
 /* one wave per query row: the two smallest approximate scores, then every column within the error band of
@@ -352,23 +442,25 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     size_t rows_chunk = ((size_t)1 << 29) / nbpad / GT * GT;          /* <= 2 GiB of scores at a time */
     if (rows_chunk < GT) rows_chunk = GT;
     if (rows_chunk > napad) rows_chunk = napad;
-    float *AT = nullptr, *BT = nullptr, *a2f = nullptr, *b2f = nullptr, *S = nullptr;
+    nn_half *AH = nullptr, *AL = nullptr, *BH = nullptr, *BL = nullptr;
+    float *a2f = nullptr, *b2f = nullptr, *S = nullptr;
     double *a2d = nullptr, *b2d = nullptr, *h_b2 = nullptr;
     int *cand = nullptr, *count = nullptr, *ovf = nullptr;
     int rc = -1, h_ovf = 0;
     double b2max = 0.0;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
-    NN_TRY(hipMalloc((void **)&AT, sizeof(float) * (size_t)NEL * napad));
-    NN_TRY(hipMalloc((void **)&BT, sizeof(float) * (size_t)NEL * nbpad));
+    NN_TRY(hipMalloc((void **)&AH, sizeof(nn_half) * (size_t)NEL * napad)); NN_TRY(hipMalloc((void **)&AL, sizeof(nn_half) * (size_t)NEL * napad));
+    NN_TRY(hipMalloc((void **)&BH, sizeof(nn_half) * (size_t)NEL * nbpad)); NN_TRY(hipMalloc((void **)&BL, sizeof(nn_half) * (size_t)NEL * nbpad));
     NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
     NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
     NN_TRY(hipMalloc((void **)&S, sizeof(float) * rows_chunk * nbpad));
     NN_TRY(hipMalloc((void **)&cand, sizeof(int) * (size_t)na * NN_CAP)); NN_TRY(hipMalloc((void **)&count, sizeof(int) * na));
     NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
     NN_TRY(hipMemsetAsync(ovf, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_nn_transpose, dim3(napad / 32, NEL / 64), dim3(256), 0, st, d_a, a_stride, d_a_sel, na, napad, AT);
-    hipLaunchKernelGGL(k_nn_transpose, dim3(nbpad / 32, NEL / 64), dim3(256), 0, st, d_b, b_stride, (const int *)nullptr, nb,
-                       nbpad, BT);
+    hipLaunchKernelGGL(k_nn_split, dim3((unsigned)(((size_t)napad * NEL + 255) / 256)), dim3(256), 0, st, d_a, a_stride, d_a_sel, na,
+                       napad, AH, AL);
+    hipLaunchKernelGGL(k_nn_split, dim3((unsigned)(((size_t)nbpad * NEL + 255) / 256)), dim3(256), 0, st, d_b, b_stride,
+                       (const int *)nullptr, nb, nbpad, BH, BL);
     hipLaunchKernelGGL(k_nn_norms, dim3(napad), dim3(64), 0, st, d_a, a_stride, d_a_sel, na, napad, a2d, a2f);
     hipLaunchKernelGGL(k_nn_norms, dim3(nbpad), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, nbpad, b2d, b2f);
     if ((h_b2 = (double *)malloc(sizeof(double) * nb)) == nullptr) goto done;
@@ -377,7 +469,7 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     for (uint32_t j = 0; j < nb; j++) b2max = h_b2[j] > b2max ? h_b2[j] : b2max;
     for (size_t r0 = 0; r0 < napad; r0 += rows_chunk) {
         const unsigned rows = (unsigned)(r0 + rows_chunk <= napad ? rows_chunk : napad - r0);
-        hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AT, napad, (unsigned)r0, BT, nbpad, a2f,
+        hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AH, AL, (unsigned)r0, BH, BL, nbpad, a2f,
                            b2f, S);
         const unsigned live = r0 + rows <= na ? rows : (na > r0 ? (unsigned)(na - r0) : 0u);
         if (live)
@@ -392,7 +484,7 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     rc = h_ovf ? 1 : 0;
 done:
 #undef NN_TRY
-    hipFree(AT); hipFree(BT); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S);
+    hipFree(AH); hipFree(AL); hipFree(BH); hipFree(BL); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S);
     hipFree(cand); hipFree(count); hipFree(ovf);
     free(h_b2);
     return rc;
@@ -476,15 +568,15 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     const unsigned napad = (na + GT - 1) / GT * GT, nbpad = (nb + GT - 1) / GT * GT;
     if ((size_t)napad * nbpad > ((size_t)1 << 31)) return 1;              /* 8 GiB of scores at most */
     const unsigned seg_rows = (na + NN_SEG - 1) / NN_SEG;
-    float *AT = nullptr, *BT = nullptr, *a2f = nullptr, *b2f = nullptr, *S = nullptr, *pm1 = nullptr, *pm2 = nullptr,
-          *thr = nullptr;
+    nn_half *AH = nullptr, *AL = nullptr, *BH = nullptr, *BL = nullptr;
+    float *a2f = nullptr, *b2f = nullptr, *S = nullptr, *pm1 = nullptr, *pm2 = nullptr, *thr = nullptr;
     double *a2d = nullptr, *b2d = nullptr, *h_n2 = nullptr;
     int *candf = nullptr, *countf = nullptr, *candb = nullptr, *countb = nullptr, *segcnt = nullptr, *ovf = nullptr;
     int rc = -1, h_ovf = 0;
     double a2max = 0.0, b2max = 0.0;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
-    NN_TRY(hipMalloc((void **)&AT, sizeof(float) * (size_t)NEL * napad));
-    NN_TRY(hipMalloc((void **)&BT, sizeof(float) * (size_t)NEL * nbpad));
+    NN_TRY(hipMalloc((void **)&AH, sizeof(nn_half) * (size_t)NEL * napad)); NN_TRY(hipMalloc((void **)&AL, sizeof(nn_half) * (size_t)NEL * napad));
+    NN_TRY(hipMalloc((void **)&BH, sizeof(nn_half) * (size_t)NEL * nbpad)); NN_TRY(hipMalloc((void **)&BL, sizeof(nn_half) * (size_t)NEL * nbpad));
     NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
     NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
     NN_TRY(hipMalloc((void **)&S, sizeof(float) * (size_t)napad * nbpad));
@@ -496,10 +588,10 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     NN_TRY(hipMalloc((void **)&candb, sizeof(int) * (size_t)nb * NN_CAP)); NN_TRY(hipMalloc((void **)&countb, sizeof(int) * nb));
     NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
     NN_TRY(hipMemsetAsync(ovf, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_nn_transpose, dim3(napad / 32, NEL / 64), dim3(256), 0, st, d_a, a_stride, (const int *)nullptr, na,
-                       napad, AT);
-    hipLaunchKernelGGL(k_nn_transpose, dim3(nbpad / 32, NEL / 64), dim3(256), 0, st, d_b, b_stride, (const int *)nullptr, nb,
-                       nbpad, BT);
+    hipLaunchKernelGGL(k_nn_split, dim3((unsigned)(((size_t)napad * NEL + 255) / 256)), dim3(256), 0, st, d_a, a_stride,
+                       (const int *)nullptr, na, napad, AH, AL);
+    hipLaunchKernelGGL(k_nn_split, dim3((unsigned)(((size_t)nbpad * NEL + 255) / 256)), dim3(256), 0, st, d_b, b_stride,
+                       (const int *)nullptr, nb, nbpad, BH, BL);
     hipLaunchKernelGGL(k_nn_norms, dim3(napad), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, napad, a2d, a2f);
     hipLaunchKernelGGL(k_nn_norms, dim3(nbpad), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, nbpad, b2d, b2f);
     if ((h_n2 = (double *)malloc(sizeof(double) * (na > nb ? na : nb))) == nullptr) goto done;
@@ -509,7 +601,7 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     NN_TRY(hipMemcpyAsync(h_n2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     NN_TRY(hipStreamSynchronize(st));
     for (uint32_t j = 0; j < nb; j++) b2max = h_n2[j] > b2max ? h_n2[j] : b2max;
-    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AT, napad, 0u, BT, nbpad, a2f, b2f, S);
+    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S);
     hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
     hipLaunchKernelGGL(k_nn_col_min2, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, pm1, pm2);
     hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nbpad, nb, b2d, a2max, thr);
@@ -527,7 +619,7 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     rc = h_ovf ? 1 : 0;
 done:
 #undef NN_TRY
-    hipFree(AT); hipFree(BT); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S); hipFree(pm1); hipFree(pm2);
+    hipFree(AH); hipFree(AL); hipFree(BH); hipFree(BL); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S); hipFree(pm1); hipFree(pm2);
     hipFree(thr); hipFree(segcnt); hipFree(candf); hipFree(countf); hipFree(candb); hipFree(countb); hipFree(ovf);
     free(h_n2);
     return rc;

@@ -201,6 +201,25 @@ inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave, bool want_ballot
     return s.wave_buf[par][srct];
 }
 
+/* wave-collective gather: every lane publishes `bytes` (<= 32) and receives all 64 lanes' data (lanes beyond the block or
+ * already finished contribute zeros) */
+inline void wave_gather(const void *mine, size_t bytes, void *all)
+{
+    static unsigned char big[2][1024][32];
+    State &s = S();
+    const unsigned t = s.cur->tid;
+    const unsigned w0 = t & ~63u;
+    const unsigned par = s.wave_op[t] & 1;
+    memcpy(big[par][t], mine, bytes);
+    uint64_t dummy;
+    wave_exchange(1, 0, true, &dummy);                 /* rendezvous (also advances the op parity) */
+    const unsigned nt = s.blockDim.x * s.blockDim.y * s.blockDim.z;
+    for (unsigned l = 0; l < 64; l++) {
+        if (w0 + l < nt) memcpy((char *)all + l * bytes, big[par][w0 + l], bytes);
+        else memset((char *)all + l * bytes, 0, bytes);
+    }
+}
+
 }  // namespace emu
 
 #define threadIdx (emu::S().threadIdx)
