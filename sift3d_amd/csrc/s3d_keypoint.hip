@@ -1161,8 +1161,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                 if (!more) break;
             }
         }
-        __syncthreads();                                      /* seg_* are rewritten by the next round */
+        /* No barrier here: the next round rewrites seg_* / chunk_row only after its own first scan barrier, which every
+         * wave reaches only once it has finished this round's chunks; waves that run out of chunks early start on the next
+         * round's row intervals instead of waiting. */
     }
+    __syncthreads();                                          /* all histogram atomics (and the window counters) are in */
     if (COUNT_ONLY) {
         if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
         return;
