@@ -116,7 +116,14 @@ def test_full512_fixture_is_self_consistent():
     assert desc.shape == ((K + every - 1) // every, 768)
     assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-5
     signs = np.random.default_rng(20260927).integers(0, 2, size=(768, 2)).astype(np.float64) * 2.0 - 1.0
+    nproj = g["proj"].shape[1]
+    assert nproj == 16
+    signs = np.concatenate([signs, np.random.default_rng(20260928).integers(0, 2, size=(768, nproj - 2)).astype(np.float64) * 2.0 - 1.0],
+                           axis=1)
     assert np.abs(desc @ signs - g["proj"][::every]).max() < 1e-12
+    # SHA-256 of every pyramid level of the reference run: 7 octaves x 6 GSS levels, 7 x 5 DoG levels
+    assert g["gss_sha"].shape == (42, 32) and g["dog_sha"].shape == (35, 32)
+    assert len({h.tobytes() for h in g["gss_sha"]}) == 42 and len({h.tobytes() for h in g["dog_sha"]}) == 35
 
 
 def test_pair512_fixture_is_self_consistent():
