@@ -350,7 +350,7 @@ def main():
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("S3D_BENCH_FORCE_SLAB"):     # FORCE_SLAB: the N > 1 code path with a world of one (1-GPU boxes)
         import torch
         import torch.distributed as dist
         if os.environ.get("S3D_BENCH_SAME_GPU"):
@@ -379,7 +379,7 @@ def main():
     if world == 1 and args.loopback > 1:
         run_loopback(args, dev)
         return
-    if world > 1 and not args.replicas:
+    if (world > 1 or (dist is not None and os.environ.get("S3D_BENCH_FORCE_SLAB"))) and not args.replicas:
         run_slab(args, dist, dev, rank, local_rank, world, full_sync)
         return
     nblobs = synth.default_nblobs(n, n, n)            # 128 000 at 512^3

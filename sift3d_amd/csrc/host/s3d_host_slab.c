@@ -354,7 +354,10 @@ static int exchange_halo(sift3d_amd_slab *sl, const s3d_lev *lv, int o, int h, i
 {
     if (sl->t.world == 1 || h <= 0) return SIFT3D_SUCCESS;
     const int z0 = sl->part[o][0], z1 = sl->part[o][1];
-    const int n = (now <= 0 || now >= h) ? h : now;
+    /* S3D_SLAB_NO_DEFER=1: every halo plane ordered with the compute stream, one communicator in use (debugging aid) */
+    static int no_defer = -1;
+    if (no_defer < 0) { const char *e = getenv("S3D_SLAB_NO_DEFER"); no_defer = e && atoi(e) ? 1 : 0; }
+    const int n = (now <= 0 || now >= h || no_defer) ? h : now;
     const size_t pb = lv->pe * sizeof(float);
     const int sides = (sl->t.rank > 0) + (sl->t.rank < sl->t.world - 1);
     COMM(sl->t.exchange(sl->t.self, lev_ptr(lv, z0), lev_ptr(lv, z0 - n), lev_ptr(lv, z1 - n), lev_ptr(lv, z1),
