@@ -286,7 +286,7 @@ k_nn_norms(const float *__restrict__ src, size_t stride, const int *__restrict__
 __global__ void __launch_bounds__(256)
 k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsigned row_base, const nn_half *__restrict__ Bh,
           const nn_half *__restrict__ Bl, unsigned nbpad, const float *__restrict__ a2, const float *__restrict__ b2,
-          float *__restrict__ S /* rows x nbpad */)
+          float *__restrict__ S /* rows x nbpad */, float *__restrict__ pm1, float *__restrict__ pm2 /* optional: see below */)
 {
     __shared__ __attribute__((aligned(16))) nn_half sm[4][GT][GLD];      /* A hi, A lo, B hi, B lo */
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -352,9 +352,38 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
             for (int r = 0; r < 16; r++) {
                 const unsigned lrow = blockIdx.y * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const float na = a2[row_base + lrow];
-                S[(size_t)lrow * nbpad + col] = (na + nb) - unscale * NN_ACC_GET(acc[tm][tn], r);
+                const float v = (na + nb) - unscale * NN_ACC_GET(acc[tm][tn], r);
+                S[(size_t)lrow * nbpad + col] = v;
+                NN_ACC_GET(acc[tm][tn], r) = v;
             }
         }
+    /* Column minima for the backward direction, while the scores are still in registers: a lane holds 32 of the 64 rows
+     * of this wave's block for each of its two columns (the other 32 sit in lane ^ 32); the two smallest per (64-row
+     * block, column) go to pm1 / pm2[block][column] -- the column scan then reads 2/64 of the matrix instead of all of
+     * it.  (Padding rows carry |a|^2 = 1e30 and never win.) */
+    if (pm1 != nullptr) {
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            float m1 = 3.0e38f, m2 = 3.0e38f;
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = NN_ACC_GET(acc[tm][tn], r);
+                    const float hi = v < m1 ? m1 : v;
+                    m1 = v < m1 ? v : m1;
+                    m2 = hi < m2 ? hi : m2;
+                }
+            const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+            const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1, s2 = m2 < o2 ? m2 : o2;
+            if (lane < 32) {
+                const unsigned col = j0 + wn * 64 + tn * 32 + lane;
+                const size_t blk = (size_t)(row_base / 64u + blockIdx.y * 2u + (unsigned)wm);
+                pm1[blk * nbpad + col] = lo;
+                pm2[blk * nbpad + col] = hi < s2 ? hi : s2;
+            }
+        }
+    }
 }
 
 /* one wave per query row: the two smallest approximate scores, then every column within the error band of
@@ -403,6 +432,7 @@ k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict_
             double *__restrict__ o_best, double *__restrict__ o_second, int *__restrict__ o_idx, int *__restrict__ overflow)
 {
     __shared__ double ssd[NN_CAP];
+    __shared__ int cidx[NN_CAP], sidx[NN_CAP];
     const unsigned i = blockIdx.x;
     if (i >= na) return;
     const int lane = threadIdx.x;
@@ -411,21 +441,29 @@ k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict_
         if (lane == 0) atomicAdd(overflow, 1);
         return;
     }
+    /* the candidate list may arrive in any order (the column scan appends with atomics): rank-sort it, the reference's
+     * scan keeps the FIRST of equal scores */
+    const int mine = lane < n ? cand[(size_t)i * NN_CAP + lane] : 0x7fffffff;
+    cidx[lane] = mine;
+    __syncthreads();
     if (lane < n) {
+        int rank = 0;
+        for (int k = 0; k < n; k++) rank += cidx[k] < mine ? 1 : 0;
         const float *pa = a + (size_t)(a_sel ? (unsigned)a_sel[i] : i) * a_stride;
-        const float *pb = b + (size_t)cand[(size_t)i * NN_CAP + lane] * b_stride;
+        const float *pb = b + (size_t)mine * b_stride;
         double s = 0.0;
         for (int e = 0; e < NEL; e++) {
             const double diff = (double)pa[e] - (double)pb[e];
             s += diff * diff;
         }
-        ssd[lane] = s;
+        ssd[rank] = s;
+        sidx[rank] = mine;
     }
     __syncthreads();
     if (lane == 0) {
         Best2 st;
         st.best = DBL_MAX; st.second = DBL_MAX; st.idx = -1;
-        for (int k = 0; k < n; k++) best2_push(st, ssd[k], cand[(size_t)i * NN_CAP + k]);
+        for (int k = 0; k < n; k++) best2_push(st, ssd[k], sidx[k]);
         o_best[i] = st.best; o_second[i] = st.second; o_idx[i] = st.idx;
     }
 }
@@ -470,7 +508,7 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     for (size_t r0 = 0; r0 < napad; r0 += rows_chunk) {
         const unsigned rows = (unsigned)(r0 + rows_chunk <= napad ? rows_chunk : napad - r0);
         hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AH, AL, (unsigned)r0, BH, BL, nbpad, a2f,
-                           b2f, S);
+                           b2f, S, (float *)nullptr, (float *)nullptr);
         const unsigned live = r0 + rows <= na ? rows : (na > r0 ? (unsigned)(na - r0) : 0u);
         if (live)
             hipLaunchKernelGGL(k_nn_rowscan, dim3(live), dim3(64), 0, st, S, nbpad, nb, (unsigned)r0, na, a2d, b2max, cand,
@@ -497,34 +535,18 @@ done:
  * the kernels below (one lane per column, rows split into segments so that enough waves are in flight), and both
  * candidate sets go through k_nn_verify.
  * ---------------------------------------------------------------------------------------------- */
-#define NN_SEG 32
+#define NN_SEG 32                    /* row segments of the column candidate scan (enough waves in flight) */
 
-/* partial (m1, m2) of every column over the rows of one segment */
+/* threshold of every column: second smallest score over all 64-row blocks (partials from the GEMM epilogue) + the error
+ * band */
 __global__ void __launch_bounds__(64)
-k_nn_col_min2(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned na, unsigned seg_rows,
-              float *__restrict__ pm1, float *__restrict__ pm2)
-{
-    const unsigned j = blockIdx.x * 64u + threadIdx.x, seg = blockIdx.y;
-    const unsigned i0 = seg * seg_rows, i1 = i0 + seg_rows < na ? i0 + seg_rows : na;
-    float m1 = 3.0e38f, m2 = 3.0e38f;
-    if (j < nb)
-        for (unsigned i = i0; i < i1; i++) {
-            const float v = S[(size_t)i * nbpad + j];
-            if (v < m1) { m2 = m1; m1 = v; } else if (v < m2) m2 = v;
-        }
-    pm1[(size_t)seg * nbpad + j] = m1;
-    pm2[(size_t)seg * nbpad + j] = m2;
-}
-
-/* threshold of every column: second smallest score over all segments + the error band */
-__global__ void __launch_bounds__(64)
-k_nn_col_thr(const float *__restrict__ pm1, const float *__restrict__ pm2, unsigned nbpad, unsigned nb,
+k_nn_col_thr(const float *__restrict__ pm1, const float *__restrict__ pm2, unsigned nblk, unsigned nbpad, unsigned nb,
              const double *__restrict__ b2d, double a2max, float *__restrict__ thr)
 {
     const unsigned j = blockIdx.x * 64u + threadIdx.x;
     if (j >= nb) return;
     float m1 = 3.0e38f, m2 = 3.0e38f;
-    for (unsigned s = 0; s < NN_SEG; s++) {
+    for (unsigned s = 0; s < nblk; s++) {
         const float o1 = pm1[(size_t)s * nbpad + j], o2 = pm2[(size_t)s * nbpad + j];
         const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1, s2 = m2 < o2 ? m2 : o2;
         m1 = lo;
@@ -534,27 +556,21 @@ k_nn_col_thr(const float *__restrict__ pm1, const float *__restrict__ pm2, unsig
     thr[j] = (float)((double)m2 + 2.0 * d + 1e-7 * fabs((double)m2));
 }
 
-/* pass 0: count the candidates of every (segment, column); pass 1: write them, in ascending row order */
+/* every row of a column whose score is within the threshold, in ONE pass over the matrix: appended through an atomic
+ * counter (k_nn_verify sorts the few it gets) */
 __global__ void __launch_bounds__(64)
 k_nn_col_cand(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned na, unsigned seg_rows,
-              const float *__restrict__ thr, int *__restrict__ segcnt, int pass, int *__restrict__ cand,
-              int *__restrict__ count)
+              const float *__restrict__ thr, int *__restrict__ cand, int *__restrict__ count)
 {
     const unsigned j = blockIdx.x * 64u + threadIdx.x, seg = blockIdx.y;
     if (j >= nb) return;
     const unsigned i0 = seg * seg_rows, i1 = i0 + seg_rows < na ? i0 + seg_rows : na;
     const float t = thr[j];
-    unsigned pos = 0;
-    if (pass == 1)
-        for (unsigned s = 0; s < seg; s++) pos += (unsigned)segcnt[(size_t)s * nbpad + j];
-    unsigned n = 0;
     for (unsigned i = i0; i < i1; i++)
         if (S[(size_t)i * nbpad + j] <= t) {
-            if (pass == 1 && pos + n < NN_CAP) cand[(size_t)j * NN_CAP + pos + n] = (int)i;
-            n++;
+            const int pos = atomicAdd(&count[j], 1);
+            if (pos < NN_CAP) cand[(size_t)j * NN_CAP + pos] = (int)i;
         }
-    if (pass == 0) segcnt[(size_t)seg * nbpad + j] = (int)n;
-    else if (seg == NN_SEG - 1) count[j] = (int)(pos + n);
 }
 
 /* Forward (rows of A over B) and backward (rows of B over A) best / second / index in one go.  Returns 1 when it
@@ -571,7 +587,8 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     nn_half *AH = nullptr, *AL = nullptr, *BH = nullptr, *BL = nullptr;
     float *a2f = nullptr, *b2f = nullptr, *S = nullptr, *pm1 = nullptr, *pm2 = nullptr, *thr = nullptr;
     double *a2d = nullptr, *b2d = nullptr, *h_n2 = nullptr;
-    int *candf = nullptr, *countf = nullptr, *candb = nullptr, *countb = nullptr, *segcnt = nullptr, *ovf = nullptr;
+    int *candf = nullptr, *countf = nullptr, *candb = nullptr, *countb = nullptr, *ovf = nullptr;
+    const unsigned nblk = napad / 64u;
     int rc = -1, h_ovf = 0;
     double a2max = 0.0, b2max = 0.0;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
@@ -580,10 +597,9 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
     NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
     NN_TRY(hipMalloc((void **)&S, sizeof(float) * (size_t)napad * nbpad));
-    NN_TRY(hipMalloc((void **)&pm1, sizeof(float) * (size_t)NN_SEG * nbpad));
-    NN_TRY(hipMalloc((void **)&pm2, sizeof(float) * (size_t)NN_SEG * nbpad));
+    NN_TRY(hipMalloc((void **)&pm1, sizeof(float) * (size_t)nblk * nbpad));
+    NN_TRY(hipMalloc((void **)&pm2, sizeof(float) * (size_t)nblk * nbpad));
     NN_TRY(hipMalloc((void **)&thr, sizeof(float) * nbpad));
-    NN_TRY(hipMalloc((void **)&segcnt, sizeof(int) * (size_t)NN_SEG * nbpad));
     NN_TRY(hipMalloc((void **)&candf, sizeof(int) * (size_t)na * NN_CAP)); NN_TRY(hipMalloc((void **)&countf, sizeof(int) * na));
     NN_TRY(hipMalloc((void **)&candb, sizeof(int) * (size_t)nb * NN_CAP)); NN_TRY(hipMalloc((void **)&countb, sizeof(int) * nb));
     NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
@@ -601,14 +617,11 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     NN_TRY(hipMemcpyAsync(h_n2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     NN_TRY(hipStreamSynchronize(st));
     for (uint32_t j = 0; j < nb; j++) b2max = h_n2[j] > b2max ? h_n2[j] : b2max;
-    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S);
+    NN_TRY(hipMemsetAsync(countb, 0, sizeof(int) * nb, st));
+    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2);
     hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
-    hipLaunchKernelGGL(k_nn_col_min2, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, pm1, pm2);
-    hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nbpad, nb, b2d, a2max, thr);
-    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, thr, segcnt, 0,
-                       candb, countb);
-    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, thr, segcnt, 1,
-                       candb, countb);
+    hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nblk, nbpad, nb, b2d, a2max, thr);
+    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, thr, candb, countb);
     hipLaunchKernelGGL(k_nn_verify, dim3(na), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, d_b, b_stride, candf,
                        countf, d_fbest, d_fsecond, d_fidx, ovf);
     hipLaunchKernelGGL(k_nn_verify, dim3(nb), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, d_a, a_stride, candb,
@@ -620,7 +633,7 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
 done:
 #undef NN_TRY
     hipFree(AH); hipFree(AL); hipFree(BH); hipFree(BL); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S); hipFree(pm1); hipFree(pm2);
-    hipFree(thr); hipFree(segcnt); hipFree(candf); hipFree(countf); hipFree(candb); hipFree(countb); hipFree(ovf);
+    hipFree(thr); hipFree(candf); hipFree(countf); hipFree(candb); hipFree(countb); hipFree(ovf);
     free(h_n2);
     return rc;
 }
