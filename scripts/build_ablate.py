@@ -16,7 +16,8 @@ os.makedirs(out_dir, exist_ok=True)
 objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and f != "s3d_keypoint.o"]
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
     o = os.path.join(out_dir, f"s3d_keypoint_a{n}.o")
-    subprocess.run([b.HIPCC, *b.HIP_FLAGS, *b.EXTRA_HIP_FLAGS.get("s3d_keypoint.hip", []), f"-DDW_ABLATE={n}", "-c",
+    define = f"-DDW_ABLATE={n}"
+    subprocess.run([b.HIPCC, *b.HIP_FLAGS, *b.EXTRA_HIP_FLAGS.get("s3d_keypoint.hip", []), define, "-c",
                     os.path.join(b.CSRC, "s3d_keypoint.hip"), "-o", o], check=True, capture_output=True)
     so = os.path.join(out_dir, f"libsift3d_amd_a{n}.so")
     subprocess.run([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so, *objs, o, "-lm", "-lz",
