@@ -457,8 +457,8 @@ def main():
                                      "method": "f32 screening of all pairs (forward and backward pass) + exact f64 verification "
                                                "of the candidates; indices bit-identical to the exhaustive f64 search"}
     if rank == 0 and K and not args.no_match:
-        # what the descriptor kernel (70 % of the step) works through, outside the timed region: the test aid of
-        # k_describe (variant bit 4) returns the number of accepted window voxels per keypoint instead of a descriptor
+        # what the descriptor kernel (65 % of the step) works through, outside the timed region: the kernel's counting
+        # instantiation returns the number of accepted window voxels per keypoint
         lib.sift.sift3d_amd_describe_window_stats.argtypes = [C.POINTER(abi.SIFT3D), C.POINTER(abi.Keypoint_store),
                                                               C.POINTER(C.c_uint)]
         st = np.zeros((K, 2), np.uint32)
@@ -468,7 +468,10 @@ def main():
             "window_voxels": wv, "lds_atomics_per_window_voxel": 24,
             "Gvox_window_per_s": round(wv / t_describe / 1e9, 1),
             "G_lds_atomic_lane_ops_per_s": round(24.0 * wv / t_describe / 1e9, 1),
-            "bound": "LDS atomic throughput (24 ds_add_u64 to data-dependent bins per window voxel), not HBM or MFMA"}
+            "lds_data_path_floor_ms": round(24.0 * (wv / 64.0) * 6.4 / 256.0 / 2.4e9 * 1e3, 2),
+            "bound": "VALU issue (about 243 instructions per window voxel, 45 of them f64) for everything but the trilinear "
+                     "back end, whose 24 conflict-free ds_add_u64 per voxel (6.4 clk per wave and CU: lds_data_path_floor_ms) "
+                     "bound it; not HBM, not MFMA -- DESIGN.md section 4, profiles/r02_describe_ablations.txt"}
     if rank == 0 and not args.no_match:
         # BASELINE configs[0] flavour, outside the timed region: the kpSift3D program on a 128^3 NIfTI-1 volume
         # (.nii.gz in, keypoint and descriptor CSVs out) -- process start, HIP initialisation, zlib and CSV
