@@ -1196,14 +1196,18 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     if (tid < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tid] = v * inv;
 }
 
+/* The kernel needs 149 KB of dynamic LDS, above the 64 KB a launch gets by default: raise the limit once per DEVICE (a
+ * process may drive several GPUs: the in-process Z-slab ranks) */
 static int dw_prepare(void)
 {
 #if !defined(S3D_EMU)
-    static int done = 0;
-    if (!done) {
+    static unsigned char done[64];
+    int dev = 0;
+    S3D_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !done[dev]) {
         S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
         S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
-        done = 1;
+        if (dev >= 0 && dev < 64) done[dev] = 1;
     }
 #endif
     return S3D_OK;
