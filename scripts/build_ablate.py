@@ -14,10 +14,15 @@ b.build()
 out_dir = os.path.join(b.LIB, "ablate")
 os.makedirs(out_dir, exist_ok=True)
 objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and f != "s3d_keypoint.o"]
-for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
+for n in sys.argv[1:] or ["1", "2", "3"]:
+    # "3" -> -DDW_ABLATE=3;  "w512:-DDW_THREADS=512,-DDW_NCOPY=8,..." -> a variant named w512 with those defines
+    if ":" in n:
+        n, defs = n.split(":", 1)
+        define = defs.split(",")
+    else:
+        define = [f"-DDW_ABLATE={n}"]
     o = os.path.join(out_dir, f"s3d_keypoint_a{n}.o")
-    define = f"-DDW_ABLATE={n}"
-    subprocess.run([b.HIPCC, *b.HIP_FLAGS, *b.EXTRA_HIP_FLAGS.get("s3d_keypoint.hip", []), define, "-c",
+    subprocess.run([b.HIPCC, *b.HIP_FLAGS, *b.EXTRA_HIP_FLAGS.get("s3d_keypoint.hip", []), *define, "-c",
                     os.path.join(b.CSRC, "s3d_keypoint.hip"), "-o", o], check=True, capture_output=True)
     so = os.path.join(out_dir, f"libsift3d_amd_a{n}.so")
     subprocess.run([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so, *objs, o, "-lm", "-lz",

@@ -51,3 +51,11 @@ for v in [int(x) for x in os.environ.get("VARIANTS", "0").split(",")]:
     print(f"variant {v}: {K} keypoints, describe {min(ts[1:]) * 1e3:.2f} ms (runs {[round(t * 1e3, 2) for t in ts]}){msg}", flush=True)
 if has_variant:
     L.s3d_k_set_variant(0)
+# SAVE=path stores this library's descriptors, CMP=path compares against another library's (SIFT3D_AMD_LIB=...)
+if os.environ.get("SAVE"):
+    np.save(os.environ["SAVE"], rec)
+if os.environ.get("CMP"):
+    other = np.load(os.environ["CMP"])
+    den = np.maximum(np.abs(other), np.abs(rec))
+    err = np.abs(other.astype(np.float64) - rec) / (1e-4 * den + 1e-7)
+    print(f"against {os.environ['CMP']}: max err/tol {err.max():.4f}", flush=True)

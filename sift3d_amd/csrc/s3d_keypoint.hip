@@ -704,12 +704,15 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  *      face near an edge -- stays on the reference's arithmetic.
  *  (5) A chunk's LDS reads (tables, the next chunk's look-up) are issued before its 96 atomics.
  */
+#ifndef DW_THREADS
 #define DW_THREADS 1024
-#define DW_WAVES (DW_THREADS / 64)
 #define DW_NCOPY 16
 #define DW_TMAX 2048                      /* entries of the weight table (squared voxel distances 0 .. DW_TMAX-1) */
-#define DW_HIST_WORDS (S3D_DESC_NUMEL * DW_NCOPY)
 #define DW_CMAP 16384                     /* chunks of a round that get a direct chunk -> row entry (the rest: binary search) */
+#endif
+#define DW_WAVES (DW_THREADS / 64)
+#define DW_HIST_WORDS (S3D_DESC_NUMEL * DW_NCOPY)
+#define DW_NOUT ((S3D_DESC_NUMEL + DW_THREADS - 1) / DW_THREADS)   /* histogram bins a thread finalises */
 
 struct DwShared {
     unsigned long long hist[DW_HIST_WORDS];
@@ -849,7 +852,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     const int cxi = (int)key.cx, cyi = (int)key.cy, czi = (int)key.cz;
     const float u2 = g.uxf * g.uxf;
     const bool use_tab = !COUNT_ONLY && g.uxf == g.uyf && g.uxf == g.uzf && um == 0.5f && (float)cxi == key.cx &&
-                         (float)cyi == key.cy && (float)czi == key.cz && g.rad2 / u2 < 1700.0f;   /* + 6 r + 9 for the chunk's last voxel stays below DW_TMAX */
+                         (float)cyi == key.cy && (float)czi == key.cz && g.rad2 / u2 < (float)(DW_TMAX - 348);   /* + 6 r + 9 for the chunk's last voxel stays below DW_TMAX */
 
     /* fixed-point grid 2^-f of the histogram (see (2) above): a contribution is bounded by the gradient bound 2^bexp
      * (level voxels are bounded by 1 -- scaled input, convex filters -- so a central difference is <= 1/u per axis) */
@@ -1175,25 +1178,36 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
 #endif
     /* merge the copies (48-bit two's complement integers: order free), then normalise / clamp / normalise */
     double ss = 0.0;
-    float v = 0.0f;
-    if (tid < S3D_DESC_NUMEL) {
-        long long acc = 0;
-        for (int w = 0; w < DW_NCOPY; w++) {
-            const unsigned long long raw = sm.hist[tid * DW_NCOPY + ((w + tid) & (DW_NCOPY - 1))];
-            acc += (long long)(raw << 16) >> 16;                      /* sign-extend the low 48 bits */
+    float v[DW_NOUT];
+#pragma unroll
+    for (int q = 0; q < DW_NOUT; q++) {
+        const int b = tid + q * DW_THREADS;
+        v[q] = 0.0f;
+        if (b < S3D_DESC_NUMEL) {
+            long long acc = 0;
+            for (int w = 0; w < DW_NCOPY; w++) {
+                const unsigned long long raw = sm.hist[b * DW_NCOPY + ((w + b) & (DW_NCOPY - 1))];
+                acc += (long long)(raw << 16) >> 16;                  /* sign-extend the low 48 bits */
+            }
+            v[q] = (float)((double)acc * unscale);
+            ss += (double)v[q] * (double)v[q];
         }
-        v = (float)((double)acc * unscale);
-        ss = (double)v * (double)v;
     }
     const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
     double norm = sqrt(dw_block_sum(ss, sm.part)) + 2.220446049250313e-16; /* + DBL_EPSILON */
     float inv = (float)(1.0 / norm);
-    v = v * inv;
-    v = v < trunc ? v : trunc;
-    ss = tid < S3D_DESC_NUMEL ? (double)v * (double)v : 0.0;
+    ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < DW_NOUT; q++) {
+        v[q] = v[q] * inv;
+        v[q] = v[q] < trunc ? v[q] : trunc;
+        if (tid + q * DW_THREADS < S3D_DESC_NUMEL) ss += (double)v[q] * (double)v[q];
+    }
     norm = sqrt(dw_block_sum(ss, sm.part)) + 2.220446049250313e-16;
     inv = (float)(1.0 / norm);
-    if (tid < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tid] = v * inv;
+#pragma unroll
+    for (int q = 0; q < DW_NOUT; q++)
+        if (tid + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tid + q * DW_THREADS] = v[q] * inv;
 }
 
 /* The kernel needs 149 KB of dynamic LDS, above the 64 KB a launch gets by default: raise the limit once per DEVICE (a
