@@ -87,6 +87,12 @@ int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny
  * dst / tmp planes in that range are scratch.  nc == 1. */
 int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0,
                        int z1, const float uf[3], const float *taps, int width, s3d_stream stream);
+/* im_scale (imutil.c:1977) folded into the filter that follows it: dst planes [z0, z1) = filter(src / *d_div), every
+ * source voxel divided as it is loaded (*d_div == 0: not divided), so the scaled image is never written.  Only for the
+ * configurations the fused kernels take -- s3d_k_sep_fir_div_eligible() != 0 -- and an error otherwise. */
+int s3d_k_sep_fir_div_eligible(int nx, int ny, int nz, const float uf[3], int width);
+int s3d_k_sep_fir_div(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
+                      const float uf[3], const float *taps, int width, const float *d_div, s3d_stream stream);
 /* Force a code path (tests / profiling): 0 = auto, 1 = generic per-axis passes, 2 = fused fast path
  * (fails if the configuration is not eligible). */
 /* The three knobs below are per calling thread (thread_local): tests and bench.py set them on the thread that then

@@ -4,7 +4,7 @@
  *
  * Data layout in HBM (per SIFT3D object, owned by a registry entry whose integer handle sits in
  * SIFT3D.kernels.downsample_2):
- *   d_im                         scaled copy of the input           nx*ny*nz f32
+ *   d_im                         the uploaded input (host callers)  nx*ny*nz f32
  *   d_level[o*L + k]             GSS level (o, k-1)                 dims >> o, f32, x fastest
  *   d_tmp                        scratch for the separable filter   octave-0 size
  *   d_bits / d_scratch           extrema bitmap (1 bit / voxel) + block counters
@@ -71,6 +71,7 @@ typedef struct {
     /* pyramid buffers */
     int nx, ny, nz, num_octaves, num_levels;
     float *d_im, *d_tmp;
+    const float *in_src;    /* input of the pyramid being built: d_im (uploaded) or the caller's device volume */
     float *d_level[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
     size_t level_elems[S3D_MAX_OCTAVES];
     unsigned long long *d_bits;             /* S3D_FUSED_KP_MAX bitmaps of bits_words words */
@@ -102,6 +103,10 @@ typedef struct {
     /* descriptor download beside the descriptor kernel: a copy stream and one event per batch */
     s3d_stream copy_stream;
     void *batch_ev[S3D_DESC_BATCHES];
+    /* extrema beside the Gaussians of the following octaves: a second stream, one event per finished octave */
+    s3d_stream ext_stream;
+    void *oct_ev[S3D_MAX_OCTAVES];
+    int extrema_enqueued;   /* build_gpyr_dev put the extrema pass on ext_stream; detect_dev collects it */
 } s3d_ctx;
 
 #define S3D_MAX_CTX 256
@@ -166,6 +171,10 @@ static void ctx_free_all(s3d_ctx *c)
     for (int i = 0; i < S3D_DESC_BATCHES; i++)
         if (c->batch_ev[i]) { s3d_rt_event_destroy(c->batch_ev[i]); c->batch_ev[i] = NULL; }
     if (c->copy_stream) { s3d_rt_stream_destroy(c->copy_stream); c->copy_stream = NULL; }
+    for (int i = 0; i < S3D_MAX_OCTAVES; i++)
+        if (c->oct_ev[i]) { s3d_rt_event_destroy(c->oct_ev[i]); c->oct_ev[i] = NULL; }
+    if (c->ext_stream) { s3d_rt_stream_destroy(c->ext_stream); c->ext_stream = NULL; }
+    c->extrema_enqueued = 0;
 }
 
 static void ctx_release(int handle)
@@ -480,15 +489,68 @@ static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const fl
     c->pyramid_on_slabs = 0;
     if (ctx_ensure_pyramid(sift3d, c)) return SIFT3D_FAILURE;
     n = (size_t)nx * ny * nz;
-    if (host_dense) DEV(s3d_rt_h2d(c->d_im, host_dense, n * sizeof(float), c->stream));
-    else DEV(s3d_rt_d2d(c->d_im, d_vol, n * sizeof(float), c->stream));
-    DEV(s3d_k_absmax(c->d_im, n, c->d_red, c->stream));
-    DEV(s3d_k_scale_div(c->d_im, n, c->d_red, c->stream));
+    /* The maximum now; the division by it rides in the first filter where that is possible (build_gpyr_dev), which then
+     * reads a device volume where the caller has it -- no copy, no scaled image. */
+    if (host_dense) {
+        DEV(s3d_rt_h2d(c->d_im, host_dense, n * sizeof(float), c->stream));
+        c->in_src = c->d_im;
+    } else {
+        c->in_src = d_vol;
+    }
+    DEV(s3d_k_absmax(c->in_src, n, c->d_red, c->stream));
     return SIFT3D_SUCCESS;
 }
 
-/* build_gpyr (sift.c:989-1050) on the device */
-static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c)
+/* detect_extrema (sift.c:1074-1212) for one octave: DoG maxima, extrema bitmaps, ordered compaction into the candidate
+ * list -- enqueued on `es` */
+static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es)
+{
+    const Pyramid *g = &sift3d->gpyr;
+    const int L = g->num_levels;
+    const int nkp = g->num_kp_levels;
+    const Image *lv = g->levels + o * L;
+    const size_t n = c->level_elems[o];
+    float *const *lp = &c->d_level[o * L];
+    const size_t nwords = (n + 63) / 64;
+    int fused = 1;                                       /* all keypoint levels in one pass over the GSS levels */
+    if (nkp <= S3D_FUSED_KP_MAX) {
+        unsigned long long *bits[S3D_FUSED_KP_MAX];
+        for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
+        if (nkp == 3) {
+            DEV(s3d_k_dogmax3((const float *const *)(lp + 1), n, c->d_red + 1, es));
+        } else {
+            for (int ks = 1; ks <= nkp; ks++) DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + ks, es));
+        }
+        fused = s3d_k_extrema_fused((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
+                                    c->d_red + 1, bits, es);
+        if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
+        if (fused == 0)
+            for (int ks = 1; ks <= nkp; ks++)
+                DEV(s3d_k_compact_bits(bits[ks - 1], nwords, c->d_cand_idx, c->d_cand_tag, ((uint32_t)o << 8) | (uint32_t)ks,
+                                       c->cand_cap, c->d_count, c->d_scratch, es));
+    }
+    for (int ks = 1; fused != 0 && ks <= nkp; ks++) {   /* DoG level ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
+        DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + 1, es));
+        DEV(s3d_k_extrema(lp[ks - 1], lp[ks], lp[ks + 1], lp[ks + 2], lv->nx, lv->ny, lv->nz, sift3d->peak_thresh,
+                          c->d_red + 1, c->d_bits, es));
+        DEV(s3d_k_compact_bits(c->d_bits, nwords, c->d_cand_idx, c->d_cand_tag, ((uint32_t)o << 8) | (uint32_t)ks,
+                               c->cand_cap, c->d_count, c->d_scratch, es));
+    }
+    return SIFT3D_SUCCESS;
+}
+
+static uint32_t candidate_capacity(const s3d_ctx *c)
+{
+    if (c->cand_cap) return c->cand_cap;
+    return (uint32_t)((size_t)c->nx * c->ny * c->nz / 256 + 4096);
+}
+
+/* build_gpyr (sift.c:989-1050) on the device.  with_extrema: the extrema pass over octave o is enqueued on a second stream
+ * as soon as that octave's filters are (an event orders them on the device), so that it runs beside the filters of the
+ * following octaves -- whose many short launches are bound by launch latency, on the host and on the device, and leave
+ * most of the GPU idle -- and so that the host's launch work for the small octaves hides under octave 0's kernels.
+ * detect_dev picks the candidate list up from c->ext_stream (c->extrema_enqueued). */
+static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
 {
     const Pyramid *g = &sift3d->gpyr;
     const GSS_filters *gss = &sift3d->gss;
@@ -496,9 +558,29 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c)
     const Image *l0 = g->levels;
     float uf[3];
     double units[3] = {sift3d->im.ux, sift3d->im.uy, sift3d->im.uz};
+    s3d_stream es = NULL;
+    static int no_overlap = -1;                           /* diagnostics: S3D_NO_EXTREMA_OVERLAP=1, read once */
+    if (no_overlap < 0) no_overlap = getenv("S3D_NO_EXTREMA_OVERLAP") != NULL;
+    c->extrema_enqueued = 0;
+    if (with_extrema && !no_overlap) {
+        if (ctx_ensure_candidates(c, candidate_capacity(c))) return SIFT3D_FAILURE;
+        if (!c->ext_stream) DEV(s3d_rt_stream_create_nonblocking(&c->ext_stream));
+        es = c->ext_stream;
+        DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), es));
+    }
     unit_factors(units, 1.0, uf);
-    DEV(s3d_k_sep_fir(c->d_im, c->d_level[0], c->d_tmp, l0->nx, l0->ny, l0->nz, 1, uf, gss->first_gauss.f.kernel,
-                      gss->first_gauss.f.width, c->stream));
+    if (c->in_src == NULL) API_FAIL("sift3d_amd: no input volume");
+    if (s3d_k_sep_fir_div_eligible(l0->nx, l0->ny, l0->nz, uf, gss->first_gauss.f.width)) {
+        DEV(s3d_k_sep_fir_div(c->in_src, c->d_level[0], c->d_tmp, l0->nx, l0->ny, l0->nz, 0, l0->nz, uf,
+                              gss->first_gauss.f.kernel, gss->first_gauss.f.width, c->d_red, c->stream));
+    } else {
+        const size_t n = (size_t)l0->nx * l0->ny * l0->nz;
+        if (c->in_src != c->d_im) DEV(s3d_rt_d2d(c->d_im, c->in_src, n * sizeof(float), c->stream));
+        DEV(s3d_k_scale_div(c->d_im, n, c->d_red, c->stream));
+        DEV(s3d_k_sep_fir(c->d_im, c->d_level[0], c->d_tmp, l0->nx, l0->ny, l0->nz, 1, uf, gss->first_gauss.f.kernel,
+                          gss->first_gauss.f.width, c->stream));
+    }
+    c->in_src = NULL;                                     /* the caller's volume is not ours beyond this call */
     for (int o = 0; o < g->num_octaves; o++) {
         const Image *lv = g->levels + o * L;
         double lu[3] = {lv->ux, lv->uy, lv->uz};
@@ -510,6 +592,12 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c)
             DEV(s3d_k_sep_fir(c->d_level[o * L + k - 1], c->d_level[o * L + k], c->d_tmp, lv->nx, lv->ny, lv->nz, 1,
                               uf, f->kernel, f->width, c->stream));
         }
+        if (es) {
+            if (!c->oct_ev[o]) DEV(s3d_rt_event_create(&c->oct_ev[o]));
+            DEV(s3d_rt_event_record(c->oct_ev[o], c->stream));
+            DEV(s3d_rt_stream_wait_event(es, c->oct_ev[o]));
+            if (extrema_octave(sift3d, c, o, es)) return SIFT3D_FAILURE;
+        }
         if (o != g->num_octaves - 1) {
             int ds = L - 1 - 2;                           /* downsample level index: max(s_end-2, first) */
             if (ds < 0) ds = 0;
@@ -517,6 +605,7 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c)
         }
     }
     c->have_pyramid = 1;
+    c->extrema_enqueued = es != NULL;
     return SIFT3D_SUCCESS;
 }
 
@@ -525,51 +614,22 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
 {
     const Pyramid *g = &sift3d->gpyr;
     const int L = g->num_levels;
-    const int nkp = g->num_kp_levels;
     s3d_pyramid_desc pd;
     uint32_t counts[2] = {0, 0};
-    uint32_t cap = c->cand_cap;
-    if (cap == 0) {
-        const size_t n0 = (size_t)c->nx * c->ny * c->nz;
-        cap = (uint32_t)(n0 / 256 + 4096);
-    }
+    uint32_t cap = candidate_capacity(c);
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (ctx_ensure_candidates(c, cap)) return SIFT3D_FAILURE;
-        DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), c->stream));
-        for (int o = 0; o < g->num_octaves; o++) {
-            const Image *lv = g->levels + o * L;
-            const size_t n = c->level_elems[o];
-            float *const *lp = &c->d_level[o * L];
-            const size_t nwords = (n + 63) / 64;
-            int fused = 1;                               /* all keypoint levels in one pass over the GSS levels */
-            if (nkp <= S3D_FUSED_KP_MAX) {
-                unsigned long long *bits[S3D_FUSED_KP_MAX];
-                for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
-                if (nkp == 3) {
-                    DEV(s3d_k_dogmax3((const float *const *)(lp + 1), n, c->d_red + 1, c->stream));
-                } else {
-                    for (int ks = 1; ks <= nkp; ks++) DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + ks, c->stream));
-                }
-                fused = s3d_k_extrema_fused((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz,
-                                            sift3d->peak_thresh, c->d_red + 1, bits, c->stream);
-                if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
-                if (fused == 0)
-                    for (int ks = 1; ks <= nkp; ks++)
-                        DEV(s3d_k_compact_bits(bits[ks - 1], nwords, c->d_cand_idx, c->d_cand_tag,
-                                               ((uint32_t)o << 8) | (uint32_t)ks, c->cand_cap, c->d_count, c->d_scratch,
-                                               c->stream));
-            }
-            for (int ks = 1; fused != 0 && ks <= nkp; ks++) {   /* DoG level ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
-                DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + 1, c->stream));
-                DEV(s3d_k_extrema(lp[ks - 1], lp[ks], lp[ks + 1], lp[ks + 2], lv->nx, lv->ny, lv->nz,
-                                  sift3d->peak_thresh, c->d_red + 1, c->d_bits, c->stream));
-                DEV(s3d_k_compact_bits(c->d_bits, nwords, c->d_cand_idx, c->d_cand_tag,
-                                       ((uint32_t)o << 8) | (uint32_t)ks, c->cand_cap, c->d_count, c->d_scratch,
-                                       c->stream));
-            }
+        s3d_stream es = c->stream;
+        if (attempt == 0 && c->extrema_enqueued) {
+            es = c->ext_stream;                           /* build_gpyr_dev enqueued the pass already */
+        } else {
+            if (ctx_ensure_candidates(c, cap)) return SIFT3D_FAILURE;
+            DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), es));
+            for (int o = 0; o < g->num_octaves; o++)
+                if (extrema_octave(sift3d, c, o, es)) return SIFT3D_FAILURE;
         }
-        DEV(s3d_rt_d2h(counts, c->d_count, sizeof(uint32_t), c->stream));
-        DEV(s3d_rt_sync(c->stream));
+        c->extrema_enqueued = 0;
+        DEV(s3d_rt_d2h(counts, c->d_count, sizeof(uint32_t), es));
+        DEV(s3d_rt_sync(es));
         if (counts[0] <= c->cand_cap) break;
         cap = counts[0] + 1024;                           /* candidate list overflowed: grow and redo */
         if (attempt == 1) API_FAIL("sift3d_amd: candidate buffer overflow");
@@ -687,7 +747,7 @@ int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoin
     if (rc == SIFT3D_SUCCESS && dense) rc = s3d_rt_sync(sift_ctx(sift3d)->stream) ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
     free(dense);
     if (rc) return SIFT3D_FAILURE;
-    if (build_gpyr_dev(sift3d, sift_ctx(sift3d))) return SIFT3D_FAILURE;
+    if (build_gpyr_dev(sift3d, sift_ctx(sift3d), 1)) return SIFT3D_FAILURE;
     return detect_dev(sift3d, sift_ctx(sift3d), kp);
 }
 
@@ -696,7 +756,7 @@ int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, in
 {
     if (d_vol == NULL || nx < 1 || ny < 1 || nz < 1) API_FAIL("sift3d_amd_detect_keypoints_dev: bad arguments");
     if (set_im_device(sift3d, NULL, d_vol, nx, ny, nz, ux, uy, uz)) return SIFT3D_FAILURE;
-    if (build_gpyr_dev(sift3d, sift_ctx(sift3d))) return SIFT3D_FAILURE;
+    if (build_gpyr_dev(sift3d, sift_ctx(sift3d), 1)) return SIFT3D_FAILURE;
     return detect_dev(sift3d, sift_ctx(sift3d), kp);
 }
 
@@ -1014,7 +1074,6 @@ int copy_SIFT3D(const SIFT3D *const src, SIFT3D *const dst)
         return SIFT3D_SUCCESS;                            /* no image yet (a multi-GPU pyramid is not copied: parameters only) */
     {
         s3d_ctx *dc;
-        const size_t n0 = (size_t)src->im.nx * src->im.ny * src->im.nz;
         const int L = src->gpyr.num_levels;
         if (!(dst->kernels.downsample_2 = ctx_new())) API_FAIL("sift3d_amd: out of device contexts");
         dc = sift_ctx(dst);
@@ -1035,7 +1094,6 @@ int copy_SIFT3D(const SIFT3D *const src, SIFT3D *const dst)
             dst->dog.levels[i].ux = src->dog.levels[i].ux; dst->dog.levels[i].uy = src->dog.levels[i].uy;
             dst->dog.levels[i].uz = src->dog.levels[i].uz; dst->dog.levels[i].s = src->dog.levels[i].s;
         }
-        DEV(s3d_rt_d2d(dc->d_im, sc->d_im, n0 * sizeof(float), dc->stream));
         if (sc->have_pyramid) {
             for (int o = 0; o < src->gpyr.num_octaves; o++)
                 for (int k = 0; k < L; k++)

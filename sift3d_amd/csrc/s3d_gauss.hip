@@ -821,10 +821,12 @@ k_bary_x_mc(const float *__restrict__ sm, float *__restrict__ dst, int nx, int n
 }
 
 /* ---- fused X+Y pass ----------------------------------------------------------------------------- */
-template <int HW>
-__global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
-k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
-           EdgeFrac efx, EdgeFrac efy)
+/* DIV: every source voxel is divided by `div` as it is loaded, i.e. the filter runs on im_scale's output (imutil.c:1977:
+ * samp / max, the same IEEE division) without that image ever being written -- the first filter of the pyramid reads the
+ * caller's volume directly. */
+template <int HW, bool DIV>
+__device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk,
+                                              const S3dTaps &taps, const EdgeFrac &efx, const EdgeFrac &efy, const float div)
 {
     constexpr int W = 2 * HW + 1;
     constexpr int PAD = (4 - HW % 4) % 4;             /* puts the body at a 16-byte aligned LDS offset */
@@ -884,6 +886,10 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
         r.b = *reinterpret_cast<const float4 *>(row + xq_ld);
         r.a0 = row[colA];
         r.a1 = row[colB];
+        if (DIV) {
+            r.b.x = r.b.x / div; r.b.y = r.b.y / div; r.b.z = r.b.z / div; r.b.w = r.b.w / div;
+            r.a0 = r.a0 / div; r.a1 = r.a1 / div;
+        }
         return r;
     };
     /* stage the row in LDS, X-filter this lane's 4 columns */
@@ -981,6 +987,23 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
     }
 }
 
+template <int HW>
+__global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
+k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
+           EdgeFrac efx, EdgeFrac efy)
+{
+    gauss_xy_body<HW, false>(src, dst, nx, ny, chunk, taps, efx, efy, 1.0f);
+}
+
+template <int HW>
+__global__ void __launch_bounds__(64, 3)
+k_gauss_xy_div(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
+               EdgeFrac efx, EdgeFrac efy, const float *__restrict__ d_div)
+{
+    const float m = *d_div;
+    gauss_xy_body<HW, true>(src, dst, nx, ny, chunk, taps, efx, efy, m == 0.0f ? 1.0f : m);   /* k_scale_div leaves an all-zero image alone */
+}
+
 /* f_j exactly as the reference's boundary pass evaluates it for uf == 1 (imutil.c:2378-2380) */
 static int edge_fracs(int n, int hw, EdgeFrac *ef)
 {
@@ -1031,7 +1054,7 @@ extern "C" void s3d_k_gauss_set_events(void *before_xy, void *between, void *aft
  * Z-slab needs valid source planes [z0-HW, z1+HW) (clamped to the volume), i.e. the neighbours' halos. */
 template <int HW>
 static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
-                       const S3dTaps &t, hipStream_t st)
+                       const S3dTaps &t, hipStream_t st, const float *d_div = nullptr)
 {
     EdgeFrac ex, ey, ez;
     if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
@@ -1044,8 +1067,12 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
     const size_t plane = (size_t)nx * ny;
     if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
     if (g_ev[0]) S3D_HIP(hipEventRecord(g_ev[0], st));
-    hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st,
-                       d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey);
+    if (d_div)
+        hipLaunchKernelGGL((k_gauss_xy_div<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st,
+                           d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey, d_div);
+    else
+        hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st,
+                           d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey);
     S3D_CHECK_LAUNCH();
     if (g_ev[1]) S3D_HIP(hipEventRecord(g_ev[1], st));
     if (!(g_gauss_mode & 1))
@@ -1101,18 +1128,18 @@ static int fast_xy_eligible(int nx, int ny, int nz, int nc, const float uf[3], i
 }
 
 static int fast_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
-                         int hw, const S3dTaps &t, hipStream_t st)
+                         int hw, const S3dTaps &t, hipStream_t st, const float *d_div = nullptr)
 {
     switch (hw) {
-    case 1: return launch_fast<1>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 2: return launch_fast<2>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 3: return launch_fast<3>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 4: return launch_fast<4>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 5: return launch_fast<5>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 6: return launch_fast<6>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 7: return launch_fast<7>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 8: return launch_fast<8>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
-    case 9: return launch_fast<9>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st);
+    case 1: return launch_fast<1>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 2: return launch_fast<2>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 3: return launch_fast<3>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 4: return launch_fast<4>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 5: return launch_fast<5>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 6: return launch_fast<6>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 7: return launch_fast<7>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 8: return launch_fast<8>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 9: return launch_fast<9>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
     default: break;
     }
     S3D_FAIL("half width not instantiated");
@@ -1244,6 +1271,25 @@ extern "C" int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp
     if (conv_axis_range(d_dst, d_tmp, nx, ny, nz, 1, 1, za, zb, taps, width, uf[1], stream)) return S3D_ERR;
     if (conv_axis_range(d_tmp, d_dst, nx, ny, nz, 1, 2, z0, z1, taps, width, uf[2], stream)) return S3D_ERR;
     return S3D_OK;
+}
+
+/* dst = filter(src / *d_div) for the configurations the fused kernels take (single channel, unit tap spacing, nx % 4 == 0):
+ * im_scale folded into the first filter of the pyramid.  s3d_k_sep_fir_div_eligible() says whether this call is available;
+ * callers scale explicitly (s3d_k_scale_div) otherwise. */
+extern "C" int s3d_k_sep_fir_div_eligible(int nx, int ny, int nz, const float uf[3], int width)
+{
+    return width >= 1 && width <= S3D_MAX_TAPS && (width & 1) && fast_eligible(nx, ny, nz, 1, uf, width);
+}
+
+extern "C" int s3d_k_sep_fir_div(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
+                                 const float uf[3], const float *taps, int width, const float *d_div, s3d_stream stream)
+{
+    S3dTaps t;
+    if (check_taps(taps, width, &t)) return S3D_ERR;
+    if (nx < 1 || ny < 1 || nz < 1 || z0 < 0 || z1 > nz || z0 >= z1 || d_div == nullptr) S3D_FAIL("bad arguments");
+    if (d_tmp == d_src || d_tmp == d_dst) S3D_FAIL("scratch must not alias src/dst");
+    if (!fast_eligible(nx, ny, nz, 1, uf, width)) S3D_FAIL("configuration not eligible for the fused scale + filter");
+    return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, width / 2, t, (hipStream_t)stream, d_div);
 }
 
 extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,

@@ -378,6 +378,52 @@ def check_expf(lib, n=1 << 22, seed=9):
     return len(idx), int((cr != got).sum())
 
 
+def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False):
+    """s3d_k_sep_fir_div (im_scale folded into the loads of the first filter) against the explicit sequence maximum ->
+    s3d_k_scale_div -> filter, bit for bit, whole volume and plane ranges; an all-zero volume stays all zero (the reference
+    does not divide by a zero maximum)."""
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    vol = np.random.default_rng(5).standard_normal((nz, ny, nx)).astype(np.float32) * np.float32(37.5)
+    if zero:
+        vol[:] = 0
+    uf = np.ones(3, np.float32)
+    L.s3d_k_sep_fir_div.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.s3d_k_sep_fir_div_eligible.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int]
+    L.s3d_k_absmax.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.s3d_k_scale_div.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    d_src, d_sc, d_a, d_b, d_t = (dev.upload(vol), dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes),
+                                  dev.malloc(vol.nbytes))
+    d_max = dev.malloc(64)
+    try:
+        assert L.s3d_k_absmax(d_src, vol.size, d_max, None) == 0
+        assert L.s3d_k_scale_div(d_sc, vol.size, d_max, None) == 0
+        scaled = dev.download(d_sc, vol.shape)
+        m = np.float32(np.abs(vol).max())
+        assert nbitdiff(scaled, vol / m if m else vol) == 0
+        for sigma in sigmas:
+            taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)
+            assert L.s3d_k_sep_fir_div_eligible(nx, ny, nz, uf.ctypes.data, taps.size) == 1
+            dev.sep_fir(d_sc, d_a, d_t, nx, ny, nz, 1, uf, taps)
+            want = dev.download(d_a, vol.shape)
+            for z0, z1 in [(0, nz)] + list(splits):
+                L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+                L.s3d_rt_memset(C.c_void_p(d_b), 0xFF, vol.nbytes, None)
+                assert L.s3d_k_sep_fir_div(d_src, d_b, d_t, nx, ny, nz, z0, z1, uf.ctypes.data, taps.ctypes.data, taps.size,
+                                           d_max, None) == 0
+                got = dev.download(d_b, vol.shape)[z0:z1]
+                nd = nbitdiff(got, want[z0:z1])
+                assert nd == 0, f"planes [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
+        # not eligible: the caller has to scale explicitly, and the call says so
+        bad = np.array([1.0, 1.0, 0.5], np.float32)
+        assert L.s3d_k_sep_fir_div_eligible(nx, ny, nz, bad.ctypes.data, 5) == 0
+        assert L.s3d_k_sep_fir_div_eligible(nx + 1, ny, nz, uf.ctypes.data, 5) == 0
+    finally:
+        for p in (d_src, d_sc, d_a, d_b, d_t, d_max):
+            dev.free(p)
+
+
 def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
     """s3d_k_sep_fir_slab on plane ranges of a fully backed volume against the whole-volume result, with the scratch
     poisoned (0xFF = NaN) so that any plane the range arithmetic forgets shows up.  Integral hw * uf is the case that

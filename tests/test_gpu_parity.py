@@ -532,3 +532,9 @@ def test_sep_fir_slab_ranges(lib, oracle, dims, units):
     nz = dims[2]
     parity.check_sep_fir_slab(lib, oracle, dims, units, (0.973294, 1.22627, 1.94659),
                               ((nz // 2, nz), (0, nz // 2), (nz // 4, nz // 4 + 9)))
+
+
+@pytest.mark.parametrize("dims,zero", [((64, 52, 48), False), ((512, 40, 36), False), ((24, 24, 20), True)])
+def test_sep_fir_div(lib, oracle, dims, zero):
+    """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit."""
+    parity.check_sep_fir_div(lib, oracle, dims, (0.973294, 1.94659), [(0, 7), (5, dims[2] - 3), (dims[2] - 6, dims[2])], zero=zero)
