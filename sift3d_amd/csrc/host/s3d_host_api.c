@@ -107,6 +107,10 @@ typedef struct {
     s3d_stream ext_stream;
     void *oct_ev[S3D_MAX_OCTAVES];
     int extrema_enqueued;   /* build_gpyr_dev put the extrema pass on ext_stream; detect_dev collects it */
+    /* pinned host staging that lives with the context (a fresh malloc of a few MB per call is an mmap plus a page fault
+     * per 4 KB): [0] descriptor keys up, [1] keypoint coordinates down, [2] keypoint rotations down */
+    void *h_stage[3];
+    size_t h_stage_bytes[3];
 } s3d_ctx;
 
 #define S3D_MAX_CTX 256
@@ -175,6 +179,11 @@ static void ctx_free_all(s3d_ctx *c)
         if (c->oct_ev[i]) { s3d_rt_event_destroy(c->oct_ev[i]); c->oct_ev[i] = NULL; }
     if (c->ext_stream) { s3d_rt_stream_destroy(c->ext_stream); c->ext_stream = NULL; }
     c->extrema_enqueued = 0;
+    for (int i = 0; i < 3; i++) {
+        if (c->h_stage[i]) s3d_rt_host_free(c->h_stage[i]);
+        c->h_stage[i] = NULL;
+        c->h_stage_bytes[i] = 0;
+    }
 }
 
 static void ctx_release(int handle)
@@ -190,6 +199,20 @@ static void ctx_release(int handle)
         ctx_free_all(c);
         free(c);
     }
+}
+
+static int ctx_stage(s3d_ctx *c, int slot, size_t bytes, void **out)
+{
+    if (c->h_stage_bytes[slot] < bytes) {
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (c->h_stage[slot]) s3d_rt_host_free(c->h_stage[slot]);
+        c->h_stage[slot] = NULL;
+        c->h_stage_bytes[slot] = 0;
+        DEV(s3d_rt_host_alloc(&c->h_stage[slot], want));
+        c->h_stage_bytes[slot] = want;
+    }
+    *out = c->h_stage[slot];
+    return SIFT3D_SUCCESS;
 }
 
 /* small always-present buffers */
@@ -658,14 +681,12 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         float *R;
         if (resize_Keypoint_store(kp, K)) return SIFT3D_FAILURE;
         if (K == 0) return SIFT3D_SUCCESS;
-        xyzos = (int32_t *)malloc((size_t)K * 5 * sizeof(int32_t));
-        R = (float *)malloc((size_t)K * 9 * sizeof(float));
-        if (!xyzos || !R) { free(xyzos); free(R); API_FAIL("sift3d_amd: out of host memory"); }
+        if (ctx_stage(c, 1, (size_t)K * 5 * sizeof(int32_t), (void **)&xyzos) ||
+            ctx_stage(c, 2, (size_t)K * 9 * sizeof(float), (void **)&R))
+            return SIFT3D_FAILURE;
         if (s3d_rt_d2h(xyzos, c->d_xyzos, (size_t)K * 5 * sizeof(int32_t), c->stream) ||
-            s3d_rt_d2h(R, c->d_Rk, (size_t)K * 9 * sizeof(float), c->stream) || s3d_rt_sync(c->stream)) {
-            free(xyzos); free(R);
+            s3d_rt_d2h(R, c->d_Rk, (size_t)K * 9 * sizeof(float), c->stream) || s3d_rt_sync(c->stream))
             API_FAIL("sift3d_amd: keypoint download failed: %s", s3d_rt_last_error());
-        }
         for (uint32_t i = 0; i < K; i++) {
             Keypoint *key = kp->buf + i;
             init_Keypoint(key);
@@ -677,7 +698,6 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
             key->sd = SIFT3D_PYR_IM_GET(&sift3d->dog, key->o, key->s)->s;
             memcpy(key->r_data, R + 9 * i, 9 * sizeof(float));
         }
-        free(xyzos); free(R);
     }
     return SIFT3D_SUCCESS;
 }
@@ -786,6 +806,17 @@ int SIFT3D_have_gpyr(const SIFT3D *const sift3d) /* sift.c:1936-1942, plus: the 
     return g->levels != NULL && g->num_levels != 0 && g->num_octaves != 0 && c != NULL && c->have_pyramid;
 }
 
+/* 2^o as ldexp(1.0, o) gives it, without the libm call for the octaves that occur */
+static inline double pow2_octave(int o) { return o >= 0 && o < 62 ? (double)(1ULL << o) : ldexp(1.0, o); }
+
+/* the per-keypoint conditions of verify_keys */
+static inline int key_is_valid(const Keypoint *key, int nx, int ny, int nz)
+{
+    const double f = pow2_octave(key->o);
+    return !(key->xd < 0 || key->yd < 0 || key->zd < 0 || key->xd * f >= (double)nx || key->yd * f >= (double)ny ||
+             key->zd * f >= (double)nz) && !(key->sd <= 0);
+}
+
 /* verify_keys, sift.c:2050-2091 */
 int s3d_verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz)
 {
@@ -796,24 +827,23 @@ int s3d_verify_keys(const Keypoint_store *const kp, int nx, int ny, int nz)
     }
     for (long i = 0; i < num; i++) {
         const Keypoint *key = kp->buf + i;
-        const double f = ldexp(1.0, key->o);
+        const double f = pow2_octave(key->o);
+        if (key_is_valid(key, nx, ny, nz)) continue;
         if (key->xd < 0 || key->yd < 0 || key->zd < 0 || key->xd * f >= (double)nx || key->yd * f >= (double)ny ||
             key->zd * f >= (double)nz) {
             S3D_MSG("verify_keys: keypoint %ld (%f, %f, %f) octave %d exceeds image dimensions (%d, %d, %d) \n", i,
                     key->xd, key->yd, key->zd, key->o, nx, ny, nz);
             return SIFT3D_FAILURE;
         }
-        if (key->sd <= 0) {
-            S3D_MSG("verify_keys: keypoint %ld has invalid scale %f \n", i, key->sd);
-            return SIFT3D_FAILURE;
-        }
+        S3D_MSG("verify_keys: keypoint %ld has invalid scale %f \n", i, key->sd);
+        return SIFT3D_FAILURE;
     }
     return SIFT3D_SUCCESS;
 }
 
 /* scalar set-up of extract_descrip (sift.c:1845-1851) in the reference's float arithmetic */
-void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave,
-                       s3d_desc_key *out)
+static inline void make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave,
+                                 s3d_desc_key *out)
 {
     const float sigma = key->sd * desc_sig_fctr;
     const float win_radius = desc_rad_fctr * sigma;
@@ -830,6 +860,11 @@ void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int
     memcpy(out->R, key->R.u.data_float ? key->R.u.data_float : key->r_data, 9 * sizeof(float));
 }
 
+void s3d_make_desc_key(const Keypoint *key, double xd, double yd, double zd, int level, int octave, s3d_desc_key *out)
+{
+    make_desc_key(key, xd, yd, zd, level, octave, out);
+}
+
 /* The descriptor kernel enumerates a keypoint's window row by row with 10-bit coordinates: a window of 1024 or more
  * voxels along an axis (voxel spacings ~50 times smaller than the keypoint scale, on volumes wider than 1024) is
  * beyond it.  Refuse loudly rather than return an empty histogram. */
@@ -838,6 +873,11 @@ int s3d_check_desc_windows(const s3d_desc_key *keys, size_t num, const s3d_pyram
     for (size_t i = 0; i < num; i++) {
         const s3d_desc_key *k = keys + i;
         const float c[3] = {k->cx, k->cy, k->cz};
+        const float *uo = pd->unitsf[k->octave];
+        /* a window spans at most 2 rad / u + 2 voxels: nothing to look at unless that comes near the limit */
+        if (2.0f * k->rad + 4.0f * uo[0] < 1000.0f * uo[0] && 2.0f * k->rad + 4.0f * uo[1] < 1000.0f * uo[1] &&
+            2.0f * k->rad + 4.0f * uo[2] < 1000.0f * uo[2])
+            continue;
         for (int a = 0; a < 3; a++) {
             const float u = pd->unitsf[k->octave][a];
             const int n = pd->dims[k->octave][a];
@@ -902,34 +942,38 @@ static int describe_dev(SIFT3D *const sift3d, s3d_ctx *c, const s3d_pyramid_desc
     return SIFT3D_SUCCESS;
 }
 
-static int describe_from_gpyr(SIFT3D *const sift3d, const Keypoint_store *const kp, SIFT3D_Descriptor *host_out)
+/* verified: the caller has run s3d_verify_keys already */
+static int describe_from_gpyr(SIFT3D *const sift3d, const Keypoint_store *const kp, SIFT3D_Descriptor *host_out, int verified)
 {
     const Pyramid *g = &sift3d->gpyr;
     s3d_ctx *c = sift_ctx(sift3d);
     const size_t num = kp->slab.num;
+    const int nx = sift3d->im.nx, ny = sift3d->im.ny, nz = sift3d->im.nz;
     s3d_pyramid_desc pd;
     s3d_desc_key *keys;
-    int rc;
-    if (s3d_verify_keys(kp, sift3d->im.nx, sift3d->im.ny, sift3d->im.nz)) return SIFT3D_FAILURE;
+    if ((long)num < 1) return s3d_verify_keys(kp, nx, ny, nz);     /* fails with the reference's message */
     if (!SIFT3D_have_gpyr(sift3d)) {
+        if (!verified && s3d_verify_keys(kp, nx, ny, nz)) return SIFT3D_FAILURE;   /* the reference checks the keys first */
         S3D_MSG("SIFT3D_extract_descriptors: no Gaussian pyramid is available. Make sure SIFT3D_detect_keypoints "
                 "was called prior to calling this function. \n");
         return SIFT3D_FAILURE;
     }
-    if ((keys = (s3d_desc_key *)malloc(num * sizeof(s3d_desc_key))) == NULL) return SIFT3D_FAILURE;
+    if (ctx_stage(c, 0, num * sizeof(s3d_desc_key), (void **)&keys)) return SIFT3D_FAILURE;
+    /* one pass over the store: verify_keys' conditions and the kernel's record per keypoint */
     for (size_t i = 0; i < num; i++) {
         const Keypoint *key = kp->buf + i;
         const int oi = key->o - g->first_octave, ki = key->s - g->first_level;
+        if (!verified && !key_is_valid(key, nx, ny, nz)) {
+            return s3d_verify_keys(kp, nx, ny, nz);                /* finds the keypoint again and says why */
+        }
         if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) {
-            free(keys);
+            if (!verified && s3d_verify_keys(kp, nx, ny, nz)) return SIFT3D_FAILURE;
             API_FAIL("SIFT3D_extract_descriptors: keypoint %zu has no pyramid level (o=%d, s=%d)", i, key->o, key->s);
         }
-        s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + i);
+        make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + i);
     }
     fill_pyr_desc(g, c->d_level, &pd);
-    rc = describe_dev(sift3d, c, &pd, keys, num, host_out);
-    free(keys);
-    return rc;
+    return describe_dev(sift3d, c, &pd, keys, num, host_out);
 }
 
 int sift3d_amd_describe_window_stats(SIFT3D *const sift3d, const Keypoint_store *const kp, unsigned int *stats)
@@ -988,7 +1032,7 @@ int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const
     desc->nx = first->nx; desc->ny = first->ny; desc->nz = first->nz;
     if (s3d_resize_descriptor_store(desc, (long)kp->slab.num)) return SIFT3D_FAILURE;
     if (sift_ctx(sift3d)->pyramid_on_slabs) return s3d_mgpu_describe(sift_ctx(sift3d)->mgpu, kp, desc->buf);
-    if (describe_from_gpyr(sift3d, kp, desc->buf)) return SIFT3D_FAILURE;
+    if (describe_from_gpyr(sift3d, kp, desc->buf, 1)) return SIFT3D_FAILURE;
     fill_desc_coords(kp, desc->buf);
     return SIFT3D_SUCCESS;
 }
@@ -997,7 +1041,7 @@ int sift3d_amd_extract_descriptors_dev(SIFT3D *const sift3d, const Keypoint_stor
 {
     if (sift_ctx(sift3d) && sift_ctx(sift3d)->pyramid_on_slabs)
         API_FAIL("sift3d_amd_extract_descriptors_dev: the pyramid is spread over several GPUs; use SIFT3D_extract_descriptors");
-    if (describe_from_gpyr(sift3d, kp, NULL)) return SIFT3D_FAILURE;
+    if (describe_from_gpyr(sift3d, kp, NULL, 0)) return SIFT3D_FAILURE;
     if (d_desc) *d_desc = sift_ctx(sift3d)->d_desc;
     return SIFT3D_SUCCESS;
 }

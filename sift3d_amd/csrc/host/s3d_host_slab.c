@@ -85,6 +85,7 @@ struct sift3d_amd_slab {
     size_t bits_words;
     uint32_t *d_scratch, *d_kscratch, *d_count;
     float *d_red;
+    int first_div;                      /* this detect folds im_scale into the first filter (s3d_k_sep_fir_div) */
     uint32_t cap;
     uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
     float *d_R, *d_Rk;
@@ -396,20 +397,26 @@ static int halo_of_level(const sift3d_amd_slab *sl, int o, int k)
     return h;
 }
 
-static int gauss(sift3d_amd_slab *sl, const s3d_lev *src, const s3d_lev *dst, int o, const Sep_FIR_filter *f)
+/* d_div != NULL: the source is divided by *d_div as it is loaded (im_scale folded into the first filter; the caller has
+ * checked s3d_k_sep_fir_div_eligible) */
+static int gauss(sift3d_amd_slab *sl, const s3d_lev *src, const s3d_lev *dst, int o, const Sep_FIR_filter *f, const float *d_div)
 {
     float uf[3];
+    const int nxo = sl->dims[o][0], nyo = sl->dims[o][1], nzo = sl->dims[o][2];
     octave_uf(sl, o, uf);
     if (o <= sl->o_shard && sl->t.world > 1) {
         const int z0 = sl->part[o][0], z1 = sl->part[o][1];
-        const size_t pe = (size_t)sl->dims[o][0] * sl->dims[o][1];
+        const size_t pe = (size_t)nxo * nyo;
         /* the scratch, seen as a view of this octave whose first backed plane is z0 - H */
         float *tmpv = (float *)((uintptr_t)sl->tmp.base - (uintptr_t)((intptr_t)(z0 - sl->H) * (intptr_t)pe * 4));
-        DEV(s3d_k_sep_fir_slab(lev_view(src), lev_view(dst), tmpv, sl->dims[o][0], sl->dims[o][1], sl->dims[o][2], z0, z1, uf,
-                               f->kernel, f->width, sl->cs));
+        if (d_div)
+            DEV(s3d_k_sep_fir_div(lev_view(src), lev_view(dst), tmpv, nxo, nyo, nzo, z0, z1, uf, f->kernel, f->width, d_div, sl->cs));
+        else
+            DEV(s3d_k_sep_fir_slab(lev_view(src), lev_view(dst), tmpv, nxo, nyo, nzo, z0, z1, uf, f->kernel, f->width, sl->cs));
+    } else if (d_div) {
+        DEV(s3d_k_sep_fir_div(lev_view(src), lev_view(dst), sl->tmp.base, nxo, nyo, nzo, 0, nzo, uf, f->kernel, f->width, d_div, sl->cs));
     } else {
-        DEV(s3d_k_sep_fir(lev_view(src), lev_view(dst), sl->tmp.base, sl->dims[o][0], sl->dims[o][1], sl->dims[o][2], 1, uf,
-                          f->kernel, f->width, sl->cs));
+        DEV(s3d_k_sep_fir(lev_view(src), lev_view(dst), sl->tmp.base, nxo, nyo, nzo, 1, uf, f->kernel, f->width, sl->cs));
     }
     return SIFT3D_SUCCESS;
 }
@@ -435,7 +442,7 @@ static int build_pyramid(sift3d_amd_slab *sl)
     const int G = sl->t.world, sharded = G > 1, nl = sl->nl;
     const GSS_filters *gss = &sl->plan.gss;
     if (exchange_halo(sl, &sl->im, 0, filter_reach(sl, &gss->first_gauss.f, 0), 0)) return SIFT3D_FAILURE;
-    if (gauss(sl, &sl->im, &sl->lev[0], 0, &gss->first_gauss.f)) return SIFT3D_FAILURE;
+    if (gauss(sl, &sl->im, &sl->lev[0], 0, &gss->first_gauss.f, sl->first_div ? sl->d_red : NULL)) return SIFT3D_FAILURE;
     for (int o = 0; o < sl->no; o++) {
         const int shard_o = sharded && o <= sl->o_shard;
         s3d_lev *L = &sl->lev[o * nl];
@@ -446,7 +453,7 @@ static int build_pyramid(sift3d_amd_slab *sl)
                 if (nowp < 1) nowp = 1;
                 if (exchange_halo(sl, &L[k - 1], o, halo_of_level(sl, o, k - 1), nowp)) return SIFT3D_FAILURE;
             }
-            if (gauss(sl, &L[k - 1], &L[k], o, f)) return SIFT3D_FAILURE;
+            if (gauss(sl, &L[k - 1], &L[k], o, f, NULL)) return SIFT3D_FAILURE;
         }
         if (shard_o && exchange_halo(sl, &L[nl - 1], o, halo_of_level(sl, o, nl - 1), 0)) return SIFT3D_FAILURE;
         if (o + 1 < sl->no) {
@@ -560,7 +567,13 @@ int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device,
     /* im_scale with the global maximum (sift.c:903, imutil.c:1977-1991) */
     DEV(s3d_k_absmax(own, n_local, sl->d_red, sl->cs));
     if (sl->t.world > 1) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red, 1, sl->cs));
-    DEV(s3d_k_scale_div(own, n_local, sl->d_red, sl->cs));
+    {   /* the division rides in the first filter's loads where the fused kernels take the configuration (the raw planes
+         * then travel as halos: a neighbour's plane divided on load is its scaled plane) */
+        float uf0[3];
+        octave_uf(sl, 0, uf0);
+        sl->first_div = s3d_k_sep_fir_div_eligible(sl->nx, sl->ny, sl->nz, uf0, sl->plan.gss.first_gauss.f.width);
+        if (!sl->first_div) DEV(s3d_k_scale_div(own, n_local, sl->d_red, sl->cs));
+    }
     if (build_pyramid(sl)) return SIFT3D_FAILURE;
     if (find_candidates(sl, &ncand)) return SIFT3D_FAILURE;
     sl->num_candidates = (long)ncand;
