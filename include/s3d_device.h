@@ -197,15 +197,18 @@ typedef struct {
  * d_mesh: table from s3d_mesh_table().  Descriptor i is written to d_out[i*out_stride .. +768),
  * order 12*(cx+4cy+16cz)+vertex (out_stride = 776 lays records out like SIFT3D_Descriptor).
  * The level buffers in pyr must be readable for 16 bytes past their last voxel (wide gathers;
- * s3d_rt_malloc adds the slack itself). */
+ * s3d_rt_malloc adds the slack itself).
+ * d_work: one uint32 of device memory owned by the caller, not shared with a launch on another stream: the kernel runs
+ * one persistent workgroup per CU and the workgroups draw their keypoints from this counter (zeroed by the call, in
+ * stream order). */
 int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
                    const float *d_mesh, float *d_out, size_t out_stride /* floats, >= 768 */,
-                   s3d_stream stream);
+                   uint32_t *d_work, s3d_stream stream);
 
 /* Test / diagnostics aid: d_stats[2i] = number of voxels the descriptor window of keypoint i accepts, d_stats[2i+1] = a
  * checksum of their coordinates, produced by the descriptor kernel's own window enumeration. */
 int s3d_k_describe_window_stats(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
-                                uint32_t *d_stats, s3d_stream stream);
+                                uint32_t *d_stats, uint32_t *d_work, s3d_stream stream);
 
 /* Self-test: d_out[i] = the kernels' window-weight exponential of d_in[i] (a restatement of glibc 2.35 expf,
  * which the reference reaches through expf() at sift.c:1401, 1890, 2333); |d_in[i]| < 80. */

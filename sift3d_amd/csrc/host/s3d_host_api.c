@@ -78,7 +78,7 @@ typedef struct {
     size_t bits_words;
     uint32_t *d_scratch;
     float *d_red;           /* small reduction slots */
-    uint32_t *d_count;      /* [0] candidates, [1] keypoints */
+    uint32_t *d_count;      /* [0] candidates, [1] keypoints, [4] work counter of the descriptor kernel */
     uint32_t cand_cap;
     uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
     uint32_t *d_kscratch;   /* block counters of s3d_k_compact_keys: cand_cap/256 + 2 (grows with cand_cap) */
@@ -923,7 +923,7 @@ static int describe_dev(SIFT3D *const sift3d, s3d_ctx *c, const s3d_pyramid_desc
             const size_t i0 = (size_t)b * per, n = i0 >= num ? 0 : (num - i0 < per ? num - i0 : per);
             if (!c->batch_ev[b]) DEV(s3d_rt_event_create(&c->batch_ev[b]));
             if (n) DEV(s3d_k_describe(pd, c->d_keys + i0, (uint32_t)n, c->d_mesh, c->d_desc + i0 * DESC_REC_FLOATS,
-                                      DESC_REC_FLOATS, c->stream));
+                                      DESC_REC_FLOATS, c->d_count + 4, c->stream));
             DEV(s3d_rt_event_record(c->batch_ev[b], c->stream));
         }
         for (int b = 0; b < S3D_DESC_BATCHES; b++) {
@@ -936,7 +936,7 @@ static int describe_dev(SIFT3D *const sift3d, s3d_ctx *c, const s3d_pyramid_desc
         DEV(s3d_rt_sync(c->stream));
         return SIFT3D_SUCCESS;
     }
-    DEV(s3d_k_describe(pd, c->d_keys, (uint32_t)num, c->d_mesh, c->d_desc, DESC_REC_FLOATS, c->stream));
+    DEV(s3d_k_describe(pd, c->d_keys, (uint32_t)num, c->d_mesh, c->d_desc, DESC_REC_FLOATS, c->d_count + 4, c->stream));
     if (host_out) DEV(s3d_rt_d2h(host_out, c->d_desc, num * sizeof(SIFT3D_Descriptor), c->stream));
     DEV(s3d_rt_sync(c->stream));
     return SIFT3D_SUCCESS;
@@ -998,7 +998,7 @@ int sift3d_amd_describe_window_stats(SIFT3D *const sift3d, const Keypoint_store 
     fill_pyr_desc(g, c->d_level, &pd);
     if (s3d_rt_malloc((void **)&d_stats, num * 2 * sizeof(uint32_t)) == 0 &&
         s3d_rt_h2d(c->d_keys, keys, num * sizeof(s3d_desc_key), c->stream) == 0 &&
-        s3d_k_describe_window_stats(&pd, c->d_keys, (uint32_t)num, d_stats, c->stream) == 0 &&
+        s3d_k_describe_window_stats(&pd, c->d_keys, (uint32_t)num, d_stats, c->d_count + 4, c->stream) == 0 &&
         s3d_rt_d2h(stats, d_stats, num * 2 * sizeof(uint32_t), c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
         rc = SIFT3D_SUCCESS;
     else

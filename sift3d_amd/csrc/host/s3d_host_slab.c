@@ -655,7 +655,7 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
     }
     if (s3d_check_desc_windows(keys, nsel, &sl->pd)) { free(keys); return SIFT3D_FAILURE; }
     if (s3d_rt_h2d(sl->d_keys, keys, nsel * sizeof(s3d_desc_key), sl->cs) ||
-        s3d_k_describe(&sl->pd, sl->d_keys, (uint32_t)nsel, sl->d_mesh, sl->d_desc, DESC_REC_FLOATS, sl->cs)) {
+        s3d_k_describe(&sl->pd, sl->d_keys, (uint32_t)nsel, sl->d_mesh, sl->d_desc, DESC_REC_FLOATS, sl->d_count + 4, sl->cs)) {
         s3d_rt_sync(sl->cs);
         free(keys);
         SLAB_FAIL("sift3d_amd slab: describe failed: %s", s3d_rt_last_error());

@@ -728,6 +728,8 @@ struct DwShared {
     unsigned short chunk_row[DW_CMAP];    /* row (thread index of the round) that chunk c belongs to */
     int wave_tot[DW_WAVES];
     unsigned win_chk, win_vox;
+    unsigned next[2];                     /* the keypoint this workgroup takes next (claimed one keypoint ahead) */
+    uint32_t nkey[2][(sizeof(s3d_desc_key) + 3) / 4];   /* ... and its record, fetched while the current one is worked on */
 };
 
 #if defined(S3D_EMU)
@@ -756,6 +758,12 @@ __device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long 
     y = z * r2 + y;
     return (float)(y * s);
 }
+
+#if defined(S3D_EMU)
+#define DW_UNIFORM(x) (x)
+#else
+#define DW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))   /* a workgroup-uniform value: to an SGPR */
+#endif
 
 #if defined(S3D_EMU)
 #define DW_RCP(x) (1.0f / (x))
@@ -819,13 +827,54 @@ __device__ __forceinline__ double dw_block_sum(double v, double *part)
 template <bool COUNT_ONLY>
 __global__ void __launch_bounds__(DW_THREADS)
 k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num, const float *__restrict__ d_mesh,
-              float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ stats)
+              float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ stats, uint32_t *__restrict__ work)
 {
     DW_SHARED_DECL;
-    const unsigned kid = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (kid >= num) return;
-    const s3d_desc_key key = keys[kid];
+
+    /* ---- once per workgroup: the tables every keypoint uses ---- */
+    if (!COUNT_ONLY)
+        for (int i = tid; i < S3D_MESH_FLOATS; i += DW_THREADS) sm.mesh[i] = d_mesh[i];
+    if (!COUNT_ONLY && tid >= 64 && tid < 64 + S3D_NFACES) {
+        const int fc = tid - 64;
+        const float *m = d_mesh;
+        const V3 e1 = v3(S3D_MESH_AT(m, fc, 0), S3D_MESH_AT(m, fc, 1), S3D_MESH_AT(m, fc, 2));
+        const V3 e2 = v3(S3D_MESH_AT(m, fc, 3), S3D_MESH_AT(m, fc, 4), S3D_MESH_AT(m, fc, 5));
+        const V3 tt = v3(S3D_MESH_AT(m, fc, 6), S3D_MESH_AT(m, fc, 7), S3D_MESH_AT(m, fc, 8));
+        const V3 nn = v3_cross(e2, e1), cc = v3_cross(e2, tt);
+        const float rec[9] = {nn.x, nn.y, nn.z, cc.x, cc.y, cc.z, S3D_MESH_AT(m, fc, 9), S3D_MESH_AT(m, fc, 10), S3D_MESH_AT(m, fc, 11)};
+        for (int k = 0; k < 9; k++) sm.fcn[k * S3D_NFACES + fc] = rec[k];
+    }
+    if (!COUNT_ONLY && tid < S3D_NFACES * 3)
+        sm.vofs[tid] = __float_as_int(d_mesh[(13 + tid / S3D_NFACES) * S3D_NFACES + tid % S3D_NFACES]) * (DW_NCOPY * 8);
+    if (tid < 32) {
+        static const unsigned long long tab[32] = {
+            0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+            0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+            0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+            0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+            0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+            0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+            0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+            0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+        sm.etab[tid] = tab[tid];
+    }
+
+    /* ---- persistent workgroup: the first keypoint by block index, every further one from the shared counter (claimed at
+     * the start of the keypoint before, so the atomic's round trip is never waited for).  One workgroup per CU stays
+     * resident for the whole launch: no workgroup launch, table load or cold start between a CU's ~120 keypoints. ---- */
+    unsigned kid = blockIdx.x;
+    for (unsigned turn = 0; kid < num; turn++) {
+    if (tid == 0) sm.next[turn & 1] = gridDim.x + atomicAdd(work, 1u);
+    s3d_desc_key key;
+    if (turn == 0) {
+        key = keys[kid];
+    } else {                                                  /* workgroup-uniform: keep it in scalar registers */
+        uint32_t kw[(sizeof(s3d_desc_key) + 3) / 4];
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(s3d_desc_key) + 3) / 4); i++) kw[i] = DW_UNIFORM(sm.nkey[turn & 1][i]);
+        __builtin_memcpy(&key, kw, sizeof(key));
+    }
     const int o = key.octave;
     const float *__restrict__ im = pyr.d_level[key.level];
     const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
@@ -868,34 +917,15 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     const double unscale = ldexp(1.0, -fbits);
 
     for (int i = tid; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
-    if (!COUNT_ONLY)
-        for (int i = tid; i < S3D_MESH_FLOATS; i += DW_THREADS) sm.mesh[i] = d_mesh[i];
-    if (!COUNT_ONLY && tid >= 64 && tid < 64 + S3D_NFACES) {
-        const int fc = tid - 64;
-        const float *m = d_mesh;
-        const V3 e1 = v3(S3D_MESH_AT(m, fc, 0), S3D_MESH_AT(m, fc, 1), S3D_MESH_AT(m, fc, 2));
-        const V3 e2 = v3(S3D_MESH_AT(m, fc, 3), S3D_MESH_AT(m, fc, 4), S3D_MESH_AT(m, fc, 5));
-        const V3 tt = v3(S3D_MESH_AT(m, fc, 6), S3D_MESH_AT(m, fc, 7), S3D_MESH_AT(m, fc, 8));
-        const V3 nn = v3_cross(e2, e1), cc = v3_cross(e2, tt);
-        const float rec[9] = {nn.x, nn.y, nn.z, cc.x, cc.y, cc.z, S3D_MESH_AT(m, fc, 9), S3D_MESH_AT(m, fc, 10), S3D_MESH_AT(m, fc, 11)};
-        for (int k = 0; k < 9; k++) sm.fcn[k * S3D_NFACES + fc] = rec[k];
-    }
-    if (!COUNT_ONLY && tid < S3D_NFACES * 3)
-        sm.vofs[tid] = __float_as_int(d_mesh[(13 + tid / S3D_NFACES) * S3D_NFACES + tid % S3D_NFACES]) * (DW_NCOPY * 8);
-    if (tid < 32) {
-        static const unsigned long long tab[32] = {
-            0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
-            0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
-            0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
-            0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
-            0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
-            0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
-            0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
-            0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
-        sm.etab[tid] = tab[tid];
-    }
     if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; }
     __syncthreads();
+    /* the next keypoint's record: loaded now (one word per lane of the first wave), parked in LDS after the chunk loop */
+    constexpr int KEY_WORDS = (int)((sizeof(s3d_desc_key) + 3) / 4);
+    uint32_t nkey_word = 0;
+    {
+        const unsigned nk = sm.next[turn & 1];
+        if (tid < KEY_WORDS && nk < num) nkey_word = reinterpret_cast<const uint32_t *>(keys + nk)[tid];
+    }
     if (use_tab) {
         /* entry i: the weight of a voxel at squared distance i * u^2, through the very float steps of sift.c:1890 */
         const int nent = (int)(g.rad2 / u2) + 2;
@@ -1169,10 +1199,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
          * round's row intervals instead of waiting. */
     }
     __syncthreads();                                          /* all histogram atomics (and the window counters) are in */
+    if (tid < KEY_WORDS) sm.nkey[(turn + 1) & 1][tid] = nkey_word;
     if (COUNT_ONLY) {
         if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
-        return;
-    }
+        __syncthreads();                                      /* before the next keypoint clears the counters */
+    } else {
 #if defined(DW_ABLATE)
     if (ablate_acc == 0x1234567ull) sm.hist[1] = 1ull;
 #endif
@@ -1208,46 +1239,70 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++)
         if (tid + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tid + q * DW_THREADS] = v[q] * inv;
+    }
+    /* every barrier above lies between thread 0's claim and this read; the slot alternates so that the next turn's claim
+     * cannot overtake a slow reader */
+    kid = DW_UNIFORM(sm.next[turn & 1]);
+    }                                                         /* next keypoint of this workgroup */
 }
 
 /* The kernel needs 149 KB of dynamic LDS, above the 64 KB a launch gets by default: raise the limit once per DEVICE (a
- * process may drive several GPUs: the in-process Z-slab ranks) */
-static int dw_prepare(void)
+ * process may drive several GPUs: the in-process Z-slab ranks).  Returns the number of workgroups of a launch: one per CU
+ * (the LDS allows one resident workgroup per CU; the workgroups are persistent and share the keypoints dynamically). */
+static int dw_prepare(unsigned *grid)
 {
 #if !defined(S3D_EMU)
     static unsigned char done[64];
+    static int ncu[64];
     int dev = 0;
     S3D_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !done[dev]) {
+        int n = 0;
         S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
         S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
-        if (dev >= 0 && dev < 64) done[dev] = 1;
+        S3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n < 1) n = 256;
+        if (dev < 0 || dev >= 64) { *grid = (unsigned)n; return S3D_OK; }
+        ncu[dev] = n;
+        done[dev] = 1;
     }
+    *grid = (unsigned)ncu[dev];
+#else
+    *grid = 3;                                                /* the emulator runs workgroups one after the other */
 #endif
     return S3D_OK;
 }
 
 /* Test / diagnostics aid: per keypoint the number of voxels the descriptor window accepts and a checksum of their
- * coordinates (d_stats[2i], d_stats[2i+1]), from the very enumeration the descriptor kernel uses. */
+ * coordinates (d_stats[2i], d_stats[2i+1]), from the very enumeration the descriptor kernel uses.  d_work: one uint32 of
+ * device scratch owned by the caller (the launch's work counter; see s3d_k_describe). */
 extern "C" int s3d_k_describe_window_stats(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
-                                           uint32_t *d_stats, s3d_stream st)
+                                           uint32_t *d_stats, uint32_t *d_work, s3d_stream st)
 {
+    unsigned grid = 0;
     if (num == 0) return S3D_OK;
-    if (dw_prepare()) return S3D_ERR;
-    hipLaunchKernelGGL((k_describe_wg<true>), dim3(num), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
-                       (const float *)nullptr, (float *)nullptr, (size_t)0, d_stats);
+    if (d_work == nullptr) S3D_FAIL("no work counter");
+    if (dw_prepare(&grid)) return S3D_ERR;
+    if (grid > num) grid = num;
+    S3D_HIP(hipMemsetAsync(d_work, 0, sizeof(uint32_t), (hipStream_t)st));
+    hipLaunchKernelGGL((k_describe_wg<true>), dim3(grid), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
+                       (const float *)nullptr, (float *)nullptr, (size_t)0, d_stats, d_work);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
 
 extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,
-                              const float *d_mesh, float *d_out, size_t out_stride, s3d_stream st)
+                              const float *d_mesh, float *d_out, size_t out_stride, uint32_t *d_work, s3d_stream st)
 {
+    unsigned grid = 0;
     if (num == 0) return S3D_OK;
     if (out_stride < S3D_DESC_NUMEL) S3D_FAIL("descriptor stride too small");
-    if (dw_prepare()) return S3D_ERR;
-    hipLaunchKernelGGL((k_describe_wg<false>), dim3(num), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
-                       d_mesh, d_out, out_stride, (uint32_t *)nullptr);
+    if (d_work == nullptr) S3D_FAIL("no work counter");
+    if (dw_prepare(&grid)) return S3D_ERR;
+    if (grid > num) grid = num;
+    S3D_HIP(hipMemsetAsync(d_work, 0, sizeof(uint32_t), (hipStream_t)st));
+    hipLaunchKernelGGL((k_describe_wg<false>), dim3(grid), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
+                       d_mesh, d_out, out_stride, (uint32_t *)nullptr, d_work);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
