@@ -145,6 +145,12 @@ int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nwords, uint32_t
 int s3d_k_compact_bits_base(const unsigned long long *d_bits, size_t nwords, uint32_t idx_base,
                             uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
                             uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream);
+/* The same for nseg bitmaps of nwords words lying seg_stride words apart (the keypoint levels of one octave), appended
+ * one after the other with tags tag, tag + 1, ..: one count / scan / emit triple instead of nseg.  d_scratch: nseg *
+ * ceil(nwords / 1024) counters. */
+int s3d_k_compact_bits_multi(const unsigned long long *d_bits, size_t nwords, int nseg, size_t seg_stride, uint32_t idx_base,
+                             uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity, uint32_t *d_count,
+                             uint32_t *d_scratch, s3d_stream stream);
 
 /* ---- keypoints ----------------------------------------------------------------------------------- */
 typedef struct {

@@ -422,7 +422,7 @@ static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
     maxwords = (n0 + 63) / 64;
     c->bits_words = maxwords;
     DEV(s3d_rt_malloc((void **)&c->d_bits, S3D_FUSED_KP_MAX * maxwords * sizeof(unsigned long long)));
-    DEV(s3d_rt_malloc((void **)&c->d_scratch, (maxwords / 1024 + 8) * sizeof(uint32_t)));     /* bitmap block counters */
+    DEV(s3d_rt_malloc((void **)&c->d_scratch, S3D_FUSED_KP_MAX * (maxwords / 1024 + 8) * sizeof(uint32_t)));   /* bitmap block counters */
     DEV(s3d_rt_malloc((void **)&c->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS));
     c->nx = l0->nx; c->ny = l0->ny; c->nz = l0->nz;
     c->num_octaves = g->num_octaves;
@@ -547,10 +547,9 @@ static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es
         fused = s3d_k_extrema_fused((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
                                     c->d_red + 1, bits, es);
         if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
-        if (fused == 0)
-            for (int ks = 1; ks <= nkp; ks++)
-                DEV(s3d_k_compact_bits(bits[ks - 1], nwords, c->d_cand_idx, c->d_cand_tag, ((uint32_t)o << 8) | (uint32_t)ks,
-                                       c->cand_cap, c->d_count, c->d_scratch, es));
+        if (fused == 0)                                 /* the nkp bitmaps in one count / scan / emit */
+            DEV(s3d_k_compact_bits_multi(bits[0], nwords, nkp, c->bits_words, 0u, c->d_cand_idx, c->d_cand_tag,
+                                         ((uint32_t)o << 8) | 1u, c->cand_cap, c->d_count, c->d_scratch, es));
     }
     for (int ks = 1; fused != 0 && ks <= nkp; ks++) {   /* DoG level ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
         DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + 1, es));

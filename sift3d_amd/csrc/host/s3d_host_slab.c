@@ -271,7 +271,7 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
         if (dmalloc(sl, &sl->d_seed, (size_t)(G + 1) * sl->seed_elems * sizeof(float), 1)) return SIFT3D_FAILURE;
     }
     if (dmalloc(sl, &sl->d_bits, S3D_FUSED_KP_MAX * sl->bits_words * sizeof(unsigned long long), 1) ||
-        dmalloc(sl, &sl->d_scratch, (sl->bits_words / 1024 + 16) * sizeof(uint32_t), 1) ||
+        dmalloc(sl, &sl->d_scratch, 3 * (sl->bits_words / 1024 + 16) * sizeof(uint32_t), 1) ||
         dmalloc(sl, &sl->d_red, 16 * sizeof(float), 1) || dmalloc(sl, &sl->d_count, 8 * sizeof(uint32_t), 1) ||
         dmalloc(sl, &sl->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS, 0))
         return SIFT3D_FAILURE;
@@ -518,9 +518,8 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
                 for (int k = 0; k < 3; k++) bits[k] = sl->d_bits + (size_t)k * sl->bits_words;
                 if (s3d_k_extrema_fused(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
                     SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
-                for (int ks = 1; ks <= 3; ks++)
-                    DEV(s3d_k_compact_bits_base(bits[ks - 1], nwords, (uint32_t)((size_t)za * pe), sl->d_cand_idx, sl->d_cand_tag,
-                                                ((uint32_t)o << 8) | (uint32_t)ks, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
+                DEV(s3d_k_compact_bits_multi(bits[0], nwords, 3, sl->bits_words, (uint32_t)((size_t)za * pe), sl->d_cand_idx,
+                                             sl->d_cand_tag, ((uint32_t)o << 8) | 1u, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
                 continue;
             }
             for (int ks = 1; ks <= nkp; ks++) {

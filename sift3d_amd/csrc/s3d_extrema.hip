@@ -222,10 +222,15 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned *total)
     return r;
 }
 
+/* The bitmaps of one octave's keypoint levels are `nseg` segments of nwords words, seg_stride words apart; workgroup
+ * b works on block b % nb of segment b / nb, so that the block counters -- and with them the output -- are in segment-major
+ * order (level, then voxel index: the reference's scan order) and one count / scan / emit triple serves all levels. */
 __global__ void __launch_bounds__(256)
-k_cb_count(const unsigned long long *__restrict__ bits, size_t nwords, unsigned *__restrict__ block_count)
+k_cb_count(const unsigned long long *__restrict__ bits, size_t nwords, unsigned *__restrict__ block_count, unsigned nb,
+           size_t seg_stride)
 {
-    const size_t w0 = (size_t)blockIdx.x * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
+    bits += (size_t)(blockIdx.x / nb) * seg_stride;
+    const size_t w0 = (size_t)(blockIdx.x % nb) * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
     unsigned c = 0;
     for (int i = 0; i < CB_WORDS_PER_THREAD; i++)
         if (w0 + i < nwords) c += (unsigned)__popcll(bits[w0 + i]);
@@ -253,9 +258,12 @@ __global__ void __launch_bounds__(256) k_cb_scan(unsigned *__restrict__ block_co
 __global__ void __launch_bounds__(256)
 k_cb_emit(const unsigned long long *__restrict__ bits, size_t nwords, const unsigned *__restrict__ block_off,
           unsigned *__restrict__ out_idx, unsigned *__restrict__ out_tag, unsigned tag, unsigned capacity,
-          unsigned idx_base)
+          unsigned idx_base, unsigned nb, size_t seg_stride)
 {
-    const size_t w0 = (size_t)blockIdx.x * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
+    const unsigned seg = blockIdx.x / nb;
+    bits += (size_t)seg * seg_stride;
+    tag += seg;                                               /* tags of consecutive levels are consecutive */
+    const size_t w0 = (size_t)(blockIdx.x % nb) * CB_WORDS_PER_BLOCK + (size_t)threadIdx.x * CB_WORDS_PER_THREAD;
     unsigned long long w[CB_WORDS_PER_THREAD];
     unsigned c = 0;
     for (int i = 0; i < CB_WORDS_PER_THREAD; i++) {
@@ -279,9 +287,9 @@ k_cb_emit(const unsigned long long *__restrict__ bits, size_t nwords, const unsi
     }
 }
 
-extern "C" int s3d_k_compact_bits_base(const unsigned long long *d_bits, size_t nwords, uint32_t idx_base,
-                                       uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
-                                       uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream);
+extern "C" int s3d_k_compact_bits_multi(const unsigned long long *d_bits, size_t nwords, int nseg, size_t seg_stride,
+                                        uint32_t idx_base, uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
+                                        uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream);
 
 extern "C" int s3d_k_compact_bits(const unsigned long long *d_bits, size_t nwords, uint32_t *d_idx, uint32_t *d_tag,
                                   uint32_t tag, uint32_t capacity, uint32_t *d_count, uint32_t *d_scratch,
@@ -295,15 +303,25 @@ extern "C" int s3d_k_compact_bits_base(const unsigned long long *d_bits, size_t 
                                        uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
                                        uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream)
 {
+    return s3d_k_compact_bits_multi(d_bits, nwords, 1, 0, idx_base, d_idx, d_tag, tag, capacity, d_count, d_scratch, stream);
+}
+
+/* nseg bitmaps of nwords words, seg_stride words apart, appended one after the other with tags tag, tag + 1, ...:
+ * d_scratch holds nseg * ceil(nwords / 1024) counters */
+extern "C" int s3d_k_compact_bits_multi(const unsigned long long *d_bits, size_t nwords, int nseg, size_t seg_stride,
+                                        uint32_t idx_base, uint32_t *d_idx, uint32_t *d_tag, uint32_t tag, uint32_t capacity,
+                                        uint32_t *d_count, uint32_t *d_scratch, s3d_stream stream)
+{
     hipStream_t st = (hipStream_t)stream;
-    if (nwords == 0) return S3D_OK;
+    if (nwords == 0 || nseg < 1) return S3D_OK;
     const unsigned nb = s3d_div_up(nwords, CB_WORDS_PER_BLOCK);
-    hipLaunchKernelGGL(k_cb_count, dim3(nb), dim3(256), 0, st, d_bits, nwords, d_scratch);
+    const unsigned nbt = nb * (unsigned)nseg;
+    hipLaunchKernelGGL(k_cb_count, dim3(nbt), dim3(256), 0, st, d_bits, nwords, d_scratch, nb, seg_stride);
     S3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_cb_scan, dim3(1), dim3(256), 0, st, d_scratch, nb, d_count);
+    hipLaunchKernelGGL(k_cb_scan, dim3(1), dim3(256), 0, st, d_scratch, nbt, d_count);
     S3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_cb_emit, dim3(nb), dim3(256), 0, st, d_bits, nwords, d_scratch, d_idx, d_tag, tag, capacity,
-                       idx_base);
+    hipLaunchKernelGGL(k_cb_emit, dim3(nbt), dim3(256), 0, st, d_bits, nwords, d_scratch, d_idx, d_tag, tag, capacity,
+                       idx_base, nb, seg_stride);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }

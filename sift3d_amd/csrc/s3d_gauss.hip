@@ -466,6 +466,7 @@ static bool launch_z_ring(int hw, const float *src, float *dst, size_t plane4, i
 }
 
 static thread_local int g_no_dyadic = 0;      /* profiling / test knob of the calling thread: force the generic kernel */
+static thread_local int g_force_z_ring = 0;   /* test knob: the marching z kernel whatever the size of its grid */
 
 static int check_taps(const float *taps, int width, S3dTaps *out)
 {
@@ -525,7 +526,10 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
             return S3D_OK;
         }
     }
-    if (vec4 && !g_no_dyadic && axis == 2 && nc == 1) {
+    /* the marching z kernel only where its grid (a wave per 64 float4 columns and 64 planes) fills the GPU: on the small
+     * octaves of a pyramid it is a handful of waves walking the volume (26-49 us at 32^3 where the plain kernel takes 6) */
+    if (vec4 && !g_no_dyadic && axis == 2 && nc == 1 &&
+        (g_force_z_ring || s3d_div_up(strides[2] / 4, 64) * (size_t)s3d_div_up((size_t)(z1 - z0), 64) >= 512)) {
         const int W = 2 * uhw + 4;
         bool done = false;
         if (W <= 16) done = launch_z_ring<16>(hw, d_src, d_dst, strides[2] / 4, nz, z0, z1, uf, uhw, W, t, (hipStream_t)st);
@@ -1032,9 +1036,15 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
 
 static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk().  Per calling thread. */
 
-/* profiling knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
- * bit 1 = no dyadic-spacing specialisation of the generic axis pass */
-extern "C" void s3d_k_gauss_set_mode(int mode) { g_gauss_mode = mode; g_no_dyadic = (mode >> 1) & 1; }
+/* profiling / test knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
+ * bit 1 = no dyadic-spacing specialisation of the generic axis pass; bit 2 = k_conv_z_ring also where its grid would not
+ * fill the GPU (tests reach it on small volumes) */
+extern "C" void s3d_k_gauss_set_mode(int mode)
+{
+    g_gauss_mode = mode & 1;
+    g_no_dyadic = (mode >> 1) & 1;
+    g_force_z_ring = (mode >> 2) & 1;
+}
 
 /* tuning knobs for profiling runs (rows / planes per marching chunk) */
 extern "C" void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z)

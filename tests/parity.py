@@ -435,20 +435,26 @@ def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
     uf = np.array([np.float32(1.0 / u) for u in units], np.float32)
     L.s3d_k_sep_fir_slab.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     d_src, d_a, d_b, d_t = dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes)
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
     try:
-        for sigma in sigmas:
-            taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)
-            dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
-            full = dev.download(d_a, vol.shape)
-            assert nbitdiff(full, oracle.sep_fir(vol, taps, units, 1.0)) == 0
-            for z0, z1 in splits:
-                L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
-                L.s3d_rt_memset(C.c_void_p(d_b), 0xFF, vol.nbytes, None)
-                assert L.s3d_k_sep_fir_slab(d_src, d_b, d_t, nx, ny, nz, z0, z1, uf.ctypes.data, taps.ctypes.data,
-                                            taps.size, None) == 0
-                got = dev.download(d_b, vol.shape)[z0:z1]
-                nd = nbitdiff(got, full[z0:z1])
-                assert nd == 0, f"slab [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
+        # mode 4: the marching z kernel (k_conv_z_ring) also on volumes whose grid would not fill the GPU -- the library
+        # picks it by grid size, these volumes are small
+        for mode in (0, 4):
+            L.s3d_k_gauss_set_mode(mode)
+            for sigma in sigmas:
+                taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)
+                dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
+                full = dev.download(d_a, vol.shape)
+                assert nbitdiff(full, oracle.sep_fir(vol, taps, units, 1.0)) == 0
+                for z0, z1 in splits:
+                    L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+                    L.s3d_rt_memset(C.c_void_p(d_b), 0xFF, vol.nbytes, None)
+                    assert L.s3d_k_sep_fir_slab(d_src, d_b, d_t, nx, ny, nz, z0, z1, uf.ctypes.data, taps.ctypes.data,
+                                                taps.size, None) == 0
+                    got = dev.download(d_b, vol.shape)[z0:z1]
+                    nd = nbitdiff(got, full[z0:z1])
+                    assert nd == 0, f"mode {mode} slab [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
     finally:
+        L.s3d_k_gauss_set_mode(0)
         for p in (d_src, d_a, d_b, d_t):
             dev.free(p)

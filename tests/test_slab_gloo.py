@@ -89,7 +89,7 @@ def test_slab_world1_equals_c_api(emu, oracle):
     (2, (32, 32, 64), (1.0, 1.0, 1.0), 130, 1, 0),
     (3, (32, 32, 96), (1.0, 1.0, 1.0), 200, 6, 0),        # an interior rank with two neighbours
     (3, (28, 36, 100), (1.0, 1.0, 1.0), 200, 7, 0),       # nz not divisible by the ranks: uneven slabs
-    (2, (32, 32, 64), (1.0, 1.0, 1.5), 130, 3, 0),        # anisotropic slices: k_conv_z_ring on slabs
+    (2, (32, 32, 64), (1.0, 1.0, 1.5), 130, 3, 0),        # anisotropic slices: fractional z taps on slabs
     (2, (24, 24, 128), (1.0, 1.0, 1.0), 260, 8, 1),       # two sharded octaves + replicated ones
     (4, (16, 16, 256), (1.0, 1.0, 1.0), 300, 9, 1),       # four ranks, octaves 0-1 sharded, seed all-gather of 4
 ])
