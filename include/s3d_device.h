@@ -134,6 +134,15 @@ int s3d_k_extrema_slab(const float *d_l0, const float *d_l1, const float *d_l2, 
 int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
                         double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
                         s3d_stream stream);
+/* The same without the DoG maxima being known beforehand, as two calls (a Z-slab rank all-reduces d_dogmax in between):
+ * s3d_k_extrema_fused_runmax zeroes d_dogmax[0..nkp), finds a superset of the extrema of planes [z0, z1) under a running
+ * lower bound of the maxima and leaves the exact maxima of those planes in d_dogmax; s3d_k_extrema_refilter applies the
+ * exact thresholds to the bitmaps.  Bitmaps identical to s3d_k_dogmax3 + s3d_k_extrema_fused, one pass over four GSS
+ * levels less.  Returns 1 (nothing done) where s3d_k_extrema_fused would. */
+int s3d_k_extrema_fused_runmax(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                               double peak_thresh, float *d_dogmax, unsigned long long *const *d_bits, s3d_stream stream);
+int s3d_k_extrema_refilter(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                           double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits, s3d_stream stream);
 /* Ordered compaction of a bitmap: appends the indices of set bits, ascending, to d_idx starting at
  * position *d_count, tags each with `tag` in d_tag, and advances *d_count.  Entries past `capacity`
  * are dropped (the count still advances, so overflow is detectable).  d_scratch: >= nwords/1024+2

@@ -539,14 +539,14 @@ static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es
     if (nkp <= S3D_FUSED_KP_MAX) {
         unsigned long long *bits[S3D_FUSED_KP_MAX];
         for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
-        if (nkp == 3) {
-            DEV(s3d_k_dogmax3((const float *const *)(lp + 1), n, c->d_red + 1, es));
-        } else {
-            for (int ks = 1; ks <= nkp; ks++) DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + ks, es));
-        }
-        fused = s3d_k_extrema_fused((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
-                                    c->d_red + 1, bits, es);
+        /* three keypoint levels, nx % 4 == 0: the DoG maxima come out of the extrema pass itself (running lower bound,
+         * then the exact thresholds on the survivors) instead of a pass of their own over four levels */
+        fused = s3d_k_extrema_fused_runmax((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz,
+                                           sift3d->peak_thresh, c->d_red + 1, bits, es);
         if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
+        if (fused == 0)
+            DEV(s3d_k_extrema_refilter((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
+                                       c->d_red + 1, bits, es));
         if (fused == 0)                                 /* the nkp bitmaps in one count / scan / emit */
             DEV(s3d_k_compact_bits_multi(bits[0], nwords, nkp, c->bits_words, 0u, c->d_cand_idx, c->d_cand_tag,
                                          ((uint32_t)o << 8) | 1u, c->cand_cap, c->d_count, c->d_scratch, es));

@@ -509,15 +509,26 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
             const size_t nwords = ((size_t)(zb - za) * pe + 63) / 64;
             const int fused = nkp == 3 && (nxo & 3) == 0;   /* all keypoint levels in one pass (s3d_k_extrema_fused) */
             if (fused) {
-                const float *l4[4], *l6[6];
+                const float *l6[6];
                 unsigned long long *bits[3];
-                for (int k = 0; k < 4; k++) l4[k] = shard_o ? lev_ptr(&L[k + 1], za) : lev_view(&L[k + 1]);
-                DEV(s3d_k_dogmax3(l4, (size_t)(shard_o ? zb - za : nzo) * pe, sl->d_red + 1, sl->cs));
-                if (shard_o) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 3, sl->cs));   /* the three maxima at once */
                 for (int k = 0; k < 6; k++) l6[k] = lev_view(&L[k]);
                 for (int k = 0; k < 3; k++) bits[k] = sl->d_bits + (size_t)k * sl->bits_words;
-                if (s3d_k_extrema_fused(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
-                    SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                if (shard_o || G == 1) {
+                    /* survivors under a running lower bound of the DoG maxima, the exact maxima of my planes as a
+                     * by-product; the maxima over all ranks (sift.c:1161-1169), then the exact thresholds on the survivors */
+                    if (s3d_k_extrema_fused_runmax(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
+                        SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                    if (shard_o) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 3, sl->cs));   /* the three maxima at once */
+                    DEV(s3d_k_extrema_refilter(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs));
+                } else {
+                    /* replicated octave: every rank holds the whole level (the maxima are over all of it, no collective --
+                     * ranks without planes are not here) and tests its own planes */
+                    const float *l4[4];
+                    for (int k = 0; k < 4; k++) l4[k] = lev_view(&L[k + 1]);
+                    DEV(s3d_k_dogmax3(l4, (size_t)nzo * pe, sl->d_red + 1, sl->cs));
+                    if (s3d_k_extrema_fused(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
+                        SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                }
                 DEV(s3d_k_compact_bits_multi(bits[0], nwords, 3, sl->bits_words, (uint32_t)((size_t)za * pe), sl->d_cand_idx,
                                              sl->d_cand_tag, ((uint32_t)o << 8) | 1u, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
                 continue;

@@ -82,11 +82,22 @@ struct ExtArgs {
     float thr_scale_unused;
 };
 
-template <int NKP>
+/* RUNMAX: the DoG maxima are not known yet.  d_runmax[s] (bit patterns of non-negative floats, zeroed before the launch)
+ * is a running maximum of |DoG(s)| over the workgroups that have finished so far: whatever a workgroup reads there is a
+ * lower bound of the true maximum, so its threshold is at most the reference's and its survivors are a SUPERSET of the
+ * reference's (the first workgroups of a launch see 0 and let through every extremum; soon the bound is the maximum of most
+ * of the volume).  Every workgroup folds the maximum of its own voxels in, so that after the launch d_runmax holds the
+ * exact maxima of the voxels the launch covered -- k_extrema_refilter then clears the survivors below the exact
+ * threshold.  Saves the separate pass over four GSS levels that k_dogmax3 is (16 of the 40 B/voxel of an octave's
+ * extrema step). */
+template <int NKP, bool RUNMAX>
 __global__ void __launch_bounds__(256)
 k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
-                const float *__restrict__ d_dogmax /* [NKP], per keypoint level */)
+                const float *__restrict__ d_dogmax /* [NKP], per keypoint level */, unsigned *__restrict__ d_runmax)
 {
+    float seen[NKP];                                       /* RUNMAX: the bound this workgroup works with */
+#pragma unroll
+    for (int s = 0; s < NKP; s++) seen[s] = RUNMAX ? __uint_as_float(__atomic_load_n(&d_runmax[s], __ATOMIC_RELAXED)) : 0.0f;
     /* voxels idx0 + 4*g .. +3 ; a wave covers 256 consecutive voxels = 4 bitmap words */
     const unsigned g = blockIdx.x * 256u + threadIdx.x;
     const unsigned idx = idx0 + 4u * g;
@@ -127,7 +138,7 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
         row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
 #pragma unroll
         for (int s = 0; s < NKP; s++) {
-            const float thr = (float)(peak * (double)d_dogmax[s]);        /* sift.c:1169 */
+            const float thr = (float)(peak * (double)(RUNMAX ? seen[s] : d_dogmax[s]));   /* sift.c:1169 */
             const float *l1 = a.l[s + 1], *l2 = a.l[s + 2];
             float left = 0.0f, right = 0.0f;              /* idx-1 / idx+4 stay inside the level for every tested voxel */
             if (row_ok && x >= 1) left = lane > 0 ? from_lo[s] : l1[idx - 1] - l2[idx - 1];
@@ -164,6 +175,24 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
             if (ok) res |= 1u << b;
         }
     }
+    if (RUNMAX) {                                          /* fold this workgroup's maxima into the running ones */
+        __shared__ float wmax[NKP][4];
+#pragma unroll
+        for (int s = 0; s < NKP; s++) {
+            float m = fmaxf(fmaxf(fabsf(d[s + 1][0]), fabsf(d[s + 1][1])), fmaxf(fabsf(d[s + 1][2]), fabsf(d[s + 1][3])));
+            for (int k = 32; k >= 1; k >>= 1) {
+                const float o = __shfl_xor(m, k);
+                m = m > o ? m : o;
+            }
+            if (lane == 0) wmax[s][threadIdx.x >> 6] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < NKP) {
+            const int s = threadIdx.x;
+            const float m = fmaxf(fmaxf(wmax[s][0], wmax[s][1]), fmaxf(wmax[s][2], wmax[s][3]));
+            if (m > seen[s]) atomicMax(&d_runmax[s], __float_as_uint(m));     /* rare once the bound has settled */
+        }
+    }
     unsigned nib[NKP];
 #pragma unroll
     for (int s = 0; s < NKP; s++) nib[s] = (res >> (4 * s)) & 15u;
@@ -177,12 +206,38 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
     }
 }
 
+/* clears the bits of survivors whose |DoG| does not exceed the exact threshold (see RUNMAX above): one thread per bitmap
+ * word of each level; nearly all words are zero */
+template <int NKP>
+__global__ void __launch_bounds__(256)
+k_extrema_refilter(ExtArgs<NKP> a, unsigned idx0, size_t nwords, double peak, const float *__restrict__ d_dogmax)
+{
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+#pragma unroll
+    for (int s = 0; s < NKP; s++) {
+        unsigned long long m = a.bits[s][w];
+        if (m == 0ull) continue;
+        const float thr = (float)(peak * (double)d_dogmax[s]);            /* sift.c:1169 */
+        const float *l1 = a.l[s + 1], *l2 = a.l[s + 2];
+        unsigned long long keep = m;
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const size_t i = (size_t)idx0 + w * 64 + (size_t)b;
+            const float v = l1[i] - l2[i];
+            if (!(v > thr || v < -thr)) keep &= ~(1ull << b);
+        }
+        a.bits[s][w] = keep;
+    }
+}
+
 /* Keypoint levels s = 0 .. nkp-1 of one octave at once.  d_levels: nkp+3 GSS levels starting at L(s-1) of
  * the first keypoint level; d_dogmax: nkp maxima (max|DoG| of each keypoint level); d_bits: nkp bitmaps.
  * Returns 1 without doing anything when not eligible (nx % 4 != 0, nkp not instantiated). */
-extern "C" int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
-                                   double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
-                                   s3d_stream st)
+static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                double peak_thresh, const float *d_dogmax, unsigned *d_runmax,
+                                unsigned long long *const *d_bits, s3d_stream st)
 {
     const size_t n = (size_t)nx * ny * nz, plane = (size_t)nx * ny;
     if (nkp != 3 || (nx & 3)) return 1;
@@ -192,9 +247,54 @@ extern "C" int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx
     for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];
     for (int k = 0; k < 3; k++) a.bits[k] = d_bits[k];
     a.thr_scale_unused = 0.0f;
-    hipLaunchKernelGGL((k_extrema_fused<3>), dim3(s3d_div_up(plane * (size_t)(z1 - z0) / 4, 256)), dim3(256), 0,
-                       (hipStream_t)st, a, (unsigned)nx, (unsigned)ny, (unsigned)nz, (unsigned)(plane * z0),
-                       (unsigned)(plane * z1), peak_thresh, d_dogmax);
+    const dim3 grid(s3d_div_up(plane * (size_t)(z1 - z0) / 4, 256));
+    if (d_runmax)
+        hipLaunchKernelGGL((k_extrema_fused<3, true>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, (unsigned)ny,
+                           (unsigned)nz, (unsigned)(plane * z0), (unsigned)(plane * z1), peak_thresh, (const float *)nullptr,
+                           d_runmax);
+    else
+        hipLaunchKernelGGL((k_extrema_fused<3, false>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, (unsigned)ny,
+                           (unsigned)nz, (unsigned)(plane * z0), (unsigned)(plane * z1), peak_thresh, d_dogmax,
+                           (unsigned *)nullptr);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+extern "C" int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                   double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
+                                   s3d_stream st)
+{
+    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, d_dogmax, nullptr, d_bits, st);
+}
+
+/* The same without knowing the DoG maxima beforehand, in two calls (a Z-slab rank all-reduces d_dogmax in between):
+ *   s3d_k_extrema_fused_runmax   zeroes d_dogmax[0..nkp), finds a superset of the extrema of planes [z0, z1) under a
+ *                                running lower bound of the maxima and leaves the exact maxima of those planes in d_dogmax;
+ *   s3d_k_extrema_refilter       applies the exact thresholds peak_thresh * d_dogmax[s] to the bitmaps.
+ * Together they produce the bitmaps of s3d_k_dogmax3 + s3d_k_extrema_fused bit for bit, without the former's pass. */
+extern "C" int s3d_k_extrema_fused_runmax(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                          double peak_thresh, float *d_dogmax, unsigned long long *const *d_bits,
+                                          s3d_stream st)
+{
+    if (nkp != 3 || (nx & 3)) return 1;
+    S3D_HIP(hipMemsetAsync(d_dogmax, 0, 3 * sizeof(float), (hipStream_t)st));
+    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, nullptr, (unsigned *)d_dogmax, d_bits, st);
+}
+
+extern "C" int s3d_k_extrema_refilter(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                      double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
+                                      s3d_stream st)
+{
+    const size_t plane = (size_t)nx * ny;
+    if (nkp != 3 || (nx & 3)) S3D_FAIL("not eligible");
+    if (z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad slab");
+    ExtArgs<3> a;
+    for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];
+    for (int k = 0; k < 3; k++) a.bits[k] = d_bits[k];
+    a.thr_scale_unused = 0.0f;
+    const size_t nwords = (plane * (size_t)(z1 - z0) + 63) / 64;
+    hipLaunchKernelGGL((k_extrema_refilter<3>), dim3(s3d_div_up(nwords, 256)), dim3(256), 0, (hipStream_t)st, a,
+                       (unsigned)(plane * z0), nwords, peak_thresh, d_dogmax);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }

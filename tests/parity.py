@@ -378,6 +378,59 @@ def check_expf(lib, n=1 << 22, seed=9):
     return len(idx), int((cr != got).sum())
 
 
+def check_extrema_runmax(lib, dims, ranges, seed=3):
+    """s3d_k_extrema_fused_runmax + s3d_k_extrema_refilter (DoG maxima found by the extrema pass itself) against
+    s3d_k_dogmax3 + s3d_k_extrema_fused: the same maxima and the same bitmaps, whole volume and plane ranges."""
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    rng = np.random.default_rng(seed)
+    n = nx * ny * nz
+    base = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    levels = [np.ascontiguousarray(base * np.float32(1.0 - 0.13 * k) + rng.standard_normal(base.shape).astype(np.float32) *
+                                   np.float32(0.05 * (k + 1))) for k in range(6)]
+    d_lv = [dev.upload(a) for a in levels]
+    nwords = (n + 63) // 64
+    d_bits = [dev.malloc(nwords * 8) for _ in range(6)]
+    d_max = dev.malloc(64)
+    P6 = (C.c_void_p * 6)(*d_lv)
+    P4 = (C.c_void_p * 4)(*d_lv[1:5])
+    Ba = (C.c_void_p * 3)(*d_bits[:3])
+    Bb = (C.c_void_p * 3)(*d_bits[3:])
+    L.s3d_k_dogmax3.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.s3d_k_extrema_fused.argtypes = sig
+    L.s3d_k_extrema_fused_runmax.argtypes = sig
+    L.s3d_k_extrema_refilter.argtypes = sig
+    try:
+        for z0, z1 in ranges:
+            for b in d_bits:
+                L.s3d_rt_memset(C.c_void_p(b), 0, nwords * 8, None)
+            # the reference order of things: maxima of the planes in the range, then the thresholded extrema
+            plane = nx * ny
+            Q4 = (C.c_void_p * 4)(*[p + 4 * plane * z0 for p in d_lv[1:5]])
+            assert L.s3d_k_dogmax3(Q4, plane * (z1 - z0), d_max, None) == 0
+            want_max = dev.download(d_max, (3,))
+            assert L.s3d_k_extrema_fused(P6, 3, nx, ny, nz, z0, z1, 0.1, d_max, Ba, None) == 0
+            assert L.s3d_k_extrema_fused_runmax(P6, 3, nx, ny, nz, z0, z1, 0.1, d_max, Bb, None) == 0
+            got_max = dev.download(d_max, (3,))
+            assert nbitdiff(got_max, want_max) == 0, (got_max, want_max)
+            assert L.s3d_k_extrema_refilter(P6, 3, nx, ny, nz, z0, z1, 0.1, d_max, Bb, None) == 0
+            w0 = plane * z0 // 64
+            nw = (plane * (z1 - z0) + 63) // 64
+            total = 0
+            for k in range(3):
+                a = dev.download(d_bits[k], (nwords * 2,)).view(np.uint64)[:nw]
+                b = dev.download(d_bits[3 + k], (nwords * 2,)).view(np.uint64)[:nw]
+                assert np.array_equal(a, b), f"planes [{z0},{z1}) level {k}: {int((a != b).sum())} bitmap words differ"
+                total += int(np.unpackbits(a.view(np.uint8)).sum())
+            assert total > 0
+            del w0
+    finally:
+        for p in d_lv + d_bits + [d_max]:
+            dev.free(p)
+
+
 def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False):
     """s3d_k_sep_fir_div (im_scale folded into the loads of the first filter) against the explicit sequence maximum ->
     s3d_k_scale_div -> filter, bit for bit, whole volume and plane ranges; an all-zero volume stays all zero (the reference

@@ -148,3 +148,9 @@ def test_sep_fir_slab_ranges(emu, oracle, dims, units):
 def test_sep_fir_div(emu, oracle, dims, zero):
     """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit."""
     parity.check_sep_fir_div(emu, oracle, dims, (0.973294, 1.94659), [(0, 7), (5, dims[2] - 3), (dims[2] - 6, dims[2])], zero=zero)
+
+
+def test_extrema_runmax(emu):
+    """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form."""
+    d = (32, 20, 18)
+    parity.check_extrema_runmax(emu, d, [(0, d[2]), (0, d[2] // 2), (d[2] // 2 - 3, d[2])])
