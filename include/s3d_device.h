@@ -281,6 +281,9 @@ int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int *d_a_sel, u
 int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t na, const float *d_b, size_t b_stride, uint32_t nb,
                          double *d_fbest, double *d_fsecond, int *d_fidx, double *d_bbest, double *d_bsecond, int *d_bidx,
                          s3d_stream stream);
+/* The screened matcher keeps its scratch (operand copies, score matrix, partial minima, candidate lists: about
+ * 4.3 B per pair) per device between calls; this gives it back. */
+void s3d_k_nn_release_scratch(void);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
  * the f64 MFMA shapes fuse multiply-add and reorder the sum, which would break bit-exactness.
  */
 #include <cfloat>
+#include <pthread.h>
 #include "s3d_common.h"
 #include "../../include/s3d_device.h"
 
@@ -286,7 +287,8 @@ k_nn_norms(const float *__restrict__ src, size_t stride, const int *__restrict__
 __global__ void __launch_bounds__(256)
 k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsigned row_base, const nn_half *__restrict__ Bh,
           const nn_half *__restrict__ Bl, unsigned nbpad, const float *__restrict__ a2, const float *__restrict__ b2,
-          float *__restrict__ S /* rows x nbpad */, float *__restrict__ pm1, float *__restrict__ pm2 /* optional: see below */)
+          float *__restrict__ S /* rows x nbpad */, float *__restrict__ pm1, float *__restrict__ pm2 /* optional: see below */,
+          float *__restrict__ rmin /* rows x nbpad/64: smallest score of every (row, 64-column block) */)
 {
     __shared__ __attribute__((aligned(16))) nn_half sm[4][GT][GLD];      /* A hi, A lo, B hi, B lo */
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -357,6 +359,25 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
                 NN_ACC_GET(acc[tm][tn], r) = v;
             }
         }
+    /* Row minima per 64-column block, while the scores are still in registers: a row of this wave's 64 x 64 block lives in
+     * one register of the 32 lanes of a half-wave (two tiles side by side): min over the two tiles, then a 5-step butterfly
+     * inside the half-wave.  The row scan then reads nbpad/64 values per row instead of the row, and only the blocks that
+     * can hold a candidate. */
+    {
+        const unsigned nblk64 = nbpad / 64u;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float m = fminf(NN_ACC_GET(acc[tm][0], r), NN_ACC_GET(acc[tm][1], r));
+#pragma unroll
+                for (int k = 1; k <= 16; k <<= 1) m = fminf(m, __shfl_xor(m, k));
+                if ((lane & 31) == 0) {
+                    const unsigned lrow = blockIdx.y * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    rmin[(size_t)lrow * nblk64 + (j0 / 64u + (unsigned)wn)] = m;
+                }
+            }
+    }
     /* Column minima for the backward direction, while the scores are still in registers: a lane holds 32 of the 64 rows
      * of this wave's block for each of its two columns (the other 32 sit in lane ^ 32); the two smallest per (64-row
      * block, column) go to pm1 / pm2[block][column] -- the column scan then reads 2/64 of the matrix instead of all of
@@ -386,41 +407,67 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
     }
 }
 
-/* one wave per query row: the two smallest approximate scores, then every column within the error band of
- * the second one, in ascending column order */
+/* one wave per query row: the two smallest approximate scores, then every column within the error band of the second
+ * one.  The row itself is only touched where it matters: the block minima (rmin, from the GEMM epilogue) give the best
+ * block and the runner-up's minimum; the row's second-smallest score is the smaller of that and the second-smallest inside
+ * the best block; the candidates can only sit in blocks whose minimum is within the threshold. */
 __global__ void __launch_bounds__(64)
-k_nn_rowscan(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned row_base, unsigned na,
-             const double *__restrict__ a2d, double b2max, int *__restrict__ cand, int *__restrict__ count)
+k_nn_rowscan(const float *__restrict__ S, const float *__restrict__ rmin, unsigned nbpad, unsigned nb, unsigned row_base,
+             unsigned na, const double *__restrict__ a2d, double b2max, int *__restrict__ cand, int *__restrict__ count)
 {
     const unsigned li = blockIdx.x, i = row_base + li;
     if (i >= na) return;
     const int lane = threadIdx.x;
     const float *row = S + (size_t)li * nbpad;
+    const unsigned nblk64 = nbpad / 64u;
+    const float *bm = rmin + (size_t)li * nblk64;
+    /* two smallest block minima and the block of the smallest */
     float m1 = 3.0e38f, m2 = 3.0e38f;
-    for (unsigned j = lane; j < nb; j += 64) {
-        const float v = row[j];
-        if (v < m1) { m2 = m1; m1 = v; } else if (v < m2) m2 = v;
+    unsigned b1 = 0;
+    for (unsigned b = lane; b < nblk64; b += 64) {
+        const float v = bm[b];
+        if (v < m1) { m2 = m1; m1 = v; b1 = b; } else if (v < m2) m2 = v;
     }
-    for (int m = 32; m >= 1; m >>= 1) {                       /* merge the lanes' (m1, m2) pairs */
+    for (int m = 32; m >= 1; m >>= 1) {
         const float o1 = __shfl_xor(m1, m), o2 = __shfl_xor(m2, m);
-        const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1;
-        const float s2 = m2 < o2 ? m2 : o2;
+        const unsigned ob = (unsigned)__shfl_xor((int)b1, m);
+        const bool mine = m1 < o1 || (m1 == o1 && b1 <= ob);
+        const float lo = mine ? m1 : o1, hi = mine ? o1 : m1, s2 = m2 < o2 ? m2 : o2;
+        b1 = mine ? b1 : ob;
         m1 = lo;
         m2 = hi < s2 ? hi : s2;
+    }
+    /* second smallest inside the best block (padding columns carry 1e30) */
+    {
+        const float v = row[b1 * 64u + (unsigned)lane];
+        float e1 = v, e2 = 3.0e38f;
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float o1 = __shfl_xor(e1, m), o2 = __shfl_xor(e2, m);
+            const float lo = e1 < o1 ? e1 : o1, hi = e1 < o1 ? o1 : e1, s2 = e2 < o2 ? e2 : o2;
+            e1 = lo;
+            e2 = hi < s2 ? hi : s2;
+        }
+        m2 = e2 < m2 ? e2 : m2;
     }
     const double an = sqrt(a2d[i]), bn = sqrt(b2max);
     const double d = 2.0 * (1e-4 * an * bn + 5e-7 * (a2d[i] + b2max));
     const float thr = (float)((double)m2 + 2.0 * d + 1e-7 * fabs((double)m2));
     unsigned n = 0;
-    for (unsigned j0 = 0; j0 < nb; j0 += 64) {
-        const unsigned j = j0 + lane;
-        const bool hit = j < nb && row[j] <= thr;
-        const unsigned long long mask = __ballot(hit ? 1 : 0);
-        if (hit) {
-            const unsigned pos = n + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < NN_CAP) cand[(size_t)i * NN_CAP + pos] = (int)j;
+    for (unsigned b0 = 0; b0 < nblk64; b0 += 64) {
+        const unsigned b = b0 + lane;
+        unsigned long long todo = __ballot(b < nblk64 && bm[b] <= thr ? 1 : 0);
+        while (todo) {                                        /* wave-uniform: ascending blocks */
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned j = (b0 + (unsigned)k) * 64u + (unsigned)lane;
+            const bool hit = j < nb && row[j] <= thr;
+            const unsigned long long mask = __ballot(hit ? 1 : 0);
+            if (hit) {
+                const unsigned pos = n + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < NN_CAP) cand[(size_t)i * NN_CAP + pos] = (int)j;
+            }
+            n += (unsigned)__popcll(mask);
         }
-        n += (unsigned)__popcll(mask);
     }
     if (lane == 0) count[i] = (int)n;
 }
@@ -468,6 +515,49 @@ k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict_
     }
 }
 
+/* Scratch of the screened matcher (operand copies, the score matrix, partial minima, candidate lists): kept per device
+ * between calls -- 18 hipMalloc / hipFree pairs, one of them several GB, cost more than the kernels of a small match --
+ * and handed out under a lock that the call holds to its end (concurrent matches in one process take turns).
+ * s3d_k_nn_release_scratch() gives the memory back. */
+#define NN_SLOTS 20
+#define NN_DEVS 16
+struct NnPool { void *p[NN_SLOTS]; size_t cap[NN_SLOTS]; };
+static NnPool g_nn_pool[NN_DEVS];
+static pthread_mutex_t g_nn_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void *nn_get(NnPool *pool, int slot, size_t bytes)
+{
+    if (pool->cap[slot] < bytes) {
+        if (pool->p[slot]) (void)hipFree(pool->p[slot]);
+        pool->p[slot] = nullptr;
+        pool->cap[slot] = 0;
+        if (hipMalloc(&pool->p[slot], bytes) != hipSuccess) { pool->p[slot] = nullptr; return nullptr; }
+        pool->cap[slot] = bytes;
+    }
+    return pool->p[slot];
+}
+
+static NnPool *nn_pool_lock(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NN_DEVS) return nullptr;
+    pthread_mutex_lock(&g_nn_lock);
+    return &g_nn_pool[dev];
+}
+
+extern "C" void s3d_k_nn_release_scratch(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NN_DEVS) return;
+    pthread_mutex_lock(&g_nn_lock);
+    for (int k = 0; k < NN_SLOTS; k++) {
+        if (g_nn_pool[dev].p[k]) (void)hipFree(g_nn_pool[dev].p[k]);
+        g_nn_pool[dev].p[k] = nullptr;
+        g_nn_pool[dev].cap[k] = 0;
+    }
+    pthread_mutex_unlock(&g_nn_lock);
+}
+
 /* Same contract as s3d_k_nn_best2.  Returns 1 (outputs undefined) when a row had more than NN_CAP
  * candidates or the operands do not qualify: the caller then runs s3d_k_nn_best2. */
 extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b,
@@ -481,19 +571,23 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     if (rows_chunk < GT) rows_chunk = GT;
     if (rows_chunk > napad) rows_chunk = napad;
     nn_half *AH = nullptr, *AL = nullptr, *BH = nullptr, *BL = nullptr;
-    float *a2f = nullptr, *b2f = nullptr, *S = nullptr;
+    float *a2f = nullptr, *b2f = nullptr, *S = nullptr, *rmin = nullptr;
     double *a2d = nullptr, *b2d = nullptr, *h_b2 = nullptr;
     int *cand = nullptr, *count = nullptr, *ovf = nullptr;
     int rc = -1, h_ovf = 0;
     double b2max = 0.0;
+    NnPool *pool = nn_pool_lock();
+    if (pool == nullptr) return 1;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
-    NN_TRY(hipMalloc((void **)&AH, sizeof(nn_half) * (size_t)NEL * napad)); NN_TRY(hipMalloc((void **)&AL, sizeof(nn_half) * (size_t)NEL * napad));
-    NN_TRY(hipMalloc((void **)&BH, sizeof(nn_half) * (size_t)NEL * nbpad)); NN_TRY(hipMalloc((void **)&BL, sizeof(nn_half) * (size_t)NEL * nbpad));
-    NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
-    NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
-    NN_TRY(hipMalloc((void **)&S, sizeof(float) * rows_chunk * nbpad));
-    NN_TRY(hipMalloc((void **)&cand, sizeof(int) * (size_t)na * NN_CAP)); NN_TRY(hipMalloc((void **)&count, sizeof(int) * na));
-    NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
+#define NN_GET(var, type, slot, bytes) do { if (((var) = (type *)nn_get(pool, slot, bytes)) == nullptr) goto done; } while (0)
+    NN_GET(AH, nn_half, 0, sizeof(nn_half) * (size_t)NEL * napad); NN_GET(AL, nn_half, 1, sizeof(nn_half) * (size_t)NEL * napad);
+    NN_GET(BH, nn_half, 2, sizeof(nn_half) * (size_t)NEL * nbpad); NN_GET(BL, nn_half, 3, sizeof(nn_half) * (size_t)NEL * nbpad);
+    NN_GET(a2f, float, 4, sizeof(float) * napad); NN_GET(b2f, float, 5, sizeof(float) * nbpad);
+    NN_GET(a2d, double, 6, sizeof(double) * napad); NN_GET(b2d, double, 7, sizeof(double) * nbpad);
+    NN_GET(S, float, 8, sizeof(float) * rows_chunk * nbpad);
+    NN_GET(rmin, float, 9, sizeof(float) * rows_chunk * (nbpad / 64));
+    NN_GET(cand, int, 10, sizeof(int) * (size_t)na * NN_CAP); NN_GET(count, int, 11, sizeof(int) * na);
+    NN_GET(ovf, int, 12, sizeof(int));
     NN_TRY(hipMemsetAsync(ovf, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_nn_split, dim3((unsigned)(((size_t)napad * NEL + 255) / 256)), dim3(256), 0, st, d_a, a_stride, d_a_sel, na,
                        napad, AH, AL);
@@ -508,10 +602,10 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     for (size_t r0 = 0; r0 < napad; r0 += rows_chunk) {
         const unsigned rows = (unsigned)(r0 + rows_chunk <= napad ? rows_chunk : napad - r0);
         hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AH, AL, (unsigned)r0, BH, BL, nbpad, a2f,
-                           b2f, S, (float *)nullptr, (float *)nullptr);
+                           b2f, S, (float *)nullptr, (float *)nullptr, rmin);
         const unsigned live = r0 + rows <= na ? rows : (na > r0 ? (unsigned)(na - r0) : 0u);
         if (live)
-            hipLaunchKernelGGL(k_nn_rowscan, dim3(live), dim3(64), 0, st, S, nbpad, nb, (unsigned)r0, na, a2d, b2max, cand,
+            hipLaunchKernelGGL(k_nn_rowscan, dim3(live), dim3(64), 0, st, S, rmin, nbpad, nb, (unsigned)r0, na, a2d, b2max, cand,
                                count);
     }
     hipLaunchKernelGGL(k_nn_verify, dim3(na), dim3(64), 0, st, d_a, a_stride, d_a_sel, na, d_b, b_stride, cand, count, d_best,
@@ -522,8 +616,9 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     rc = h_ovf ? 1 : 0;
 done:
 #undef NN_TRY
-    hipFree(AH); hipFree(AL); hipFree(BH); hipFree(BL); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S);
-    hipFree(cand); hipFree(count); hipFree(ovf);
+#undef NN_GET
+    if (rc < 0) (void)hipStreamSynchronize(st);              /* nothing of this call may still use the scratch */
+    pthread_mutex_unlock(&g_nn_lock);
     free(h_b2);
     return rc;
 }
@@ -556,21 +651,25 @@ k_nn_col_thr(const float *__restrict__ pm1, const float *__restrict__ pm2, unsig
     thr[j] = (float)((double)m2 + 2.0 * d + 1e-7 * fabs((double)m2));
 }
 
-/* every row of a column whose score is within the threshold, in ONE pass over the matrix: appended through an atomic
- * counter (k_nn_verify sorts the few it gets) */
+/* every row of a column whose score is within the threshold: only the 64-row blocks whose column minimum (pm1, from the
+ * GEMM epilogue) is within it are read; appended through an atomic counter (k_nn_verify sorts the few it gets) */
 __global__ void __launch_bounds__(64)
-k_nn_col_cand(const float *__restrict__ S, unsigned nbpad, unsigned nb, unsigned na, unsigned seg_rows,
-              const float *__restrict__ thr, int *__restrict__ cand, int *__restrict__ count)
+k_nn_col_cand(const float *__restrict__ S, const float *__restrict__ pm1, unsigned nbpad, unsigned nb, unsigned na,
+              unsigned blk_per_seg, unsigned nblk, const float *__restrict__ thr, int *__restrict__ cand, int *__restrict__ count)
 {
     const unsigned j = blockIdx.x * 64u + threadIdx.x, seg = blockIdx.y;
     if (j >= nb) return;
-    const unsigned i0 = seg * seg_rows, i1 = i0 + seg_rows < na ? i0 + seg_rows : na;
+    const unsigned s0 = seg * blk_per_seg, s1 = s0 + blk_per_seg < nblk ? s0 + blk_per_seg : nblk;
     const float t = thr[j];
-    for (unsigned i = i0; i < i1; i++)
-        if (S[(size_t)i * nbpad + j] <= t) {
-            const int pos = atomicAdd(&count[j], 1);
-            if (pos < NN_CAP) cand[(size_t)j * NN_CAP + pos] = (int)i;
-        }
+    for (unsigned sb = s0; sb < s1; sb++) {
+        if (!(pm1[(size_t)sb * nbpad + j] <= t)) continue;
+        const unsigned i0 = sb * 64u, i1 = i0 + 64u < na ? i0 + 64u : na;
+        for (unsigned i = i0; i < i1; i++)
+            if (S[(size_t)i * nbpad + j] <= t) {
+                const int pos = atomicAdd(&count[j], 1);
+                if (pos < NN_CAP) cand[(size_t)j * NN_CAP + pos] = (int)i;
+            }
+    }
 }
 
 /* Forward (rows of A over B) and backward (rows of B over A) best / second / index in one go.  Returns 1 when it
@@ -583,26 +682,30 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     if (na < 2 || nb < 2 || (a_stride & 3) || (b_stride & 3)) return 1;
     const unsigned napad = (na + GT - 1) / GT * GT, nbpad = (nb + GT - 1) / GT * GT;
     if ((size_t)napad * nbpad > ((size_t)1 << 31)) return 1;              /* 8 GiB of scores at most */
-    const unsigned seg_rows = (na + NN_SEG - 1) / NN_SEG;
     nn_half *AH = nullptr, *AL = nullptr, *BH = nullptr, *BL = nullptr;
-    float *a2f = nullptr, *b2f = nullptr, *S = nullptr, *pm1 = nullptr, *pm2 = nullptr, *thr = nullptr;
+    float *a2f = nullptr, *b2f = nullptr, *S = nullptr, *pm1 = nullptr, *pm2 = nullptr, *thr = nullptr, *rmin = nullptr;
     double *a2d = nullptr, *b2d = nullptr, *h_n2 = nullptr;
     int *candf = nullptr, *countf = nullptr, *candb = nullptr, *countb = nullptr, *ovf = nullptr;
     const unsigned nblk = napad / 64u;
+    const unsigned blk_per_seg = (nblk + NN_SEG - 1) / NN_SEG;
     int rc = -1, h_ovf = 0;
     double a2max = 0.0, b2max = 0.0;
+    NnPool *pool = nn_pool_lock();
+    if (pool == nullptr) return 1;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
-    NN_TRY(hipMalloc((void **)&AH, sizeof(nn_half) * (size_t)NEL * napad)); NN_TRY(hipMalloc((void **)&AL, sizeof(nn_half) * (size_t)NEL * napad));
-    NN_TRY(hipMalloc((void **)&BH, sizeof(nn_half) * (size_t)NEL * nbpad)); NN_TRY(hipMalloc((void **)&BL, sizeof(nn_half) * (size_t)NEL * nbpad));
-    NN_TRY(hipMalloc((void **)&a2f, sizeof(float) * napad)); NN_TRY(hipMalloc((void **)&b2f, sizeof(float) * nbpad));
-    NN_TRY(hipMalloc((void **)&a2d, sizeof(double) * napad)); NN_TRY(hipMalloc((void **)&b2d, sizeof(double) * nbpad));
-    NN_TRY(hipMalloc((void **)&S, sizeof(float) * (size_t)napad * nbpad));
-    NN_TRY(hipMalloc((void **)&pm1, sizeof(float) * (size_t)nblk * nbpad));
-    NN_TRY(hipMalloc((void **)&pm2, sizeof(float) * (size_t)nblk * nbpad));
-    NN_TRY(hipMalloc((void **)&thr, sizeof(float) * nbpad));
-    NN_TRY(hipMalloc((void **)&candf, sizeof(int) * (size_t)na * NN_CAP)); NN_TRY(hipMalloc((void **)&countf, sizeof(int) * na));
-    NN_TRY(hipMalloc((void **)&candb, sizeof(int) * (size_t)nb * NN_CAP)); NN_TRY(hipMalloc((void **)&countb, sizeof(int) * nb));
-    NN_TRY(hipMalloc((void **)&ovf, sizeof(int)));
+#define NN_GET(var, type, slot, bytes) do { if (((var) = (type *)nn_get(pool, slot, bytes)) == nullptr) goto done; } while (0)
+    NN_GET(AH, nn_half, 0, sizeof(nn_half) * (size_t)NEL * napad); NN_GET(AL, nn_half, 1, sizeof(nn_half) * (size_t)NEL * napad);
+    NN_GET(BH, nn_half, 2, sizeof(nn_half) * (size_t)NEL * nbpad); NN_GET(BL, nn_half, 3, sizeof(nn_half) * (size_t)NEL * nbpad);
+    NN_GET(a2f, float, 4, sizeof(float) * napad); NN_GET(b2f, float, 5, sizeof(float) * nbpad);
+    NN_GET(a2d, double, 6, sizeof(double) * napad); NN_GET(b2d, double, 7, sizeof(double) * nbpad);
+    NN_GET(S, float, 8, sizeof(float) * (size_t)napad * nbpad);
+    NN_GET(rmin, float, 9, sizeof(float) * (size_t)napad * (nbpad / 64));
+    NN_GET(candf, int, 10, sizeof(int) * (size_t)na * NN_CAP); NN_GET(countf, int, 11, sizeof(int) * na);
+    NN_GET(ovf, int, 12, sizeof(int));
+    NN_GET(pm1, float, 13, sizeof(float) * (size_t)nblk * nbpad);
+    NN_GET(pm2, float, 14, sizeof(float) * (size_t)nblk * nbpad);
+    NN_GET(thr, float, 15, sizeof(float) * nbpad);
+    NN_GET(candb, int, 16, sizeof(int) * (size_t)nb * NN_CAP); NN_GET(countb, int, 17, sizeof(int) * nb);
     NN_TRY(hipMemsetAsync(ovf, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_nn_split, dim3((unsigned)(((size_t)napad * NEL + 255) / 256)), dim3(256), 0, st, d_a, a_stride,
                        (const int *)nullptr, na, napad, AH, AL);
@@ -618,10 +721,12 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     NN_TRY(hipStreamSynchronize(st));
     for (uint32_t j = 0; j < nb; j++) b2max = h_n2[j] > b2max ? h_n2[j] : b2max;
     NN_TRY(hipMemsetAsync(countb, 0, sizeof(int) * nb, st));
-    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2);
-    hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
+    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2,
+                       rmin);
+    hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, rmin, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
     hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nblk, nbpad, nb, b2d, a2max, thr);
-    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, nbpad, nb, na, seg_rows, thr, candb, countb);
+    hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, pm1, nbpad, nb, na, blk_per_seg, nblk, thr, candb,
+                       countb);
     hipLaunchKernelGGL(k_nn_verify, dim3(na), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, d_b, b_stride, candf,
                        countf, d_fbest, d_fsecond, d_fidx, ovf);
     hipLaunchKernelGGL(k_nn_verify, dim3(nb), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, d_a, a_stride, candb,
@@ -632,8 +737,9 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     rc = h_ovf ? 1 : 0;
 done:
 #undef NN_TRY
-    hipFree(AH); hipFree(AL); hipFree(BH); hipFree(BL); hipFree(a2f); hipFree(b2f); hipFree(a2d); hipFree(b2d); hipFree(S); hipFree(pm1); hipFree(pm2);
-    hipFree(thr); hipFree(candf); hipFree(countf); hipFree(candb); hipFree(countb); hipFree(ovf);
+#undef NN_GET
+    if (rc < 0) (void)hipStreamSynchronize(st);              /* nothing of this call may still use the scratch */
+    pthread_mutex_unlock(&g_nn_lock);
     free(h_n2);
     return rc;
 }
