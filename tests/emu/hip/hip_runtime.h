@@ -292,7 +292,8 @@ static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+/* S3D_EMU_DEVICES: how many "GPUs" the emulator reports (the in-process N-GPU mode wants one per rank) */
+static inline hipError_t hipGetDeviceCount(int *n) { const char *e = getenv("S3D_EMU_DEVICES"); *n = e ? atoi(e) : 1; return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }

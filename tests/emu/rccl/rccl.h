@@ -1,0 +1,37 @@
+/* tests/emu/rccl/rccl.h -- TEST INFRASTRUCTURE ONLY.
+ * The handful of RCCL declarations csrc/s3d_rccl.hip uses, so that the transport compiles into the CPU emulator build
+ * (tests/emu/build_emu.sh) and can be driven against tests/emu/mock_rccl.c, an in-process stand-in for librccl.so.1
+ * whose "devices" are host memory.  Enumerator values as in RCCL's rccl.h.  Never seen by the product build, which
+ * includes the real <rccl/rccl.h> of ROCm. */
+#ifndef S3D_EMU_RCCL_H
+#define S3D_EMU_RCCL_H
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                           ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+#ifdef __cplusplus
+}
+#endif
+#endif

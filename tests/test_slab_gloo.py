@@ -189,3 +189,21 @@ def test_slab_gloo(emu, tmp_path, world, dims, units, nblobs, seed, o_shard):
     assert np.array_equal(got["xyzos"], want_x) and np.array_equal(got["sd"], want_sd)
     assert np.array_equal(got["R"], want_R)
     assert np.array_equal(got["desc"], want_b) and np.array_equal(got["dxyzs"], want_c)
+
+
+@pytest.mark.parametrize("args", [
+    ("ranks", 3, 32, 32, 96, 200, 6),          # an interior rank: halos to both neighbours on both lanes
+    ("ranks", 4, 16, 16, 256, 300, 9),         # two sharded octaves: the seed all-gather and 4 x 2 communicators
+    ("plain", 2, 32, 32, 64, 130, 11),         # SIFT3D_detect_keypoints with sift3d_amd_set_num_gpus(2, 0): ncclCommInitAll
+])
+def test_rccl_transport_against_mock(emu, args):
+    """csrc/s3d_rccl.hip with a world larger than one: driven, in a fresh process, against tests/emu/mock_rccl.c (an
+    in-process librccl.so.1 whose ranks are threads) -- peer arithmetic, both communicators, staging and call order must
+    reproduce the single-process result bit for bit (tests/rccl_mock_worker.py asserts it)."""
+    del emu                                                        # built (with the mock) by the fixture
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_mock_worker.py")] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["world"] == args[1] and rec["keypoints"] > 5
