@@ -871,11 +871,16 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     if (turn == 0) {
         key = keys[kid];
     } else {                                                  /* workgroup-uniform: keep it in scalar registers */
-        uint32_t kw[(sizeof(s3d_desc_key) + 3) / 4];
+        const uint32_t *kw = sm.nkey[turn & 1];               /* field by field: a memcpy through an array put `key` in scratch */
+        key.cx = __uint_as_float(DW_UNIFORM(kw[0])); key.cy = __uint_as_float(DW_UNIFORM(kw[1]));
+        key.cz = __uint_as_float(DW_UNIFORM(kw[2])); key.sigma = __uint_as_float(DW_UNIFORM(kw[3]));
+        key.rad = __uint_as_float(DW_UNIFORM(kw[4])); key.half = __uint_as_float(DW_UNIFORM(kw[5]));
+        key.binf = __uint_as_float(DW_UNIFORM(kw[6]));
+        key.level = (int)DW_UNIFORM(kw[7]); key.octave = (int)DW_UNIFORM(kw[8]);
 #pragma unroll
-        for (int i = 0; i < (int)((sizeof(s3d_desc_key) + 3) / 4); i++) kw[i] = DW_UNIFORM(sm.nkey[turn & 1][i]);
-        __builtin_memcpy(&key, kw, sizeof(key));
+        for (int i = 0; i < 9; i++) key.R[i] = __uint_as_float(DW_UNIFORM(kw[9 + i]));
     }
+    static_assert(sizeof(s3d_desc_key) == 18 * sizeof(uint32_t), "s3d_desc_key layout");
     const int o = key.octave;
     const float *__restrict__ im = pyr.d_level[key.level];
     const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
