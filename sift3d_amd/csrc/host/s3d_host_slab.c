@@ -99,6 +99,8 @@ struct sift3d_amd_slab {
     uint32_t h_counts[2];
     s3d_pyramid_desc pd;
     size_t desc_cap;
+    void *h_keys;                       /* pinned staging of the descriptor keys, kept between calls */
+    size_t h_keys_bytes;
     s3d_desc_key *d_keys;
     float *d_desc;
     long num_candidates, num_keypoints;
@@ -192,6 +194,7 @@ void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
     dfree(&sl->d_cand_idx); dfree(&sl->d_cand_tag); dfree(&sl->d_keep); dfree(&sl->d_R); dfree(&sl->d_Rk);
     dfree(&sl->d_xyzos); dfree(&sl->d_orient); dfree(&sl->d_mesh); dfree(&sl->d_sigma);
     dfree(&sl->d_keys); dfree(&sl->d_desc);
+    if (sl->h_keys) s3d_rt_host_free(sl->h_keys);
     if (sl->ev_ready) s3d_rt_event_destroy(sl->ev_ready);
     if (sl->ev_done) s3d_rt_event_destroy(sl->ev_done);
     if (sl->ms) s3d_rt_stream_destroy(sl->ms);
@@ -648,26 +651,31 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
             return SIFT3D_FAILURE;
         sl->desc_cap = nsel;
     }
-    if ((keys = (s3d_desc_key *)malloc(nsel * sizeof(s3d_desc_key))) == NULL) SLAB_FAIL("sift3d_amd slab: out of host memory");
+    if (sl->h_keys_bytes < nsel * sizeof(s3d_desc_key)) {
+        const size_t want = nsel * sizeof(s3d_desc_key) + nsel * sizeof(s3d_desc_key) / 4 + 4096;
+        if (sl->h_keys) s3d_rt_host_free(sl->h_keys);
+        sl->h_keys = NULL;
+        sl->h_keys_bytes = 0;
+        DEV(s3d_rt_host_alloc(&sl->h_keys, want));
+        sl->h_keys_bytes = want;
+    }
+    keys = (s3d_desc_key *)sl->h_keys;
     for (size_t j = 0; j < nsel; j++) {
         const Keypoint *key = kp->buf + (sel ? sel[j] : j);
         const int oi = key->o - g->first_octave, ki = key->s - g->first_level;
         if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) {
-            free(keys);
             SLAB_FAIL("sift3d_amd slab: keypoint %zu has no pyramid level (o=%d, s=%d)", sel ? sel[j] : j, key->o, key->s);
         }
         if (sl->t.world > 1 && sift3d_amd_slab_owner(sl, key) != sl->t.rank) {
-            free(keys);
             SLAB_FAIL("sift3d_amd slab: keypoint %zu (z=%g, octave %d) is not in rank %d's slab", sel ? sel[j] : j, key->zd,
                       key->o, sl->t.rank);
         }
         s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + j);
     }
-    if (s3d_check_desc_windows(keys, nsel, &sl->pd)) { free(keys); return SIFT3D_FAILURE; }
+    if (s3d_check_desc_windows(keys, nsel, &sl->pd)) return SIFT3D_FAILURE;
     if (s3d_rt_h2d(sl->d_keys, keys, nsel * sizeof(s3d_desc_key), sl->cs) ||
         s3d_k_describe(&sl->pd, sl->d_keys, (uint32_t)nsel, sl->d_mesh, sl->d_desc, DESC_REC_FLOATS, sl->d_count + 4, sl->cs)) {
         s3d_rt_sync(sl->cs);
-        free(keys);
         SLAB_FAIL("sift3d_amd slab: describe failed: %s", s3d_rt_last_error());
     }
     if (out) {
@@ -677,14 +685,12 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
             if (!sel) e = nsel;
             if (s3d_rt_d2h(out + (sel ? sel[j] : j), sl->d_desc + j * DESC_REC_FLOATS, (e - j) * sizeof(SIFT3D_Descriptor), sl->cs)) {
                 s3d_rt_sync(sl->cs);
-                free(keys);
-                SLAB_FAIL("sift3d_amd slab: descriptor download failed: %s", s3d_rt_last_error());
+                    SLAB_FAIL("sift3d_amd slab: descriptor download failed: %s", s3d_rt_last_error());
             }
             j = e;
         }
     }
-    if (s3d_rt_sync(sl->cs)) { free(keys); SLAB_FAIL("sift3d_amd slab: describe failed: %s", s3d_rt_last_error()); }
-    free(keys);
+    if (s3d_rt_sync(sl->cs)) { SLAB_FAIL("sift3d_amd slab: describe failed: %s", s3d_rt_last_error()); }
     if (out)
         for (size_t j = 0; j < nsel; j++) {
             const size_t i = sel ? sel[j] : j;
