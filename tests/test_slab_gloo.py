@@ -207,3 +207,20 @@ def test_rccl_transport_against_mock(emu, args):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     assert rec["world"] == args[1] and rec["keypoints"] > 5
+
+
+def test_more_gpus_than_devices_is_refused(emu):
+    """sift3d_amd_set_num_gpus(n, 0) with fewer visible devices than n: the detect fails with a message, nothing hangs."""
+    L = emu.sift
+    s = abi.SIFT3D()
+    assert L.init_SIFT3D(C.byref(s)) == 0
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 4, 0) == 0          # the emulator reports one device
+    vol = synth.blobs(32, 32, 64, 100, 2)
+    im = emu.image_from_numpy(vol, (1.0, 1.0, 1.0))
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) != 0
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 1, 0) == 0          # back to one GPU: the same struct works
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0 and kp.slab.num > 0
+    emu.free_image(im)
+    L.cleanup_SIFT3D(C.byref(s))
