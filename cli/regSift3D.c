@@ -58,7 +58,7 @@ static void usage(void)
            "	have very different resolutions, for example registering 5mm \n"
            "	to 1mm slices. \n"
            "\n",
-           0.8, 5.0, 500);
+           SIFT3D_nn_thresh_default, SIFT3D_err_thresh_default, SIFT3D_num_iter_default);
     print_opts_SIFT3D();
 }
 

@@ -376,6 +376,11 @@ void cleanup_Slab(Slab *const slab);                                     /* imut
 int init_Mat_rm_p(Mat_rm *const mat, const void *const p, const int num_rows, const int num_cols,
                   const Mat_rm_type type, const int set_zero);           /* imutil.c:655 */
 int eigen_Mat_rm(Mat_rm *A, Mat_rm *Q, Mat_rm *L);                       /* imutil.c:2992 (Jacobi instead of LAPACK dsyevd) */
+int transpose_Mat_rm(const Mat_rm *const src, Mat_rm *const dst);        /* imutil.c:3338 */
+/* Defaults the reference exports as data (its regSift3D prints them: cli/regSift3D.c:83-84) */
+extern const double SIFT3D_nn_thresh_default;                            /* reg.h:20, reg.c:24 */
+extern const double SIFT3D_err_thresh_default;                           /* imutil.h:33, imutil.c:102 */
+extern const int SIFT3D_num_iter_default;                                /* imutil.h:34, imutil.c:103 */
 int copy_Pyramid(const Pyramid *const src, Pyramid *const dst);          /* imutil.c:3995 */
 int write_pyramid(const char *path, Pyramid *pyr);                       /* imutil.c:4093 (after sift3d_amd_download_pyramid) */
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Profiling builds of the library with -DDW_ABLATE=n in s3d_keypoint.hip (pieces of the descriptor kernel switched off:
-1 rows + scan only, 2 no LDS atomics, 3 no back end) -> sift3d_amd/lib/ablate/libsift3d_amd_a<n>.so.  Results of these
-builds are WRONG by construction; they exist to be timed (SIFT3D_AMD_LIB=... python scripts/describe_ab.py)."""
+"""Variant builds of the library that differ in the compile-time switches of s3d_keypoint.hip
+("name:-DDW_THREADS=512,-DDW_NCOPY=8,..." or "nofma:-DDW_NO_FMA") -> sift3d_amd/lib/ablate/libsift3d_amd_a<name>.so, to be
+timed against each other on the GPU box (scripts/describe_variants.sh; SIFT3D_AMD_LIB=... python scripts/describe_ab.py).
+The ablation blocks of round 2 (-DDW_ABLATE=n: pieces of the kernel switched off, profiles/r02_describe_ablations.txt)
+no longer exist in the kernel source."""
 import os
 import subprocess
 import sys
@@ -14,7 +16,7 @@ b.build()
 out_dir = os.path.join(b.LIB, "ablate")
 os.makedirs(out_dir, exist_ok=True)
 objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and f != "s3d_keypoint.o"]
-for n in sys.argv[1:] or ["1", "2", "3"]:
+for n in sys.argv[1:]:
     # "3" -> -DDW_ABLATE=3;  "w512:-DDW_THREADS=512,-DDW_NCOPY=8,..." -> a variant named w512 with those defines
     if ":" in n:
         n, defs = n.split(":", 1)

@@ -524,6 +524,32 @@ int init_Mat_rm_p(Mat_rm *const mat, const void *const p, const int num_rows, co
     return SIFT3D_SUCCESS;
 }
 
+/* dst = src^T (imutil.c:3338-3379).  dst takes src's element type and is resized (so a static-memory dst of another size
+ * fails, as resize_Mat_rm has it); an empty src is an error; src and dst must not share storage. */
+int transpose_Mat_rm(const Mat_rm *const src, Mat_rm *const dst)
+{
+    const int nr = src->num_rows, nc = src->num_cols;
+    size_t es;
+    if (nr < 1 || nc < 1) return SIFT3D_FAILURE;
+    switch (src->type) {
+    case SIFT3D_DOUBLE: es = sizeof(double); break;
+    case SIFT3D_FLOAT: es = sizeof(float); break;
+    case SIFT3D_INT: es = sizeof(int); break;
+    default: return SIFT3D_FAILURE;
+    }
+    dst->type = src->type;
+    dst->num_rows = nc;
+    dst->num_cols = nr;
+    if (resize_Mat_rm(dst)) return SIFT3D_FAILURE;
+    {
+        const char *in = (const char *)src->u.data_double;
+        char *out = (char *)dst->u.data_double;
+        for (int r = 0; r < nr; r++)
+            for (int c = 0; c < nc; c++) memcpy(out + ((size_t)c * nr + r) * es, in + ((size_t)r * nc + c) * es, es);
+    }
+    return SIFT3D_SUCCESS;
+}
+
 /* Eigen-decomposition of a symmetric matrix (imutil.c:2992-3075: LAPACK dsyevd, all eigenvalues ascending in the
  * n x 1 matrix L, eigenvectors in the COLUMNS of Q; Q may be NULL).  LAPACK is not linked into this library: cyclic
  * Jacobi in double, which for symmetric input is accurate to the last few ulps like dsyevd; eigenvector signs are as

@@ -66,11 +66,16 @@ int concat_Mat_rm(const Mat_rm *const src1, const Mat_rm *const src2, Mat_rm *co
     return SIFT3D_SUCCESS;
 }
 
+/* ---- exported defaults (data symbols of libimutil / libreg that callers link: cli/regSift3D.c:83-84) ---- */
+const double SIFT3D_nn_thresh_default = 0.8;        /* reg.c:24 */
+const double SIFT3D_err_thresh_default = 5.0;       /* imutil.c:102 */
+const int SIFT3D_num_iter_default = 500;            /* imutil.c:103 */
+
 /* ---- Ransac parameters ---------------------------------------------------------------------------- */
 void init_Ransac(Ransac *const ran)
 {
-    ran->err_thresh = 5.0;             /* SIFT3D_err_thresh_default, imutil.c:102 */
-    ran->num_iter = 500;               /* SIFT3D_num_iter_default, imutil.c:103 */
+    ran->err_thresh = SIFT3D_err_thresh_default;
+    ran->num_iter = SIFT3D_num_iter_default;
 }
 
 int set_err_thresh_Ransac(Ransac *const ran, double err_thresh)
@@ -502,7 +507,7 @@ int im_resample(const Image *const src, const double *const units, const interp_
 /* ---- Reg_SIFT3D ----------------------------------------------------------------------------------- */
 int init_Reg_SIFT3D(Reg_SIFT3D *const reg)
 {
-    reg->nn_thresh = 0.8;              /* SIFT3D_nn_thresh_default, reg.c:24 */
+    reg->nn_thresh = SIFT3D_nn_thresh_default;
     init_SIFT3D_Descriptor_store(&reg->desc_src);
     init_SIFT3D_Descriptor_store(&reg->desc_ref);
     init_Ransac(&reg->ran);

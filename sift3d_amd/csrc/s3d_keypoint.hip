@@ -784,14 +784,19 @@ __device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long 
  * face (the discontinuous part, see s3d_math.h) is unchanged: a 1e-6 error cannot carry a sample across the 2e-5 margin.
  * Straight-line code: *safe tells the caller whether the result stands or the sequential search has to decide (the four
  * voxels of a chunk run this back to back so that the scheduler can interleave them; the rare searches follow). */
+#if defined(S3D_EMU) || defined(DW_NO_FMA)
+#define DW_FMAF(a, b, c) ((a) * (b) + (c))                 /* -ffp-contract=off: two roundings */
+#else
+#define DW_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))     /* one v_fma_f32 where only a continuous quantity is formed */
+#endif
 __device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, const float *__restrict__ fcn, V3 g, V3 *bary, bool *safe)
 {
     const float ax = fabsf(g.x), ay = fabsf(g.y), az = fabsf(g.z);
     const float c0 = 0.57735027f, c1 = 0.35682209f, c2 = 0.93417236f;
     const float s0 = c0 * (ax + ay + az);
-    const float s1 = c1 * ax + c2 * az;
-    const float s2 = c2 * ax + c1 * ay;
-    const float s3 = c2 * ay + c1 * az;
+    const float s1 = DW_FMAF(c1, ax, c2 * az);
+    const float s2 = DW_FMAF(c2, ax, c1 * ay);
+    const float s3 = DW_FMAF(c2, ay, c1 * az);
     int t = 0;
     float best = s0;
     if (s1 > best) { best = s1; t = 1; }
@@ -800,9 +805,9 @@ __device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, cons
     const int key = (g.x < 0.0f ? 1 : 0) | (g.y < 0.0f ? 2 : 0) | (g.z < 0.0f ? 4 : 0) | (t << 3);
     const int face = __float_as_int(mesh[S3D_LUT_OFFSET + key]);
     const float *f = fcn + face;
-    const float det = f[0 * S3D_NFACES] * g.x + f[1 * S3D_NFACES] * g.y + f[2 * S3D_NFACES] * g.z;
-    const float ny = f[3 * S3D_NFACES] * g.x + f[4 * S3D_NFACES] * g.y + f[5 * S3D_NFACES] * g.z;
-    const float nz = f[6 * S3D_NFACES] * g.x + f[7 * S3D_NFACES] * g.y + f[8 * S3D_NFACES] * g.z;
+    const float det = DW_FMAF(f[2 * S3D_NFACES], g.z, DW_FMAF(f[1 * S3D_NFACES], g.y, f[0 * S3D_NFACES] * g.x));
+    const float ny = DW_FMAF(f[5 * S3D_NFACES], g.z, DW_FMAF(f[4 * S3D_NFACES], g.y, f[3 * S3D_NFACES] * g.x));
+    const float nz = DW_FMAF(f[8 * S3D_NFACES], g.z, DW_FMAF(f[7 * S3D_NFACES], g.y, f[6 * S3D_NFACES] * g.x));
     const float inv = DW_RCP(det);
     V3 b;
     b.y = ny * inv;
@@ -814,15 +819,25 @@ __device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, cons
     return face;
 }
 
-__device__ __forceinline__ double dw_block_sum(double v, double *part)
+__device__ __forceinline__ double dw_block_sum(double v, double *part, int tid)
 {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    if ((tid & 63) == 0) part[tid >> 6] = v;
     __syncthreads();
     double r = 0.0;
     for (int w = 0; w < DW_WAVES; w++) r += part[w];
     __syncthreads();
     return r;
+}
+
+/* A value the optimiser cannot see through: address arithmetic derived from it is redone where it is used instead of
+ * being hoisted out of the persistent keypoint loop and held (or spilled) across the whole chunk loop. */
+__device__ __forceinline__ int dw_opaque(int x)
+{
+#if !defined(S3D_EMU)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
 }
 
 template <bool COUNT_ONLY>
@@ -918,11 +933,12 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const unsigned long long per_copy = (unsigned long long)(wx > 0 ? wx : 1) * (unsigned)(wy > 0 ? wy : 1) * (unsigned)(wz > 0 ? wz : 1) / DW_NCOPY + 4096ull;
         while ((1ull << head) < per_copy) head++;
     }
-    const int fbits = 47 - bexp - head;
+    const int fbits = (int)DW_UNIFORM(47 - bexp - head);      /* frexp leaves bexp in a vector register: back to scalar */
     const double Mfix = ldexp(1.5, 52 - fbits);
     const double unscale = ldexp(1.0, -fbits);
 
-    for (int i = tid; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
+    const int tz = dw_opaque(tid);
+    for (int i = tz; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
     if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; }
     __syncthreads();
     /* the next keypoint's record: loaded now (one word per lane of the first wave), parked in LDS after the chunk loop */
@@ -930,21 +946,18 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     uint32_t nkey_word = 0;
     {
         const unsigned nk = sm.next[turn & 1];
-        if (tid < KEY_WORDS && nk < num) nkey_word = reinterpret_cast<const uint32_t *>(keys + nk)[tid];
+        if (tz < KEY_WORDS && nk < num) nkey_word = reinterpret_cast<const uint32_t *>(keys + nk)[tz];
     }
     if (use_tab) {
         /* entry i: the weight of a voxel at squared distance i * u^2, through the very float steps of sift.c:1890 */
         const int nent = (int)(g.rad2 / u2) + 2;
-        for (int i = tid; i < nent; i += DW_THREADS) {
+        for (int i = tz; i < nent; i += DW_THREADS) {
             const float sq = (float)i * u2;
             sm.wtab[i] = s3d_expf_tab((float)((double)(-0.5f * sq) * inv_sig2), sm.etab);
         }
         __syncthreads();
     }
 
-#if defined(DW_ABLATE)
-    unsigned long long ablate_acc = 0;
-#endif
     const unsigned copy8 = (unsigned)(lane & (DW_NCOPY - 1)) * 8u;
     char *const hbase = reinterpret_cast<char *>(sm.hist);
 
@@ -962,37 +975,57 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
+#if !defined(DW_NO_FMA) && !defined(S3D_EMU)
+        /* The rotated gradient only feeds continuous quantities here (|grad|, barycentric weights) and a face choice that
+         * is accepted with a 2e-5 margin: fused forms (1e-7 relative) are as good.  Whatever DECIDES near a boundary --
+         * a sample close to a face edge, |grad|^2 close to the floor -- is redone by resolve() on the reference's
+         * arithmetic from the unrotated gradient kept in v.g*. */
+        gr.x = DW_FMAF(g.r02, gz, DW_FMAF(g.r01, gy, g.r00 * gx));
+        gr.y = DW_FMAF(g.r12, gz, DW_FMAF(g.r11, gy, g.r10 * gx));
+        gr.z = DW_FMAF(g.r22, gz, DW_FMAF(g.r21, gy, g.r20 * gx));
+        const float gg = DW_FMAF(gr.z, gr.z, DW_FMAF(gr.y, gr.y, gr.x * gr.x));
+        const bool floor_unsure = fabsf(gg - (float)S3D_BARY_EPS_D) < 1e-4f * (float)S3D_BARY_EPS_D;
+#else
         gr.x = g.r00 * gx + g.r01 * gy + g.r02 * gz;
         gr.y = g.r10 * gx + g.r11 * gy + g.r12 * gz;
         gr.z = g.r20 * gx + g.r21 * gy + g.r22 * gz;
         const float gg = gr.x * gr.x + gr.y * gr.y + gr.z * gr.z;
+        const bool floor_unsure = false;
+#endif
         V3 bary;
         bool safe;
         const int face = dw_face_fast(sm.mesh, sm.fcn, gr, &bary, &safe);
         const bool live = valid && !((double)gg < S3D_BARY_EPS_D);       /* icos_hist_bin's floor on |grad|^2, sift.c:1655 */
         const float mag = DW_SQRT(gg);
         v.face = live ? face : -1;
-        v.safe = safe || !live;
+        v.safe = (safe && !floor_unsure) || !(live || (valid && floor_unsure));
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
         v.vbx = vbx; v.vby = vby; v.vbz = vbz;
+#if !defined(DW_NO_FMA) && !defined(S3D_EMU)
+        v.gx = gx; v.gy = gy; v.gz = gz;
+#else
         v.gx = gr.x; v.gy = gr.y; v.gz = gr.z;
+#endif
         return v;
     };
     /* the sample lies within 2e-5 of a face edge (or the look-up missed): the reference's sequential search decides */
     auto resolve = [&](DwVox &v) {
         if (v.safe) return;
         V3 bary = v3(0.0f, 0.0f, 0.0f);
-        v.face = s3d_icos_bin(sm.mesh, v3(v.gx, v.gy, v.gz), &bary);
-        const float mag = DW_SQRT(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
+#if !defined(DW_NO_FMA) && !defined(S3D_EMU)
+        const float rx = g.r00 * v.gx + g.r01 * v.gy + g.r02 * v.gz;
+        const float ry = g.r10 * v.gx + g.r11 * v.gy + g.r12 * v.gz;
+        const float rz = g.r20 * v.gx + g.r21 * v.gy + g.r22 * v.gz;
+#else
+        const float rx = v.gx, ry = v.gy, rz = v.gz;
+#endif
+        v.face = s3d_icos_bin(sm.mesh, v3(rx, ry, rz), &bary);           /* -1 below the floor on |grad|^2 */
+        const float mag = DW_SQRT(rx * rx + ry * ry + rz * rz);
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
     };
     /* back: the trilinear spread over 8 cells x 3 vertices */
     auto back = [&](const DwVox &v) {
         if (v.face < 0) return;
-#if defined(DW_ABLATE) && DW_ABLATE == 3          /* profiling build: no back end at all */
-        if (v.m0 == 123.456f) sm.hist[0] = 1ull;
-        return;
-#endif
         /* base cell and offsets inside it; the clamps only matter for the last-bit slack of the stepped coordinates */
         int ibx = (int)v.vbx, iby = (int)v.vby, ibz = (int)v.vbz;
         ibx = ibx > 3 ? 3 : ibx; iby = iby > 3 ? 3 : iby; ibz = ibz > 3 ? 3 : ibz;
@@ -1014,15 +1047,9 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                     const double wc = wxy * wzs[iz];
                     constexpr int DCB = S3D_NVERT * DW_NCOPY * 8;
                     const int dc = (ix + 4 * iy + 16 * iz) * DCB;                          /* compile-time byte offset */
-#if defined(DW_ABLATE) && DW_ABLATE == 2          /* profiling build: the arithmetic without the LDS atomics */
-                    ablate_acc ^= (unsigned long long)__double_as_longlong(fma(m0, wc, Mfix)) + (unsigned long long)(p0 + dc - hbase);
-                    ablate_acc ^= (unsigned long long)__double_as_longlong(fma(m1, wc, Mfix)) + (unsigned long long)(p1 + dc - hbase);
-                    ablate_acc ^= (unsigned long long)__double_as_longlong(fma(m2, wc, Mfix)) + (unsigned long long)(p2 + dc - hbase);
-#else
                     atomicAdd(reinterpret_cast<unsigned long long *>(p0 + dc), (unsigned long long)__double_as_longlong(fma(m0, wc, Mfix)));
                     atomicAdd(reinterpret_cast<unsigned long long *>(p1 + dc), (unsigned long long)__double_as_longlong(fma(m1, wc, Mfix)));
                     atomicAdd(reinterpret_cast<unsigned long long *>(p2 + dc), (unsigned long long)__double_as_longlong(fma(m2, wc, Mfix)));
-#endif
                 }
             }
     };
@@ -1055,20 +1082,10 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const float *p = im + ((size_t)ch.z * plane + (size_t)ch.y * nx + ch.x0);
         /* p[-1..4], and p[0..3] of the four neighbouring rows (reads up to 3 floats past the last voxel
          * of a row: level buffers carry 16 bytes of slack, see s3d_device.h) */
-#if defined(DW_ABLATE) && DW_ABLATE == 4          /* profiling build: no global loads (synthetic neighbours) */
-        {
-            const float a = (float)(ch.x0 & 7) * 1e-2f, b = (float)(ch.y & 7) * 1e-2f, cc = (float)(ch.z & 7) * 1e-2f;
-            L.xa.x = a; L.xa.y = b; L.xb.x = cc; L.xb.y = a + b; L.xb.z = b + cc; L.xb.w = a - cc;
-            L.ym.x = a; L.ym.y = b; L.ym.z = cc; L.ym.w = a; L.yp.x = b + 0.01f; L.yp.y = cc; L.yp.z = a; L.yp.w = b;
-            L.zm.x = cc; L.zm.y = a; L.zm.z = b; L.zm.w = cc; L.zp.x = a; L.zp.y = b + 0.02f; L.zp.z = cc; L.zp.w = a;
-            if (p == nullptr) L.xa.x = 1.0f;
-        }
-#else
         L.xa = *(const f2u *)(p - 1);
         L.xb = *(const f4u *)(p + 1);
         L.ym = *(const f4u *)(p - nx); L.yp = *(const f4u *)(p + nx);
         L.zm = *(const f4u *)(p - (ptrdiff_t)plane); L.zp = *(const f4u *)(p + plane);
-#endif
         if (use_tab) {                  /* squared voxel distance: d2(x + 1) = d2(x) + 2 dx + 1 */
             const int dxi = ch.x0 - cxi, dyi = ch.y - cyi, dzi = ch.z - czi;
             const int d2 = dxi * dxi + dyi * dyi + dzi * dzi;
@@ -1096,9 +1113,10 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         /* ---- A1: this thread's row ---- */
         int len = 0;
         unsigned first = 0;
-        if (r0 + tid < nrows) {
+        const int tr = dw_opaque(tid), ln = tr & 63;        /* this round's own copy: see dw_opaque */
+        if (r0 + tr < nrows) {
             int by;
-            const int bz = fdiv_small(r0 + tid, wy, inv_wy, &by);
+            const int bz = fdiv_small(r0 + tr, wy, inv_wy, &by);
             const int y = g.ys + by, z = g.zs + bz;
             const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
             const float s2 = g.rad2 - dy * dy - dz * dz;
@@ -1134,21 +1152,24 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         int incl = nchunk;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl(incl, lane >= d ? lane - d : lane);
-            if (lane >= d) incl += up;
+            const int up = __shfl(incl, ln >= d ? ln - d : ln);
+            if (ln >= d) incl += up;
         }
-        if (lane == 63) sm.wave_tot[tid >> 6] = incl;
+        if (ln == 63) sm.wave_tot[tr >> 6] = incl;
         __syncthreads();
         int before = 0;
-        for (int w = 0; w < (tid >> 6); w++) before += sm.wave_tot[w];
-        sm.seg_first[tid] = first;
-        sm.seg_len[tid] = (unsigned short)len;
-        sm.seg_off[tid] = before + incl - nchunk;
-        if (tid == DW_THREADS - 1) sm.seg_off[DW_THREADS] = before + incl;
+        for (int w = 0; w < (tr >> 6); w++) before += sm.wave_tot[w];
+        sm.seg_first[tr] = first;
+        sm.seg_len[tr] = (unsigned short)len;
+        sm.seg_off[tr] = before + incl - nchunk;
+        if (tr == DW_THREADS - 1) sm.seg_off[DW_THREADS] = before + incl;
+        /* the next keypoint's record has arrived by now: park it (slot (turn + 1) & 1 was last read at the top of the
+         * previous turn) instead of carrying it through the chunk loop in a register */
+        if (r0 == 0 && tr < KEY_WORDS) sm.nkey[(turn + 1) & 1][tr] = nkey_word;
         {   /* chunk -> row map: every row enters itself for its own chunks (ten dependent LDS reads of a binary search per
              * chunk become one) */
             const int c0 = before + incl - nchunk;
-            for (int q = 0; q < nchunk && c0 + q < DW_CMAP; q++) sm.chunk_row[c0 + q] = (unsigned short)tid;
+            for (int q = 0; q < nchunk && c0 + q < DW_CMAP; q++) sm.chunk_row[c0 + q] = (unsigned short)tr;
         }
         __syncthreads();
         const int total = sm.seg_off[DW_THREADS];
@@ -1161,11 +1182,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                     atomicAdd(&sm.win_chk, ((unsigned)(ch.x0 + j - g.xs) | (ch.fv & ~1023u)) * 2654435761u);
                 atomicAdd(&sm.win_vox, (unsigned)ch.nval);
             }
-#if defined(DW_ABLATE) && DW_ABLATE == 1          /* profiling build: rows + scan only */
-        } else if (tid < total && tid > 4096) {
-#else
         } else if (tid < total) {
-#endif
             int c = tid;
             DwChunk ch = lookup(c);
             DwLoads L = gather(ch);
@@ -1176,13 +1193,6 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                 desc_window(g, ch.x0, ch.y, ch.z, &sq0, &vbx, &vby, &vbz);
                 vbx = vbx > 0.0f ? vbx : 0.0f; vby = vby > 0.0f ? vby : 0.0f; vbz = vbz > 0.0f ? vbz : 0.0f;
                 DwVox v0, v1, v2, v3;
-#if defined(DW_ABLATE) && DW_ABLATE == 5          /* profiling build: look-ups and loads only */
-                ablate_acc += (unsigned long long)(L.xa.x + L.xb.w + L.ym.x + L.yp.y + L.zm.z + L.zp.w + L.w0 + L.w3 + vbx);
-                c += DW_THREADS;
-                if (c >= total) break;
-                ch = lookup(c); L = gather(ch);
-                continue;
-#endif
                 /* all four unconditionally (lanes past the end of their row compute on the slack they loaded and are
                  * marked dead): one straight-line block the scheduler can interleave */
                 v0 = front(true, vbx, vby, vbz, L.w0, L.xb.x - L.xa.x, L.yp.x - L.ym.x, L.zp.x - L.zm.x);
@@ -1205,20 +1215,18 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
          * round's row intervals instead of waiting. */
     }
     __syncthreads();                                          /* all histogram atomics (and the window counters) are in */
-    if (tid < KEY_WORDS) sm.nkey[(turn + 1) & 1][tid] = nkey_word;
+    const int tm = dw_opaque(tid);
+    if (nrows <= 0 && tm < KEY_WORDS) sm.nkey[(turn + 1) & 1][tm] = nkey_word;     /* no round ran */
     if (COUNT_ONLY) {
         if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
         __syncthreads();                                      /* before the next keypoint clears the counters */
     } else {
-#if defined(DW_ABLATE)
-    if (ablate_acc == 0x1234567ull) sm.hist[1] = 1ull;
-#endif
     /* merge the copies (48-bit two's complement integers: order free), then normalise / clamp / normalise */
     double ss = 0.0;
     float v[DW_NOUT];
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++) {
-        const int b = tid + q * DW_THREADS;
+        const int b = tm + q * DW_THREADS;
         v[q] = 0.0f;
         if (b < S3D_DESC_NUMEL) {
             long long acc = 0;
@@ -1231,20 +1239,20 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         }
     }
     const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
-    double norm = sqrt(dw_block_sum(ss, sm.part)) + 2.220446049250313e-16; /* + DBL_EPSILON */
+    double norm = sqrt(dw_block_sum(ss, sm.part, tm)) + 2.220446049250313e-16; /* + DBL_EPSILON */
     float inv = (float)(1.0 / norm);
     ss = 0.0;
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++) {
         v[q] = v[q] * inv;
         v[q] = v[q] < trunc ? v[q] : trunc;
-        if (tid + q * DW_THREADS < S3D_DESC_NUMEL) ss += (double)v[q] * (double)v[q];
+        if (tm + q * DW_THREADS < S3D_DESC_NUMEL) ss += (double)v[q] * (double)v[q];
     }
-    norm = sqrt(dw_block_sum(ss, sm.part)) + 2.220446049250313e-16;
+    norm = sqrt(dw_block_sum(ss, sm.part, tm)) + 2.220446049250313e-16;
     inv = (float)(1.0 / norm);
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++)
-        if (tid + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tid + q * DW_THREADS] = v[q] * inv;
+        if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tm + q * DW_THREADS] = v[q] * inv;
     }
     /* every barrier above lies between thread 0's claim and this read; the slot alternates so that the next turn's claim
      * cannot overtake a slow reader */

@@ -116,7 +116,62 @@ def main():
                         nblobs=np.array(30), seed=np.array(5), scale=np.array(37.0), offset=np.array(3.0),
                         input_sha256=np.array(sha(vol)), out=ref.image_to_numpy(out))
     match_golden()
+    variants_golden()
     print("done")
+
+
+def variants_golden():
+    """6. rows a14 / a15: dense descriptors with dense_rotate = 1 (sift.c:2521-2588, 2295-2343) on an isotropic and an
+    anisotropic volume -> dense_rotate.npz; SIFT3D_extract_raw_descriptors (sift.c:2131-2195) and
+    SIFT3D_assign_orientations (sift.c:1534-1604) on the reference's own keypoints -> raw.npz."""
+    cases = [((20, 18, 16), (1.0, 1.0, 1.0), 5), ((18, 16, 14), (1.0, 1.0, 2.0), 6)]
+    d = {"n": np.array(len(cases)), "scale": np.array(37.0), "offset": np.array(3.0)}
+    for i, (dims, units, seed) in enumerate(cases):
+        nx, ny, nz = dims
+        nblobs = max(8, nx * ny * nz // 300)
+        vol = (synth.blobs(nx, ny, nz, nblobs, seed) * 37.0 + 3.0).astype(np.float32)
+        s = abi.SIFT3D()
+        assert ref.sift.init_SIFT3D(C.byref(s)) == 0
+        s.dense_rotate = 1
+        im = ref.image_from_numpy(vol, units)
+        out = abi.Image()
+        ref.imutil.init_im(C.byref(out))
+        assert ref.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out)) == 0
+        d.update({f"dims_{i}": np.array(dims), f"units_{i}": np.array(units, np.float64), f"nblobs_{i}": np.array(nblobs),
+                  f"seed_{i}": np.array(seed), f"input_sha256_{i}": np.array(sha(vol)), f"out_{i}": ref.image_to_numpy(out)})
+        ref.free_image(im)
+        ref.free_image(out)
+        ref.sift.cleanup_SIFT3D(C.byref(s))
+        print("dense_rotate", dims, units, "max", float(np.abs(d[f"out_{i}"]).max()))
+    np.savez_compressed(os.path.join(OUT, "dense_rotate.npz"), **d)
+
+    cases = [((48, 48, 48), (1.0, 1.0, 2.0), 250, 2), ((40, 36, 44), (1.0, 1.0, 1.0), 150, 4)]
+    d = {"n": np.array(len(cases))}
+    for i, (dims, units, nblobs, seed) in enumerate(cases):
+        nx, ny, nz = dims
+        vol = synth.blobs(nx, ny, nz, nblobs, seed)
+        s = abi.SIFT3D()
+        assert ref.sift.init_SIFT3D(C.byref(s)) == 0
+        im = ref.image_from_numpy(vol, units)
+        kp = abi.Keypoint_store()
+        ref.sift.init_Keypoint_store(C.byref(kp))
+        assert ref.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        xyzos, sd, R = ref.keypoints_to_numpy(kp)
+        desc = abi.SIFT3D_Descriptor_store()
+        ref.sift.init_SIFT3D_Descriptor_store(C.byref(desc))
+        assert ref.sift.SIFT3D_extract_raw_descriptors(C.byref(s), C.byref(im), C.byref(kp), C.byref(desc)) == 0
+        bins, xyzs = ref.descriptors_to_numpy(desc)
+        conf = C.POINTER(C.c_double)()
+        assert ref.sift.SIFT3D_assign_orientations(C.byref(s), C.byref(im), C.byref(kp), C.byref(conf)) == 0
+        _, _, R_raw = ref.keypoints_to_numpy(kp)
+        K = len(xyzos)
+        d.update({f"dims_{i}": np.array(dims), f"units_{i}": np.array(units, np.float64), f"nblobs_{i}": np.array(nblobs),
+                  f"seed_{i}": np.array(seed), f"input_sha256_{i}": np.array(sha(vol)), f"xyzos_{i}": xyzos, f"sd_{i}": sd,
+                  f"R_{i}": R, f"raw_bins_{i}": bins, f"raw_xyzs_{i}": xyzs, f"R_assigned_{i}": R_raw,
+                  f"conf_{i}": np.array([conf[k] for k in range(K)], np.float64)})
+        ref.sift.cleanup_SIFT3D(C.byref(s))
+        print("raw", dims, units, "K =", K, "rejected orientations", int((d[f"conf_{i}"] < 0).sum()))
+    np.savez_compressed(os.path.join(OUT, "raw.npz"), **d)
 
 
 def match_golden():
@@ -145,5 +200,7 @@ def match_golden():
 if __name__ == "__main__":
     if sys.argv[1:] == ["match"]:
         match_golden()
+    elif sys.argv[1:] == ["variants"]:
+        variants_golden()
     else:
         main()

@@ -196,6 +196,55 @@ def check_dense_rotate(lib, oracle, dims, units, seed=5):
     assert ok.all(), f"dense_rotate: {(~ok).sum()} of {got.size} beyond tolerance, max abs {np.abs(got - want).max()}"
 
 
+def dense_rotate_api(lib, vol, units):
+    """SIFT3D_extract_dense_descriptors with dense_rotate = 1 through the C API of `lib` (product or reference)."""
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    s.dense_rotate = 1
+    im = lib.image_from_numpy(vol, units)
+    out = abi.Image()
+    lib.imutil.init_im(C.byref(out))
+    assert lib.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out)) == 0
+    got = lib.image_to_numpy(out)
+    lib.free_image(im)
+    lib.free_image(out)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+    return got
+
+
+def raw_variants_api(lib, vol, units):
+    """detect, then the two raw-image entry points (sift.c:2131, 1534) through the C API of `lib`:
+    (xyzos, sd, R, raw bins, raw xyzs, R after SIFT3D_assign_orientations, conf)."""
+    s, im, kp = run_detect(lib, vol, units)
+    xyzos, sd, R = lib.keypoints_to_numpy(kp)
+    d = abi.SIFT3D_Descriptor_store()
+    lib.sift.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert lib.sift.SIFT3D_extract_raw_descriptors(C.byref(s), C.byref(im), C.byref(kp), C.byref(d)) == 0
+    bins, xyzs = lib.descriptors_to_numpy(d)
+    conf = C.POINTER(C.c_double)()
+    assert lib.sift.SIFT3D_assign_orientations(C.byref(s), C.byref(im), C.byref(kp), C.byref(conf)) == 0
+    _, _, R2 = lib.keypoints_to_numpy(kp)
+    cf = np.array([conf[i] for i in range(len(xyzos))], np.float64)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+    return xyzos, sd, R, bins, xyzs, R2, cf
+
+
+def oracle_raw_variants(oracle, vol, units, xyzos, sd, R):
+    """The restatement's leg of rows a15: orc_smooth_scale_raw + orc_describe_volume + orc_eig_ori on given keypoints."""
+    K = len(xyzos)
+    sm = oracle.smooth_scale_raw(vol, units)
+    f = 2.0 ** xyzos[:, 3]
+    wb, wx = oracle.describe_volume(sm, units, xyzos[:, :3] * f[:, None], np.zeros(K, np.int32), sd, R)
+    R2 = np.zeros((K, 3, 3), np.float32)
+    cf = np.zeros(K, np.float64)
+    for i in range(K):
+        rej, Ro, c = oracle.eig_ori(sm, units, (xyzos[i, :3] * f[i]).astype(np.float32), sd[i])
+        if rej:
+            Ro, c = np.eye(3, dtype=np.float32), -1.0
+        R2[i], cf[i] = Ro, c
+    return wb, wx, R2, cf
+
+
 def check_raw_variants(lib, oracle, dims, units, nblobs, seed=2):
     nx, ny, nz = dims
     vol = synth.blobs(nx, ny, nz, nblobs, seed)

@@ -25,6 +25,7 @@ def _bind(u):
     u.cleanup_Mat_rm.argtypes = [P(abi.Mat_rm)]
     u.cleanup_Mat_rm.restype = None
     u.eigen_Mat_rm.argtypes = [P(abi.Mat_rm), P(abi.Mat_rm), P(abi.Mat_rm)]
+    u.transpose_Mat_rm.argtypes = [P(abi.Mat_rm), P(abi.Mat_rm)]
     u.init_Pyramid.argtypes = [P(abi.Pyramid)]
     u.init_Pyramid.restype = None
     u.cleanup_Pyramid.argtypes = [P(abi.Pyramid)]
@@ -175,3 +176,40 @@ def test_mesh_and_slab_lifecycle(lib, reference):
         u.init_Slab(C.byref(s))
         assert not s.buf and s.num == 0 and s.buf_size == 0
         u.cleanup_Slab(C.byref(s))
+
+
+@pytest.mark.parametrize("mtype,dtype", [(0, np.float64), (1, np.float32), (2, np.int32)])
+def test_transpose_Mat_rm_like_the_reference(lib, reference, mtype, dtype):
+    """transpose_Mat_rm (imutil.c:3338; used per keypoint at sift.c:1856, 2312): values, the resized dst taking src's type,
+    failure on an empty src and on a static-memory dst of another size -- the same on both libraries."""
+    src_v = (np.arange(15).reshape(3, 5) * 1.5 - 7).astype(dtype)
+    got = []
+    for u in (_bind(lib.imutil), _bind(reference.imutil)):
+        a, b, e = abi.Mat_rm(), abi.Mat_rm(), abi.Mat_rm()
+        assert u.init_Mat_rm(C.byref(a), 3, 5, mtype, 0) == 0
+        assert u.init_Mat_rm(C.byref(b), 2, 2, 0, 0) == 0          # another size and type: resized, retyped
+        C.memmove(a.data, src_v.ctypes.data, src_v.nbytes)
+        assert u.transpose_Mat_rm(C.byref(a), C.byref(b)) == 0
+        assert (b.num_rows, b.num_cols, b.type) == (5, 3, mtype)
+        out = np.frombuffer(C.string_at(b.data, src_v.nbytes), dtype).reshape(5, 3).copy()
+        assert u.init_Mat_rm(C.byref(e), 0, 0, mtype, 0) == 0
+        rc_empty = u.transpose_Mat_rm(C.byref(e), C.byref(b))
+        buf = np.zeros(4, dtype)
+        st = abi.Mat_rm()
+        assert u.init_Mat_rm_p(C.byref(st), buf.ctypes.data, 2, 2, mtype, 0) == 0
+        rc_static = u.transpose_Mat_rm(C.byref(a), C.byref(st))
+        got.append((out, rc_empty != 0, rc_static != 0))
+        for m in (a, b, e):
+            u.cleanup_Mat_rm(C.byref(m))
+    assert np.array_equal(got[0][0], src_v.T) and np.array_equal(got[1][0], src_v.T)
+    assert got[0][1:] == got[1][1:] == (True, True)
+
+
+def test_exported_defaults_equal_the_reference(lib, reference):
+    """The three `const` data symbols callers link (cli/regSift3D.c:83-84): same names, types, values."""
+    for name, ctype, where in (("SIFT3D_nn_thresh_default", C.c_double, "reg"),
+                               ("SIFT3D_err_thresh_default", C.c_double, "imutil"),
+                               ("SIFT3D_num_iter_default", C.c_int, "imutil")):
+        mine = ctype.in_dll(lib.imutil, name).value
+        ref = ctype.in_dll(getattr(reference, where), name).value
+        assert mine == ref, name

@@ -196,6 +196,39 @@ def test_raw_variants(lib, oracle):
     parity.check_raw_variants(lib, oracle, (64, 64, 64), (1, 1, 2), 250)
 
 
+def test_dense_rotate_golden(lib):
+    """Row a14 straight against the unmodified reference's output (tests/golden/dense_rotate.npz; no oracle in the
+    loop).  Orientations are decided exactly; the sphere histograms are integer sums here and sequential f32 sums in
+    the reference: 1e-4 relative to the volume's largest bin."""
+    g = np.load(os.path.join(GOLDEN, "dense_rotate.npz"))
+    for i in range(int(g["n"])):
+        nx, ny, nz = (int(v) for v in g[f"dims_{i}"])
+        vol = (synth.blobs(nx, ny, nz, int(g[f"nblobs_{i}"]), int(g[f"seed_{i}"])) * float(g["scale"]) + float(g["offset"])).astype(np.float32)
+        assert sha(vol) == str(g[f"input_sha256_{i}"])
+        got = parity.dense_rotate_api(lib, vol, tuple(g[f"units_{i}"]))
+        want = g[f"out_{i}"]
+        scale = np.abs(want).max()
+        ok = rel_close(got / scale, want / scale, rtol=1e-4, atol=1e-7)
+        assert ok.all(), f"case {i}: {(~ok).sum()} of {got.size} beyond tolerance, max abs {np.abs(got - want).max()}"
+
+
+def test_raw_variants_golden(lib):
+    """Row a15 straight against the unmodified reference's output (tests/golden/raw.npz): keypoints identical,
+    SIFT3D_extract_raw_descriptors within 1e-4 relative, SIFT3D_assign_orientations' R within 1e-5 with the same
+    rejections and confidences."""
+    g = np.load(os.path.join(GOLDEN, "raw.npz"))
+    for i in range(int(g["n"])):
+        nx, ny, nz = (int(v) for v in g[f"dims_{i}"])
+        vol = synth.blobs(nx, ny, nz, int(g[f"nblobs_{i}"]), int(g[f"seed_{i}"]))
+        assert sha(vol) == str(g[f"input_sha256_{i}"])
+        xyzos, sd, R, bins, xyzs, R2, cf = parity.raw_variants_api(lib, vol, tuple(g[f"units_{i}"]))
+        assert np.array_equal(xyzos, g[f"xyzos_{i}"]) and np.array_equal(sd, g[f"sd_{i}"])
+        assert np.array_equal(xyzs, g[f"raw_xyzs_{i}"])
+        assert rel_close(bins, g[f"raw_bins_{i}"]).all()
+        assert np.abs(R2 - g[f"R_assigned_{i}"]).max() <= 1e-5
+        assert np.array_equal(cf < 0, g[f"conf_{i}"] < 0) and np.abs(cf - g[f"conf_{i}"]).max() <= 1e-6
+
+
 @pytest.mark.parametrize("n1,seed,thr", [(70, 1, 0.8), (9, 2, 0.95), (1000, 3, 0.8), (3001, 4, 0.7)])
 def test_nn_match_vs_oracle(lib, oracle, n1, seed, thr):
     assert parity.check_nn_match(lib, oracle, n1, seed, thr) > 0

@@ -71,6 +71,30 @@ def test_dense(oracle):
     assert nbitdiff(out, g["out"]) == 0
 
 
+def test_dense_rotate(oracle):
+    """Row a14 (dense_rotate = 1) against the reference's output (tests/golden/make_golden.py, variants_golden)."""
+    g = np.load(os.path.join(GOLDEN, "dense_rotate.npz"))
+    for i in range(int(g["n"])):
+        nx, ny, nz = (int(v) for v in g[f"dims_{i}"])
+        vol = (synth.blobs(nx, ny, nz, int(g[f"nblobs_{i}"]), int(g[f"seed_{i}"])) * float(g["scale"]) + float(g["offset"])).astype(np.float32)
+        assert sha(vol) == str(g[f"input_sha256_{i}"])
+        assert nbitdiff(oracle.dense_rotate(vol, tuple(g[f"units_{i}"])), g[f"out_{i}"]) == 0, i
+
+
+def test_raw_variants(oracle):
+    """Row a15 (raw-image descriptors and orientations) against the reference's output."""
+    from tests import parity
+    g = np.load(os.path.join(GOLDEN, "raw.npz"))
+    for i in range(int(g["n"])):
+        nx, ny, nz = (int(v) for v in g[f"dims_{i}"])
+        vol = synth.blobs(nx, ny, nz, int(g[f"nblobs_{i}"]), int(g[f"seed_{i}"]))
+        assert sha(vol) == str(g[f"input_sha256_{i}"])
+        wb, wx, wR2, wcf = parity.oracle_raw_variants(oracle, vol, tuple(g[f"units_{i}"]), g[f"xyzos_{i}"], g[f"sd_{i}"], g[f"R_{i}"])
+        assert nbitdiff(wb, g[f"raw_bins_{i}"]) == 0 and np.array_equal(wx, g[f"raw_xyzs_{i}"])
+        assert nbitdiff(wR2, g[f"R_assigned_{i}"].reshape(-1, 3, 3).astype(np.float32)) == 0
+        assert np.array_equal(wcf, g[f"conf_{i}"]) and (wcf < 0).any()      # the fixture includes rejected orientations
+
+
 def test_eig3_against_numpy(oracle):
     import ctypes as C
     rng = np.random.default_rng(7)

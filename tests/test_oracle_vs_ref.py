@@ -60,3 +60,31 @@ def test_nn_match_live(oracle, reference, n1, seed, thr):
     rc, want, _ = parity.nn_match_api(reference, d1, d2, thr)
     assert rc == 0
     assert np.array_equal(oracle.nn_match(d1, d2, thr), want)
+
+
+@pytest.mark.parametrize("dims,units,seed", [((20, 18, 16), (1, 1, 1), 5), ((18, 16, 14), (1, 1, 2), 6),
+                                             ((17, 19, 15), (1, 0.7, 1.3), 7)])
+def test_dense_rotate_live(oracle, reference, dims, units, seed):
+    """Row a14: orc_dense_rotate against SIFT3D_extract_dense_descriptors with dense_rotate = 1 of the unmodified
+    reference (sift.c:2521-2588, 2295-2343), bit for bit."""
+    from tests import parity
+    nx, ny, nz = dims
+    vol = (synth.blobs(nx, ny, nz, max(8, nx * ny * nz // 300), seed) * 37.0 + 3.0).astype(np.float32)
+    want = parity.dense_rotate_api(reference, vol, units)
+    got = oracle.dense_rotate(vol, units)
+    assert want.shape == got.shape == (nz, ny, nx, 12) and np.abs(want).max() > 1.0
+    assert nbitdiff(got, want) == 0
+
+
+@pytest.mark.parametrize("dims,units,nblobs,seed", [((48, 48, 48), (1, 1, 2), 250, 2), ((44, 40, 36), (1, 0.8, 1.5), 200, 9)])
+def test_raw_variants_live(oracle, reference, dims, units, nblobs, seed):
+    """Row a15: SIFT3D_extract_raw_descriptors (sift.c:2131-2195) and SIFT3D_assign_orientations (sift.c:1534-1604) of
+    the unmodified reference against orc_smooth_scale_raw + orc_describe_volume + orc_eig_ori, bit for bit."""
+    from tests import parity
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    xyzos, sd, R, bins, xyzs, R2, cf = parity.raw_variants_api(reference, vol, units)
+    assert len(xyzos) >= 10
+    wb, wx, wR2, wcf = parity.oracle_raw_variants(oracle, vol, units, xyzos, sd, R)
+    assert nbitdiff(bins, wb) == 0 and np.array_equal(xyzs, wx)
+    assert nbitdiff(R2.reshape(-1, 3, 3).astype(np.float32), wR2) == 0 and np.array_equal(cf, wcf)

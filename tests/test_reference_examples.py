@@ -1,4 +1,5 @@
-"""Source-level drop-in check: the reference's own example programs (examples/featuresC.c, registerC.c, ioC.c)
+"""Source-level drop-in check: the reference's own example programs (examples/featuresC.c, registerC.c, ioC.c) and its
+command-line programs (cli/kpSift3D.c, denseSift3D.c, regSift3D.c)
 are compiled UNCHANGED, from where they lie under /root/reference, against include/compat/*.h and
 libsift3d_amd.so, and run (device work on the SIMT emulator build, interposed with LD_PRELOAD) on synthetic
 volumes placed under the file names the examples hard-code.  Skipped where the reference tree is absent
@@ -12,11 +13,12 @@ import numpy as np
 import pytest
 
 from sift3d_amd import build as _b, synth
-from tests.test_cli import _csv, _nii_f32
+from tests.test_cli import _csv, _dense_end_to_end, _kp_end_to_end, _nii_f32
 from tests.test_host_io import nifti1_bytes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXAMPLES = "/root/reference/examples"
+REF_CLI = "/root/reference/cli"
 EMU = os.path.join(ROOT, "tests", "emu")
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(EXAMPLES), reason="reference tree not present")
@@ -82,3 +84,45 @@ def test_registerC(built, tmp_path):
     assert A.shape == (3, 4) and np.abs(A[:, :3] - np.eye(3)).max() < 0.1
     w, _ = _nii_f32(str(tmp_path / "2_warped.nii.gz"))
     assert w.shape == (48, 44, 40) and np.isfinite(w).all() and np.abs(w).max() > 0
+
+
+@pytest.fixture(scope="module")
+def ref_cli(tmp_path_factory):
+    """cli/*.c of the reference, as they lie, against include/compat + libsift3d_amd.so (row f3/f4: "the reference's
+    command lines").  regSift3D links the three exported defaults (cli/regSift3D.c:83-84)."""
+    _b.build()
+    subprocess.run(["sh", os.path.join(EMU, "build_emu.sh")], check=True, capture_output=True)
+    out = tmp_path_factory.mktemp("refcli")
+    exes = {}
+    for name in ("kpSift3D", "denseSift3D", "regSift3D"):
+        exe = str(out / name)
+        subprocess.run(["gcc", "-std=gnu11", "-w", f"-I{ROOT}/include/compat", os.path.join(REF_CLI, name + ".c"), "-o", exe,
+                        f"-L{ROOT}/sift3d_amd/lib", "-lsift3d_amd", "-lm", f"-Wl,-rpath,{ROOT}/sift3d_amd/lib"],
+                       check=True, capture_output=True)
+        exes[name] = exe
+    return exes
+
+
+def test_reference_regSift3D_help_prints_the_exported_defaults(ref_cli):
+    r = subprocess.run([ref_cli["regSift3D"], "--help"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith("Usage: regSift3D [source.nii] [reference.nii]")
+    assert "(default: 0.80)" in r.stdout and "(default: 5.0)" in r.stdout and "(default: 500)" in r.stdout
+    # ... and from "Other options:" on it is the text our own cli/regSift3D.c prints (above that line ours leaves out the
+    # DICOM output formats, which this library does not write)
+    mine = subprocess.run([os.path.join(ROOT, "sift3d_amd", "bin", "regSift3D"), "--help"], capture_output=True, text=True, timeout=60)
+    assert mine.stdout.split("Other options:")[1] == r.stdout.split("Other options:")[1]
+
+
+def test_reference_kpSift3D_source_end_to_end(ref_cli, oracle, tmp_path):
+    _kp_end_to_end(ref_cli, oracle, tmp_path, (24, 20, 18), 40, 3, 1, {"LD_PRELOAD": os.path.join(EMU, "libsift3d_emu.so")})
+
+
+def test_reference_denseSift3D_source_end_to_end(ref_cli, oracle, tmp_path):
+    _dense_end_to_end(ref_cli, oracle, tmp_path, (14, 13, 12), {"LD_PRELOAD": os.path.join(EMU, "libsift3d_emu.so")})
+
+
+def test_reference_regSift3D_source_one_registration(ref_cli, tmp_path):
+    from tests.test_reg import _reg_end_to_end
+    n = _reg_end_to_end(tmp_path, (48, 44, 40), 500, (2, 1, 1), {"LD_PRELOAD": os.path.join(EMU, "libsift3d_emu.so")},
+                        exe=ref_cli["regSift3D"])
+    assert n >= 5

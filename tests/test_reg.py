@@ -225,8 +225,9 @@ def test_resample_gpu_vs_reference(host, reference):
     assert nbitdiff(outs[0][0], outs[1][0]) == 0
 
 
-def _reg_end_to_end(tmp_path, dims, nblobs, shift, env):
+def _reg_end_to_end(tmp_path, dims, nblobs, shift, env, exe=None):
     _b.build()
+    exe = exe or os.path.join(BIN, "regSift3D")
     nx, ny, nz = dims
     a = synth.blobs(nx, ny, nz, nblobs, 21)
     b = np.roll(a, shift, axis=(2, 1, 0)).copy()                          # ref(x) = src(x - shift)
@@ -236,7 +237,7 @@ def _reg_end_to_end(tmp_path, dims, nblobs, shift, env):
             f.write(nifti1_bytes(np.ascontiguousarray(v.transpose(2, 1, 0)), units))
     mt, tf, wp = (str(tmp_path / "out" / n) for n in ("matches.csv", "tform.csv", "warped.nii.gz"))
     cc, ky, ln = (str(tmp_path / "out" / n) for n in ("concat.nii.gz", "keys.nii.gz", "lines.nii.gz"))
-    r = run(os.path.join(BIN, "regSift3D"), "--matches", mt, "--transform", tf, "--warped", wp, "--concat", cc, "--keys", ky,
+    r = run(exe, "--matches", mt, "--transform", tf, "--warped", wp, "--concat", cc, "--keys", ky,
             "--lines", ln, str(tmp_path / "src.nii.gz"), str(tmp_path / "ref.nii.gz"), env=env)
     assert r.returncode == 0, r.stderr
     for path in (cc, ky, ln):                                             # source | reference side by side
