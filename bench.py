@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- detect+describe throughput of the HIP path and the roofline of its dominant kernel.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU under torchrun)
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU)
+
+N > 1 runs N GPUs either way: launched plainly, ONE process drives the N GPUs with one host thread per rank and RCCL
+communicators from ncclCommInitAll (no launcher, no torch); under torchrun every process is one rank, torch.distributed
+over GLOO ships rank 0's 128-byte ncclUniqueId and carries the barriers -- the only RCCL in the process is the one
+csrc/s3d_rccl.hip opens.  Fewer than N visible GPUs, or a WORLD_SIZE that is not N: exit status 2, no number.
 
 A step = one pass of the hot path over one synthetic volume that is ALREADY RESIDENT IN HBM:
 SIFT3D_detect_keypoints (copy + scale + 36 Gaussian applications + extrema + orientation; the small
@@ -150,7 +156,7 @@ def slab_job(L, dev, transport, dims, steps, warmup, sync_all, tag):
     over the ranks with this rank's stream drained.  Returns this rank's measurements."""
     from sift3d_amd import slab as S
     nx, ny, nz = dims
-    sl = S.Slab(L, transport, nx, ny, nz)
+    sl = S.Slab(L, transport, nx, ny, nz, params=bench_params())
     inf = sl.info()
     nblobs = synth.default_nblobs(nx, ny, nz)
     t0 = time.perf_counter()
@@ -173,6 +179,7 @@ def slab_job(L, dev, transport, dims, steps, warmup, sync_all, tag):
     t0 = time.perf_counter()
     sl.describe(to_host=False)
     t_describe = time.perf_counter() - t0
+    split = sl.info()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -182,7 +189,8 @@ def slab_job(L, dev, transport, dims, steps, warmup, sync_all, tag):
     inf = sl.info()
     out = {"elapsed": elapsed, "detect_ms": t_detect * 1e3, "describe_ms": t_describe * 1e3, "keypoints": int(inf.num_keypoints),
            "candidates": int(inf.num_candidates), "halo_bytes": float(inf.halo_bytes), "o_shard": int(inf.o_shard),
-           "halo": int(inf.halo), "slices": int(inf.z1 - inf.z0), "device_GiB": inf.device_bytes / 2**30, "nblobs": nblobs}
+           "halo": int(inf.halo), "slices": int(inf.z1 - inf.z0), "device_GiB": inf.device_bytes / 2**30, "nblobs": nblobs,
+           "comm_ms": float(split.comm_ms), "halo_wait_ms": float(split.halo_wait_ms)}
     dev.free(d_vol)
     sl.close()
     return out
@@ -196,12 +204,117 @@ def slab_summary(per_rank, dims, steps, world, transport_name):
         "keypoints": sum(r["keypoints"] for r in per_rank), "extrema_candidates": sum(r["candidates"] for r in per_rank),
         "detect_ms": round(max(r["detect_ms"] for r in per_rank), 3), "describe_ms": round(max(r["describe_ms"] for r in per_rank), 3),
         "keypoints_per_rank": [r["keypoints"] for r in per_rank], "slices_per_rank": [r["slices"] for r in per_rank],
+        # GPU time (HIP events) of the split step's detect, per rank: comm_ms = the compute stream inside halo exchanges /
+        # all-reduces / the seed all-gather (transfer + waiting for the peers); halo_wait_ms = how long it then stood
+        # waiting for the deferred halo planes (0 = they overlapped the pyramid kernels completely)
+        "comm_ms_per_rank": [round(r["comm_ms"], 3) for r in per_rank],
+        "halo_wait_ms_per_rank": [round(r["halo_wait_ms"], 3) for r in per_rank],
+        "detect_ms_per_rank": [round(r["detect_ms"], 3) for r in per_rank],
+        "describe_ms_per_rank": [round(r["describe_ms"], 3) for r in per_rank],
         "sharded_octaves": r0["o_shard"] + 1, "halo_planes": r0["halo"],
         "halo_MB_per_step_all_ranks": round(sum(r["halo_bytes"] for r in per_rank) / 1e6, 1),
         "HBM_GiB_per_rank": round(max(r["device_GiB"] for r in per_rank), 2),
         "Mvox_s": round(float(nx) * ny * nz * steps / elapsed / 1e6, 1), "ms_per_step": round(elapsed / steps * 1e3, 3),
         "parallelism": f"Z-slab x{world}, host C driver (csrc/host/s3d_host_slab.c), transport: {transport_name}; halos between "
                        f"Z-neighbours, max all-reduce for the scale / peak thresholds, all-gather of the coarse-octave seed"}
+
+
+def bench_params():
+    """Test aid: S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2" shrinks the descriptor windows so that the multi-rank path can
+    be driven on volumes of a few dozen slices (the CPU tests); unset = default SIFT3D parameters."""
+    e = os.environ.get("S3D_BENCH_PARAMS")
+    if not e:
+        return None
+    return {k: float(v) for k, v in (kv.split("=") for kv in e.split(","))}
+
+
+def slab_result(args, per_rank, extra, dims, world, tname, rccl):
+    elapsed, cfg = slab_summary(per_rank, dims, args.steps, world, tname)
+    nvox = float(dims[0]) * dims[1] * dims[2]
+    pdesc = "default SIFT3D parameters" if not bench_params() else f"TEST parameters {bench_params()}"
+    cfg["workload"] = (f"one {dims[0]}x{dims[1]}x{dims[2]} float32 blobs+noise volume ({per_rank[0]['nblobs']} blobs), unit voxels, "
+                       f"{pdesc}, Z-slab sharded: {per_rank[0]['slices']} slices per GPU; detect + describe "
+                       f"all keypoints, slabs and descriptors resident in HBM")
+    if rccl is not None:
+        cfg["rccl_ranks"], cfg["rccl_version"] = rccl       # what the communicator itself reports (ncclCommCount, ncclGetVersion)
+    result = {"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+              "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+              "dtype": "f32", "data": "synthetic", "config": cfg}
+    if extra is not None:
+        _, c3 = slab_summary(extra, (1024, 1024, 1024), 2, world, tname)
+        c3["workload"] = f"BASELINE configs[3]: one 1024^3 volume, Z-slabs of {extra[0]['slices']} slices on {world} GPUs"
+        result["config"]["strong_1024"] = c3
+    return result
+
+
+def run_inprocess(args, dev):
+    """N > 1 launched plainly: this ONE process drives the N GPUs -- one host thread per rank (thread r: GPU r), RCCL
+    communicators from ncclCommInitAll (sift3d_amd_rccl_create_all), the C Z-slab driver on device-resident slabs.  The
+    same transport and driver a relinked caller gets from sift3d_amd_set_num_gpus(&sift3d, N, 0); no launcher, no
+    torch.distributed, one RCCL instance."""
+    import threading
+    from sift3d_amd import slab as S
+    L = sift3d_amd.cdll()
+    N = args.gpus
+    ndev = dev.device_count()
+    if ndev < N:
+        log(f"bench.py: --gpus {N} requested, {ndev} GPU(s) visible: refusing to benchmark fewer GPUs than asked for")
+        raise SystemExit(2)
+    n = args.size
+    dims = (args.strong_size,) * 3 if args.strong else (n, n, n * N)
+    tr = S.rccl_all_transports(L, N)
+    rccl = S.rccl_info(L, tr[0])
+    if rccl[0] != N:
+        log(f"bench.py: the RCCL communicator has {rccl[0]} ranks, not {N}")
+        raise SystemExit(2)
+    tname = "RCCL, one process (ncclCommInitAll; ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip)"
+    bar = threading.Barrier(N)
+
+    def job(r, what, steps, warmup, tag):
+        dev.check(dev.L.s3d_rt_set_device(r), "set_device")          # per thread
+
+        def sync_all():
+            dev.sync()
+            bar.wait()
+        return slab_job(L, dev, tr[r], what, steps, warmup, sync_all, tag)
+
+    def run(what, steps, warmup, tag):
+        out, err = [None] * N, [None] * N
+
+        def body(r):
+            try:
+                out[r] = job(r, what, steps, warmup, tag)
+            except BaseException as e:                                 # noqa: BLE001
+                err[r] = e
+                bar.abort()                                            # host barrier ...
+                for q in range(N):                                     # ... and the ranks' transports: nobody waits for ever
+                    if tr[q].abort:
+                        tr[q].abort(tr[q].self)
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for r, e_ in enumerate(err):
+            if e_ is not None and not isinstance(e_, threading.BrokenBarrierError):
+                log(f"bench.py: rank {r} failed: {e_}")
+        if any(e_ is not None for e_ in err):
+            raise SystemExit(3)
+        return out
+
+    per_rank = run(dims, args.steps, args.warmup, "timed")
+    extra = None
+    if not args.no_match and not args.strong and N in (2, 4, 8, 16) and n >= 512:
+        extra = run((1024, 1024, 1024), 2, 1, "configs[3]")
+    result = slab_result(args, per_rank, extra, dims, N, tname, rccl)
+    dev.check(dev.L.s3d_rt_set_device(0), "set_device")
+    if not args.no_roofline:
+        add_roofline(result, dev, n)
+    print(json.dumps(result), flush=True)
+    for r in range(N):
+        tr[r].destroy(tr[r].self)
 
 
 def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
@@ -213,7 +326,7 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
     from sift3d_amd import slab as S
     L = sift3d_amd.cdll()
     same_gpu = bool(os.environ.get("S3D_BENCH_SAME_GPU"))
-    tname, tr, keep = "RCCL (ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip)", None, None
+    tname, tr, keep = "RCCL, one process per GPU (ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip; id shipped over gloo)", None, None
     ok = 0.0
     if not same_gpu:
         try:
@@ -221,12 +334,18 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
             ok = 1.0
         except Exception as e:              # the decision to fall back must be collective
             log(f"[rank {rank}] RCCL transport unavailable: {e}")
-    flag = torch.tensor([ok], device="cpu" if same_gpu else "cuda")
+    flag = torch.tensor([ok])                                # the process group is gloo: host tensors
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    rccl = None
     if float(flag.item()) == 0.0:
-        keep = S.DistTransport(L, dist, device=f"cuda:{local_rank}", stage_via_host=same_gpu)
+        keep = S.DistTransport(L, dist, device=f"cuda:{local_rank}", stage_via_host=True)
         tr = keep.struct
-        tname = "torch.distributed callbacks (" + ("gloo, staged through the host" if same_gpu else "nccl") + ")"
+        tname = "torch.distributed callbacks (gloo, staged through the host) -- RCCL did NOT initialise"
+    else:
+        rccl = S.rccl_info(L, tr)
+        if rccl[0] != world:
+            log(f"[rank {rank}] the RCCL communicator has {rccl[0]} ranks, not {world}")
+            raise SystemExit(2)
 
     def gather(m):
         box = [None] * world
@@ -237,22 +356,10 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
     dims = (args.strong_size,) * 3 if args.strong else (n, n, n * world)
     per_rank = gather(slab_job(L, dev, tr, dims, args.steps, args.warmup, full_sync, "timed"))
     extra = None
-    if not args.no_match and not args.strong and world in (2, 4, 8, 16):
+    if not args.no_match and not args.strong and world in (2, 4, 8, 16) and n >= 512:
         extra = gather(slab_job(L, dev, tr, (1024, 1024, 1024), 2, 1, full_sync, "configs[3]"))
     if rank == 0:
-        elapsed, cfg = slab_summary(per_rank, dims, args.steps, world, tname)
-        nvox = float(dims[0]) * dims[1] * dims[2]
-        cfg["workload"] = (f"one {dims[0]}x{dims[1]}x{dims[2]} float32 blobs+noise volume ({per_rank[0]['nblobs']} blobs), unit voxels, "
-                           f"default SIFT3D parameters, Z-slab sharded: {per_rank[0]['slices']} slices per GPU; detect + describe "
-                           f"all keypoints, slabs and descriptors resident in HBM")
-        result = {"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": world,
-                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                  "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-                  "dtype": "f32", "data": "synthetic", "config": cfg}
-        if extra is not None:
-            _, c3 = slab_summary(extra, (1024, 1024, 1024), 2, world, tname)
-            c3["workload"] = f"BASELINE configs[3]: one 1024^3 volume, Z-slabs of {extra[0]['slices']} slices on {world} GPUs"
-            result["config"]["strong_1024"] = c3
+        result = slab_result(args, per_rank, extra, dims, world, tname, rccl)
         if not args.no_roofline:
             add_roofline(result, dev, n)
         print(json.dumps(result), flush=True)
@@ -347,20 +454,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    launched = "WORLD_SIZE" in os.environ                       # under torchrun: one process per rank
+    if launched and world != args.gpus:
+        log(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a number for a different GPU count")
+        raise SystemExit(2)
     dist = None
     if world > 1 or os.environ.get("S3D_BENCH_FORCE_SLAB"):     # FORCE_SLAB: the N > 1 code path with a world of one (1-GPU boxes)
         import torch
         import torch.distributed as dist
+        # gloo for the bootstrap (a 128-byte id, a flag, the barriers): the process then holds ONE RCCL, the one the
+        # transport opens -- not PyTorch's bundled copy beside it
         if os.environ.get("S3D_BENCH_SAME_GPU"):
-            # debugging aid for a 1-GPU box: all ranks share GPU 0, collectives staged through gloo
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            local_rank = 0                                       # debugging aid for a 1-GPU box: all ranks share GPU 0
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo")
 
     lib = sift3d_amd.load()
     dev = sift3d_amd.load_device()
@@ -378,6 +485,12 @@ def main():
     n = args.size
     if world == 1 and args.loopback > 1:
         run_loopback(args, dev)
+        return
+    if not launched and args.gpus > 1 and not os.environ.get("S3D_BENCH_FORCE_SLAB"):
+        if args.replicas:
+            log("bench.py: --replicas needs one process per GPU (torchrun)")
+            raise SystemExit(2)
+        run_inprocess(args, dev)
         return
     if (world > 1 or (dist is not None and os.environ.get("S3D_BENCH_FORCE_SLAB"))) and not args.replicas:
         run_slab(args, dist, dev, rank, local_rank, world, full_sync)
@@ -425,7 +538,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     K = int(kp.slab.num)

@@ -39,6 +39,7 @@ int s3d_rt_d2h(void *dst, const void *d_src, size_t bytes, s3d_stream stream);
 int s3d_rt_d2d(void *d_dst, const void *d_src, size_t bytes, s3d_stream stream);
 int s3d_rt_memset(void *d_ptr, int value, size_t bytes, s3d_stream stream);
 int s3d_rt_sync(s3d_stream stream);
+int s3d_rt_sync_timeout(s3d_stream stream, double timeout_s);   /* 0 drained, 1 still busy after timeout_s, -1 error */
 int s3d_rt_stream_create(s3d_stream *stream);
 int s3d_rt_stream_create_nonblocking(s3d_stream *stream);   /* does not synchronise with the NULL stream */
 int s3d_rt_stream_destroy(s3d_stream stream);

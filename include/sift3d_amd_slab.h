@@ -51,6 +51,12 @@ typedef struct sift3d_amd_transport {
     /* the same for host memory (keypoint lists; small) */
     int (*allgather_host)(void *self, const void *send, void *recv, size_t bytes);
     void (*destroy)(void *self);
+    /* Optional (may be NULL).  Called by a rank that has failed, or by whoever notices that one has (the in-process
+     * driver calls it on every rank's transport; a rank whose wait exceeds SIFT3D_SLAB_TIMEOUT_S calls it on its own):
+     * every pending and every later operation of this transport fails promptly instead of waiting for a peer that will
+     * never arrive.  RCCL: ncclCommAbort on both communicators; loop-back: the group's barrier is poisoned.  May be
+     * called from any thread, more than once.  An aborted transport can only be destroyed. */
+    void (*abort)(void *self);
 } sift3d_amd_transport;
 
 /* In-process loop-back: `world` ranks = `world` host threads of this process; collectives are a barrier plus
@@ -67,6 +73,9 @@ int sift3d_amd_rccl_unique_id(unsigned char id[SIFT3D_AMD_RCCL_ID_BYTES]);
 int sift3d_amd_rccl_create(const unsigned char id[SIFT3D_AMD_RCCL_ID_BYTES], int rank, int world,
                            sift3d_amd_transport *t);
 int sift3d_amd_rccl_create_all(int world, const int *devices, sift3d_amd_transport *t);
+/* What the communicator itself says: ranks of lane 0's communicator (ncclCommCount) and the library's version code
+ * (ncclGetVersion: e.g. 22707 = 2.27.7).  For the record a benchmark keeps: that bytes moved over RCCL, and which. */
+int sift3d_amd_rccl_info(const sift3d_amd_transport *t, int *comm_ranks, int *version);
 
 /* ---- one rank ---------------------------------------------------------------------------------------- */
 typedef struct sift3d_amd_slab sift3d_amd_slab;
@@ -82,6 +91,12 @@ typedef struct {
     double halo_bytes;        /* bytes this rank sent in the last detect (halos + seed all-gather) */
     double device_bytes;      /* HBM allocated by this rank */
     double detect_ms, describe_ms; /* host wall time of the last sift3d_amd_slab_detect / _describe on this rank */
+    /* GPU time (HIP events) of the last detect: comm_ms = the compute stream inside transport operations ordered with
+     * it (lane-0 halo exchanges, all-reduces, the seed all-gather: transfer + waiting for the peers to arrive);
+     * halo_wait_ms = how long the compute stream then stood waiting for the deferred (lane-1) halo planes before the
+     * orientation step -- 0 when they overlapped the pyramid kernels completely. */
+    double comm_ms, halo_wait_ms;
+    long num_described;       /* keypoints this rank described in the last describe (after load balancing) */
 } sift3d_amd_slab_info;
 
 /* Plan and allocate rank t->rank of a t->world-way job on an nx x ny x nz volume with the parameters of
@@ -106,6 +121,14 @@ int sift3d_amd_slab_gather(sift3d_amd_slab *sl, const Keypoint_store *kp, const 
                            Keypoint_store *kp_all, SIFT3D_Descriptor_store *desc_all);
 /* rank owning a keypoint (by its z in its octave), -1 if outside the volume */
 int sift3d_amd_slab_owner(const sift3d_amd_slab *sl, const Keypoint *key);
+
+/* Seconds a rank waits for its stream (i.e. for its peers) before it aborts its transport and fails: environment
+ * variable SIFT3D_SLAB_TIMEOUT_S, default 120, 0 = wait for ever. */
+
+/* TEST HOOK: the next time rank `rank` passes point `where` it fails as if an allocation / copy had failed there
+ * (1: slab_create, 2: detect before any collective, 3: detect inside the pyramid after the first halo exchange,
+ * 4: detect before the candidate lists are sized, 5: describe).  One shot; rank < 0 disarms. */
+void sift3d_amd_slab_test_inject(int rank, int where);
 
 /* ---- one process, N GPUs, behind the reference entry points ------------------------------------------- */
 #define SIFT3D_AMD_SLAB_LOOPBACK 1   /* all ranks on the current device, loop-back transport (testing) */

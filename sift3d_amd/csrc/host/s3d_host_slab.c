@@ -26,6 +26,7 @@
 #include "sift3d_amd_slab.h"
 
 #define DESC_REC_FLOATS (sizeof(SIFT3D_Descriptor) / sizeof(float)) /* 776 */
+#define SLAB_MAX_OPS 96          /* timed transport operations per detect (2 sharded octaves x 6 levels + all-reduces: ~25) */
 
 static __thread char g_slab_err[512];
 #define SLAB_FAIL(...)                                           \
@@ -41,6 +42,28 @@ static __thread char g_slab_err[512];
 #define COMM(call)                                                                       \
     do {                                                                                 \
         if ((call) != 0) SLAB_FAIL("sift3d_amd slab: transport: %s failed", #call);      \
+    } while (0)
+
+/* Seconds a rank waits for its stream / its peers before it gives up (include/sift3d_amd_slab.h) */
+static double slab_timeout_s(void)
+{
+    static double t = -1.0;
+    if (t < 0.0) { const char *e = getenv("SIFT3D_SLAB_TIMEOUT_S"); t = e ? atof(e) : 120.0; if (t < 0.0) t = 0.0; }
+    return t;
+}
+
+/* test hook (sift3d_amd_slab_test_inject): one-shot failure of rank g_inject_rank at point g_inject_where */
+static volatile int g_inject_rank = -1, g_inject_where = 0;
+void sift3d_amd_slab_test_inject(int rank, int where) { g_inject_where = where; g_inject_rank = rank; }
+static int injected(int rank, int where)
+{
+    if (g_inject_rank != rank || g_inject_where != where) return 0;
+    g_inject_rank = -1;
+    return 1;
+}
+#define INJECT(sl, where)                                                                                         \
+    do {                                                                                                          \
+        if (injected((sl)->t.rank, (where))) SLAB_FAIL("sift3d_amd slab: injected failure %d on rank %d", (where), (sl)->t.rank); \
     } while (0)
 
 static double now_ms(void)
@@ -103,9 +126,57 @@ struct sift3d_amd_slab {
     size_t h_keys_bytes;
     s3d_desc_key *d_keys;
     float *d_desc;
-    long num_candidates, num_keypoints;
-    double halo_bytes, device_bytes, detect_ms, describe_ms;
+    long num_candidates, num_keypoints, num_described;
+    double halo_bytes, device_bytes, detect_ms, describe_ms, comm_ms, halo_wait_ms;
+    /* GPU-side timing of the transport operations of a detect: event pairs around every operation ordered with the
+     * compute stream, and the moment the compute stream starts to wait for the deferred lane */
+    void *ev_op[2 * SLAB_MAX_OPS], *ev_reach;
+    int n_ops, have_reach;
 };
+
+/* A transport operation that is ordered with the compute stream, bracketed by a pair of events: what the stream spends
+ * between them is transfer time plus the time it waits for the peers to arrive (sift3d_amd_slab_info.comm_ms). */
+static void op_begin(sift3d_amd_slab *sl)
+{
+    if (sl->t.world > 1 && sl->n_ops < SLAB_MAX_OPS) s3d_rt_event_record(sl->ev_op[2 * sl->n_ops], sl->cs);
+}
+static void op_end(sift3d_amd_slab *sl)
+{
+    if (sl->t.world > 1 && sl->n_ops < SLAB_MAX_OPS) s3d_rt_event_record(sl->ev_op[2 * sl->n_ops++ + 1], sl->cs);
+}
+#define COMM_TIMED(sl, call)                                                              \
+    do {                                                                                  \
+        op_begin(sl);                                                                     \
+        if ((call) != 0) SLAB_FAIL("sift3d_amd slab: transport: %s failed", #call);       \
+        op_end(sl);                                                                       \
+    } while (0)
+
+/* after the compute stream has drained: the sums of the event pairs of this detect */
+static void collect_comm_times(sift3d_amd_slab *sl)
+{
+    float ms;
+    sl->comm_ms = sl->halo_wait_ms = 0.0;
+    for (int i = 0; i < sl->n_ops; i++)
+        if (s3d_rt_event_elapsed_ms(sl->ev_op[2 * i], sl->ev_op[2 * i + 1], &ms) == 0) sl->comm_ms += (double)ms;
+    if (sl->have_reach && s3d_rt_event_elapsed_ms(sl->ev_reach, sl->ev_done, &ms) == 0 && ms > 0.0f) sl->halo_wait_ms = (double)ms;
+    sl->n_ops = sl->have_reach = 0;
+}
+
+/* Drain the compute stream -- which, with more than one rank, means: wait for the peers.  Not for ever: past the
+ * time limit the rank aborts its transport (so that whoever waits for IT is released as well) and fails. */
+static int slab_sync(sift3d_amd_slab *sl)
+{
+    int rc;
+    if (sl->t.world == 1) { DEV(s3d_rt_sync(sl->cs)); return SIFT3D_SUCCESS; }
+    rc = s3d_rt_sync_timeout(sl->cs, slab_timeout_s());
+    if (rc == 1) {
+        if (sl->t.abort) sl->t.abort(sl->t.self);
+        SLAB_FAIL("sift3d_amd slab: rank %d waited more than %g s for its peers (SIFT3D_SLAB_TIMEOUT_S); transport aborted",
+                  sl->t.rank, slab_timeout_s());
+    }
+    if (rc) SLAB_FAIL("sift3d_amd slab: stream failed: %s", s3d_rt_last_error());
+    return SIFT3D_SUCCESS;
+}
 
 static int dmalloc(sift3d_amd_slab *sl, void *pp, size_t bytes, int zero)
 {
@@ -195,6 +266,9 @@ void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
     dfree(&sl->d_xyzos); dfree(&sl->d_orient); dfree(&sl->d_mesh); dfree(&sl->d_sigma);
     dfree(&sl->d_keys); dfree(&sl->d_desc);
     if (sl->h_keys) s3d_rt_host_free(sl->h_keys);
+    for (int i = 0; i < 2 * SLAB_MAX_OPS; i++)
+        if (sl->ev_op[i]) s3d_rt_event_destroy(sl->ev_op[i]);
+    if (sl->ev_reach) s3d_rt_event_destroy(sl->ev_reach);
     if (sl->ev_ready) s3d_rt_event_destroy(sl->ev_ready);
     if (sl->ev_done) s3d_rt_event_destroy(sl->ev_done);
     if (sl->ms) s3d_rt_stream_destroy(sl->ms);
@@ -234,6 +308,11 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
     DEV(s3d_rt_stream_create(&sl->ms));
     DEV(s3d_rt_event_create(&sl->ev_ready));
     DEV(s3d_rt_event_create(&sl->ev_done));
+    if (G > 1) {
+        DEV(s3d_rt_event_create(&sl->ev_reach));
+        for (int i = 0; i < 2 * SLAB_MAX_OPS; i++) DEV(s3d_rt_event_create(&sl->ev_op[i]));
+    }
+    INJECT(sl, 1);
 
     /* ---- buffers ---- */
     const int hal = G > 1 ? sl->H : 0;
@@ -329,6 +408,8 @@ int sift3d_amd_slab_get_info(const sift3d_amd_slab *sl, sift3d_amd_slab_info *in
     info->num_candidates = sl->num_candidates; info->num_keypoints = sl->num_keypoints;
     info->halo_bytes = sl->halo_bytes; info->device_bytes = sl->device_bytes;
     info->detect_ms = sl->detect_ms; info->describe_ms = sl->describe_ms;
+    info->comm_ms = sl->comm_ms; info->halo_wait_ms = sl->halo_wait_ms;
+    info->num_described = sl->num_described;
     return SIFT3D_SUCCESS;
 }
 
@@ -364,8 +445,8 @@ static int exchange_halo(sift3d_amd_slab *sl, const s3d_lev *lv, int o, int h, i
     const int n = (now <= 0 || now >= h || no_defer) ? h : now;
     const size_t pb = lv->pe * sizeof(float);
     const int sides = (sl->t.rank > 0) + (sl->t.rank < sl->t.world - 1);
-    COMM(sl->t.exchange(sl->t.self, lev_ptr(lv, z0), lev_ptr(lv, z0 - n), lev_ptr(lv, z1 - n), lev_ptr(lv, z1),
-                        (size_t)n * pb, 0, sl->cs));
+    COMM_TIMED(sl, sl->t.exchange(sl->t.self, lev_ptr(lv, z0), lev_ptr(lv, z0 - n), lev_ptr(lv, z1 - n), lev_ptr(lv, z1),
+                                  (size_t)n * pb, 0, sl->cs));
     sl->halo_bytes += (double)sides * n * pb;
     if (n < h) {
         DEV(s3d_rt_event_record(sl->ev_ready, sl->cs));
@@ -381,6 +462,8 @@ static int exchange_halo(sift3d_amd_slab *sl, const s3d_lev *lv, int o, int h, i
 static int finish_halos(sift3d_amd_slab *sl)
 {
     if (sl->pending) {
+        DEV(s3d_rt_event_record(sl->ev_reach, sl->cs));         /* from here on the compute stream waits for lane 1 */
+        sl->have_reach = 1;
         DEV(s3d_rt_event_record(sl->ev_done, sl->ms));
         DEV(s3d_rt_stream_wait_event(sl->cs, sl->ev_done));
         sl->pending = 0;
@@ -445,6 +528,7 @@ static int build_pyramid(sift3d_amd_slab *sl)
     const int G = sl->t.world, sharded = G > 1, nl = sl->nl;
     const GSS_filters *gss = &sl->plan.gss;
     if (exchange_halo(sl, &sl->im, 0, filter_reach(sl, &gss->first_gauss.f, 0), 0)) return SIFT3D_FAILURE;
+    INJECT(sl, 3);
     if (gauss(sl, &sl->im, &sl->lev[0], 0, &gss->first_gauss.f, sl->first_div ? sl->d_red : NULL)) return SIFT3D_FAILURE;
     for (int o = 0; o < sl->no; o++) {
         const int shard_o = sharded && o <= sl->o_shard;
@@ -472,7 +556,7 @@ static int build_pyramid(sift3d_amd_slab *sl)
                 const int b = sl->t.rank == G - 1 ? sl->dims[o + 1][2] : sl->bounds[sl->t.rank + 1] >> (o + 1);
                 float *mine = sl->d_seed + (size_t)G * sl->seed_elems;
                 if (b > a) DEV(s3d_k_decimate2(lev_ptr(&L[ds], 2 * a), nxo, nyo, 2 * (b - a), mine, sl->cs));
-                COMM(sl->t.allgather(sl->t.self, mine, sl->d_seed, sl->seed_elems * sizeof(float), sl->cs));
+                COMM_TIMED(sl, sl->t.allgather(sl->t.self, mine, sl->d_seed, sl->seed_elems * sizeof(float), sl->cs));
                 sl->halo_bytes += (double)(G - 1) * sl->seed_elems * sizeof(float);
                 for (int q = 0; q < G; q++) {
                     const int qa = sl->bounds[q] >> (o + 1);
@@ -500,6 +584,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
         cap = (uint32_t)(nloc / 128 + 4096);
     }
     for (;;) {
+        INJECT(sl, 4);
         if (ensure_candidates(sl, cap)) return SIFT3D_FAILURE;
         DEV(s3d_rt_memset(sl->d_count, 0, 8 * sizeof(uint32_t), sl->cs));
         for (int o = 0; o < sl->no; o++) {
@@ -521,7 +606,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
                      * by-product; the maxima over all ranks (sift.c:1161-1169), then the exact thresholds on the survivors */
                     if (s3d_k_extrema_fused_runmax(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
                         SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
-                    if (shard_o) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 3, sl->cs));   /* the three maxima at once */
+                    if (shard_o) COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 3, sl->cs));   /* the three maxima at once */
                     DEV(s3d_k_extrema_refilter(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs));
                 } else {
                     /* replicated octave: every rank holds the whole level (the maxima are over all of it, no collective --
@@ -539,7 +624,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
             for (int ks = 1; ks <= nkp; ks++) {
                 if (shard_o) {      /* max |DoG| over my planes, then over the ranks (sift.c:1161-1169) */
                     DEV(s3d_k_dogmax(lev_ptr(&L[ks], za), lev_ptr(&L[ks + 1], za), (size_t)(zb - za) * pe, sl->d_red + 1, sl->cs));
-                    COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 1, sl->cs));
+                    COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 1, sl->cs));
                 } else {            /* replicated octave: every rank sees the whole level */
                     DEV(s3d_k_dogmax(lev_view(&L[ks]), lev_view(&L[ks + 1]), (size_t)nzo * pe, sl->d_red + 1, sl->cs));
                 }
@@ -550,14 +635,14 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
             }
         }
         DEV(s3d_rt_d2h(sl->h_counts, sl->d_count, sizeof(uint32_t), sl->cs));
-        DEV(s3d_rt_sync(sl->cs));
+        if (slab_sync(sl)) return SIFT3D_FAILURE;
         /* the redo decision must be collective: a rank that looped alone would re-enter the all-reduces */
         sl->h_flag = sl->h_counts[0] > sl->cap ? 1.0f : 0.0f;
         if (G > 1) {
             DEV(s3d_rt_h2d(sl->d_red + 8, &sl->h_flag, sizeof(float), sl->cs));
-            COMM(sl->t.allreduce_max(sl->t.self, sl->d_red + 8, 1, sl->cs));
+            COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red + 8, 1, sl->cs));
             DEV(s3d_rt_d2h(&sl->h_flag, sl->d_red + 8, sizeof(float), sl->cs));
-            DEV(s3d_rt_sync(sl->cs));
+            if (slab_sync(sl)) return SIFT3D_FAILURE;
         }
         if (sl->h_flag == 0.0f) break;
         cap = sl->h_counts[0] + 1024 > sl->cap ? sl->h_counts[0] + 1024 : sl->cap + 1024;
@@ -566,20 +651,39 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
     return SIFT3D_SUCCESS;
 }
 
+static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp);
+
+/* A rank that fails here has peers that are waiting for it, or soon will be: it aborts its transport on the way out, so
+ * that every rank returns SIFT3D_FAILURE instead of hanging (the loop-back group is poisoned as a whole; with RCCL the
+ * in-process driver aborts the other ranks' communicators too, other processes run into SIFT3D_SLAB_TIMEOUT_S). */
 int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp)
+{
+    const double t0 = now_ms();
+    const int rc = slab_detect(sl, vol, on_device, kp);
+    sl->detect_ms = now_ms() - t0;
+    if (rc != SIFT3D_SUCCESS && sl->t.world > 1) {
+        if (sl->t.abort) sl->t.abort(sl->t.self);
+        sl->pending = 0;
+        sl->n_ops = sl->have_reach = 0;
+    }
+    return rc;
+}
+
+static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp)
 {
     const int z0 = sl->part[0][0], z1 = sl->part[0][1];
     const size_t n_local = (size_t)(z1 - z0) * sl->nx * sl->ny;
     float *own = lev_ptr(&sl->im, z0);
     uint32_t ncand = 0, K;
-    const double t0 = now_ms();
     if (vol == NULL) SLAB_FAIL("sift3d_amd_slab_detect: no volume");
+    INJECT(sl, 2);
     sl->halo_bytes = 0.0;
+    sl->n_ops = sl->have_reach = 0;
     if (on_device) DEV(s3d_rt_d2d(own, vol, n_local * sizeof(float), sl->cs));
     else DEV(s3d_rt_h2d(own, vol, n_local * sizeof(float), sl->cs));
     /* im_scale with the global maximum (sift.c:903, imutil.c:1977-1991) */
     DEV(s3d_k_absmax(own, n_local, sl->d_red, sl->cs));
-    if (sl->t.world > 1) COMM(sl->t.allreduce_max(sl->t.self, sl->d_red, 1, sl->cs));
+    if (sl->t.world > 1) COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red, 1, sl->cs));
     {   /* the division rides in the first filter's loads where the fused kernels take the configuration (the raw planes
          * then travel as halos: a neighbour's plane divided on load is its scaled plane) */
         float uf0[3];
@@ -589,6 +693,7 @@ int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device,
     }
     if (build_pyramid(sl)) return SIFT3D_FAILURE;
     if (find_candidates(sl, &ncand)) return SIFT3D_FAILURE;
+    collect_comm_times(sl);                 /* find_candidates drained the stream: every pair is complete */
     sl->num_candidates = (long)ncand;
     sl->num_keypoints = 0;
     kp->nx = sl->nx; kp->ny = sl->ny; kp->nz = sl->nz;
@@ -631,11 +736,44 @@ int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device,
         }
         free(xyzos); free(R);
     }
-    sl->detect_ms = now_ms() - t0;
     return SIFT3D_SUCCESS;
 }
 
 /* ---- describe --------------------------------------------------------------------------------------------------- */
+/* Planes [*zlo, *zhi] of its level that the descriptor kernel reads for `key` (window + the gradient's z +- 1, clamped
+ * like desc_bounds in csrc/s3d_keypoint.hip), in octave voxels. */
+static void key_window_z(const sift3d_amd_slab *sl, const Keypoint *key, int oi, long *zlo, long *zhi)
+{
+    s3d_desc_key k;
+    const int nzo = sl->dims[oi][2];
+    float lo, hi;
+    s3d_make_desc_key(key, key->xd, key->yd, key->zd, 0, oi, &k);
+    lo = floorf(k.cz - k.rad / (float)sl->lunits[oi][2]);
+    hi = ceilf(k.cz + k.rad / (float)sl->lunits[oi][2]);
+    if (lo < 1.0f) lo = 1.0f;
+    if (hi > (float)(nzo - 2)) hi = (float)(nzo - 2);
+    *zlo = (long)lo - 1;
+    *zhi = (long)hi + 1;
+}
+
+/* Can this rank describe `key` from the planes it holds?  Replicated octaves: always.  Sharded octaves: the window must
+ * lie inside the slab extended by the halo planes that level actually receives (H for the keypoint levels s = 0..nkp-1,
+ * only a filter's reach for the others) -- a caller-supplied keypoint with a larger scale, or on another level, would
+ * otherwise read planes nobody filled. */
+static int rank_holds_window(const sift3d_amd_slab *sl, const Keypoint *key, int oi, int ki)
+{
+    long zlo, zhi, a, b;
+    int hv;
+    if (sl->t.world == 1 || oi > sl->o_shard) return 1;
+    hv = halo_of_level(sl, oi, ki);
+    a = (long)sl->part[oi][0] - hv;
+    b = (long)sl->part[oi][1] + hv;                       /* exclusive */
+    if (a < 0) a = 0;
+    if (b > sl->dims[oi][2]) b = sl->dims[oi][2];
+    key_window_z(sl, key, oi, &zlo, &zhi);
+    return zlo >= a && zhi < b;
+}
+
 /* Descriptors of kp->buf[sel[j]], j < nsel (sel == NULL: all of kp), of keypoints this rank owns.  Records go to
  * sl->d_desc[j]; with `out` they are also copied to out[sel[j]] (runs of consecutive indices in one transfer each),
  * coordinate fields filled as sift.c:1920-1925. */
@@ -643,7 +781,11 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
 {
     const Pyramid *g = &sl->plan.gpyr;
     s3d_desc_key *keys;
+    const double t0 = now_ms();
+    sl->num_described = (long)nsel;
+    sl->describe_ms = 0.0;
     if (nsel == 0) return SIFT3D_SUCCESS;
+    INJECT(sl, 5);
     if (sl->desc_cap < nsel) {
         dfree(&sl->d_keys); dfree(&sl->d_desc);
         sl->desc_cap = 0;
@@ -666,9 +808,9 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
         if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) {
             SLAB_FAIL("sift3d_amd slab: keypoint %zu has no pyramid level (o=%d, s=%d)", sel ? sel[j] : j, key->o, key->s);
         }
-        if (sl->t.world > 1 && sift3d_amd_slab_owner(sl, key) != sl->t.rank) {
-            SLAB_FAIL("sift3d_amd slab: keypoint %zu (z=%g, octave %d) is not in rank %d's slab", sel ? sel[j] : j, key->zd,
-                      key->o, sl->t.rank);
+        if (!rank_holds_window(sl, key, oi, ki)) {
+            SLAB_FAIL("sift3d_amd slab: the descriptor window of keypoint %zu (z=%g, scale %g, octave %d, level %d) leaves the "
+                      "planes rank %d holds of that level", sel ? sel[j] : j, key->zd, key->sd, key->o, key->s, sl->t.rank);
         }
         s3d_make_desc_key(key, key->xd, key->yd, key->zd, oi * g->num_levels + ki, oi, keys + j);
     }
@@ -699,14 +841,15 @@ static int describe_sel(sift3d_amd_slab *sl, const Keypoint_store *kp, const siz
             out[i].xd = key->xd * f; out[i].yd = key->yd * f; out[i].zd = key->zd * f;
             out[i].sd = key->sd;
         }
+    sl->describe_ms = now_ms() - t0;
     return SIFT3D_SUCCESS;
 }
 
 int sift3d_amd_slab_describe(sift3d_amd_slab *sl, const Keypoint_store *kp, SIFT3D_Descriptor_store *desc, const float **d_desc)
 {
     const size_t num = kp->slab.num;
-    const double t0 = now_ms();
     if (d_desc) *d_desc = NULL;
+    sl->num_described = 0;
     if (desc) { desc->nx = sl->nx; desc->ny = sl->ny; desc->nz = sl->nz; }
     if (num == 0) {                           /* a rank may own no keypoints: not an error here */
         if (desc) { free(desc->buf); desc->buf = NULL; desc->num = 0; }
@@ -716,7 +859,6 @@ int sift3d_amd_slab_describe(sift3d_amd_slab *sl, const Keypoint_store *kp, SIFT
     if (desc && s3d_resize_descriptor_store(desc, (long)num)) return SIFT3D_FAILURE;
     if (describe_sel(sl, kp, NULL, num, desc ? desc->buf : NULL)) return SIFT3D_FAILURE;
     if (d_desc) *d_desc = sl->d_desc;
-    sl->describe_ms = now_ms() - t0;
     return SIFT3D_SUCCESS;
 }
 
@@ -768,7 +910,16 @@ int sift3d_amd_slab_gather(sift3d_amd_slab *sl, const Keypoint_store *kp, const 
     for (int q = 0; q < G; q++) { if (counts[q] > maxk) maxk = counts[q]; total += counts[q]; }
     kp_all->nx = sl->nx; kp_all->ny = sl->ny; kp_all->nz = sl->nz;
     if (desc_all) { desc_all->nx = sl->nx; desc_all->ny = sl->ny; desc_all->nz = sl->nz; }
-    if (total == 0) { rc = resize_Keypoint_store(kp_all, 0); goto done; }
+    if (want_desc && (long)desc->num != K) {              /* the records are taken one per keypoint */
+        S3D_MSG("sift3d_amd_slab_gather: %ld keypoints but %ld descriptors\n", K, (long)desc->num);
+        if (sl->t.world > 1 && sl->t.abort) sl->t.abort(sl->t.self);     /* the peers are on their way into the gathers */
+        goto done;
+    }
+    if (total == 0) {
+        rc = resize_Keypoint_store(kp_all, 0);
+        if (rc == SIFT3D_SUCCESS && desc_all) { free(desc_all->buf); desc_all->buf = NULL; desc_all->num = 0; }
+        goto done;
+    }
     mine = (kp_rec *)calloc((size_t)maxk, sizeof(kp_rec));
     all = (kp_rec *)calloc((size_t)maxk * G, sizeof(kp_rec));
     lists = (const kp_rec **)calloc((size_t)G, sizeof(*lists));
@@ -823,8 +974,11 @@ done:
  * with a single GPU (all ranks on one device) and under the CPU emulator. */
 typedef struct {
     int world, alive;
-    pthread_barrier_t bar;
     pthread_mutex_t lock;
+    pthread_cond_t cv;
+    int arrived;
+    unsigned long gen;
+    volatile int failed;               /* poisoned: a rank has failed (lb_abort) or a wait has timed out */
     const void *slot[2][256];          /* published pointers: [0] lo / generic, [1] hi */
     float red[256][16];
 } lb_group;
@@ -834,6 +988,48 @@ typedef struct {
     int rank;
 } lb_rank;
 
+/* Barrier over the group's ranks that can be broken: -1 (for every rank, now and later) once the group is poisoned.
+ * A rank that waits longer than SIFT3D_SLAB_TIMEOUT_S poisons the group itself. */
+static int lb_barrier(lb_group *g)
+{
+    int rc;
+    pthread_mutex_lock(&g->lock);
+    if (!g->failed) {
+        const unsigned long gen = g->gen;
+        if (++g->arrived == g->world) {
+            g->arrived = 0;
+            g->gen++;
+            pthread_cond_broadcast(&g->cv);
+        } else {
+            const double lim = slab_timeout_s();
+            struct timespec until;
+            clock_gettime(CLOCK_REALTIME, &until);
+            until.tv_sec += (time_t)lim;
+            until.tv_nsec += (long)((lim - (double)(time_t)lim) * 1e9);
+            if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+            while (g->gen == gen && !g->failed) {
+                if (lim <= 0.0) pthread_cond_wait(&g->cv, &g->lock);
+                else if (pthread_cond_timedwait(&g->cv, &g->lock, &until) != 0 && g->gen == gen) {
+                    g->failed = 1;
+                    pthread_cond_broadcast(&g->cv);
+                }
+            }
+        }
+    }
+    rc = g->failed ? -1 : 0;
+    pthread_mutex_unlock(&g->lock);
+    return rc;
+}
+
+static void lb_abort(void *self)
+{
+    lb_group *g = ((lb_rank *)self)->g;
+    pthread_mutex_lock(&g->lock);
+    g->failed = 1;
+    pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->lock);
+}
+
 static int lb_allreduce_max(void *self, float *d_buf, int n, void *stream)
 {
     lb_rank *me = (lb_rank *)self;
@@ -841,13 +1037,13 @@ static int lb_allreduce_max(void *self, float *d_buf, int n, void *stream)
     float v[16];
     if (n > 16) return -1;
     if (s3d_rt_d2h(g->red[me->rank], d_buf, (size_t)n * sizeof(float), stream) || s3d_rt_sync(stream)) return -1;
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     for (int i = 0; i < n; i++) {
         v[i] = g->red[0][i];
         for (int q = 1; q < g->world; q++)
             if (g->red[q][i] > v[i]) v[i] = g->red[q][i];
     }
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     if (s3d_rt_h2d(d_buf, v, (size_t)n * sizeof(float), stream) || s3d_rt_sync(stream)) return -1;
     return 0;
 }
@@ -862,11 +1058,11 @@ static int lb_exchange(void *self, const void *d_send_lo, void *d_recv_lo, const
     if (s3d_rt_sync(stream)) rc = -1;
     g->slot[0][me->rank] = d_send_lo;
     g->slot[1][me->rank] = d_send_hi;
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     if (me->rank > 0 && s3d_rt_d2d(d_recv_lo, g->slot[1][me->rank - 1], bytes, stream)) rc = -1;
     if (me->rank < g->world - 1 && s3d_rt_d2d(d_recv_hi, g->slot[0][me->rank + 1], bytes, stream)) rc = -1;
     if (s3d_rt_sync(stream)) rc = -1;
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     return rc;
 }
 
@@ -877,11 +1073,11 @@ static int lb_allgather(void *self, const void *d_send, void *d_recv, size_t byt
     int rc = 0;
     if (s3d_rt_sync(stream)) rc = -1;
     g->slot[0][me->rank] = d_send;
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     for (int q = 0; q < g->world; q++)
         if (s3d_rt_d2d((char *)d_recv + (size_t)q * bytes, g->slot[0][q], bytes, stream)) rc = -1;
     if (s3d_rt_sync(stream)) rc = -1;
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     return rc;
 }
 
@@ -890,9 +1086,9 @@ static int lb_allgather_host(void *self, const void *send, void *recv, size_t by
     lb_rank *me = (lb_rank *)self;
     lb_group *g = me->g;
     g->slot[0][me->rank] = send;
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     for (int q = 0; q < g->world; q++) memcpy((char *)recv + (size_t)q * bytes, g->slot[0][q], bytes);
-    pthread_barrier_wait(&g->bar);
+    if (lb_barrier(g)) return -1;
     return 0;
 }
 
@@ -906,7 +1102,7 @@ static void lb_destroy(void *self)
     pthread_mutex_unlock(&g->lock);
     free(me);
     if (last) {
-        pthread_barrier_destroy(&g->bar);
+        pthread_cond_destroy(&g->cv);
         pthread_mutex_destroy(&g->lock);
         free(g);
     }
@@ -918,8 +1114,8 @@ int sift3d_amd_loopback_create(int world, sift3d_amd_transport *t)
     if (world < 1 || world > 256) SLAB_FAIL("sift3d_amd_loopback_create: world must be in [1, 256]");
     if ((g = (lb_group *)calloc(1, sizeof(*g))) == NULL) SLAB_FAIL("sift3d_amd_loopback_create: out of memory");
     g->world = g->alive = world;
-    pthread_barrier_init(&g->bar, NULL, (unsigned)world);
     pthread_mutex_init(&g->lock, NULL);
+    pthread_cond_init(&g->cv, NULL);
     for (int r = 0; r < world; r++) {
         lb_rank *me = (lb_rank *)calloc(1, sizeof(*me));
         if (!me) SLAB_FAIL("sift3d_amd_loopback_create: out of memory");
@@ -930,6 +1126,7 @@ int sift3d_amd_loopback_create(int world, sift3d_amd_transport *t)
         t[r].allgather = lb_allgather;
         t[r].allgather_host = lb_allgather_host;
         t[r].destroy = lb_destroy;
+        t[r].abort = lb_abort;
     }
     return SIFT3D_SUCCESS;
 }
@@ -1011,7 +1208,12 @@ static void *mgpu_thread(void *arg)
     struct s3d_mgpu *m = j->m;
     const int r = j->r;
     j->rc = SIFT3D_FAILURE;
-    if (s3d_rt_set_device(m->dev[r])) { snprintf(j->err, sizeof(j->err), "%s", s3d_rt_last_error()); return NULL; }
+    if (s3d_rt_set_device(m->dev[r])) {
+        snprintf(j->err, sizeof(j->err), "%s", s3d_rt_last_error());
+        for (int q = 0; q < m->ngpu; q++)
+            if (m->t[q].abort) m->t[q].abort(m->t[q].self);
+        return NULL;
+    }
     switch (j->op) {
     case 0:
         j->rc = sift3d_amd_slab_create(&m->sl[r], j->params, &m->t[r], m->nx, m->ny, m->nz, m->units[0], m->units[1], m->units[2], NULL);
@@ -1025,7 +1227,14 @@ static void *mgpu_thread(void *arg)
     default:
         j->rc = describe_sel(m->sl[r], j->kp, j->sel, j->nsel, j->out);
     }
-    if (j->rc) snprintf(j->err, sizeof(j->err), "%.250s", g_slab_err);
+    if (j->rc) {
+        /* The peers of a failed rank are waiting for it or soon will be: every rank's transport is aborted (the loop-back
+         * group is poisoned, RCCL kernels that spin on this rank's data leave), so that each of them returns
+         * SIFT3D_FAILURE and mgpu_run() gets its threads back. */
+        snprintf(j->err, sizeof(j->err), "%.250s", g_slab_err);
+        for (int q = 0; q < m->ngpu; q++)
+            if (m->t[q].abort) m->t[q].abort(m->t[q].self);
+    }
     return NULL;
 }
 
@@ -1095,7 +1304,9 @@ int s3d_mgpu_detect(struct s3d_mgpu **pm, const SIFT3D *p, const float *host_den
     memset(jobs, 0, sizeof(mgpu_job) * (size_t)m->ngpu);
     for (int r = 0; r < m->ngpu; r++) { jobs[r].m = m; jobs[r].r = r; jobs[r].op = 1; jobs[r].host = host_dense; }
     if (mgpu_run(m, jobs)) {
+        /* the transports have been aborted: drop the slabs, the next detect on this struct sets everything up afresh */
         S3D_MSG("sift3d_amd: multi-GPU detect failed: %s\n", g_slab_err);
+        mgpu_teardown(m);
         return SIFT3D_FAILURE;
     }
     {   /* global list in the reference order */
@@ -1120,6 +1331,94 @@ int s3d_mgpu_detect(struct s3d_mgpu **pm, const SIFT3D *p, const float *host_den
     return SIFT3D_SUCCESS;
 }
 
+/* ---- who describes which keypoint --------------------------------------------------------------------------------
+ * The descriptor kernel is ~70 % of a detect + describe, and its cost follows the keypoints, not the voxels: a volume
+ * whose structure sits in a few slabs would leave the other GPUs idle.  Any rank can describe a keypoint whose window
+ * lies inside the planes it holds -- its slab plus H halo planes on the levels s = 0..nkp-1, everything in the
+ * replicated octaves -- and the result does not depend on who does it (same kernel, same voxels, integer histograms).
+ * So, starting from "the owner of the keypoint's z describes it":
+ *   (1) keypoints of the replicated octaves go to whichever rank is least loaded at that point;
+ *   (2) neighbouring ranks level out: while rank q carries more than its neighbour by more than the threshold, it hands
+ *       over the keypoints nearest to their common boundary whose windows the neighbour holds (a few sweeps up and down
+ *       the ranks, so that load can travel more than one slab where the halos allow it).
+ * Cost model: the number of window voxels, ~ (sd / octave voxel size)^3.  SIFT3D_SLAB_BALANCE = threshold as a ratio
+ * (default 1.1; 0 = off: every keypoint stays with its owner). */
+typedef struct { double dist; size_t idx; } bal_item;
+static int bal_cmp(const void *a, const void *b)
+{
+    const double d = ((const bal_item *)a)->dist - ((const bal_item *)b)->dist;
+    return d < 0 ? -1 : d > 0;
+}
+
+static void balance_describe(const struct s3d_mgpu *m, const Keypoint_store *kp, int *assign)
+{
+    const size_t num = kp->slab.num;
+    const int G = m->ngpu;
+    const sift3d_amd_slab *s0 = m->sl[0];
+    const Pyramid *g = &s0->plan.gpyr;
+    double load[256] = {0}, thr = 1.1, total = 0.0;
+    double *cost;
+    bal_item *cand;
+    const char *e = getenv("SIFT3D_SLAB_BALANCE");
+    if (e) thr = atof(e);
+    if (thr <= 0.0 || G < 2 || num == 0) return;
+    if (thr < 1.01) thr = 1.01;
+    cost = (double *)malloc(num * sizeof(double));
+    cand = (bal_item *)malloc(num * sizeof(bal_item));
+    if (!cost || !cand) { free(cost); free(cand); return; }
+    for (size_t i = 0; i < num; i++) {
+        const Keypoint *k = kp->buf + i;
+        const double r = k->sd / ldexp(1.0, k->o);
+        cost[i] = r * r * r;
+        load[assign[i]] += cost[i];
+        total += cost[i];
+    }
+    /* (1) replicated octaves: free to go anywhere */
+    for (size_t i = 0; i < num; i++) {
+        const Keypoint *k = kp->buf + i;
+        int best = assign[i];
+        if (k->o - g->first_octave <= s0->o_shard) continue;
+        for (int q = 0; q < G; q++)
+            if (load[q] + 1e-12 * total < load[best]) best = q;
+        if (best != assign[i] && load[best] + cost[i] < load[assign[i]]) {
+            load[assign[i]] -= cost[i];
+            load[best] += cost[i];
+            assign[i] = best;
+        }
+    }
+    /* (2) neighbours level out */
+    for (int sweep = 0; sweep < 2 * G; sweep++) {
+        int moved = 0;
+        for (int step = 0; step < G - 1; step++) {
+            const int q = (sweep & 1) ? G - 2 - step : step;           /* pair (q, q + 1), alternately upwards and downwards */
+            const int from = load[q] > load[q + 1] ? q : q + 1, to = from == q ? q + 1 : q;
+            size_t nc = 0;
+            if (load[from] <= thr * load[to] || load[from] - load[to] < 1e-9 * total) continue;
+            for (size_t i = 0; i < num; i++) {
+                const Keypoint *k = kp->buf + i;
+                const int oi = k->o - g->first_octave, ki = k->s - g->first_level;
+                if (assign[i] != from || oi > s0->o_shard) continue;
+                if (!rank_holds_window(m->sl[to], k, oi, ki)) continue;
+                /* distance to the common boundary, in base slices: hand over the nearest first */
+                cand[nc].dist = to > from ? -(k->zd * ldexp(1.0, k->o)) : k->zd * ldexp(1.0, k->o);
+                cand[nc].idx = i;
+                nc++;
+            }
+            if (nc == 0) continue;
+            qsort(cand, nc, sizeof(bal_item), bal_cmp);
+            for (size_t c = 0; c < nc && load[from] - load[to] > 2.0 * cost[cand[c].idx]; c++) {
+                const size_t i = cand[c].idx;
+                load[from] -= cost[i];
+                load[to] += cost[i];
+                assign[i] = to;
+                moved = 1;
+            }
+        }
+        if (!moved) break;
+    }
+    free(cost); free(cand);
+}
+
 int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descriptor *out)
 {
     const size_t num = kp->slab.num;
@@ -1128,12 +1427,20 @@ int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descr
     size_t *sel, *fill, cnt[256] = {0};
     int *owner, rc;
     if (!m->built) SLAB_FAIL("sift3d_amd: no multi-GPU pyramid: call SIFT3D_detect_keypoints first");
-    if ((owner = (int *)malloc(num * sizeof(int))) == NULL) SLAB_FAIL("sift3d_amd: out of memory");
+    if ((owner = (int *)malloc((num + 1) * sizeof(int))) == NULL) SLAB_FAIL("sift3d_amd: out of memory");
     for (size_t i = 0; i < num; i++) {
-        owner[i] = sift3d_amd_slab_owner(m->sl[0], kp->buf + i);
+        const Keypoint *k = kp->buf + i;
+        const Pyramid *g = &m->sl[0]->plan.gpyr;
+        const int oi = k->o - g->first_octave, ki = k->s - g->first_level;
+        owner[i] = sift3d_amd_slab_owner(m->sl[0], k);
         if (owner[i] < 0) { free(owner); SLAB_FAIL("sift3d_amd: keypoint %zu lies outside the volume", i); }
-        cnt[owner[i]]++;
+        if (oi < 0 || oi >= g->num_octaves || ki < 0 || ki >= g->num_levels) {
+            free(owner);
+            SLAB_FAIL("sift3d_amd: keypoint %zu has no pyramid level (o=%d, s=%d)", i, k->o, k->s);
+        }
     }
+    balance_describe(m, kp, owner);
+    for (size_t i = 0; i < num; i++) cnt[owner[i]]++;
     sel = (size_t *)malloc((num + 1) * sizeof(size_t));
     fill = (size_t *)calloc(256, sizeof(size_t));
     if (!sel || !fill) { free(owner); free(sel); free(fill); SLAB_FAIL("sift3d_amd: out of memory"); }
@@ -1149,7 +1456,10 @@ int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descr
         for (size_t i = 0; i < num; i++) sel[fill[owner[i]]++] = i;
     }
     rc = mgpu_run(m, jobs);
-    if (rc) S3D_MSG("sift3d_amd: multi-GPU describe failed: %s\n", g_slab_err);
+    if (rc) {
+        S3D_MSG("sift3d_amd: multi-GPU describe failed: %s\n", g_slab_err);
+        mgpu_teardown(m);                       /* the transports were aborted with the failed rank */
+    }
     free(owner); free(sel); free(fill);
     return rc;
 }

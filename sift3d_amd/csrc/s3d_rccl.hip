@@ -26,6 +26,9 @@ struct Api {
     decltype(&ncclCommInitRank) CommInitRank;
     decltype(&ncclCommInitAll) CommInitAll;
     decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclCommAbort) CommAbort;
+    decltype(&ncclCommCount) CommCount;
+    decltype(&ncclGetVersion) GetVersion;
     decltype(&ncclAllReduce) AllReduce;
     decltype(&ncclAllGather) AllGather;
     decltype(&ncclSend) Send;
@@ -55,7 +58,8 @@ int load_api()
         s3d_rt_set_error("dlsym", "nccl" #name);                                  \
         rc = S3D_ERR;                                                             \
     }
-            S3D_SYM(GetUniqueId) S3D_SYM(CommInitRank) S3D_SYM(CommInitAll) S3D_SYM(CommDestroy) S3D_SYM(AllReduce)
+            S3D_SYM(GetUniqueId) S3D_SYM(CommInitRank) S3D_SYM(CommInitAll) S3D_SYM(CommDestroy) S3D_SYM(CommAbort)
+            S3D_SYM(CommCount) S3D_SYM(GetVersion) S3D_SYM(AllReduce)
             S3D_SYM(AllGather) S3D_SYM(Send) S3D_SYM(Recv) S3D_SYM(GroupStart) S3D_SYM(GroupEnd) S3D_SYM(GetErrorString)
 #undef S3D_SYM
             if (rc == S3D_OK) g_api.h = h;
@@ -75,16 +79,31 @@ int load_api()
         }                                                                  \
     } while (0)
 
+/* Staging for the host-side all-gathers (keypoint records, descriptor records, the second unique id): allocated ONCE
+ * when the rank is created and driven through the rank's own non-blocking stream.  Nothing after creation calls
+ * hipMalloc / hipFree or touches the NULL stream: in the one-process mode N rank threads share the process, and a
+ * device-synchronising call on one of them while another has RCCL kernels in flight is the classic way to deadlock a
+ * collective.  Larger payloads go through in pieces of STAGE_PIECE bytes per rank. */
+constexpr size_t STAGE_PIECE = (size_t)8 << 20;
+
 struct Rank {
     ncclComm_t comm[2];      /* lane 0, lane 1 */
     int rank, world;
-    void *d_stage;           /* device staging for allgather_host */
-    size_t stage_bytes;
+    char *d_stage;           /* (world + 1) x STAGE_PIECE bytes */
+    hipStream_t hs;          /* stream of the host-side gathers */
+    pthread_mutex_t lock;    /* abort vs destroy */
+    volatile int aborted;
 };
+
+#define S3D_ALIVE(me)                                                                      \
+    do {                                                                                   \
+        if ((me)->aborted) { s3d_rt_set_error("rccl transport", "aborted"); return S3D_ERR; } \
+    } while (0)
 
 int rc_allreduce_max(void *self, float *d_buf, int n, void *stream)
 {
     Rank *me = (Rank *)self;
+    S3D_ALIVE(me);
     S3D_NCCL(g_api.AllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclMax, me->comm[0], (hipStream_t)stream));
     return S3D_OK;
 }
@@ -93,6 +112,7 @@ int rc_exchange(void *self, const void *d_send_lo, void *d_recv_lo, const void *
                 int lane, void *stream)
 {
     Rank *me = (Rank *)self;
+    S3D_ALIVE(me);
     ncclComm_t c = me->comm[lane ? 1 : 0];
     hipStream_t st = (hipStream_t)stream;
     if (bytes == 0) return S3D_OK;
@@ -112,38 +132,83 @@ int rc_exchange(void *self, const void *d_send_lo, void *d_recv_lo, const void *
 int rc_allgather(void *self, const void *d_send, void *d_recv, size_t bytes, void *stream)
 {
     Rank *me = (Rank *)self;
+    S3D_ALIVE(me);
     S3D_NCCL(g_api.AllGather(d_send, d_recv, bytes, ncclUint8, me->comm[0], (hipStream_t)stream));
     return S3D_OK;
 }
 
-/* host lists (keypoint records, a few MB): staged through HBM so that the one fabric serves everything */
+/* wait for the rank's gather stream, but not for ever: a peer that never arrives must not hang this rank */
+int stage_wait(Rank *me)
+{
+    static double timeout = -1.0;
+    if (timeout < 0.0) { const char *e = getenv("SIFT3D_SLAB_TIMEOUT_S"); timeout = e ? atof(e) : 120.0; }
+    const int rc = s3d_rt_sync_timeout((s3d_stream)me->hs, timeout);
+    if (rc == 1) s3d_rt_set_error("rccl transport", "timed out waiting for the peers of a host-side all-gather");
+    return rc ? S3D_ERR : S3D_OK;
+}
+
+/* host lists (keypoint records, a few MB; descriptor records when a caller gathers them): through HBM, so that the
+ * one fabric serves everything; piecewise through the fixed staging (every rank passes the same `bytes`, so every rank
+ * makes the same number of pieces) */
 int rc_allgather_host(void *self, const void *send, void *recv, size_t bytes)
 {
     Rank *me = (Rank *)self;
-    const size_t need = bytes * (size_t)(me->world + 1);
-    if (need > me->stage_bytes) {
-        if (me->d_stage) S3D_HIP(hipFree(me->d_stage));
-        me->d_stage = nullptr;
-        me->stage_bytes = 0;
-        S3D_HIP(hipMalloc(&me->d_stage, need));
-        me->stage_bytes = need;
+    char *d_all = me->d_stage, *d_mine = d_all + STAGE_PIECE * (size_t)me->world;
+    for (size_t off = 0; off < bytes; off += STAGE_PIECE) {
+        const size_t nb = bytes - off < STAGE_PIECE ? bytes - off : STAGE_PIECE;
+        S3D_ALIVE(me);
+        S3D_HIP(hipMemcpyAsync(d_mine, (const char *)send + off, nb, hipMemcpyHostToDevice, me->hs));
+        S3D_NCCL(g_api.AllGather(d_mine, d_all, nb, ncclUint8, me->comm[0], me->hs));
+        for (int r = 0; r < me->world; r++)
+            S3D_HIP(hipMemcpyAsync((char *)recv + (size_t)r * bytes + off, d_all + (size_t)r * nb, nb, hipMemcpyDeviceToHost, me->hs));
+        if (stage_wait(me)) return S3D_ERR;
     }
-    char *d_all = (char *)me->d_stage, *d_mine = d_all + bytes * (size_t)me->world;
-    S3D_HIP(hipMemcpy(d_mine, send, bytes, hipMemcpyHostToDevice));
-    S3D_NCCL(g_api.AllGather(d_mine, d_all, bytes, ncclUint8, me->comm[0], (hipStream_t) nullptr));
-    S3D_HIP(hipStreamSynchronize(nullptr));
-    S3D_HIP(hipMemcpy(recv, d_all, bytes * (size_t)me->world, hipMemcpyDeviceToHost));
     return S3D_OK;
+}
+
+/* ncclCommAbort on both lanes: kernels of this rank that wait for a peer leave, later calls fail (S3D_ALIVE) */
+void rc_abort(void *self)
+{
+    Rank *me = (Rank *)self;
+    if (me == nullptr) return;
+    pthread_mutex_lock(&me->lock);
+    if (!me->aborted) {
+        me->aborted = 1;
+        for (int l = 0; l < 2; l++)
+            if (me->comm[l]) { g_api.CommAbort(me->comm[l]); me->comm[l] = nullptr; }
+    }
+    pthread_mutex_unlock(&me->lock);
 }
 
 void rc_destroy(void *self)
 {
     Rank *me = (Rank *)self;
     if (me == nullptr) return;
+    pthread_mutex_lock(&me->lock);
     for (int l = 0; l < 2; l++)
-        if (me->comm[l]) g_api.CommDestroy(me->comm[l]);
+        if (me->comm[l]) { g_api.CommDestroy(me->comm[l]); me->comm[l] = nullptr; }
+    pthread_mutex_unlock(&me->lock);
+    if (me->hs) (void)hipStreamDestroy(me->hs);
     if (me->d_stage) (void)hipFree(me->d_stage);
+    pthread_mutex_destroy(&me->lock);
     free(me);
+}
+
+/* the calling thread's current device is the rank's GPU */
+Rank *rank_new(int rank, int world)
+{
+    Rank *me = (Rank *)calloc(1, sizeof(Rank));
+    if (me == nullptr) { s3d_rt_set_error("rccl transport", "out of memory"); return nullptr; }
+    me->rank = rank;
+    me->world = world;
+    pthread_mutex_init(&me->lock, nullptr);
+    if (hipMalloc((void **)&me->d_stage, STAGE_PIECE * (size_t)(world + 1)) != hipSuccess ||
+        hipStreamCreateWithFlags(&me->hs, hipStreamNonBlocking) != hipSuccess) {
+        s3d_rt_set_error("rccl transport", "staging allocation failed");
+        rc_destroy(me);
+        return nullptr;
+    }
+    return me;
 }
 
 void fill(sift3d_amd_transport *t, Rank *me)
@@ -156,6 +221,7 @@ void fill(sift3d_amd_transport *t, Rank *me)
     t->allgather = rc_allgather;
     t->allgather_host = rc_allgather_host;
     t->destroy = rc_destroy;
+    t->abort = rc_abort;
 }
 
 }  // namespace
@@ -177,27 +243,34 @@ extern "C" int sift3d_amd_rccl_create(const unsigned char id[SIFT3D_AMD_RCCL_ID_
 {
     if (load_api()) return S3D_ERR;
     if (world < 1 || rank < 0 || rank >= world) S3D_FAIL("bad rank / world");
-    Rank *me = (Rank *)calloc(1, sizeof(Rank));
-    if (me == nullptr) S3D_FAIL("out of memory");
-    me->rank = rank;
-    me->world = world;
+    Rank *me = rank_new(rank, world);
+    if (me == nullptr) return S3D_ERR;
     ncclUniqueId u, u2;
     memcpy(&u, id, sizeof(u));
-    S3D_NCCL(g_api.CommInitRank(&me->comm[0], world, u, rank));
-    /* second lane: rank 0 draws another id and all-gathers it (the first slot is rank 0's) over lane 0 */
-    if (rank == 0) S3D_NCCL(g_api.GetUniqueId(&u2));
-    else memset(&u2, 0, sizeof(u2));
-    {
-        void *d = nullptr;
-        S3D_HIP(hipMalloc(&d, sizeof(u2) * (size_t)(world + 1)));
-        char *d_all = (char *)d, *d_mine = d_all + sizeof(u2) * (size_t)world;
-        S3D_HIP(hipMemcpy(d_mine, &u2, sizeof(u2), hipMemcpyHostToDevice));
-        S3D_NCCL(g_api.AllGather(d_mine, d_all, sizeof(u2), ncclUint8, me->comm[0], (hipStream_t) nullptr));
-        S3D_HIP(hipStreamSynchronize(nullptr));
-        S3D_HIP(hipMemcpy(&u2, d_all, sizeof(u2), hipMemcpyDeviceToHost));
-        S3D_HIP(hipFree(d));
+    ncclResult_t r = g_api.CommInitRank(&me->comm[0], world, u, rank);
+    if (r == ncclSuccess) {
+        /* second lane: rank 0 draws another id, which travels over lane 0 (slot 0 of an all-gather is rank 0's) */
+        if (rank == 0) r = g_api.GetUniqueId(&u2);
+        else memset(&u2, 0, sizeof(u2));
     }
-    S3D_NCCL(g_api.CommInitRank(&me->comm[1], world, u2, rank));
+    if (r == ncclSuccess) {
+        ncclUniqueId *all = (ncclUniqueId *)malloc(sizeof(u2) * (size_t)world);
+        if (all == nullptr || rc_allgather_host(me, &u2, all, sizeof(u2))) {
+            free(all);
+            rc_abort(me);
+            rc_destroy(me);
+            return S3D_ERR;
+        }
+        u2 = all[0];
+        free(all);
+        r = g_api.CommInitRank(&me->comm[1], world, u2, rank);
+    }
+    if (r != ncclSuccess) {
+        s3d_rt_set_error("ncclCommInitRank", g_api.GetErrorString(r));
+        rc_abort(me);                 /* peers blocked in their own initialisation of this communicator are released */
+        rc_destroy(me);
+        return S3D_ERR;
+    }
     fill(t, me);
     return S3D_OK;
 }
@@ -207,16 +280,48 @@ extern "C" int sift3d_amd_rccl_create_all(int world, const int *devices, sift3d_
     if (load_api()) return S3D_ERR;
     if (world < 1 || world > 256) S3D_FAIL("bad world");
     ncclComm_t c0[256], c1[256];
-    S3D_NCCL(g_api.CommInitAll(c0, world, devices));
-    S3D_NCCL(g_api.CommInitAll(c1, world, devices));
-    for (int r = 0; r < world; r++) {
-        Rank *me = (Rank *)calloc(1, sizeof(Rank));
-        if (me == nullptr) S3D_FAIL("out of memory");
-        me->rank = r;
-        me->world = world;
-        me->comm[0] = c0[r];
-        me->comm[1] = c1[r];
-        fill(&t[r], me);
+    Rank *rk[256];
+    int cur = 0, built = 0, ok = 1, have0 = 0, have1 = 0;
+    memset(rk, 0, sizeof(rk));
+    S3D_HIP(hipGetDevice(&cur));
+    for (int r = 0; r < world && ok; r++) {          /* staging and streams first: they live on the ranks' own devices */
+        if (hipSetDevice(devices[r]) != hipSuccess || (rk[r] = rank_new(r, world)) == nullptr) ok = 0;
+        else built = r + 1;
     }
+    (void)hipSetDevice(cur);
+    if (ok) {
+        ncclResult_t r = g_api.CommInitAll(c0, world, devices);
+        have0 = r == ncclSuccess;
+        if (have0) { r = g_api.CommInitAll(c1, world, devices); have1 = r == ncclSuccess; }
+        if (r != ncclSuccess) { s3d_rt_set_error("ncclCommInitAll", g_api.GetErrorString(r)); ok = 0; }
+    }
+    (void)hipSetDevice(cur);
+    if (!ok) {                                        /* nothing is left behind on a failed set-up */
+        for (int r = 0; r < built; r++) {
+            if (have0) rk[r]->comm[0] = c0[r];
+            if (have1) rk[r]->comm[1] = c1[r];
+            rc_abort(rk[r]);
+        }
+        for (int r = 0; r < built; r++) rc_destroy(rk[r]);
+        return S3D_ERR;
+    }
+    for (int r = 0; r < world; r++) {
+        rk[r]->comm[0] = c0[r];
+        rk[r]->comm[1] = c1[r];
+        fill(&t[r], rk[r]);
+    }
+    return S3D_OK;
+}
+
+extern "C" int sift3d_amd_rccl_info(const sift3d_amd_transport *t, int *comm_ranks, int *version)
+{
+    if (t == nullptr || t->allreduce_max != rc_allreduce_max) S3D_FAIL("not an RCCL transport");
+    const Rank *me = (const Rank *)t->self;
+    int n = 0, v = 0;
+    S3D_ALIVE(me);
+    S3D_NCCL(g_api.CommCount(me->comm[0], &n));
+    S3D_NCCL(g_api.GetVersion(&v));
+    if (comm_ranks) *comm_ranks = n;
+    if (version) *version = v;
     return S3D_OK;
 }

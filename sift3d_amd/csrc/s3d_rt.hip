@@ -1,5 +1,7 @@
 /* s3d_rt.hip -- runtime plumbing behind the C-ABI: device memory, copies, streams, events, errors.
  * No compute.  There is deliberately no CPU path: with no HIP device every entry point fails. */
+#include <time.h>
+
 #include "s3d_common.h"
 
 static thread_local char g_err[512] = "";
@@ -53,6 +55,25 @@ extern "C" int s3d_rt_memset(void *d_ptr, int value, size_t bytes, s3d_stream st
     return S3D_OK;
 }
 extern "C" int s3d_rt_sync(s3d_stream st) { S3D_HIP(hipStreamSynchronize((hipStream_t)st)); return S3D_OK; }
+/* hipStreamSynchronize with a deadline: 0 = the stream has drained, 1 = still busy after timeout_s seconds (the caller
+ * decides what to abort), -1 = error.  Polls hipStreamQuery: a short spin, then 20 us naps (a wait that ends within the
+ * spin costs nothing extra; the Z-slab driver has a handful of such waits per detect).  timeout_s <= 0: plain wait. */
+extern "C" int s3d_rt_sync_timeout(s3d_stream st, double timeout_s)
+{
+    if (timeout_s <= 0.0) { S3D_HIP(hipStreamSynchronize((hipStream_t)st)); return S3D_OK; }
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned long it = 0;; it++) {
+        const hipError_t e = hipStreamQuery((hipStream_t)st);
+        if (e == hipSuccess) return S3D_OK;
+        if (e != hipErrorNotReady) { s3d_rt_set_error("hipStreamQuery", hipGetErrorString(e)); return S3D_ERR; }
+        if (it < 2000) continue;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > timeout_s) return 1;
+        const struct timespec nap = {0, 20000};
+        nanosleep(&nap, nullptr);
+    }
+}
 extern "C" int s3d_rt_stream_create(s3d_stream *st)
 {
     hipStream_t s;

@@ -7,6 +7,7 @@ The driver itself -- partitioning, halo exchange schedule, kernel sequence -- is
 * ``loopback_transports``  the library's in-process transport (ranks = host threads, possibly sharing one GPU);
 * ``rccl_transport``       RCCL for one-process-per-GPU jobs: rank 0's 128-byte id is shipped by
                            ``torch.distributed`` (that is all PyTorch does here);
+* ``rccl_all_transports``  RCCL for one process driving N GPUs (ncclCommInitAll), one host thread per rank;
 * ``DistTransport``        a callback transport over ``torch.distributed`` -- gloo in the world_size-2/3 CPU tests
                            (kernels under the SIMT emulator, "device" memory = host memory), and the fall-back of
                            ``bench.py`` should RCCL refuse to initialise;
@@ -30,19 +31,21 @@ EXCHANGE_T = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, 
 ALLGATHER_T = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
 ALLGATHER_HOST_T = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t)
 DESTROY_T = C.CFUNCTYPE(None, _vp)
+ABORT_T = C.CFUNCTYPE(None, _vp)
 
 
 class Transport(C.Structure):              # sift3d_amd_transport
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("self", _vp), ("allreduce_max", ALLREDUCE_T),
                 ("exchange", EXCHANGE_T), ("allgather", ALLGATHER_T), ("allgather_host", ALLGATHER_HOST_T),
-                ("destroy", DESTROY_T)]
+                ("destroy", DESTROY_T), ("abort", ABORT_T)]
 
 
 class SlabInfo(C.Structure):               # sift3d_amd_slab_info
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("z0", C.c_int), ("z1", C.c_int), ("o_shard", C.c_int),
                 ("halo", C.c_int), ("num_octaves", C.c_int), ("num_levels", C.c_int), ("num_candidates", C.c_long),
                 ("num_keypoints", C.c_long), ("halo_bytes", C.c_double), ("device_bytes", C.c_double), ("detect_ms", C.c_double),
-                ("describe_ms", C.c_double)]
+                ("describe_ms", C.c_double), ("comm_ms", C.c_double), ("halo_wait_ms", C.c_double),
+                ("num_described", C.c_long)]
 
 
 def bind(L: C.CDLL) -> C.CDLL:
@@ -79,9 +82,13 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.s3d_rt_sync.argtypes = [_vp]
     L.s3d_rt_last_error.restype = C.c_char_p
     L.sift3d_amd_last_error.restype = C.c_char_p
-    if hasattr(L, "sift3d_amd_rccl_unique_id"):          # absent from the CPU emulator build
+    L.sift3d_amd_slab_test_inject.argtypes = [C.c_int, C.c_int]
+    L.sift3d_amd_slab_test_inject.restype = None
+    if hasattr(L, "sift3d_amd_rccl_unique_id"):          # absent from builds without the RCCL transport
         L.sift3d_amd_rccl_unique_id.argtypes = [C.c_char_p]
         L.sift3d_amd_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int, P(Transport)]
+        L.sift3d_amd_rccl_create_all.argtypes = [C.c_int, P(C.c_int), P(Transport)]
+        L.sift3d_amd_rccl_info.argtypes = [P(Transport), P(C.c_int), P(C.c_int)]
     L._slab_bound = True
     return L
 
@@ -107,9 +114,29 @@ def loopback_transports(L: C.CDLL, world: int):
     return arr
 
 
+def rccl_all_transports(L: C.CDLL, world: int, devices=None):
+    """RCCL communicators for `world` GPUs of THIS process (ncclCommInitAll): transport r drives devices[r]; the caller
+    runs one host thread per rank with that device current.  No launcher, no torch.distributed."""
+    bind(L)
+    arr = (Transport * world)()
+    devs = (C.c_int * world)(*(devices if devices is not None else range(world)))
+    if L.sift3d_amd_rccl_create_all(world, devs, arr) != 0:
+        raise RuntimeError("sift3d_amd_rccl_create_all: " + (L.s3d_rt_last_error() or b"").decode())
+    return arr
+
+
+def rccl_info(L: C.CDLL, t: Transport):
+    """(ranks of the communicator, RCCL version code) as the library reports them."""
+    bind(L)
+    n, v = C.c_int(), C.c_int()
+    if L.sift3d_amd_rccl_info(C.byref(t), C.byref(n), C.byref(v)) != 0:
+        raise RuntimeError("sift3d_amd_rccl_info: " + (L.s3d_rt_last_error() or b"").decode())
+    return n.value, v.value
+
+
 def rccl_transport(L: C.CDLL, dist, rank: int, world: int) -> Transport:
-    """RCCL communicators for this process's current HIP device; `dist` (torch.distributed, any backend) only carries
-    rank 0's unique id to the other ranks."""
+    """RCCL communicators for this process's current HIP device; `dist` (torch.distributed, any backend -- gloo will
+    do) only carries rank 0's unique id to the other ranks."""
     import torch
     bind(L)
     buf = C.create_string_buffer(RCCL_ID_BYTES)

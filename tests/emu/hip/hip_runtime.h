@@ -286,6 +286,8 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipErrorNotReady 600
+static inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
 #define hipStreamNonBlocking 1

@@ -20,7 +20,7 @@ typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;
 typedef int ncclDataType_t;
 typedef int ncclRedOp_t;
-enum { ncclSuccess = 0, ncclInvalidArgument = 4, ncclInvalidUsage = 5 };
+enum { ncclSuccess = 0, ncclSystemError = 2, ncclInvalidArgument = 4, ncclInvalidUsage = 5 };
 
 #define MAXW 64
 typedef struct Group {
@@ -31,6 +31,7 @@ typedef struct Group {
     const void *sbuf[MAXW];
     int arrived;
     unsigned long gen;
+    int aborted;                                          /* ncclCommAbort on any rank's communicator: every wait ends */
     struct { const void *src; size_t bytes; int state; } box[MAXW][MAXW];   /* [from][to]; 0 empty, 1 posted, 2 consumed */
     struct Group *next;
 } Group;
@@ -58,19 +59,24 @@ static Group *group_new(const char id[128], int world)
     return g;
 }
 
-/* reusable barrier over the ranks of a group */
-static void barrier(Group *g)
+/* reusable barrier over the ranks of a group; -1 once the group has been aborted */
+static int barrier(Group *g)
 {
+    int rc;
     pthread_mutex_lock(&g->mu);
     const unsigned long gen = g->gen;
-    if (++g->arrived == g->world) {
+    if (g->aborted) {
+        /* nothing */
+    } else if (++g->arrived == g->world) {
         g->arrived = 0;
         g->gen++;
         pthread_cond_broadcast(&g->cv);
     } else {
-        while (g->gen == gen) pthread_cond_wait(&g->cv, &g->mu);
+        while (g->gen == gen && !g->aborted) pthread_cond_wait(&g->cv, &g->mu);
     }
+    rc = g->aborted ? -1 : 0;
     pthread_mutex_unlock(&g->mu);
+    return rc;
 }
 
 ncclResult_t ncclGetUniqueId(ncclUniqueId *u)
@@ -98,9 +104,10 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     pthread_mutex_lock(&g->mu);                          /* like the real call: returns when every rank has joined */
     g->joined++;
     pthread_cond_broadcast(&g->cv);
-    while (g->joined < g->world) pthread_cond_wait(&g->cv, &g->mu);
+    while (g->joined < g->world && !g->aborted) pthread_cond_wait(&g->cv, &g->mu);
+    const int dead = g->aborted;
     pthread_mutex_unlock(&g->mu);
-    return ncclSuccess;
+    return dead ? ncclSystemError : ncclSuccess;
 }
 
 ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist)
@@ -124,6 +131,23 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist)
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) { free(comm); return ncclSuccess; }
 
+/* Like the real call: this rank's pending and future operations end.  The mock's operations block on the host until
+ * the partners arrive, so the whole group is released (on hardware the peers' kernels would spin until their own
+ * communicators are aborted too -- which is what the driver does: it aborts every rank's transport). */
+ncclResult_t ncclCommAbort(ncclComm_t comm)
+{
+    Group *g = comm->g;
+    pthread_mutex_lock(&g->mu);
+    g->aborted = 1;
+    pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->mu);
+    free(comm);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) { *count = comm->g->world; return ncclSuccess; }
+ncclResult_t ncclGetVersion(int *version) { *version = 99999; return ncclSuccess; }   /* recognisably not a real RCCL */
+
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c, hipStream_t st)
 {
     Group *g = c->g;
@@ -133,7 +157,7 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
     pthread_mutex_lock(&g->mu);
     g->sbuf[c->rank] = send;
     pthread_mutex_unlock(&g->mu);
-    barrier(g);
+    if (barrier(g)) return ncclSystemError;
     tmp = (float *)malloc(sizeof(float) * (count ? count : 1));
     for (size_t i = 0; i < count; i++) {
         float m = ((const float *)g->sbuf[0])[i];
@@ -143,11 +167,10 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
         }
         tmp[i] = m;
     }
-    barrier(g);                                          /* everybody has read everybody's input (in-place calls) */
+    if (barrier(g)) { free(tmp); return ncclSystemError; }   /* everybody has read everybody's input (in-place calls) */
     memcpy(recv, tmp, sizeof(float) * count);
     free(tmp);
-    barrier(g);
-    return ncclSuccess;
+    return barrier(g) ? ncclSystemError : ncclSuccess;
 }
 
 ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclComm_t c, hipStream_t st)
@@ -159,10 +182,9 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     pthread_mutex_lock(&g->mu);
     g->sbuf[c->rank] = send;
     pthread_mutex_unlock(&g->mu);
-    barrier(g);
+    if (barrier(g)) return ncclSystemError;
     for (int r = 0; r < g->world; r++) memmove((char *)recv + (size_t)r * bytes, g->sbuf[r], bytes);
-    barrier(g);
-    return ncclSuccess;
+    return barrier(g) ? ncclSystemError : ncclSuccess;
 }
 
 /* ---- grouped point-to-point ------------------------------------------------------------------------------------- */
@@ -178,7 +200,8 @@ static ncclResult_t run_ops(void)
         Group *g = o->c->g;
         if (!o->is_send) continue;
         pthread_mutex_lock(&g->mu);
-        while (g->box[o->c->rank][o->peer].state != 0) pthread_cond_wait(&g->cv, &g->mu);
+        while (g->box[o->c->rank][o->peer].state != 0 && !g->aborted) pthread_cond_wait(&g->cv, &g->mu);
+        if (g->aborted) { pthread_mutex_unlock(&g->mu); t_nops = 0; return ncclSystemError; }
         g->box[o->c->rank][o->peer].src = o->buf;
         g->box[o->c->rank][o->peer].bytes = o->bytes;
         g->box[o->c->rank][o->peer].state = 1;
@@ -190,7 +213,8 @@ static ncclResult_t run_ops(void)
         Group *g = o->c->g;
         if (o->is_send) continue;
         pthread_mutex_lock(&g->mu);
-        while (g->box[o->peer][o->c->rank].state != 1) pthread_cond_wait(&g->cv, &g->mu);
+        while (g->box[o->peer][o->c->rank].state != 1 && !g->aborted) pthread_cond_wait(&g->cv, &g->mu);
+        if (g->aborted) { pthread_mutex_unlock(&g->mu); t_nops = 0; return ncclSystemError; }
         if (g->box[o->peer][o->c->rank].bytes != o->bytes) {
             fprintf(stderr, "mock rccl: rank %d expects %zu bytes from rank %d, which sends %zu\n", o->c->rank, o->bytes, o->peer,
                     g->box[o->peer][o->c->rank].bytes);
@@ -207,7 +231,8 @@ static ncclResult_t run_ops(void)
         Group *g = o->c->g;
         if (!o->is_send) continue;
         pthread_mutex_lock(&g->mu);
-        while (g->box[o->c->rank][o->peer].state != 2) pthread_cond_wait(&g->cv, &g->mu);
+        while (g->box[o->c->rank][o->peer].state != 2 && !g->aborted) pthread_cond_wait(&g->cv, &g->mu);
+        if (g->aborted) { pthread_mutex_unlock(&g->mu); t_nops = 0; return ncclSystemError; }
         g->box[o->c->rank][o->peer].state = 0;
         pthread_cond_broadcast(&g->cv);
         pthread_mutex_unlock(&g->mu);

@@ -22,6 +22,9 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
 ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count);
+ncclResult_t ncclGetVersion(int *version);
 ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
                            ncclComm_t comm, hipStream_t stream);
 ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,

