@@ -191,13 +191,19 @@ static void ctx_release(int handle)
     s3d_ctx *c;
     if (handle < 1 || handle > S3D_MAX_CTX) return;
     pthread_mutex_lock(&g_ctx_lock);
+    int live = 0;
     c = g_ctx[handle - 1];
     g_ctx[handle - 1] = NULL;
+    for (int i = 0; i < S3D_MAX_CTX; i++) live += g_ctx[i] != NULL;
     pthread_mutex_unlock(&g_ctx_lock);
     if (c) {
         s3d_mgpu_free(c->mgpu);
         ctx_free_all(c);
         free(c);
+        /* The matcher's scratch (score matrix and operand copies, up to ~9 GiB at 31 k x 31 k) is kept per device between
+         * calls.  It belongs to no SIFT3D struct, so it goes when the last one does: a process that is done with its
+         * structs gets the memory back, one that matches in a loop keeps a struct alive anyway. */
+        if (live == 0) s3d_k_nn_release_scratch();
     }
 }
 

@@ -523,7 +523,14 @@ k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict_
 #define NN_DEVS 16
 struct NnPool { void *p[NN_SLOTS]; size_t cap[NN_SLOTS]; };
 static NnPool g_nn_pool[NN_DEVS];
-static pthread_mutex_t g_nn_lock = PTHREAD_MUTEX_INITIALIZER;
+/* one lock per device pool: matches on different GPUs of one process (the in-process Z-slab ranks) do not take turns */
+static pthread_mutex_t g_nn_locks[NN_DEVS] = {
+    PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
+    PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
+    PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER,
+    PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER};
+static_assert(NN_DEVS == 16, "initialiser list of g_nn_locks");
+#define NN_UNLOCK(pool) pthread_mutex_unlock(&g_nn_locks[(pool) - g_nn_pool])
 
 static void *nn_get(NnPool *pool, int slot, size_t bytes)
 {
@@ -541,7 +548,7 @@ static NnPool *nn_pool_lock(void)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NN_DEVS) return nullptr;
-    pthread_mutex_lock(&g_nn_lock);
+    pthread_mutex_lock(&g_nn_locks[dev]);
     return &g_nn_pool[dev];
 }
 
@@ -549,13 +556,32 @@ extern "C" void s3d_k_nn_release_scratch(void)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NN_DEVS) return;
-    pthread_mutex_lock(&g_nn_lock);
+    pthread_mutex_lock(&g_nn_locks[dev]);
     for (int k = 0; k < NN_SLOTS; k++) {
         if (g_nn_pool[dev].p[k]) (void)hipFree(g_nn_pool[dev].p[k]);
         g_nn_pool[dev].p[k] = nullptr;
         g_nn_pool[dev].cap[k] = 0;
     }
-    pthread_mutex_unlock(&g_nn_lock);
+    pthread_mutex_unlock(&g_nn_locks[dev]);
+}
+
+/* The f16 hi / lo split (every element x 2^8: hi = f16, lo = f16 of the remainder) stays inside the error band of the
+ * scan only while no element overflows f16 (|x| 2^8 < 65504) and the remainders are not swallowed by f16's subnormal
+ * step (6e-8 / 2^8 per element: 6.4e-9 per descriptor, to be small against 1e-4 |b|): descriptors as the library
+ * produces them -- unit norm, elements <= 0.2 -- are far inside, stores a caller built or read from a file need not be.
+ * So the squared norms, which come to the host anyway, decide: every norm finite, in [1e-3, 200].  Anything else
+ * (including NaN, which no comparison of the scan would ever accept) goes to the exhaustive kernel. */
+static bool nn_norms_qualify(const double *n2, uint32_t n, double *n2max)
+{
+    double mx = 0.0;
+    bool ok = true;
+    for (uint32_t i = 0; i < n; i++) {
+        const double v = n2[i];
+        if (!(v >= 1e-6 && v <= 4e4)) ok = false;        /* false for NaN as well */
+        mx = v > mx ? v : mx;
+    }
+    *n2max = mx;
+    return ok;
 }
 
 /* Same contract as s3d_k_nn_best2.  Returns 1 (outputs undefined) when a row had more than NN_CAP
@@ -595,10 +621,18 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
                        (const int *)nullptr, nb, nbpad, BH, BL);
     hipLaunchKernelGGL(k_nn_norms, dim3(napad), dim3(64), 0, st, d_a, a_stride, d_a_sel, na, napad, a2d, a2f);
     hipLaunchKernelGGL(k_nn_norms, dim3(nbpad), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, nbpad, b2d, b2f);
-    if ((h_b2 = (double *)malloc(sizeof(double) * nb)) == nullptr) goto done;
-    NN_TRY(hipMemcpyAsync(h_b2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
-    NN_TRY(hipStreamSynchronize(st));
-    for (uint32_t j = 0; j < nb; j++) b2max = h_b2[j] > b2max ? h_b2[j] : b2max;
+    if ((h_b2 = (double *)malloc(sizeof(double) * (na > nb ? na : nb))) == nullptr) goto done;
+    {
+        double a2max = 0.0;
+        bool ok;
+        NN_TRY(hipMemcpyAsync(h_b2, a2d, sizeof(double) * na, hipMemcpyDeviceToHost, st));
+        NN_TRY(hipStreamSynchronize(st));
+        ok = nn_norms_qualify(h_b2, na, &a2max);
+        NN_TRY(hipMemcpyAsync(h_b2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+        NN_TRY(hipStreamSynchronize(st));
+        ok = nn_norms_qualify(h_b2, nb, &b2max) && ok;
+        if (!ok) { rc = 1; goto done; }                   /* operands outside the split's range: the exhaustive kernel */
+    }
     for (size_t r0 = 0; r0 < napad; r0 += rows_chunk) {
         const unsigned rows = (unsigned)(r0 + rows_chunk <= napad ? rows_chunk : napad - r0);
         hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AH, AL, (unsigned)r0, BH, BL, nbpad, a2f,
@@ -618,7 +652,7 @@ done:
 #undef NN_TRY
 #undef NN_GET
     if (rc < 0) (void)hipStreamSynchronize(st);              /* nothing of this call may still use the scratch */
-    pthread_mutex_unlock(&g_nn_lock);
+    NN_UNLOCK(pool);
     free(h_b2);
     return rc;
 }
@@ -714,12 +748,16 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     hipLaunchKernelGGL(k_nn_norms, dim3(napad), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, napad, a2d, a2f);
     hipLaunchKernelGGL(k_nn_norms, dim3(nbpad), dim3(64), 0, st, d_b, b_stride, (const int *)nullptr, nb, nbpad, b2d, b2f);
     if ((h_n2 = (double *)malloc(sizeof(double) * (na > nb ? na : nb))) == nullptr) goto done;
-    NN_TRY(hipMemcpyAsync(h_n2, a2d, sizeof(double) * na, hipMemcpyDeviceToHost, st));
-    NN_TRY(hipStreamSynchronize(st));
-    for (uint32_t i = 0; i < na; i++) a2max = h_n2[i] > a2max ? h_n2[i] : a2max;
-    NN_TRY(hipMemcpyAsync(h_n2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
-    NN_TRY(hipStreamSynchronize(st));
-    for (uint32_t j = 0; j < nb; j++) b2max = h_n2[j] > b2max ? h_n2[j] : b2max;
+    {
+        bool ok;
+        NN_TRY(hipMemcpyAsync(h_n2, a2d, sizeof(double) * na, hipMemcpyDeviceToHost, st));
+        NN_TRY(hipStreamSynchronize(st));
+        ok = nn_norms_qualify(h_n2, na, &a2max);
+        NN_TRY(hipMemcpyAsync(h_n2, b2d, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+        NN_TRY(hipStreamSynchronize(st));
+        ok = nn_norms_qualify(h_n2, nb, &b2max) && ok;
+        if (!ok) { rc = 1; goto done; }                   /* operands outside the split's range: the exhaustive kernel */
+    }
     NN_TRY(hipMemsetAsync(countb, 0, sizeof(int) * nb, st));
     hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2,
                        rmin);
@@ -739,7 +777,7 @@ done:
 #undef NN_TRY
 #undef NN_GET
     if (rc < 0) (void)hipStreamSynchronize(st);              /* nothing of this call may still use the scratch */
-    pthread_mutex_unlock(&g_nn_lock);
+    NN_UNLOCK(pool);
     free(h_n2);
     return rc;
 }

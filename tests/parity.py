@@ -399,6 +399,30 @@ def check_nn_match_duplicates(lib, oracle, thr=0.8):
     return int((want >= 0).sum())
 
 
+def check_nn_match_unnormalised(lib, oracle, thr=0.8):
+    """Descriptor stores a caller built (or read from a file) need not be unit vectors.  The screened matcher's f16
+    hi / lo split only holds for norms in [1e-3, 200]: everything else -- very large, very small, a NaN row -- must go to
+    the exhaustive kernel and still return the reference's matches (it used to produce inf / NaN scores and
+    drop the true neighbour silently)."""
+    from tests.util import rand_desc, match_sets
+    base = rand_desc(90, 41)
+    n = 0
+    for scale in (1000.0, 300.0, 1e-4):                              # |x| 2^8 beyond f16 / remainders below its subnormals
+        d1 = (base * np.float32(scale)).astype(np.float32)
+        d2 = match_sets(d1, 141)
+        want = oracle.nn_match(d1, d2, thr)
+        rc, got, _ = nn_match_api(lib, d1, d2, thr)
+        assert rc == 0 and np.array_equal(got, want), scale
+        n += int((want >= 0).sum())
+    d1 = base.copy()
+    d2 = match_sets(d1, 142)
+    d2[5, 17] = np.nan                                               # one poisoned record in the second set
+    want = oracle.nn_match(d1, d2, thr)
+    rc, got, _ = nn_match_api(lib, d1, d2, thr)
+    assert rc == 0 and np.array_equal(got, want)
+    return n + int((want >= 0).sum())
+
+
 def check_expf(lib, n=1 << 22, seed=9):
     """The kernels' window-weight exponential against the host libm's expf -- the function the reference calls
     (sift.c:1401, 1890, 2333) -- bit for bit, on n arguments covering the window range [-4.5, 0] densely and

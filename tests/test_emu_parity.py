@@ -128,6 +128,10 @@ def test_nn_match_candidate_overflow(emu, oracle):
     assert parity.check_nn_match_duplicates(emu, oracle) >= 3
 
 
+def test_nn_match_unnormalised_stores(emu, oracle):
+    assert parity.check_nn_match_unnormalised(emu, oracle) > 20
+
+
 def test_window_weight_expf_matches_host_libm(emu):
     """s3d_expf restates glibc's expf; the descriptor is discontinuous in the window weight (s3d_math.h)."""
     nchecked, ndiff_cr = parity.check_expf(emu, n=1 << 18)

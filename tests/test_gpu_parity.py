@@ -247,6 +247,12 @@ def test_nn_match_candidate_overflow(lib, oracle):
     assert parity.check_nn_match_duplicates(lib, oracle) >= 3
 
 
+def test_nn_match_unnormalised_stores(lib, oracle):
+    """Stores outside the screened matcher's operand range (norms beyond [1e-3, 200], a NaN record) go to the exhaustive
+    kernel: the reference's matches all the same."""
+    assert parity.check_nn_match_unnormalised(lib, oracle) > 20
+
+
 @pytest.mark.parametrize("n1,seed", [(3001, 4), (1000, 3)])
 def test_nn_match_exhaustive_kernel(lib, oracle, n1, seed):
     """The exhaustive f64 kernel (the fallback of the screened matcher) on its own."""

@@ -88,3 +88,17 @@ def test_raw_variants_live(oracle, reference, dims, units, nblobs, seed):
     wb, wx, wR2, wcf = parity.oracle_raw_variants(oracle, vol, units, xyzos, sd, R)
     assert nbitdiff(bins, wb) == 0 and np.array_equal(xyzs, wx)
     assert nbitdiff(R2.reshape(-1, 3, 3).astype(np.float32), wR2) == 0 and np.array_equal(cf, wcf)
+
+
+@pytest.mark.parametrize("scale,poison", [(1000.0, False), (1e-4, False), (1.0, True)])
+def test_nn_match_unnormalised_live(oracle, reference, scale, poison):
+    """The matcher restatement on stores that are not unit vectors, and with a NaN record: what the reference does."""
+    from tests import parity
+    from tests.util import rand_desc, match_sets
+    d1 = (rand_desc(90, 41) * np.float32(scale)).astype(np.float32)
+    d2 = match_sets(d1, 141)
+    if poison:
+        d2[5, 17] = np.nan
+    rc, want, _ = parity.nn_match_api(reference, d1, d2, 0.8)
+    assert rc == 0
+    assert np.array_equal(oracle.nn_match(d1, d2, 0.8), want)
