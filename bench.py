@@ -423,8 +423,18 @@ def add_roofline(result, dev, n):
             traffic_source = "profiles/pmc_gauss.json was measured on a different s3d_gauss.hip: not used"
     except Exception:
         traffic = None
+    # What the kernel physically does, next to the algorithmic figure: the PMC bytes of one launch over the same
+    # HIP-event time.  `frac` credits the fusion (two algorithmic passes for one read and one write of the volume);
+    # `physical_frac` is the DRAM-side rate against the same 8 TB/s -- the guide's float4-copy ceiling is 6.29 TB/s.
+    phys = traffic / (worst["xy_ms"] * 1e-3) / 1e9 if traffic else None
     result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                          "physical_GBs": round(phys, 1) if phys else None,
+                          "physical_frac": round(phys / HBM_PEAK_GBS, 4) if phys else None,
+                          "physical_frac_of_copy_ceiling": round(phys / 6290.0, 4) if phys else None,
+                          "time_source": f"HIP events on the launch stream inside this run (s3d_k_gauss_set_events), mean of 5 launches: "
+                                         f"{worst['xy_ms']} ms; the rocprofv3 --kernel-trace --stats average of the same kernel is kept in "
+                                         f"profiles/ (per round: r03_*_kernel_stats.md) and is a few per cent shorter (no event overhead)",
                           "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
                                     f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
     result["config"]["gauss_apps"] = apps

@@ -838,6 +838,11 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
     constexpr int NR = (PAD + 4 + 2 * HW + 3) / 4;    /* float4 LDS reads per lane */
     constexpr int LINE = XY_STRIP + 4 * NR;           /* >= PAD + XY_STRIP + 2 HW, multiple of 4 */
     __shared__ __attribute__((aligned(16))) float line2[2][LINE];   /* double buffered */
+    /* the edge lanes' blend weights (1 - f_j, f_j): two registers that are live across the whole march and only touched
+     * once per row by a handful of lanes.  At HW = 8 the register allocator spilled exactly these to scratch, and the
+     * reload inside the row loop came with s_waitcnt vmcnt(0): every prefetched source row was waited for before the
+     * blend.  Parked in LDS (read with lgkmcnt) they cost the march nothing. */
+    __shared__ float2 edge_w[64];
 
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * XY_STRIP;
@@ -877,6 +882,7 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
             }
         }
     }
+    edge_w[lane] = make_float2(1.0f - fj, fj);
     const bool live = xq < nx;                        /* nx % 4 == 0: a lane is all-in or all-out */
     const int xq_ld = live ? xq : nx - 4;             /* clamped, aligned, always readable */
 
@@ -903,7 +909,10 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
         lbuf ^= 1;
         *reinterpret_cast<float4 *>(&line[OFF + 4 * lane]) = r.b;
         s3d_wave_lds_sync();                           /* body before edge slots */
-        if (slot >= 0) line[slot] = isblend ? ((1.0f - fj) * r.a0 + fj * r.a1) : r.a0;
+        if (slot >= 0) {
+            const float2 w = edge_w[lane];
+            line[slot] = isblend ? (w.x * r.a0 + w.y * r.a1) : r.a0;
+        }
         s3d_wave_lds_sync();
         float v[4 * NR];
 #pragma unroll
@@ -991,8 +1000,11 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
     }
 }
 
+/* >= 3 waves per SIMD caps the ring kernels at 168 VGPRs: enough up to HW = 8 (width 17, the widest filter of the default
+ * bank) without a private segment; wider filters take 2 waves per SIMD rather than spill inside the march */
+#define GAUSS_XY_WAVES(HW) ((HW) >= 9 ? 2 : 3)
 template <int HW>
-__global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
+__global__ void __launch_bounds__(64, GAUSS_XY_WAVES(HW))
 k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
            EdgeFrac efx, EdgeFrac efy)
 {
@@ -1000,7 +1012,7 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
 }
 
 template <int HW>
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, GAUSS_XY_WAVES(HW))
 k_gauss_xy_div(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
                EdgeFrac efx, EdgeFrac efy, const float *__restrict__ d_div)
 {

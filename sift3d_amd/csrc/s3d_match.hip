@@ -290,7 +290,10 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
           float *__restrict__ S /* rows x nbpad */, float *__restrict__ pm1, float *__restrict__ pm2 /* optional: see below */,
           float *__restrict__ rmin /* rows x nbpad/64: smallest score of every (row, 64-column block) */)
 {
-    __shared__ __attribute__((aligned(16))) nn_half sm[4][GT][GLD];      /* A hi, A lo, B hi, B lo */
+    /* Two LDS buffers: while the waves multiply out of one, the next k-step's panels (already in registers: their global
+     * loads were issued a whole step earlier) are stored into the other -- ONE barrier per k-step instead of two, and no
+     * MFMA-free stretch between "store" and "multiply".  80 KB of the CU's 160 KB. */
+    __shared__ __attribute__((aligned(16))) nn_half sm[2][4][GT][GLD];   /* [buffer][A hi, A lo, B hi, B lo] */
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     const unsigned i0 = row_base + blockIdx.y * GT, j0 = blockIdx.x * GT;
     nn_acc16 acc[2][2];
@@ -309,28 +312,35 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
                 stage[p][u] = *reinterpret_cast<const nn_h8 *>(gsrc[p] + (size_t)row * NEL + e0 + 8 * q);
             }
     };
-    fetch(0);
-    for (int e0 = 0; e0 < NEL; e0 += GKH) {
-        __syncthreads();
+    auto park = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int c = t + 256 * u, row = c >> 2, q = c & 3;
-                *reinterpret_cast<nn_h8 *>(&sm[p][row][8 * q]) = stage[p][u];
+                *reinterpret_cast<nn_h8 *>(&sm[buf][p][row][8 * q]) = stage[p][u];
             }
-        __syncthreads();
-        if (e0 + GKH < NEL) fetch(e0 + GKH);
+    };
+    fetch(0);
+    park(0);
+    if (GKH < NEL) fetch(GKH);
+    __syncthreads();
+    int buf = 0;
+    for (int e0 = 0; e0 < NEL; e0 += GKH, buf ^= 1) {
+        if (e0 + GKH < NEL) {
+            park(buf ^ 1);                                  /* step e0 + GKH: read by nobody before the barrier below */
+            if (e0 + 2 * GKH < NEL) fetch(e0 + 2 * GKH);
+        }
 #pragma unroll
         for (int kk = 0; kk < GKH; kk += 16) {
             nn_h8 ah[2], al[2], bh[2], bl[2];
             const int ko = kk + 8 * (lane >> 5), rl = lane & 31;
 #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
-                ah[tt] = *reinterpret_cast<const nn_h8 *>(&sm[0][wm * 64 + tt * 32 + rl][ko]);
-                al[tt] = *reinterpret_cast<const nn_h8 *>(&sm[1][wm * 64 + tt * 32 + rl][ko]);
-                bh[tt] = *reinterpret_cast<const nn_h8 *>(&sm[2][wn * 64 + tt * 32 + rl][ko]);
-                bl[tt] = *reinterpret_cast<const nn_h8 *>(&sm[3][wn * 64 + tt * 32 + rl][ko]);
+                ah[tt] = *reinterpret_cast<const nn_h8 *>(&sm[buf][0][wm * 64 + tt * 32 + rl][ko]);
+                al[tt] = *reinterpret_cast<const nn_h8 *>(&sm[buf][1][wm * 64 + tt * 32 + rl][ko]);
+                bh[tt] = *reinterpret_cast<const nn_h8 *>(&sm[buf][2][wn * 64 + tt * 32 + rl][ko]);
+                bl[tt] = *reinterpret_cast<const nn_h8 *>(&sm[buf][3][wn * 64 + tt * 32 + rl][ko]);
             }
 #pragma unroll
             for (int tm = 0; tm < 2; tm++)
@@ -341,6 +351,7 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
                     nn_mfma(acc[tm][tn], al[tm], bh[tn]);
                 }
         }
+        __syncthreads();                                    /* buffer `buf` is free, buffer `buf ^ 1` is complete */
     }
     /* D register r of a lane: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of its 32 x 32 tile */
     const float unscale = 2.0f / (NN_SCALE * NN_SCALE);
