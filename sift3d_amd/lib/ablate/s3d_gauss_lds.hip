@@ -838,6 +838,12 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
     constexpr int NR = (PAD + 4 + 2 * HW + 3) / 4;    /* float4 LDS reads per lane */
     constexpr int LINE = XY_STRIP + 4 * NR;           /* >= PAD + XY_STRIP + 2 HW, multiple of 4 */
     __shared__ __attribute__((aligned(16))) float line2[2][LINE];   /* double buffered */
+    /* the edge lanes' blend weights (1 - f_j, f_j): two registers that are live across the whole march and only touched
+     * once per row by a handful of lanes.  At HW = 8 the register allocator spilled exactly these to scratch, and the
+     * reload inside the row loop came with s_waitcnt vmcnt(0): every prefetched source row was waited for before the
+     * blend.  Parked in LDS (read with lgkmcnt) they cost the march nothing. */
+    __shared__ float2 edge_w[64];
+
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * XY_STRIP;
     const int xq = x0 + 4 * lane;                     /* this lane's 4 output columns */
@@ -876,9 +882,7 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
             }
         }
     }
-    /* fj < 0 marks "no blend" (f_j itself lies in (0, 1)): one register instead of a flag and a weight pair -- at HW = 8 the
-     * allocator had spilled exactly such a pair to scratch and reloaded it inside the row loop */
-    if (!isblend) fj = -1.0f;
+    edge_w[lane] = make_float2(1.0f - fj, fj);
     const bool live = xq < nx;                        /* nx % 4 == 0: a lane is all-in or all-out */
     const int xq_ld = live ? xq : nx - 4;             /* clamped, aligned, always readable */
 
@@ -906,11 +910,8 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
         *reinterpret_cast<float4 *>(&line[OFF + 4 * lane]) = r.b;
         s3d_wave_lds_sync();                           /* body before edge slots */
         if (slot >= 0) {
-            float f = fj;
-#if !defined(S3D_EMU)
-            asm volatile("" : "+v"(f));                    /* keeps (1 - f) from being hoisted into a second long-lived register */
-#endif
-            line[slot] = f >= 0.0f ? ((1.0f - f) * r.a0 + f * r.a1) : r.a0;
+            const float2 w = edge_w[lane];
+            line[slot] = isblend ? (w.x * r.a0 + w.y * r.a1) : r.a0;
         }
         s3d_wave_lds_sync();
         float v[4 * NR];

@@ -838,6 +838,7 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
     constexpr int NR = (PAD + 4 + 2 * HW + 3) / 4;    /* float4 LDS reads per lane */
     constexpr int LINE = XY_STRIP + 4 * NR;           /* >= PAD + XY_STRIP + 2 HW, multiple of 4 */
     __shared__ __attribute__((aligned(16))) float line2[2][LINE];   /* double buffered */
+
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * XY_STRIP;
     const int xq = x0 + 4 * lane;                     /* this lane's 4 output columns */
@@ -876,9 +877,6 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
             }
         }
     }
-    /* fj < 0 marks "no blend" (f_j itself lies in (0, 1)): one register instead of a flag and a weight pair -- at HW = 8 the
-     * allocator had spilled exactly such a pair to scratch and reloaded it inside the row loop */
-    if (!isblend) fj = -1.0f;
     const bool live = xq < nx;                        /* nx % 4 == 0: a lane is all-in or all-out */
     const int xq_ld = live ? xq : nx - 4;             /* clamped, aligned, always readable */
 
@@ -905,13 +903,7 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
         lbuf ^= 1;
         *reinterpret_cast<float4 *>(&line[OFF + 4 * lane]) = r.b;
         s3d_wave_lds_sync();                           /* body before edge slots */
-        if (slot >= 0) {
-            float f = fj;
-#if !defined(S3D_EMU)
-            asm volatile("" : "+v"(f));                    /* keeps (1 - f) from being hoisted into a second long-lived register */
-#endif
-            line[slot] = f >= 0.0f ? ((1.0f - f) * r.a0 + f * r.a1) : r.a0;
-        }
+        if (slot >= 0) line[slot] = isblend ? ((1.0f - fj) * r.a0 + fj * r.a1) : r.a0;
         s3d_wave_lds_sync();
         float v[4 * NR];
 #pragma unroll
@@ -999,11 +991,8 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
     }
 }
 
-/* >= 3 waves per SIMD caps the ring kernels at 168 VGPRs: enough up to HW = 8 (width 17, the widest filter of the default
- * bank) without a private segment; wider filters take 2 waves per SIMD rather than spill inside the march */
-#define GAUSS_XY_WAVES(HW) ((HW) >= 9 ? 2 : 3)
 template <int HW>
-__global__ void __launch_bounds__(64, GAUSS_XY_WAVES(HW))
+__global__ void __launch_bounds__(64, 3)      /* >= 3 waves per SIMD: caps the ring kernels at 168 VGPRs */
 k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
            EdgeFrac efx, EdgeFrac efy)
 {
@@ -1011,7 +1000,7 @@ k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int n
 }
 
 template <int HW>
-__global__ void __launch_bounds__(64, GAUSS_XY_WAVES(HW))
+__global__ void __launch_bounds__(64, 3)
 k_gauss_xy_div(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
                EdgeFrac efx, EdgeFrac efy, const float *__restrict__ d_div)
 {
