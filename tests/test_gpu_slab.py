@@ -139,6 +139,11 @@ def test_rccl_transport_with_a_world_of_one(hip):
     g = np.zeros(5, np.int64)
     assert t.allgather_host(t.self, h.ctypes.data, g.ctypes.data, h.nbytes) == 0 and np.array_equal(g, h)
     assert t.exchange(t.self, d_a, d_b, d_a, d_b, 12, 1, None) == 0          # no neighbours: nothing moves
+    ranks, version = S.rccl_info(L, t)                                       # what the communicator itself reports
+    assert ranks == 1 and version >= 20000
+    big = np.arange(3 * (1 << 20) + 5, dtype=np.int64)                       # 24 MiB: three pieces of the fixed staging + a tail
+    gbig = np.zeros_like(big)
+    assert t.allgather_host(t.self, big.ctypes.data, gbig.ctypes.data, big.nbytes) == 0 and np.array_equal(gbig, big)
     vol = synth.blobs(64, 64, 64, 250, 3)
     want = single_gpu(hip, vol)
     sl = S.Slab(L, t, 64, 64, 64)
@@ -147,9 +152,90 @@ def test_rccl_transport_with_a_world_of_one(hip):
     assert np.array_equal(abi.Sift3dLib.keypoints_to_numpy(sl.kp)[0], want[0])
     assert np.array_equal(abi.Sift3dLib.descriptors_to_numpy(sl.desc)[0], want[3])
     sl.close()
+    t.abort(t.self)                                                          # ncclCommAbort on both lanes ...
+    assert t.allreduce_max(t.self, d_a, 3, None) != 0                        # ... after which every operation fails at once
+    t.abort(t.self)                                                          # idempotent
     t.destroy(t.self)
     dev.free(d_a)
     dev.free(d_b)
+
+
+def test_failed_rank_does_not_hang_on_the_device(hip):
+    """The abort path on real streams (loop-back ranks sharing this GPU): rank 1 fails in the middle of the pyramid, after
+    the first halo exchange, with kernels and copies of both ranks in flight.  SIFT3D_detect_keypoints must come back with
+    SIFT3D_FAILURE (pytest-timeout / the driver's limit is the no-hang assertion), and the same struct must then produce the
+    single-GPU result.  The same for a failure inside a describe."""
+    L = S.bind(hip.sift)
+    vol = synth.blobs(96, 80, 192, 1400, 5)
+    want = single_gpu(hip, vol)
+    s = S.make_params(L)
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 2, S.SLAB_LOOPBACK) == 0
+    im = hip.image_from_numpy(vol)
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    d = abi.SIFT3D_Descriptor_store()
+    L.init_SIFT3D_Descriptor_store(C.byref(d))
+    for where in (3, 2, 5):
+        if where == 5:
+            assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        L.sift3d_amd_slab_test_inject(1, where)
+        try:
+            if where == 5:
+                assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) != 0
+            else:
+                assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) != 0
+        finally:
+            L.sift3d_amd_slab_test_inject(-1, 0)
+        assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        x, sd, R = hip.keypoints_to_numpy(kp)
+        bins, xyzs = hip.descriptors_to_numpy(d)
+        assert np.array_equal(x, want[0]) and np.array_equal(R, want[2]) and np.array_equal(bins, want[3]), where
+    L.cleanup_SIFT3D(C.byref(s))
+    hip.free_image(im)
+
+
+def test_describe_load_balance_on_the_device(hip):
+    """Structure crowded into the top quarter of the volume, four loop-back ranks: with balancing the owner's neighbour
+    takes the windows its halo planes hold and the replicated octaves spread out; stores bit-identical to the single-GPU
+    run with and without (the halo planes a neighbour describes from are the owner's planes, bit for bit)."""
+    L = S.bind(hip.sift)
+    nx, ny, nz = 96, 96, 384
+    rng = np.random.default_rng(3)
+    vol = (rng.standard_normal((nz, ny, nx)) * 1e-3).astype(np.float32)
+    vol[288:] += synth.blobs(nx, ny, 96, 2200, 8)
+    want = single_gpu(hip, vol)
+    assert len(want[0]) > 100
+    counts = {}
+    for balance in ("0", "1.1"):
+        os.environ["SIFT3D_SLAB_BALANCE"] = balance
+        try:
+            s = S.make_params(L)
+            assert L.sift3d_amd_set_num_gpus(C.byref(s), 4, S.SLAB_LOOPBACK) == 0
+            im = hip.image_from_numpy(vol)
+            kp = abi.Keypoint_store()
+            L.init_Keypoint_store(C.byref(kp))
+            d = abi.SIFT3D_Descriptor_store()
+            L.init_SIFT3D_Descriptor_store(C.byref(d))
+            assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+            assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+            x, sd, R = hip.keypoints_to_numpy(kp)
+            bins, xyzs = hip.descriptors_to_numpy(d)
+            assert np.array_equal(x, want[0]) and np.array_equal(R, want[2]) and np.array_equal(bins, want[3])
+            per = []
+            for r in range(4):
+                inf = S.SlabInfo()
+                assert L.sift3d_amd_get_slab_info(C.byref(s), r, C.byref(inf)) == 0
+                per.append(int(inf.num_described))
+            counts[balance] = per
+            L.cleanup_SIFT3D(C.byref(s))
+            hip.free_image(im)
+        finally:
+            del os.environ["SIFT3D_SLAB_BALANCE"]
+    off, on = counts["0"], counts["1.1"]
+    print("described per rank: owner rule", off, "balanced", on)
+    assert sum(off) == sum(on) == len(want[0]) and max(off) > 0.8 * sum(off)
+    assert max(on) < max(off) and on[2] > off[2]
 
 
 WORKER = r'''
