@@ -1,6 +1,11 @@
 /* s3d_host_draw.c -- the picture outputs of regSift3D: two volumes side by side, their
  * keypoints as small cubes, their matches as line segments.  Host C, nothing on the device.
  *
+ * SCOPE NOTE.  Drawing as such is outside the hot-path scope.  This file exists only because
+ * row f4 names the regSift3D program "with its full option surface" and its --concat / --keys / --lines outputs are these
+ * functions (cli/regSift3D.c); nothing of the detect / describe / match path calls into it, and no round since round 1
+ * has spent work here.
+ *
  *   convert_Mat_rm                         imutil.c:567-629
  *   im_pad / im_concat                     imutil.c:1471-1503, 1613-1683
  *   draw_lines (draw_points is in s3d_host_io.c)   imutil.c:1063-1155
