@@ -498,7 +498,9 @@ def test_two_volume_config_vs_reference_golden(lib, fixture):
     against the reference's matches.  The matcher is bit-exact on equal descriptors (test_nn_match*); here the two
     descriptor sets differ by up to 1e-4 relative, which may move a ratio test sitting on the 0.8 threshold:
     at most 1 decision in 5000 may differ, and a differing decision must involve a rejection (never two different
-    partners)."""
+    partners).  Measured in every GPU run of rounds 1-3: 0 differing decisions on both fixtures
+    (profiles/r0*_golden_pair512*_parity.json); the allowance stays because it is what the 1e-4 contract implies, not
+    because it is used."""
     import hashlib
     gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture)
     if not os.path.exists(gpath):
