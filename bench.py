@@ -352,12 +352,26 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
         dist.all_gather_object(box, m)
         return box
 
+    def job(what, steps, warmup, tag):
+        """A rank whose job fails has aborted its transport (the C driver does); its peers would run into
+        SIFT3D_SLAB_TIMEOUT_S.  Leaving at once with a non-zero status lets the launcher take the whole job down
+        instead: no number is better than a number after a two-minute wait for a dead rank."""
+        try:
+            return slab_job(L, dev, tr, what, steps, warmup, full_sync, tag)
+        except BaseException as e:                              # noqa: BLE001
+            log(f"[rank {rank}] {tag} job failed: {e}")
+            if tr is not None and tr.abort:
+                tr.abort(tr.self)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3)
+
     n = args.size
     dims = (args.strong_size,) * 3 if args.strong else (n, n, n * world)
-    per_rank = gather(slab_job(L, dev, tr, dims, args.steps, args.warmup, full_sync, "timed"))
+    per_rank = gather(job(dims, args.steps, args.warmup, "timed"))
     extra = None
     if not args.no_match and not args.strong and world in (2, 4, 8, 16) and n >= 512:
-        extra = gather(slab_job(L, dev, tr, (1024, 1024, 1024), 2, 1, full_sync, "configs[3]"))
+        extra = gather(job((1024, 1024, 1024), 2, 1, "configs[3]"))
     if rank == 0:
         result = slab_result(args, per_rank, extra, dims, world, tname, rccl)
         if not args.no_roofline:

@@ -13,6 +13,8 @@ echo "== torchrun form, world of one (gloo bootstrap, RCCL communicators of one 
 S3D_BENCH_FORCE_SLAB=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 timeout 300 python bench.py --gpus 1 --steps 2 --warmup 1 --no-match --no-cpu-baseline --no-roofline >> gpurun_out/multi_gpu_paths.txt 2>&1; echo "exit $?" >> gpurun_out/multi_gpu_paths.txt
 echo "== loop-back, 2 ranks on this GPU, 512x512x1024 (decomposition overhead, not scaling)" >> gpurun_out/multi_gpu_paths.txt
 timeout 300 python bench.py --loopback 2 --steps 2 --warmup 1 --no-match --no-cpu-baseline --no-roofline >> gpurun_out/multi_gpu_paths.txt 2>&1; echo "exit $?" >> gpurun_out/multi_gpu_paths.txt
+echo "== torchrun, two ranks sharing this GPU (gloo bootstrap; callback transport over gloo since two ranks cannot share one GPU over RCCL)" >> gpurun_out/multi_gpu_paths.txt
+S3D_BENCH_SAME_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --size 256 --steps 2 --warmup 1 --no-match --no-roofline >> gpurun_out/multi_gpu_paths.txt 2>&1; echo "exit $?" >> gpurun_out/multi_gpu_paths.txt
 cat gpurun_out/multi_gpu_paths.txt | cut -c1-400
 if [ -n "$DO_CPU512" ]; then
   ( OMP_NUM_THREADS=64 OPENBLAS_NUM_THREADS=1 timeout 900 python bench.py --cpu-baseline-worker 512 > gpurun_out/cpu_baseline_512.json 2> gpurun_out/cpu_baseline_512.err; echo "cpu512 exit $?" >> gpurun_out/cpu_baseline_512.err )
