@@ -16,6 +16,10 @@ timeout 300 python bench.py --loopback 2 --steps 2 --warmup 1 --no-match --no-cp
 echo "== torchrun, two ranks sharing this GPU (gloo bootstrap; callback transport over gloo since two ranks cannot share one GPU over RCCL)" >> gpurun_out/multi_gpu_paths.txt
 S3D_BENCH_SAME_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --size 256 --steps 2 --warmup 1 --no-match --no-roofline >> gpurun_out/multi_gpu_paths.txt 2>&1; echo "exit $?" >> gpurun_out/multi_gpu_paths.txt
 cat gpurun_out/multi_gpu_paths.txt | cut -c1-400
+if [ -n "$DO_FUZZ" ]; then
+  ( timeout 600 python scripts/fuzz_parity.py ${FUZZ_SECONDS:-120} ${FUZZ_SEED:-31} > gpurun_out/fuzz_parity.log 2>&1; echo "fuzz exit $?" >> gpurun_out/fuzz_parity.log )
+  tail -n 4 gpurun_out/fuzz_parity.log
+fi
 if [ -n "$DO_CPU512" ]; then
   ( OMP_NUM_THREADS=64 OPENBLAS_NUM_THREADS=1 timeout 900 python bench.py --cpu-baseline-worker 512 > gpurun_out/cpu_baseline_512.json 2> gpurun_out/cpu_baseline_512.err; echo "cpu512 exit $?" >> gpurun_out/cpu_baseline_512.err )
   cat gpurun_out/cpu_baseline_512.json
