@@ -75,6 +75,21 @@ def test_bench_gpus_n_without_a_launcher(emu):
     assert "ncclCommInitAll" in cfg["parallelism"] and cfg["halo_MB_per_step_all_ranks"] > 0
 
 
+def test_bench_without_rccl_falls_back_and_says_so(emu):
+    """N "GPUs" but no usable RCCL (here: the real librccl.so.1 without a device, no mock preloaded): the N ranks still run,
+    over the loop-back transport, and the line says that this is not the RCCL number."""
+    e = dict(os.environ, PYTHONPATH=ROOT, SIFT3D_AMD_LIB=os.path.join(EMU_DIR, "libsift3d_emu.so"), S3D_EMU_DEVICES="2",
+             S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_PRELOAD"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "32", "--steps", "1", "--warmup", "0",
+                        "--no-roofline", "--no-cpu-baseline", "--no-match"], capture_output=True, text=True, timeout=900, env=e)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and "RCCL did NOT initialise" in rec["config"]["parallelism"] and "rccl_ranks" not in rec["config"]
+    assert "falling back" in p.stderr
+
+
 def test_bench_refuses_to_benchmark_fewer_gpus_than_asked(emu):
     p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "1"})
     assert p.returncode == 2 and "{" not in p.stdout and "refusing" in p.stderr
