@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B builds of the library that differ only in csrc/s3d_gauss.hip, taken from git revisions:
-    python scripts/build_gauss_variants.py name=rev [name=rev ...]   ->  sift3d_amd/lib/ablate/libsift3d_amd_g<name>.so
-(to be timed against each other on the GPU box: SIFT3D_AMD_LIB=... python scripts/gauss_time.py)."""
+"""A/B builds of the library that differ only in one csrc/<file>.hip, taken from git revisions:
+    python scripts/build_file_variants.py <file> name=rev [name=rev ...]   ->  sift3d_amd/lib/ablate/libsift3d_amd_g<name>.so
+(to be timed against each other on the GPU box: SIFT3D_AMD_LIB=... python scripts/gauss_time.py / match_ab.py)."""
 import os
 import subprocess
 import sys
@@ -13,13 +13,14 @@ from sift3d_amd import build as b   # noqa: E402
 b.build()
 out_dir = os.path.join(b.LIB, "ablate")
 os.makedirs(out_dir, exist_ok=True)
-objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and f != "s3d_gauss.o"]
-for spec in sys.argv[1:]:
+objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and f != sys.argv[1] + ".o"]
+FILE = sys.argv[1]
+for spec in sys.argv[2:]:
     name, rev = spec.split("=")
-    src = os.path.join(out_dir, f"s3d_gauss_{name}.hip")
+    src = os.path.join(out_dir, f"{FILE}_{name}.hip")
     with open(src, "wb") as f:
-        f.write(subprocess.run(["git", "show", f"{rev}:sift3d_amd/csrc/s3d_gauss.hip"], cwd=ROOT, check=True, capture_output=True).stdout)
-    o = os.path.join(out_dir, f"s3d_gauss_{name}.o")
+        f.write(subprocess.run(["git", "show", f"{rev}:sift3d_amd/csrc/{FILE}.hip"], cwd=ROOT, check=True, capture_output=True).stdout)
+    o = os.path.join(out_dir, f"{FILE}_{name}.o")
     subprocess.run([b.HIPCC, *b.HIP_FLAGS, "-x", "hip", "-c", src, "-o", o], check=True, capture_output=True)
     so = os.path.join(out_dir, f"libsift3d_amd_g{name}.so")
     subprocess.run([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so, *objs, o, "-lm", "-lz", "-lpthread", "-ldl"],
