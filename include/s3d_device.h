@@ -105,6 +105,11 @@ void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z);
 void s3d_k_gauss_set_events(void *before_xy, void *between, void *after_z);
 /* profiling knob, see s3d_gauss.hip */
 void s3d_k_gauss_set_mode(int mode);
+/* Volumes of up to max_voxels output voxels run the three passes of an application in one launch (k_gauss3_tile: the
+ * coarse octaves of a pyramid, bound by launch and L2 latency); 0 = never, < 0 = the default (64^3, or S3D_TILE3_MAX).
+ * Per calling thread.  s3d_k_gauss_tile3_launches: how many such launches the calling thread has made (tests). */
+void s3d_k_gauss_set_tile3(long max_voxels);
+long s3d_k_gauss_tile3_launches(void);
 int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz,
                        int nc, const float uf[3], const float *taps, int width, int path,
                        s3d_stream stream);
@@ -182,6 +187,27 @@ int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint3
                  const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
                  float *d_R, uint32_t *d_keep, double *d_conf,
                  void *d_scratch /* s3d_k_orient_scratch_bytes(num) bytes */, s3d_stream stream);
+/* The same with the levels' window tables: d_tabs = s3d_k_orient_tab_bytes(pyr) bytes of device memory the call fills
+ * (one launch, a wave per level) and the window sums then replay -- the window of a candidate with an integer centre
+ * away from the faces of the volume, in a level with equal power-of-two units, is a property of its level (which
+ * voxels, in which order, with which weights), so the row intervals, scans and weights need not be redone per
+ * candidate.  Same results, bit for bit; d_tabs == NULL is s3d_k_orient. */
+#define S3D_ORI_TAB_TURNS 128                /* turns of 64 lanes a table holds (default parameters: 11-27) */
+typedef struct { int off, nval, pad0, pad1; float w[4]; } s3d_ori_ent;   /* a lane's four x-consecutive voxels of one turn */
+typedef struct {
+    int n_turns;                             /* 0: no table for this level (the general path serves it) */
+    int rb[6];                               /* the window's bounding box relative to the centre: xs xe ys ye zs ze */
+    int pad;
+    s3d_ori_ent ent[S3D_ORI_TAB_TURNS * 64];
+} s3d_ori_tab;
+size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr);
+int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                     const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                     float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream stream);
+/* Test / profiling knob of the calling thread: how s3d_k_orient_tab uses the tables -- 0 not at all, 1 one kernel that
+ * replays or enumerates per candidate, 2 a table-walk kernel plus the general kernel for the candidates it flags (the
+ * default; fewer registers, more waves per SIMD); anything else restores the default (or S3D_ORI_MODE). */
+void s3d_k_set_orient_mode(int mode);
 /* Candidates are processed in chunks of S3D_ORIENT_CHUNK; the scratch holds one chunk's window sums. */
 #define S3D_ORIENT_CHUNK (1u << 20)
 #define S3D_ORIENT_SCRATCH_BYTES 128u

@@ -84,6 +84,8 @@ typedef struct {
     uint32_t *d_kscratch;   /* block counters of s3d_k_compact_keys: cand_cap/256 + 2 (grows with cand_cap) */
     float *d_R, *d_Rk;
     void *d_orient;         /* s3d_k_orient scratch for cand_cap candidates */
+    void *d_oritab;         /* the levels' window tables (s3d_k_orient_tab), s3d_k_orient_tab_bytes of the last pyramid */
+    size_t oritab_bytes;
     int32_t *d_xyzos;
     double *d_sigma;
     double h_sigma[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];   /* staging for the async upload to d_sigma */
@@ -159,7 +161,8 @@ static void ctx_free_pyramid(s3d_ctx *c)
     for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&c->d_level[i]);
     dfree(&c->d_bits); dfree(&c->d_scratch);
     dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep); dfree(&c->d_kscratch);
-    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_sigma); dfree(&c->d_orient);
+    dfree(&c->d_R); dfree(&c->d_Rk); dfree(&c->d_xyzos); dfree(&c->d_sigma); dfree(&c->d_orient); dfree(&c->d_oritab);
+    c->oritab_bytes = 0;
     c->nx = c->ny = c->nz = c->num_octaves = c->num_levels = 0;
     c->cand_cap = 0;
     c->have_pyramid = 0;
@@ -673,8 +676,14 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         double *const sig = c->h_sigma;                   /* lives in the context: the copy below is asynchronous */
         for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
         DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
-        DEV(s3d_k_orient(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
-                         c->d_R, c->d_keep, NULL, c->d_orient, c->stream));
+        if (c->oritab_bytes < s3d_k_orient_tab_bytes(&pd)) {
+            dfree(&c->d_oritab);
+            c->oritab_bytes = 0;
+            DEV(s3d_rt_malloc(&c->d_oritab, s3d_k_orient_tab_bytes(&pd)));
+            c->oritab_bytes = s3d_k_orient_tab_bytes(&pd);
+        }
+        DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
+                             c->d_R, c->d_keep, NULL, c->d_orient, c->d_oritab, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
                                c->d_Rk, c->d_count + 1, c->d_kscratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));

@@ -114,6 +114,8 @@ struct sift3d_amd_slab {
     float *d_R, *d_Rk;
     int32_t *d_xyzos;
     void *d_orient;
+    void *d_oritab;                     /* the levels' window tables (s3d_k_orient_tab) */
+    size_t oritab_bytes;
     size_t orient_bytes;
     float *d_mesh;
     double *d_sigma;
@@ -263,7 +265,7 @@ void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
     dfree(&sl->im.base); dfree(&sl->tmp.base); dfree(&sl->d_seed);
     dfree(&sl->d_bits); dfree(&sl->d_scratch); dfree(&sl->d_kscratch); dfree(&sl->d_count); dfree(&sl->d_red);
     dfree(&sl->d_cand_idx); dfree(&sl->d_cand_tag); dfree(&sl->d_keep); dfree(&sl->d_R); dfree(&sl->d_Rk);
-    dfree(&sl->d_xyzos); dfree(&sl->d_orient); dfree(&sl->d_mesh); dfree(&sl->d_sigma);
+    dfree(&sl->d_xyzos); dfree(&sl->d_orient); dfree(&sl->d_oritab); dfree(&sl->d_mesh); dfree(&sl->d_sigma);
     dfree(&sl->d_keys); dfree(&sl->d_desc);
     if (sl->h_keys) s3d_rt_host_free(sl->h_keys);
     for (int i = 0; i < 2 * SLAB_MAX_OPS; i++)
@@ -707,8 +709,14 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
             sl->orient_bytes = need;
         }
     }
-    DEV(s3d_k_orient(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, NULL, ncand, sl->d_sigma, sl->plan.corner_thresh, sl->d_R,
-                     sl->d_keep, NULL, sl->d_orient, sl->cs));
+    if (sl->oritab_bytes < s3d_k_orient_tab_bytes(&sl->pd)) {
+        dfree(&sl->d_oritab);
+        sl->oritab_bytes = 0;
+        if (dmalloc(sl, &sl->d_oritab, s3d_k_orient_tab_bytes(&sl->pd), 0)) return SIFT3D_FAILURE;
+        sl->oritab_bytes = s3d_k_orient_tab_bytes(&sl->pd);
+    }
+    DEV(s3d_k_orient_tab(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, NULL, ncand, sl->d_sigma, sl->plan.corner_thresh, sl->d_R,
+                         sl->d_keep, NULL, sl->d_orient, sl->d_oritab, sl->cs));
     DEV(s3d_k_compact_keys(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, sl->d_R, sl->d_keep, ncand, sl->d_xyzos, sl->d_Rk,
                            sl->d_count + 1, sl->d_kscratch, sl->cs));
     DEV(s3d_rt_d2h(sl->h_counts + 1, sl->d_count + 1, sizeof(uint32_t), sl->cs));

@@ -1264,6 +1264,190 @@ extern "C" int s3d_k_dense_bary_blur(const float *d_smooth, float *d_dst, float 
     return 1;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 3. small volumes: the three passes of one application in ONE launch
+ * ------------------------------------------------------------------------------------------------
+ * The coarse octaves of a pyramid are a few thousand to a few hundred thousand voxels: their axis passes are not bound
+ * by bandwidth but by latency -- a pass over 32^3 voxels takes 5-7 us whatever it does (17 taps, each a dependent
+ * load -> use out of L2), and an octave is 15 of them in a row.  Here one workgroup produces an output tile from its
+ * source region (tile + h voxels on every side, h = ceil(hw * uf) + 1: what the three passes reach, clipped to the
+ * volume -- the mirror rules only ever point back inside): region -> LDS, x pass over the region's rows, y pass over its
+ * planes, z pass to memory; every intermediate is rounded to f32 exactly where the separate passes store it.
+ * The tap coordinates depend on the position along the filtered axis alone: one thread per position of the tile
+ * evaluates the reference's coordinate loop (incl. its interior drift and the mirror rules, verbatim k_conv_axis)
+ * once and leaves (source index, frac) per tap in LDS; the passes read them back.  Same taps, order and expression per
+ * element: bit-identical to k_conv_axis for any tap spacing.  Halo re-computation costs 1.5-2.5x the arithmetic of a
+ * volume this size, i.e. nothing; what it buys is one launch instead of three and LDS latency instead of L2 latency. */
+#define G3_THREADS 256
+#define G3_SMEM_FLOATS 15872                 /* 62 KB of the 64 KB a launch gets without asking */
+#define G3_MAX_HW 9
+
+struct G3Geom {
+    int nx, ny, nz, z0, z1;                   /* volume; output planes [z0, z1) */
+    int tx, ty, tz;                           /* tile */
+    int hx, hy, hz;                           /* halo per axis */
+    int uhx, uhy, uhz;                        /* ceil(hw * uf) per axis */
+    float ufx, ufy, ufz;
+};
+
+/* (source index relative to `org`, frac) of tap k = 0 .. 2 hw for the output at position p: the loop of k_conv_axis */
+__device__ __forceinline__ void g3_tap_table(int2 *__restrict__ row, int p, int n, int hw, float uf, int uhw, int org)
+{
+    const int dim_end = n - 1;
+    if (p >= uhw && p <= n - 2 - uhw) {
+        float coord = (float)p;
+        for (int d = -hw; d <= hw; d++) {
+            const float step = (float)d * uf;
+            coord = coord - step;
+            const int lo = (int)coord;
+            const float frac = coord - (float)lo;
+            row[d + hw] = make_int2(lo - org, __float_as_int(frac));
+            coord = coord + step;
+        }
+    } else {
+        for (int d = -hw; d <= hw; d++) {
+            const float step = (float)d * uf;
+            float coord = (float)p - step;
+            if ((int)coord < 0)
+                coord = -coord;
+            else if ((int)coord >= dim_end)
+                coord = 2.0f * (float)dim_end - coord - 0.1f;
+            const int lo = (int)coord;
+            const float frac = coord - (float)lo;
+            row[d + hw] = make_int2(lo - org, __float_as_int(frac));
+        }
+    }
+}
+
+template <int HW>
+__device__ __forceinline__ float g3_point(const float *__restrict__ s, int sa, const int2 *__restrict__ row, const S3dTaps &taps)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2 * HW + 1; k++) {
+        const int2 e = row[k];
+        const float frac = __int_as_float(e.y);
+        const float a = s[e.x * sa], b = s[(e.x + 1) * sa];
+        acc = acc + taps.t[k] * ((1.0f - frac) * a + frac * b);
+    }
+    return acc;
+}
+
+template <int HW>
+__global__ void __launch_bounds__(G3_THREADS)
+k_gauss3_tile(const float *__restrict__ src, float *__restrict__ dst, G3Geom g, S3dTaps taps)
+{
+    __shared__ __attribute__((aligned(16))) float smem[G3_SMEM_FLOATS];
+    constexpr int NT = 2 * HW + 1;
+    const int tid = threadIdx.x;
+    /* tile and region, clipped to the volume (z: the tile to the output planes, the region to the volume) */
+    const int bx = (int)blockIdx.x * g.tx, by = (int)blockIdx.y * g.ty, bz = g.z0 + (int)blockIdx.z * g.tz;
+    auto lower = [](int a, int b) { return a < b ? a : b; };
+    auto upper = [](int a, int b) { return a > b ? a : b; };
+    const int ex = lower(bx + g.tx, g.nx), ey = lower(by + g.ty, g.ny), ez = lower(bz + g.tz, g.z1);
+    const int rx0 = upper(bx - g.hx, 0), ry0 = upper(by - g.hy, 0), rz0 = upper(bz - g.hz, 0);
+    const int RX = lower(ex + g.hx, g.nx) - rx0, RY = lower(ey + g.hy, g.ny) - ry0, RZ = lower(ez + g.hz, g.nz) - rz0;
+    const int TX = ex - bx, TY = ey - by, TZ = ez - bz;
+    int2 *const tabx = reinterpret_cast<int2 *>(smem);
+    int2 *const taby = tabx + g.tx * NT, *const tabz = taby + g.ty * NT;
+    float *const A = reinterpret_cast<float *>(tabz + g.tz * NT);        /* [RZ][RY][RX], later [RZ][TY][TX] */
+    float *const B = A + (g.tx + 2 * g.hx) * (g.ty + 2 * g.hy) * (g.tz + 2 * g.hz);   /* [RZ][RY][TX] */
+
+    if (tid < TX) g3_tap_table(tabx + tid * NT, bx + tid, g.nx, HW, g.ufx, g.uhx, rx0);
+    else if (tid >= 64 && tid < 64 + TY) g3_tap_table(taby + (tid - 64) * NT, by + tid - 64, g.ny, HW, g.ufy, g.uhy, ry0);
+    else if (tid >= 128 && tid < 128 + TZ) g3_tap_table(tabz + (tid - 128) * NT, bz + tid - 128, g.nz, HW, g.ufz, g.uhz, rz0);
+    {
+        const int rows = RZ * RY;
+        for (int r = tid / 32; r < rows; r += G3_THREADS / 32) {         /* 32 lanes per region row */
+            const int z = r / RY, y = r - z * RY;
+            const float *p = src + ((size_t)(rz0 + z) * g.ny + (size_t)(ry0 + y)) * g.nx + rx0;
+            for (int x = tid & 31; x < RX; x += 32) A[r * RX + x] = p[x];
+        }
+    }
+    __syncthreads();
+    {   /* x: A[RZ][RY][RX] -> B[RZ][RY][TX] */
+        const int n = RZ * RY * TX;
+        for (int i = tid; i < n; i += G3_THREADS) {
+            const int r = i / TX, x = i - r * TX;
+            B[i] = g3_point<HW>(A + r * RX, 1, tabx + x * NT, taps);
+        }
+    }
+    __syncthreads();
+    {   /* y: B[RZ][RY][TX] -> A[RZ][TY][TX] */
+        const int n = RZ * TY * TX, pl = TY * TX;
+        for (int i = tid; i < n; i += G3_THREADS) {
+            const int z = i / pl, q = i - z * pl, y = q / TX, x = q - y * TX;
+            A[i] = g3_point<HW>(B + z * RY * TX + x, TX, taby + y * NT, taps);
+        }
+    }
+    __syncthreads();
+    {   /* z: A[RZ][TY][TX] -> dst */
+        const int n = TZ * TY * TX, pl = TY * TX;
+        for (int i = tid; i < n; i += G3_THREADS) {
+            const int z = i / pl, q = i - z * pl, y = q / TX, x = q - y * TX;
+            dst[((size_t)(bz + z) * g.ny + (size_t)(by + y)) * g.nx + bx + x] = g3_point<HW>(A + q, pl, tabz + z * NT, taps);
+        }
+    }
+}
+
+/* volumes up to this many output voxels take the tile kernel (0: never).  Per calling thread; the initial value comes
+ * from the environment (S3D_TILE3_MAX) once per process, for profiling runs. */
+static long tile3_default()
+{
+    static long v = -1;
+    if (v < 0) {
+        const char *e = getenv("S3D_TILE3_MAX");
+        v = e ? atol(e) : 64L * 64L * 64L;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+static thread_local long g_tile3_max = -1;
+static thread_local long g_tile3_launches = 0;
+extern "C" void s3d_k_gauss_set_tile3(long max_voxels) { g_tile3_max = max_voxels; }   /* < 0: back to the default */
+extern "C" long s3d_k_gauss_tile3_launches(void) { return g_tile3_launches; }            /* of the calling thread (tests) */
+
+/* 1: launched; 0: not eligible (the caller takes the three passes); -1: error */
+static int tile3_dispatch(const float *d_src, float *d_dst, int nx, int ny, int nz, int z0, int z1, const float uf[3],
+                          int hw, const S3dTaps &t, hipStream_t st)
+{
+    const long lim = g_tile3_max >= 0 ? g_tile3_max : tile3_default();
+    const size_t nvox = (size_t)nx * ny * (size_t)(z1 - z0);
+    if (hw < 1 || hw > G3_MAX_HW || d_src == d_dst || nvox > (size_t)lim || g_no_dyadic) return 0;
+    if (nx > (1 << 22) || ny > (1 << 22) || nz > (1 << 22)) return 0;
+    G3Geom g;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.z0 = z0; g.z1 = z1;
+    g.ufx = uf[0]; g.ufy = uf[1]; g.ufz = uf[2];
+    g.uhx = (int)ceilf((float)hw * uf[0]); g.uhy = (int)ceilf((float)hw * uf[1]); g.uhz = (int)ceilf((float)hw * uf[2]);
+    if (g.uhx >= nx - 1 || g.uhy >= ny - 1 || g.uhz >= nz - 1) return 0;      /* the passes refuse these with a message */
+    g.hx = g.uhx + 1; g.hy = g.uhy + 1; g.hz = g.uhz + 1;
+    /* the largest tile that fits the LDS and still gives every CU two workgroups; else the smallest that fits */
+    static const int cand[][3] = {{32, 8, 8}, {16, 16, 8}, {16, 8, 8}, {8, 8, 8}, {8, 8, 4}, {8, 4, 4}};
+    const int nt = 2 * hw + 1;
+    int pick = -1;
+    for (int i = 0; i < (int)(sizeof(cand) / sizeof(cand[0])); i++) {
+        const int tx = cand[i][0], ty = cand[i][1], tz = cand[i][2];
+        const size_t need = 2 * (size_t)(tx + ty + tz) * nt + (size_t)(tx + 2 * g.hx) * (ty + 2 * g.hy) * (tz + 2 * g.hz) +
+                            (size_t)tx * (ty + 2 * g.hy) * (tz + 2 * g.hz);
+        if (need > G3_SMEM_FLOATS) continue;
+        pick = i;
+        if ((size_t)s3d_div_up(nx, tx) * s3d_div_up(ny, ty) * s3d_div_up((size_t)(z1 - z0), tz) >= 512) break;
+    }
+    if (pick < 0) return 0;
+    g.tx = cand[pick][0]; g.ty = cand[pick][1]; g.tz = cand[pick][2];
+    const dim3 grid(s3d_div_up(nx, g.tx), s3d_div_up(ny, g.ty), s3d_div_up((size_t)(z1 - z0), g.tz)), block(G3_THREADS);
+    if (grid.y > 65535u || grid.z > 65535u) return 0;
+    switch (hw) {
+#define S3D_G3(H) case H: hipLaunchKernelGGL((k_gauss3_tile<H>), grid, block, 0, st, d_src, d_dst, g, t); break;
+    S3D_G3(1) S3D_G3(2) S3D_G3(3) S3D_G3(4) S3D_G3(5) S3D_G3(6) S3D_G3(7) S3D_G3(8) S3D_G3(9)
+#undef S3D_G3
+    default: return 0;
+    }
+    if (hipGetLastError() != hipSuccess) { s3d_rt_set_error("k_gauss3_tile", "launch failed"); return -1; }
+    g_tile3_launches++;
+    return 1;
+}
+
 /* Z-slab form of s3d_k_sep_fir.  The three pointers are VIEWS addressed by
  * global z: element (x,y,z) of the nx x ny x nz volume lives at view[(z*ny + y)*nx + x], but only the
  * planes the caller owns plus halos need to be backed by memory.  Produces dst planes [z0, z1); reads
@@ -1284,6 +1468,10 @@ extern "C" int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp
      * then lands just below an integer and interpolates with the plane beyond (weight ~1e-6: one ulp of the output) */
     const int h = (int)ceilf((float)hw * uf[2]) + 1;
     const int za = z0 - h > 0 ? z0 - h : 0, zb = z1 + h < nz ? z1 + h : nz;
+    {
+        const int r3 = tile3_dispatch(d_src, d_dst, nx, ny, nz, z0, z1, uf, hw, t, st);
+        if (r3) return r3 < 0 ? S3D_ERR : S3D_OK;
+    }
     if (fast_xy_eligible(nx, ny, nz, 1, uf, width) && !g_no_dyadic) {
         if (fast_xy_dispatch(d_src, d_tmp, nx, ny, za, zb, hw, t, st)) return S3D_ERR;
         return conv_axis_range(d_tmp, d_dst, nx, ny, nz, 1, 2, z0, z1, taps, width, uf[2], stream);
@@ -1327,6 +1515,10 @@ extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp
     if (fast && path != 1) return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, 0, nz, width / 2, t, st);
     if (path != 1 && d_src != d_dst && fast_mc_eligible(nx, ny, nz, nc, uf, width))
         return fast_mc_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, nc, width / 2, t, st);
+    if (path != 1 && nc == 1) {                                          /* small volume: one launch for the three passes */
+        const int r3 = tile3_dispatch(d_src, d_dst, nx, ny, nz, 0, nz, uf, width / 2, t, st);
+        if (r3) return r3 < 0 ? S3D_ERR : S3D_OK;
+    }
     if (path != 1 && fast_xy_eligible(nx, ny, nz, nc, uf, width)) {      /* x, y fused: src -> tmp ; z generic: tmp -> dst */
         if (fast_xy_dispatch(d_src, d_tmp, nx, ny, 0, nz, width / 2, t, st)) return S3D_ERR;
         return s3d_k_conv_axis(d_tmp, d_dst, nx, ny, nz, nc, 2, taps, width, uf[2], stream);

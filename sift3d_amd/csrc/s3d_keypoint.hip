@@ -156,12 +156,20 @@ __device__ __forceinline__ int orient_finish(const float vr[2][3], float gwx, fl
     return score < corner_thresh ? 0 : 1;
 }
 
+/* PHASE 0 builds, PHASE 1 replays the window table of a level (s3d_ori_tab): for a candidate with an integer centre
+ * away from the volume's faces, in a level with equal power-of-two units -- every detected candidate of a unit-voxel
+ * volume but the few near a face -- the window is the SAME set of voxel offsets, visited in the SAME order by the same
+ * lanes, with the SAME weights, whatever the candidate: row intervals, scans, look-ups and the weight table are level
+ * properties.  PHASE 0 (one wave per level) runs the sweep below once for a stand-in centre and records what every lane
+ * does in every turn; PHASE 1 checks that the candidate's own bounding box (relative to its centre) is the table's and
+ * then just walks the table -- lane for lane the operations of the general path, hence the same bits. */
+#define ORI_TAB_CENTRE 256
 template <int PHASE>
 __global__ void __launch_bounds__(64)
 k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
               const float *__restrict__ d_center, uint32_t cand0, uint32_t num, const double *__restrict__ d_sigma,
               double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
-              double *__restrict__ d_conf)
+              double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs)
 {
     __shared__ __attribute__((aligned(16))) float term[3][64];
     __shared__ float gw_s[3];
@@ -173,16 +181,22 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     const int lane = threadIdx.x;
     if (cand >= num) return;
     if (PHASE == 2 && d_keep[cand] != 2u) return;
+    if (PHASE == 4 && d_keep[cand] != 3u) return;          /* PHASE 3 served this one from its level's table */
     double *scr = d_scr + (size_t)blockIdx.x * ORI_SCR;
-    const unsigned tag = d_tag ? d_tag[cand] : 0u;        /* no tags: every candidate lives in level 0 */
+    const unsigned tag = PHASE == 0 ? (((cand / (unsigned)pyr.num_levels) << 8) | (cand % (unsigned)pyr.num_levels))
+                                    : (d_tag ? d_tag[cand] : 0u);        /* no tags: every candidate lives in level 0 */
     const int o = (int)(tag >> 8), k = (int)(tag & 255u);
     const int li = o * pyr.num_levels + k;
     const float *__restrict__ im = pyr.d_level[li];
+    /* PHASE 0: the stand-in centre sits in an unbounded volume (the table is only used where no clamp is active) */
     const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
+    const int bnx = PHASE == 0 ? (1 << 20) : nx, bny = PHASE == 0 ? (1 << 20) : ny, bnz = PHASE == 0 ? (1 << 20) : nz;
     const float uxf = pyr.unitsf[o][0], uyf = pyr.unitsf[o][1], uzf = pyr.unitsf[o][2];
     const unsigned plane = (unsigned)nx * (unsigned)ny;
     float vcx, vcy, vcz;
-    if (d_center) {                                        /* raw-image variant: arbitrary centres */
+    if (PHASE == 0) {
+        vcx = vcy = vcz = (float)ORI_TAB_CENTRE;
+    } else if (d_center) {                                 /* raw-image variant: arbitrary centres */
         vcx = d_center[3 * (size_t)cand + 0]; vcy = d_center[3 * (size_t)cand + 1]; vcz = d_center[3 * (size_t)cand + 2];
     } else {
         const unsigned idx = d_idx ? d_idx[cand] : cand;   /* no index list: one candidate per voxel (dense) */
@@ -197,9 +211,9 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     const double inv_sig2 = 1.0 / sig2;
 
     int xs, xe, ys, ye, zs, ze;
-    ori_bounds(vcx, rad, uxf, nx, &xs, &xe);
-    ori_bounds(vcy, rad, uyf, ny, &ys, &ye);
-    ori_bounds(vcz, rad, uzf, nz, &zs, &ze);
+    ori_bounds(vcx, rad, uxf, bnx, &xs, &xe);
+    ori_bounds(vcy, rad, uyf, bny, &ys, &ye);
+    ori_bounds(vcz, rad, uzf, bnz, &zs, &ze);
     const int wx = xe - xs + 1, wy = ye - ys + 1, wz = ze - zs + 1;
     const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
 
@@ -227,7 +241,22 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     const int cxi = (int)vcx, cyi = (int)vcy, czi = (int)vcz;
     const bool use_tab = uxf == uyf && uxf == uzf && um == 0.5f && (float)cxi == vcx && (float)cyi == vcy &&
                          (float)czi == vcz && rad2 / (double)u2 < (double)(ORI_WTAB - 2);
-    if (use_tab) {
+    /* PHASE 1: does the level's window table describe this candidate's window? */
+    bool replay = false;
+    if ((PHASE == 1 || PHASE == 3) && tabs != nullptr && d_center == nullptr && use_tab) {
+        const s3d_ori_tab *T = tabs + li;
+        replay = T->n_turns > 0 && xs - cxi == T->rb[0] && xe - cxi == T->rb[1] && ys - cyi == T->rb[2] &&
+                 ye - cyi == T->rb[3] && zs - czi == T->rb[4] && ze - czi == T->rb[5];
+    }
+    if (PHASE == 0 && !use_tab) {                          /* no table for this level: the general path serves it */
+        if (lane == 0) tabs[li].n_turns = 0;
+        return;
+    }
+    if (PHASE == 3) {                                      /* table walk only; PHASE 4 takes what is flagged here */
+        if (lane == 0) d_keep[cand] = replay ? 0u : 3u;
+        if (!replay) return;
+    }
+    if (use_tab && !replay) {
         const int nent = (int)(rad2 / (double)u2) + 2;
         for (int i = lane; i < nent; i += 64) wtab[i] = weight((float)i * u2);
         s3d_wave_lds_sync();
@@ -318,7 +347,37 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
         }
     };
 
-    if (PHASE == 1) {
+    if (PHASE == 0) {
+        /* ---- the window table of this level: what sweep(4, ...) hands every lane in every turn ---- */
+        s3d_ori_tab *T = tabs + li;
+        int turn = 0;
+        sweep(4, [&](bool valid, int x0, int y, int z, int nval) {
+            if (turn < S3D_ORI_TAB_TURNS) {
+                s3d_ori_ent e;
+                e.off = 0; e.nval = 0; e.pad0 = 0; e.pad1 = 0;
+                e.w[0] = e.w[1] = e.w[2] = e.w[3] = 0.0f;
+                if (valid) {
+                    const int d2yz = (y - cyi) * (y - cyi) + (z - czi) * (z - czi);
+                    e.off = (z - czi) * (int)plane + (y - cyi) * nx + (x0 - cxi);
+                    e.nval = nval;
+                    for (int j = 0; j < nval; j++) {
+                        const int dxi = x0 + j - cxi;
+                        e.w[j] = wtab[dxi * dxi + d2yz];
+                    }
+                }
+                T->ent[turn * 64 + lane] = e;
+            }
+            turn++;
+        });
+        if (lane == 0) {
+            T->n_turns = turn <= S3D_ORI_TAB_TURNS ? turn : 0;            /* too long for the table: general path */
+            T->rb[0] = xs - cxi; T->rb[1] = xe - cxi; T->rb[2] = ys - cyi; T->rb[3] = ye - cyi;
+            T->rb[4] = zs - czi; T->rb[5] = ze - czi;
+            T->pad = 0;
+        }
+        return;
+    }
+    if (PHASE == 1 || PHASE == 3 || PHASE == 4) {
     /* ---- pass 1 (parallel): f64 structure tensor, and for the window gradient sum(w*grad) both its
      * (to f64 accuracy) exact value gd and sum|term| per component, which bounds how far the
      * reference's sequential f32 accumulation can be from gd ------------------------------------- */
@@ -327,9 +386,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     int cnt = 0;
     /* four x-consecutive voxels per lane and turn: one row decode and five wide unaligned loads (the level
      * buffers carry the slack, s3d_device.h) instead of four decodes and 24 dword loads */
-    sweep(4, [&](bool valid, int x0, int y, int z, int nval) {
-        if (!valid) return;
-        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
+    auto accumulate = [&](const float *p, int nval, float w0, float w1, float w2, float w3) {
         const f4u ca = *(const f4u *)(p - 1);
         const f2u cb = *(const f2u *)(p + 3);
         const f4u yp = *(const f4u *)(p + nx), ym = *(const f4u *)(p - nx);
@@ -337,14 +394,11 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
         const float cx[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
         const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
         const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
-        const float dy = ((float)y - vcy) * uyf, dz = ((float)z - vcz) * uzf;
-        const int d2yz = (y - cyi) * (y - cyi) + (z - czi) * (z - czi);
+        const float wv[4] = {w0, w1, w2, w3};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j >= nval) break;
-            const float dx = ((float)(x0 + j) - vcx) * uxf;
-            const int dxi = x0 + j - cxi;
-            const float w = use_tab ? wtab[dxi * dxi + d2yz] : weight(dx * dx + dy * dy + dz * dz);
+            const float w = wv[j];
             const float gx = 0.5f * (cx[j + 2] - cx[j]) * iux;
             const float gy = 0.5f * (ypv[j] - ymv[j]) * iuy;
             const float gz = 0.5f * (zpv[j] - zmv[j]) * iuz;
@@ -360,7 +414,37 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
             sax += fabs((double)tx); say += fabs((double)ty); saz += fabs((double)tz);
             cnt++;
         }
+    };
+    if (PHASE != 4 && replay) {
+        /* the level's table: this lane's chunk of every turn, the next turn's entry fetched while this one is worked on */
+        const s3d_ori_tab *T = tabs + li;
+        const int nt = T->n_turns;
+        const float *pc = im + ((size_t)czi * plane + (size_t)cyi * nx + cxi);
+        const s3d_ori_ent *E = T->ent + lane;
+        s3d_ori_ent e = E[0];
+        for (int t = 0; t < nt; t++) {
+            s3d_ori_ent en = e;
+            if (t + 1 < nt) en = E[(size_t)(t + 1) * 64];
+            if (e.nval > 0) accumulate(pc + e.off, e.nval, e.w[0], e.w[1], e.w[2], e.w[3]);
+            e = en;
+        }
+    } else if (PHASE != 3) {
+    sweep(4, [&](bool valid, int x0, int y, int z, int nval) {
+        if (!valid) return;
+        const float *p = im + ((size_t)z * plane + (size_t)y * nx + x0);
+        const float dy = ((float)y - vcy) * uyf, dz = ((float)z - vcz) * uzf;
+        const int d2yz = (y - cyi) * (y - cyi) + (z - czi) * (z - czi);
+        float wv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j >= nval) break;
+            const float dx = ((float)(x0 + j) - vcx) * uxf;
+            const int dxi = x0 + j - cxi;
+            wv[j] = use_tab ? wtab[dxi * dxi + d2yz] : weight(dx * dx + dy * dy + dz * dz);
+        }
+        accumulate(p, nval, wv[0], wv[1], wv[2], wv[3]);
     });
+    }
     for (int m = 32; m >= 1; m >>= 1) {                    /* xor butterfly: every lane ends with the totals */
         a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
         a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
@@ -519,27 +603,69 @@ extern "C" size_t s3d_k_orient_scratch_bytes(uint32_t num)
     return (size_t)(num < S3D_ORIENT_CHUNK ? num : S3D_ORIENT_CHUNK) * S3D_ORIENT_SCRATCH_BYTES;
 }
 
-extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
-                            const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                            float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, s3d_stream st)
+static thread_local int g_orient_mode = -1;                       /* test knob of the calling thread, see s3d_k_orient_tab */
+extern "C" void s3d_k_set_orient_mode(int mode) { g_orient_mode = mode >= 0 && mode <= 2 ? mode : -1; }
+
+extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
+{
+    return sizeof(s3d_ori_tab) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
+}
+
+extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                                const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream st)
 {
     if (num == 0) return S3D_OK;
     if (!d_scratch) return S3D_ERR;
     double *scr = (double *)d_scratch;
+    s3d_ori_tab *tabs = (d_center == nullptr && d_tag != nullptr) ? (s3d_ori_tab *)d_tabs : nullptr;   /* per-level sigmas only */
+    /* diagnostics, read once: S3D_ORI_MODE=0 no tables; 1 one kernel that replays or enumerates per candidate; 2 (default)
+     * a table-walk kernel (fewer registers: more waves per SIMD) + the general kernel for what it flags */
+    static int env_mode = -1;
+    if (env_mode < 0) {
+        const char *e = getenv("S3D_ORI_MODE");
+        env_mode = e ? atoi(e) : 2;
+        if (env_mode < 0 || env_mode > 2) env_mode = 2;
+    }
+    const int mode = g_orient_mode >= 0 ? g_orient_mode : env_mode;
+    if (mode == 0) tabs = nullptr;
+    if (tabs) {
+        const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
+        hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, d_sigma, corner_thresh,
+                           (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs);
+        S3D_CHECK_LAUNCH();
+    }
     const uint32_t chunk = g_orient_chunk;
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
-        hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
-                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf);
+        if (tabs && mode == 2) {
+            hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
+            S3D_CHECK_LAUNCH();
+            hipLaunchKernelGGL((k_orient_wave<4>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
+        } else {
+            hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
+        }
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
                            d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
-                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf);
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
         S3D_CHECK_LAUNCH();
     }
     return S3D_OK;
+}
+
+extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                            const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                            float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, s3d_stream st)
+{
+    return s3d_k_orient_tab(pyr, d_idx, d_tag, d_center, num, d_sigma, corner_thresh, d_R, d_keep, d_conf, d_scratch,
+                            nullptr, st);
 }
 
 /* ---- stable compaction of the surviving candidates ----------------------------------------------- */

@@ -42,6 +42,7 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
+static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
 static inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
 
 typedef int hipError_t;

@@ -562,9 +562,12 @@ def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
     L.s3d_k_sep_fir_slab.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     d_src, d_a, d_b, d_t = dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes)
     L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    L.s3d_k_gauss_set_tile3.argtypes = [C.c_long]
     try:
         # mode 4: the marching z kernel (k_conv_z_ring) also on volumes whose grid would not fill the GPU -- the library
-        # picks it by grid size, these volumes are small
+        # picks it by grid size, these volumes are small.  The one-launch tile kernel would take volumes this small
+        # before any of the pass kernels: off here, check_sep_fir_tile3 is its test.
+        L.s3d_k_gauss_set_tile3(0)
         for mode in (0, 4):
             L.s3d_k_gauss_set_mode(mode)
             for sigma in sigmas:
@@ -582,5 +585,156 @@ def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
                     assert nd == 0, f"mode {mode} slab [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
     finally:
         L.s3d_k_gauss_set_mode(0)
+        L.s3d_k_gauss_set_tile3(-1)
         for p in (d_src, d_a, d_b, d_t):
             dev.free(p)
+
+
+def check_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits=()):
+    """k_gauss3_tile (the three passes of one application in one launch, for small volumes) against the oracle and
+    against the three separate passes, whole volumes and Z-slab plane ranges, bit for bit; the launch counter says that
+    the tile kernel is what ran."""
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    vol = np.random.default_rng(3).standard_normal((nz, ny, nx)).astype(np.float32)
+    uf = np.array([np.float32(1.0 / u) for u in units], np.float32)
+    L.s3d_k_sep_fir_slab.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.s3d_k_gauss_set_tile3.argtypes = [C.c_long]
+    L.s3d_k_gauss_tile3_launches.restype = C.c_long
+    d_src, d_a, d_b, d_t = dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes)
+    try:
+        for sigma in sigmas:
+            taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)
+            want = oracle.sep_fir(vol, taps, units, 1.0)
+            L.s3d_k_gauss_set_tile3(0)
+            n0 = L.s3d_k_gauss_tile3_launches()
+            dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
+            assert L.s3d_k_gauss_tile3_launches() == n0
+            passes = dev.download(d_a, vol.shape)
+            assert nbitdiff(passes, want) == 0
+            L.s3d_k_gauss_set_tile3(1 << 40)
+            L.s3d_rt_memset(C.c_void_p(d_a), 0xFF, vol.nbytes, None)
+            L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+            dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
+            assert L.s3d_k_gauss_tile3_launches() == n0 + 1, f"tile kernel not taken (dims={dims} units={units} width={taps.size})"
+            got = dev.download(d_a, vol.shape)
+            nd = nbitdiff(got, want)
+            assert nd == 0, f"tile kernel: {nd} of {got.size} differ (dims={dims} units={units} sigma={sigma} width={taps.size})"
+            for z0, z1 in splits:
+                L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+                L.s3d_rt_memset(C.c_void_p(d_b), 0xFF, vol.nbytes, None)
+                n1 = L.s3d_k_gauss_tile3_launches()
+                assert L.s3d_k_sep_fir_slab(d_src, d_b, d_t, nx, ny, nz, z0, z1, uf.ctypes.data, taps.ctypes.data,
+                                            taps.size, None) == 0
+                assert L.s3d_k_gauss_tile3_launches() == n1 + 1
+                out = dev.download(d_b, vol.shape)
+                nd = nbitdiff(out[z0:z1], want[z0:z1])
+                assert nd == 0, f"tile kernel, planes [{z0},{z1}) sigma {sigma}: {nd} elements differ"
+                rest = np.concatenate([out[:z0].ravel(), out[z1:].ravel()]).view(np.uint32)
+                assert (rest == 0xFFFFFFFF).all(), "tile kernel wrote outside its plane range"
+    finally:
+        L.s3d_k_gauss_set_tile3(-1)
+        for p in (d_src, d_a, d_b, d_t):
+            dev.free(p)
+
+
+# ---- orientation: the levels' window tables -----------------------------------------------------------------
+class _PyrDesc(C.Structure):                 # s3d_pyramid_desc (include/s3d_device.h)
+    _fields_ = [("d_level", C.c_void_p * 256), ("dims", (C.c_int * 3) * 16), ("unitsf", (C.c_float * 3) * 16),
+                ("num_octaves", C.c_int), ("num_levels", C.c_int), ("first_level", C.c_int)]
+
+
+_ORI_TURNS = 128
+_ORI_TAB_DT = np.dtype([("n_turns", "<i4"), ("rb", "<i4", 6), ("pad", "<i4"),
+                        ("ent", [("off", "<i4"), ("nval", "<i4"), ("pad", "<i4", 2), ("w", "<f4", 4)], _ORI_TURNS * 64)])
+
+
+def check_orient_tables(lib, dims, units, sigmas, ncand, seed=0, expect_tables=True, mode=2):
+    """s3d_k_orient_tab (window sums replayed from per-level tables) against s3d_k_orient (every candidate enumerates its
+    own window): rotation matrices, keep flags AND the raw window sums left in the scratch must agree bit for bit, for
+    candidates in the interior, on the faces and in the corners of the volume.  Levels: one octave, len(sigmas) levels."""
+    dev = dev_of(lib)
+    L = dev.L
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = dims
+    nl = len(sigmas)
+    from scipy.ndimage import gaussian_filter
+    vols = [gaussian_filter(rng.standard_normal((nz, ny, nx)), 1.5 + 0.5 * i).astype(np.float32) for i in range(nl)]
+    pd = _PyrDesc()
+    d_lv = [dev.upload(v) for v in vols]
+    for i, p_ in enumerate(d_lv):
+        pd.d_level[i] = p_
+    pd.dims[0][0], pd.dims[0][1], pd.dims[0][2] = nx, ny, nz
+    for a in range(3):
+        pd.unitsf[0][a] = float(units[a])
+    pd.num_octaves, pd.num_levels, pd.first_level = 1, nl, 0
+    # candidates: random voxels at least one voxel inside (the detector never reports a face voxel), plus the corners and
+    # face centres of that range
+    xs = rng.integers(1, nx - 1, ncand); ys = rng.integers(1, ny - 1, ncand); zs = rng.integers(1, nz - 1, ncand)
+    half = ncand // 2                                                  # half of them around the centre: whole windows
+    xs[:half] = rng.integers(nx // 2 - 3, nx // 2 + 4, half); ys[:half] = rng.integers(ny // 2 - 3, ny // 2 + 4, half)
+    zs[:half] = rng.integers(nz // 2 - 3, nz // 2 + 4, half)
+    ext = [(x, y, z) for x in (1, nx // 2, nx - 2) for y in (1, ny // 2, ny - 2) for z in (1, nz // 2, nz - 2)]
+    xs = np.concatenate([xs, [e[0] for e in ext]]); ys = np.concatenate([ys, [e[1] for e in ext]]); zs = np.concatenate([zs, [e[2] for e in ext]])
+    n = xs.size
+    idx = (zs * ny * nx + ys * nx + xs).astype(np.uint32)
+    tag = rng.integers(0, nl, n).astype(np.uint32)                      # octave 0, level k
+    sig = np.asarray(sigmas, np.float64)
+    d_idx, d_tag, d_sig = dev.upload(idx), dev.upload(tag), dev.upload(sig)
+    L.s3d_k_orient_tab_bytes.restype = C.c_size_t
+    L.s3d_k_orient_tab_bytes.argtypes = [C.c_void_p]
+    L.s3d_k_orient_scratch_bytes.restype = C.c_size_t
+    L.s3d_k_orient_scratch_bytes.argtypes = [C.c_uint32]
+    tab_bytes = L.s3d_k_orient_tab_bytes(C.byref(pd))
+    assert tab_bytes == _ORI_TAB_DT.itemsize * nl
+    scr_bytes = L.s3d_k_orient_scratch_bytes(n)
+    d_R = [dev.malloc(n * 36) for _ in range(2)]
+    d_keep = [dev.malloc(n * 4) for _ in range(2)]
+    d_scr = [dev.malloc(scr_bytes) for _ in range(2)]
+    d_tab = dev.malloc(tab_bytes)
+    L.s3d_k_orient_tab.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_double,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.s3d_k_set_orient_mode.argtypes = [C.c_int]
+    try:
+        L.s3d_k_set_orient_mode(mode)
+        for i, tabs in enumerate((None, d_tab)):
+            L.s3d_rt_memset(C.c_void_p(d_scr[i]), 0, scr_bytes, None)
+            assert L.s3d_k_orient_tab(C.byref(pd), d_idx, d_tag, None, n, d_sig, 0.4, d_R[i], d_keep[i], None, d_scr[i],
+                                      tabs, None) == 0
+        assert L.s3d_rt_sync(None) == 0
+        R = [dev.download(p_, (n, 9)) for p_ in d_R]
+        keep = [dev.download(p_, (n,), np.uint32) for p_ in d_keep]
+        scr = [dev.download(p_, (n, 16), np.float64) for p_ in d_scr]
+        tabs = np.frombuffer(dev.download(d_tab, (tab_bytes,), np.uint8).tobytes(), _ORI_TAB_DT)
+        assert np.array_equal(keep[0], keep[1])
+        assert nbitdiff(R[0], R[1]) == 0
+        # the window sums (13 doubles per candidate; the last three slots are rewritten by the decision step)
+        assert np.array_equal(scr[0][:, :13].view(np.uint64), scr[1][:, :13].view(np.uint64)), "window sums differ"
+        assert set(np.unique(keep[0])) <= {0, 1}
+        # the tables themselves: present where the units allow, consistent with the voxel counts the sums report
+        replayed = 0
+        for k in range(nl):
+            t = tabs[k]
+            if not expect_tables:
+                assert t["n_turns"] == 0
+                continue
+            assert 0 < t["n_turns"] <= _ORI_TURNS, f"level {k}: no table"
+            ent = t["ent"][: t["n_turns"] * 64]
+            nvox = int(ent["nval"].sum())
+            rb = t["rb"]
+            assert rb[0] == -rb[1] and rb[2] == -rb[3] and rb[4] == -rb[5]
+            inter = (tag == k) & (xs + rb[0] >= 1) & (xs + rb[1] <= nx - 2) & (ys + rb[2] >= 1) & (ys + rb[3] <= ny - 2) & \
+                    (zs + rb[4] >= 1) & (zs + rb[5] <= nz - 2)
+            replayed += int(inter.sum())
+            # a candidate whose window is the table's visits exactly the table's voxels
+            assert (scr[1][inter, 12] == nvox).all(), f"level {k}: voxel counts of interior candidates differ from the table's"
+            w = ent["w"][ent["nval"] > 0]
+            assert (w[:, 0] > 0).all() and (w <= 1.0).all()
+        if expect_tables:
+            assert replayed >= n // 4, f"only {replayed} of {n} candidates could take their level's table: the test is too small"
+        return int((keep[0] == 1).sum()), replayed
+    finally:
+        L.s3d_k_set_orient_mode(-1)
+        for p_ in d_lv + d_R + d_keep + d_scr + [d_idx, d_tag, d_sig, d_tab]:
+            dev.free(p_)

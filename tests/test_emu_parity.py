@@ -77,6 +77,19 @@ def test_orientation_chunk_loop(emu, oracle):
             emu.sift.s3d_k_set_orient_chunk(0)
 
 
+@pytest.mark.parametrize("dims,units,sigmas,expect", [
+    ((40, 36, 34), (1, 1, 1), (2.0, 2.5, 3.2), True),          # the detector's case: unit voxels
+    ((30, 28, 26), (2, 2, 2), (4.0, 5.0), True),               # octave 1: units 2, sigma in the same units
+    ((32, 30, 28), (1, 1, 1.5), (2.0, 2.5), False),            # anisotropic: no tables, the general path serves all
+])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_orient_tables(emu, dims, units, sigmas, expect, mode):
+    """Window sums replayed from the levels' tables (one kernel that decides per candidate / a table-walk kernel plus the
+    general kernel for the rest) equal the sums every candidate enumerates for itself, bit for bit."""
+    kept, replayed = parity.check_orient_tables(emu, dims, units, sigmas, 150, expect_tables=expect, mode=mode)
+    assert kept > 0
+
+
 def test_raw_variants(emu, oracle):
     parity.check_raw_variants(emu, oracle, (32, 32, 32), (1, 1, 1), 40)
 
@@ -146,6 +159,22 @@ def test_sep_fir_slab_ranges(emu, oracle, dims, units):
     nz = dims[2]
     parity.check_sep_fir_slab(emu, oracle, dims, units, (0.973294, 1.22627, 1.94659),
                               ((nz // 2, nz), (0, nz // 2), (nz // 4, nz // 4 + 9)))
+
+
+S3 = (0.7, 0.973294, 1.94659)                                         # widths 5, 7, 13
+
+
+@pytest.mark.parametrize("dims,units,sigmas,splits", [
+    ((32, 32, 32), (8, 8, 8), S3 + (2.6,), [(0, 9), (9, 32), (13, 21)]),   # octave 3 of a pyramid: tile 8x8x8, halo 2; width 17
+    ((40, 24, 20), (4, 4, 4), S3 + (2.6,), [(0, 7), (7, 20)]),             # octave 2: halo 3, tiles clipped in x
+    ((23, 19, 17), (2, 2, 2), S3, [(3, 11)]),                              # odd dims, taps half a voxel apart, halo up to 4
+    ((21, 18, 26), (1, 1, 1.5), S3, [(0, 10), (10, 26)]),                  # non-dyadic spacing along z: the drifting coordinate
+    ((9, 7, 6), (2, 4, 2), S3[:2], []),                                    # smaller than one tile
+    ((17, 22, 19), (1, 1, 1), S3, [(5, 12)]),                              # unit spacing (nx % 4 != 0: not the streaming path's)
+])
+def test_sep_fir_tile3(emu, oracle, dims, units, sigmas, splits):
+    """The one-launch tile kernel for small volumes: bit-identical to the oracle and to the three passes."""
+    parity.check_sep_fir_tile3(emu, oracle, dims, units, sigmas, splits)
 
 
 @pytest.mark.parametrize("dims,zero", [((32, 28, 24), False), ((24, 24, 20), True)])

@@ -575,6 +575,40 @@ def test_sep_fir_slab_ranges(lib, oracle, dims, units):
                               ((nz // 2, nz), (0, nz // 2), (nz // 4, nz // 4 + 9)))
 
 
+S3 = (0.7, 0.973294, 1.94659)                                         # widths 5, 7, 13
+
+
+@pytest.mark.parametrize("dims,units,sigmas,splits", [
+    ((64, 64, 64), (8, 8, 8), S3 + (2.6,), [(0, 19), (19, 64), (23, 41)]),     # octave 3 of the 512^3 pyramid; width 17
+    ((128, 128, 128), (4, 4, 4), (1.94659, 2.6), [(0, 50), (50, 128)]),        # octave 2 (tile 32x8x8, halo 3)
+    ((32, 32, 32), (16, 16, 16), S3 + (2.6,), [(0, 9), (9, 32)]),
+    ((8, 8, 8), (64, 64, 64), S3 + (2.6,), []),                                # the last octave
+    ((40, 24, 20), (4, 4, 4), S3 + (2.6,), [(0, 7), (7, 20)]),
+    ((23, 19, 17), (2, 2, 2), S3, [(3, 11)]),
+    ((21, 18, 26), (1, 1, 1.5), S3, [(0, 10), (10, 26)]),
+    ((33, 47, 29), (1, 0.7, 1.3), S3, [(4, 17)]),
+    ((9, 7, 6), (2, 4, 2), S3[:2], []),
+    ((17, 22, 19), (1, 1, 1), S3, [(5, 12)]),
+])
+def test_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits):
+    """The one-launch tile kernel for small volumes (k_gauss3_tile): bit-identical to the oracle and to the three passes,
+    whole volumes and plane ranges, dyadic and non-dyadic tap spacings."""
+    parity.check_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dims,units,sigmas,expect", [
+    ((96, 88, 80), (1, 1, 1), (2.0159, 2.5398, 3.2), True),
+    ((64, 60, 56), (2, 2, 2), (4.0317, 5.0797, 6.4), True),
+    ((48, 40, 44), (1, 1, 1.5), (2.0, 2.5), False),
+])
+def test_orient_tables(lib, dims, units, sigmas, expect, mode):
+    """Orientation window sums replayed from the levels' tables equal the sums every candidate enumerates for itself, bit
+    for bit (R, keep flags and the 13 raw sums per candidate), interior, face and corner candidates alike."""
+    kept, replayed = parity.check_orient_tables(lib, dims, units, sigmas, 4000, expect_tables=expect, mode=mode)
+    assert kept > 0
+
+
 @pytest.mark.parametrize("dims,zero", [((64, 52, 48), False), ((512, 40, 36), False), ((24, 24, 20), True)])
 def test_sep_fir_div(lib, oracle, dims, zero):
     """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit."""
