@@ -4,7 +4,7 @@ cd "$R"; mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 out=gpurun_out/match_round.txt
 : > $out
-for v in shipped gmold shipped gmold; do
+for v in ${VARIANTS_M:-shipped gmold shipped gmold}; do
   lib=$R/sift3d_amd/lib/ablate/libsift3d_amd_$v.so
   [ "$v" = "shipped" ] && lib=$R/sift3d_amd/lib/libsift3d_amd.so
   echo "== $v" >> $out

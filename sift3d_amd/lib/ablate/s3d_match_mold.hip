@@ -283,27 +283,51 @@ k_nn_norms(const float *__restrict__ src, size_t stride, const int *__restrict__
  * 32 halves) go through LDS with a row pitch of 40 halves (conflict-free ds_read_b128 of the fragments: lane l reads row
  * l & 31 at halves 8 (l >> 5) ..), the next step's global loads are in flight while the current one multiplies. */
 #define GKH 32                       /* halves of k per step */
+#define GEMM_GM 8u                   /* tiles per block of co-resident workgroups: rows ... */
+#define GEMM_GN 32u                  /* ... and columns (a multiple of 8: one column group per XCD) */
 #define GLD 40                       /* LDS row pitch in halves */
 __global__ void __launch_bounds__(256)
 k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsigned row_base, const nn_half *__restrict__ Bh,
           const nn_half *__restrict__ Bl, unsigned nbpad, const float *__restrict__ a2, const float *__restrict__ b2,
           float *__restrict__ S /* rows x nbpad */, float *__restrict__ pm1, float *__restrict__ pm2 /* optional: see below */,
-          float *__restrict__ rmin /* rows x nbpad/64: smallest score of every (row, 64-column block) */)
+          float *__restrict__ rmin /* rows x nbpad/64: smallest score of every (row, 64-column block) */,
+          unsigned nti_real, unsigned ntj_real /* tiles of the score matrix; the grid is padded to whole GEMM_GM x GEMM_GN blocks */)
 {
     /* Two LDS buffers: while the waves multiply out of one, the next k-step's panels (already in registers: their global
      * loads were issued a whole step earlier) are stored into the other -- ONE barrier per k-step instead of two, and no
      * MFMA-free stretch between "store" and "multiply".  80 KB of the CU's 160 KB. */
     __shared__ __attribute__((aligned(16))) nn_half sm[2][4][GT][GLD];   /* [buffer][A hi, A lo, B hi, B lo] */
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const unsigned i0 = row_base + blockIdx.y * GT, j0 = blockIdx.x * GT;
+    /* Which tile this workgroup computes.  In launch order (x fastest) a row of tiles shares its A panel but streams the whole
+     * of B past every row: 244 rows x 96 MB at 31 k x 31 k, and that operand traffic, not the matrix cores, set the pace.
+     * Instead the 256 workgroups that are resident together cover a block of GEMM_GM x GEMM_GN tiles (8 A panels + 32 B
+     * panels: 16 MB for 256 tiles instead of 96 MB for 244), and because consecutive workgroup ids go to the eight XCDs
+     * round-robin, XCD k takes the GEMM_GN / 8 columns [4k, 4k + 4) of the block with all GEMM_GM rows: 12 panels, under
+     * 5 MB, for its 32 tiles -- what its own L2 can hold. */
+    unsigned tile_i, tile_j;
+    {
+        /* grid = (GEMM_GM * GEMM_GN workgroups of a block, blocks row-major): nn_gemm_grid */
+        const unsigned gj_count = (ntj_real + GEMM_GN - 1) / GEMM_GN;
+        const unsigned blk = blockIdx.y, in = blockIdx.x;
+        const unsigned gi = blk / gj_count, gj = blk - gi * gj_count;
+        const unsigned xcd = in & 7u, local = in >> 3;               /* local: 0 .. GEMM_GM * GEMM_GN / 8 - 1 */
+        tile_i = gi * GEMM_GM + local % GEMM_GM;
+        tile_j = gj * GEMM_GN + xcd * (GEMM_GN / 8u) + local / GEMM_GM;
+        if (tile_i >= nti_real || tile_j >= ntj_real) return;        /* padding of the last block row / column */
+    }
+    const unsigned i0 = row_base + tile_i * GT, j0 = tile_j * GT;
     nn_acc16 acc[2][2];
     for (int tm = 0; tm < 2; tm++)
         for (int tn = 0; tn < 2; tn++)
             for (int r = 0; r < 16; r++) NN_ACC_GET(acc[tm][tn], r) = 0.0f;
     /* staging: per panel 128 rows x 4 quarters of 8 halves = 512 16-byte pieces, two per thread */
     const nn_half *gsrc[4] = {Ah + (size_t)i0 * NEL, Al + (size_t)i0 * NEL, Bh + (size_t)j0 * NEL, Bl + (size_t)j0 * NEL};
-    nn_h8 stage[4][2];
-    auto fetch = [&](int e0) {
+    /* Two register stages: the panels of k-steps s + 2 and s + 3 are in flight from global memory while step s is multiplied
+     * out of one LDS buffer and step s + 1 is stored into the other.  With a single stage the loads of the next step had one
+     * step's worth of MFMAs (~770 clk) to arrive and the wave then stood at s_waitcnt vmcnt for the rest of an L2 / fabric
+     * round trip on every step: that, not the matrix cores and not the operand bandwidth, was the kernel's pace. */
+    nn_h8 st0[4][2], st1[4][2];
+    auto fetch = [&](nn_h8 (&stage)[4][2], int e0) {
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -312,7 +336,7 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
                 stage[p][u] = *reinterpret_cast<const nn_h8 *>(gsrc[p] + (size_t)row * NEL + e0 + 8 * q);
             }
     };
-    auto park = [&](int buf) {
+    auto park = [&](int buf, const nn_h8 (&stage)[4][2]) {
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -321,16 +345,7 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
                 *reinterpret_cast<nn_h8 *>(&sm[buf][p][row][8 * q]) = stage[p][u];
             }
     };
-    fetch(0);
-    park(0);
-    if (GKH < NEL) fetch(GKH);
-    __syncthreads();
-    int buf = 0;
-    for (int e0 = 0; e0 < NEL; e0 += GKH, buf ^= 1) {
-        if (e0 + GKH < NEL) {
-            park(buf ^ 1);                                  /* step e0 + GKH: read by nobody before the barrier below */
-            if (e0 + 2 * GKH < NEL) fetch(e0 + 2 * GKH);
-        }
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < GKH; kk += 16) {
             nn_h8 ah[2], al[2], bh[2], bl[2];
@@ -342,16 +357,43 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
                 bh[tt] = *reinterpret_cast<const nn_h8 *>(&sm[buf][2][wn * 64 + tt * 32 + rl][ko]);
                 bl[tt] = *reinterpret_cast<const nn_h8 *>(&sm[buf][3][wn * 64 + tt * 32 + rl][ko]);
             }
+            /* product by product over the four accumulator tiles, not tile by tile: an MFMA that adds to the accumulator the
+             * previous one wrote waits for it (SQ_WAIT_INST_ANY was 53 % of the wave cycles with the three products of a tile
+             * back to back); with three other tiles' MFMAs in between the matrix pipe stays fed */
 #pragma unroll
             for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-                for (int tn = 0; tn < 2; tn++) {
-                    nn_mfma(acc[tm][tn], ah[tm], bh[tn]);
-                    nn_mfma(acc[tm][tn], ah[tm], bl[tn]);
-                    nn_mfma(acc[tm][tn], al[tm], bh[tn]);
-                }
+                for (int tn = 0; tn < 2; tn++) nn_mfma(acc[tm][tn], ah[tm], bh[tn]);
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) nn_mfma(acc[tm][tn], ah[tm], bl[tn]);
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) nn_mfma(acc[tm][tn], al[tm], bh[tn]);
         }
-        __syncthreads();                                    /* buffer `buf` is free, buffer `buf ^ 1` is complete */
+    };
+    constexpr int NSTEP = NEL / GKH;
+    static_assert(NEL % (2 * GKH) == 0, "the k loop is unrolled by two");
+    fetch(st0, 0);
+    fetch(st1, GKH);
+    park(0, st0);
+    fetch(st0, 2 * GKH);
+    __syncthreads();
+    for (int sidx = 0; sidx < NSTEP; sidx += 2) {
+        /* step sidx out of buffer 0; step sidx + 1 (in st1) into buffer 1; step sidx + 3 on its way into st1 */
+        park(1, st1);
+        if (sidx + 3 < NSTEP) fetch(st1, (sidx + 3) * GKH);
+        multiply(0);
+        __syncthreads();
+        /* step sidx + 1 out of buffer 1; step sidx + 2 (in st0) into buffer 0; step sidx + 4 on its way into st0 */
+        if (sidx + 2 < NSTEP) {
+            park(0, st0);
+            if (sidx + 4 < NSTEP) fetch(st0, (sidx + 4) * GKH);
+        }
+        multiply(1);
+        __syncthreads();
     }
     /* D register r of a lane: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of its 32 x 32 tile */
     const float unscale = 2.0f / (NN_SCALE * NN_SCALE);
@@ -363,7 +405,7 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
             const float nb = b2[col];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const unsigned lrow = blockIdx.y * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const unsigned lrow = tile_i * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const float na = a2[row_base + lrow];
                 const float v = (na + nb) - unscale * NN_ACC_GET(acc[tm][tn], r);
                 S[(size_t)lrow * nbpad + col] = v;
@@ -384,7 +426,7 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
 #pragma unroll
                 for (int k = 1; k <= 16; k <<= 1) m = fminf(m, __shfl_xor(m, k));
                 if ((lane & 31) == 0) {
-                    const unsigned lrow = blockIdx.y * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const unsigned lrow = tile_i * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     rmin[(size_t)lrow * nblk64 + (j0 / 64u + (unsigned)wn)] = m;
                 }
             }
@@ -410,12 +452,20 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
             const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1, s2 = m2 < o2 ? m2 : o2;
             if (lane < 32) {
                 const unsigned col = j0 + wn * 64 + tn * 32 + lane;
-                const size_t blk = (size_t)(row_base / 64u + blockIdx.y * 2u + (unsigned)wm);
+                const size_t blk = (size_t)(row_base / 64u + tile_i * 2u + (unsigned)wm);
                 pm1[blk * nbpad + col] = lo;
                 pm2[blk * nbpad + col] = hi < s2 ? hi : s2;
             }
         }
     }
+}
+
+/* grid of k_nn_gemm for ntj x nti tiles: whole GEMM_GM x GEMM_GN blocks, as (x = GEMM_GM * GEMM_GN workgroups per
+ * block, y = blocks) -- the kernel derives its tile from the linear workgroup id */
+static dim3 nn_gemm_grid(unsigned ntj, unsigned nti)
+{
+    const unsigned bi = (nti + GEMM_GM - 1) / GEMM_GM, bj = (ntj + GEMM_GN - 1) / GEMM_GN;
+    return dim3(GEMM_GM * GEMM_GN, bi * bj);
 }
 
 /* one wave per query row: the two smallest approximate scores, then every column within the error band of the second
@@ -646,8 +696,8 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     }
     for (size_t r0 = 0; r0 < napad; r0 += rows_chunk) {
         const unsigned rows = (unsigned)(r0 + rows_chunk <= napad ? rows_chunk : napad - r0);
-        hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, rows / GT), dim3(256), 0, st, AH, AL, (unsigned)r0, BH, BL, nbpad, a2f,
-                           b2f, S, (float *)nullptr, (float *)nullptr, rmin);
+        hipLaunchKernelGGL(k_nn_gemm, nn_gemm_grid(nbpad / GT, rows / GT), dim3(256), 0, st, AH, AL, (unsigned)r0, BH, BL, nbpad, a2f,
+                           b2f, S, (float *)nullptr, (float *)nullptr, rmin, rows / GT, nbpad / GT);
         const unsigned live = r0 + rows <= na ? rows : (na > r0 ? (unsigned)(na - r0) : 0u);
         if (live)
             hipLaunchKernelGGL(k_nn_rowscan, dim3(live), dim3(64), 0, st, S, rmin, nbpad, nb, (unsigned)r0, na, a2d, b2max, cand,
@@ -770,8 +820,8 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
         if (!ok) { rc = 1; goto done; }                   /* operands outside the split's range: the exhaustive kernel */
     }
     NN_TRY(hipMemsetAsync(countb, 0, sizeof(int) * nb, st));
-    hipLaunchKernelGGL(k_nn_gemm, dim3(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2,
-                       rmin);
+    hipLaunchKernelGGL(k_nn_gemm, nn_gemm_grid(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2,
+                       rmin, napad / GT, nbpad / GT);
     hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, rmin, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
     hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nblk, nbpad, nb, b2d, a2max, thr);
     hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, pm1, nbpad, nb, na, blk_per_seg, nblk, thr, candb,

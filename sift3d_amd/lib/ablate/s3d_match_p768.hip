@@ -418,24 +418,11 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
     };
     constexpr int NSTEP = NEL / GKH;
     static_assert(NEL % (2 * GKH) == 0, "the k loop is unrolled by two");
-#if defined(NN_GEMM_CLOCKS)          /* profiling build: shader-clock and 100 MHz stamps of one workgroup in the middle of the grid */
-    const long long ck0 = clock64(), wk0 = wall_clock64();
-#endif
     fetch(st0, 0);
     fetch(st1, GKH);
     park(0, st0);
     fetch(st0, 2 * GKH);
-    /* The tile's squared norms ride in the padding of the panel rows (halves 32, 33 of a row of pitch 40: the stores above
-     * never touch them) until the epilogue needs them.  Loading them there instead cost the epilogue a third of the tile's
-     * time: loads and stores return in order on one counter, so every norm loaded after a batch of score stores waited
-     * for those stores' round trip to memory. */
-    if (t < GT) *reinterpret_cast<float *>(&sm[0][0][t][GKH]) = a2[i0 + (unsigned)t];
-    else *reinterpret_cast<float *>(&sm[0][2][t - GT][GKH]) = b2[j0 + (unsigned)(t - GT)];
-    static_assert(GLD >= GKH + 2 && GT == 128, "norms live in the row padding; one per thread");
     __syncthreads();
-#if defined(NN_GEMM_CLOCKS)
-    const long long ck1 = clock64();
-#endif
     /* step s multiplies out of buffer s & 1 while step s + 1 (in a register stage since two steps ago) is stored into the
      * other buffer and step s + 3 starts on its way into that stage.  Past the end the stores and loads repeat the last
      * panels (never read): no branches inside a step, one scheduling region between two barriers. */
@@ -445,33 +432,42 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
         kstep(1, st0, (sidx + 4 < NSTEP ? sidx + 4 : NSTEP - 1) * GKH);
         __syncthreads();
     }
-#if defined(NN_GEMM_CLOCKS)
-    const long long ck2 = clock64();
-#endif
     /* D register r of a lane: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of its 32 x 32 tile */
     const float unscale = 2.0f / (NN_SCALE * NN_SCALE);
-    /* scores into the accumulator registers (the norms come out of the panel rows' padding); they leave for memory at
-     * the very end, through LDS, as whole 256-byte row segments */
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
         for (int tn = 0; tn < 2; tn++) {
-            const float nb = *reinterpret_cast<const float *>(&sm[0][2][wn * 64 + tn * 32 + (lane & 31)][GKH]);
+            const unsigned col = j0 + wn * 64 + tn * 32 + (lane & 31);
+            const float nb = b2[col];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int trow = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float na = *reinterpret_cast<const float *>(&sm[0][0][trow][GKH]);
-                NN_ACC_GET(acc[tm][tn], r) = (na + nb) - unscale * NN_ACC_GET(acc[tm][tn], r);
+                const unsigned lrow = tile_i * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float na = a2[row_base + lrow];
+                const float v = (na + nb) - unscale * NN_ACC_GET(acc[tm][tn], r);
+                S[(size_t)lrow * nbpad + col] = v;
+                NN_ACC_GET(acc[tm][tn], r) = v;
             }
         }
-    /* LDS after the k loop: buffer 1 is dead (the last step multiplied out of it before the final barrier), buffer 0 only
-     * holds the norms: the score tiles are transposed through the array once every wave is done with the norms. */
-    constexpr int TPITCH = 68;                              /* floats per row of a wave's 64 x 64 score block in LDS */
-    float *const lds_f = reinterpret_cast<float *>(&sm[0][0][0][0]);
-    static_assert(4 * 64 * TPITCH * sizeof(float) <= sizeof(sm), "the four waves' score blocks fit");
-#if defined(NN_GEMM_CLOCKS)
-    const long long ck2b = clock64();
-#endif
+    /* Row minima per 64-column block, while the scores are still in registers: a row of this wave's 64 x 64 block lives in
+     * one register of the 32 lanes of a half-wave (two tiles side by side): min over the two tiles, then a 5-step butterfly
+     * inside the half-wave.  The row scan then reads nbpad/64 values per row instead of the row, and only the blocks that
+     * can hold a candidate. */
+    {
+        const unsigned nblk64 = nbpad / 64u;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float m = fminf(NN_ACC_GET(acc[tm][0], r), NN_ACC_GET(acc[tm][1], r));
+#pragma unroll
+                for (int k = 1; k <= 16; k <<= 1) m = fminf(m, __shfl_xor(m, k));
+                if ((lane & 31) == 0) {
+                    const unsigned lrow = tile_i * GT + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    rmin[(size_t)lrow * nblk64 + (j0 / 64u + (unsigned)wn)] = m;
+                }
+            }
+    }
     /* Column minima for the backward direction, while the scores are still in registers: a lane holds 32 of the 64 rows
      * of this wave's block for each of its two columns (the other 32 sit in lane ^ 32); the two smallest per (64-row
      * block, column) go to pm1 / pm2[block][column] -- the column scan then reads 2/64 of the matrix instead of all of
@@ -499,51 +495,6 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
             }
         }
     }
-#if defined(NN_GEMM_CLOCKS)
-    const long long ck2c = clock64();
-#endif
-    __syncthreads();                                        /* every wave is done with the norms */
-    {   /* this wave's 64 x 64 scores: registers -> its LDS block (row-major) */
-        float *const tb = lds_f + wave * 64 * TPITCH;
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    tb[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TPITCH + tn * 32 + (lane & 31)] = NN_ACC_GET(acc[tm][tn], r);
-        __syncthreads();                                    /* (a wave only reads its own block: any wave-level fence would do) */
-        /* Row minima per 64-column block: lane l takes row l of the block -- 16 ds_read_b128 and 63 v_min instead of a
-         * 5-step cross-lane butterfly per register (32 of them: 17.7 k clocks through ds_bpermute, 6.4 k through DPP).
-         * The row scan then reads nbpad/64 values per row instead of the row, and only the blocks that can hold a
-         * candidate. */
-        {
-            const float *rowp = tb + lane * TPITCH;
-            float m = 3.0e38f;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const float4 q = *reinterpret_cast<const float4 *>(rowp + 4 * c);
-                m = fminf(fminf(m, q.x), fminf(q.y, fminf(q.z, q.w)));
-            }
-            rmin[(size_t)(tile_i * GT + wm * 64 + (unsigned)lane) * (nbpad / 64u) + (j0 / 64u + (unsigned)wn)] = m;
-        }
-        /* ... and out: 16 stores of 4 rows x 256 bytes */
-        const unsigned col = j0 + wn * 64 + 4 * (lane & 15);
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int brow = 4 * i + (lane >> 4);
-            const float4 q = *reinterpret_cast<const float4 *>(&tb[brow * TPITCH + 4 * (lane & 15)]);
-            *reinterpret_cast<float4 *>(&S[(size_t)(tile_i * GT + wm * 64 + (unsigned)brow) * nbpad + col]) = q;
-        }
-    }
-#if defined(NN_GEMM_CLOCKS)
-    if (t == 0 && blockIdx.y == gridDim.y / 2 && (blockIdx.x & 63u) == 0) {
-        const long long ck3 = clock64(), wk3 = wall_clock64();
-        printf("gemm wg (%u,%u): prologue %lld loop %lld (%lld per k-step) epilogue %lld (scores %lld, column minima %lld, transpose + row minima + stores %lld) shader clocks; total %lld clocks = %lld ticks of 10 ns -> %.3f GHz\n",
-               blockIdx.x, blockIdx.y, ck1 - ck0, ck2 - ck1, (ck2 - ck1) / NSTEP, ck3 - ck2, ck2b - ck2, ck2c - ck2b, ck3 - ck2c, ck3 - ck0, wk3 - wk0,
-               (double)(ck3 - ck0) / (10.0 * (double)(wk3 - wk0)));
-    }
-#endif
 }
 
 /* grid of k_nn_gemm for ntj x nti tiles: whole GEMM_GM x GEMM_GN blocks, as (x = GEMM_GM * GEMM_GN workgroups per
