@@ -180,10 +180,11 @@ extern "C" int s3d_k_nn_best2(const float* d_a, size_t a_stride, const int* d_a_
  * terms (<= 768 2^-24 |a||b| = 4.6e-5 |a||b|, the same bound as an f32 FMA chain) plus 2^-21 |a||b| from the split: inside
  * d = 1e-4 |a||b| + ... , so the candidate sets -- and with the exact f64 verification every result bit -- are unchanged. */
 #define NN_SCALE 256.0f
-/* Row pitch of the f16 copies in halves.  Not NEL: rows 1536 bytes apart put the 16 rows a wave's load touches on half of
- * the L2 channels (1536 = 6 x 256); an odd multiple of 128 bytes spreads them over all. */
+/* Row pitch of the f16 copies in halves.  (Rows 1536 bytes apart put the 16 rows a wave's load touches on every other
+ * 256-byte boundary; pitches of 1600, 1664 and 1792 bytes were timed against it -- no difference, profiles/
+ * r03_match_gemm_experiments.txt -- so the copies stay dense.) */
 #ifndef NN_PITCH
-#define NN_PITCH (NEL + 64)
+#define NN_PITCH NEL
 #endif
 #if defined(S3D_EMU)
 typedef unsigned short nn_half;
