@@ -165,11 +165,11 @@ __device__ __forceinline__ int orient_finish(const float vr[2][3], float gwx, fl
  * then just walks the table -- lane for lane the operations of the general path, hence the same bits. */
 #define ORI_TAB_CENTRE 256
 template <int PHASE>
-__global__ void __launch_bounds__(64)
-k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
-              const float *__restrict__ d_center, uint32_t cand0, uint32_t num, const double *__restrict__ d_sigma,
-              double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
-              double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs)
+__device__ __forceinline__ void
+orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
+           const float *__restrict__ d_center, unsigned cand, unsigned slot, uint32_t num, const double *__restrict__ d_sigma,
+           double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
+           double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs)
 {
     __shared__ __attribute__((aligned(16))) float term[3][64];
     __shared__ float gw_s[3];
@@ -177,12 +177,12 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     __shared__ unsigned row_first[64];
     __shared__ unsigned short row_len[64];
     __shared__ float wtab[ORI_WTAB];
-    const unsigned cand = cand0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (cand >= num) return;
     if (PHASE == 2 && d_keep[cand] != 2u) return;
     if (PHASE == 4 && d_keep[cand] != 3u) return;          /* PHASE 3 served this one from its level's table */
-    double *scr = d_scr + (size_t)blockIdx.x * ORI_SCR;
+    if (PHASE == 4) s3d_wave_lds_sync();                   /* the previous candidate of this wave is done with the LDS tables */
+    double *scr = d_scr + (size_t)slot * ORI_SCR;
     const unsigned tag = PHASE == 0 ? (((cand / (unsigned)pyr.num_levels) << 8) | (cand % (unsigned)pyr.num_levels))
                                     : (d_tag ? d_tag[cand] : 0u);        /* no tags: every candidate lives in level 0 */
     const int o = (int)(tag >> 8), k = (int)(tag & 255u);
@@ -382,7 +382,11 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
      * (to f64 accuracy) exact value gd and sum|term| per component, which bounds how far the
      * reference's sequential f32 accumulation can be from gd ------------------------------------- */
     double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-    double gdx = 0, gdy = 0, gdz = 0, sax = 0, say = 0, saz = 0;
+    /* window gradient and sum |term| per lane in f32: a lane adds a few dozen terms, the butterfly six more, so the sum is
+     * within (terms per lane + 6) 2^-24 sum|t| of the exact one -- a fiftieth of what the reference's own sequential f32
+     * sum is allowed to be off, and k_orient_decide widens its margin by exactly that (scr[13] = most terms a lane added).
+     * In f64 these six sums were 9 of a voxel's 22 double-rate instructions. */
+    float gdx = 0, gdy = 0, gdz = 0, sax = 0, say = 0, saz = 0;
     int cnt = 0;
     /* four x-consecutive voxels per lane and turn: one row decode and five wide unaligned loads (the level
      * buffers carry the slack, s3d_device.h) instead of four decodes and 24 dword loads */
@@ -410,8 +414,8 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
             a00 = fma(gxw, gxd, a00); a01 = fma(gxw, gyd, a01); a02 = fma(gxw, gzd, a02);
             a11 = fma(gyw, gyd, a11); a12 = fma(gyw, gzd, a12); a22 = fma(gzw, gzd, a22);
             const float tx = gx * w, ty = gy * w, tz = gz * w;
-            gdx += (double)tx; gdy += (double)ty; gdz += (double)tz;
-            sax += fabs((double)tx); say += fabs((double)ty); saz += fabs((double)tz);
+            gdx = gdx + tx; gdy = gdy + ty; gdz = gdz + tz;
+            sax = sax + fabsf(tx); say = say + fabsf(ty); saz = saz + fabsf(tz);
             cnt++;
         }
     };
@@ -445,18 +449,23 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
         accumulate(p, nval, wv[0], wv[1], wv[2], wv[3]);
     });
     }
+    int lane_terms = cnt;
     for (int m = 32; m >= 1; m >>= 1) {                    /* xor butterfly: every lane ends with the totals */
         a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
         a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
-        gdx += __shfl_xor(gdx, m); gdy += __shfl_xor(gdy, m); gdz += __shfl_xor(gdz, m);
-        sax += __shfl_xor(sax, m); say += __shfl_xor(say, m); saz += __shfl_xor(saz, m);
+        gdx = gdx + __shfl_xor(gdx, m); gdy = gdy + __shfl_xor(gdy, m); gdz = gdz + __shfl_xor(gdz, m);
+        sax = sax + __shfl_xor(sax, m); say = say + __shfl_xor(say, m); saz = saz + __shfl_xor(saz, m);
         cnt += __shfl_xor(cnt, m);
+        const int ot = __shfl_xor(lane_terms, m);
+        lane_terms = lane_terms > ot ? lane_terms : ot;
     }
 
     if (lane == 0) {
         scr[0] = a00; scr[1] = a01; scr[2] = a02; scr[3] = a11; scr[4] = a12; scr[5] = a22;
-        scr[6] = gdx; scr[7] = gdy; scr[8] = gdz; scr[9] = sax; scr[10] = say; scr[11] = saz;
+        scr[6] = (double)gdx; scr[7] = (double)gdy; scr[8] = (double)gdz;
+        scr[9] = (double)sax; scr[10] = (double)say; scr[11] = (double)saz;
         scr[12] = (double)cnt;
+        scr[13] = (double)lane_terms;                       /* read by k_orient_decide before it parks the eigenvectors here */
     }
     return;
     }
@@ -510,6 +519,25 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
     if (d_conf) d_conf[cand] = keep || conf > 0.0 ? conf : 0.0;
 }
 
+/* One wave per candidate (candidate cand0 + blockIdx.x of a chunk of nchunk); PHASE 4 -- the few candidates the table
+ * walk flagged -- is a fixed grid of waves that each look through a stride of the chunk: a launch of one workgroup per
+ * candidate that returns at once for nine in ten of them cost 0.43 ms at 120 k candidates. */
+template <int PHASE>
+__global__ void __launch_bounds__(64)
+k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
+              const float *__restrict__ d_center, uint32_t cand0, uint32_t nchunk, uint32_t num, const double *__restrict__ d_sigma,
+              double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
+              double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs)
+{
+    if (PHASE == 4) {
+        for (unsigned c = blockIdx.x; c < nchunk; c += gridDim.x)
+            orient_one<4>(pyr, d_idx, d_tag, d_center, cand0 + c, c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, d_conf, tabs);
+    } else {
+        orient_one<PHASE>(pyr, d_idx, d_tag, d_center, cand0 + blockIdx.x, blockIdx.x, num, d_sigma, corner_thresh, d_scr, d_R,
+                          d_keep, d_conf, tabs);
+    }
+}
+
 __global__ void __launch_bounds__(64)
 k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R,
                 uint32_t *__restrict__ d_keep, double *__restrict__ d_conf)
@@ -521,6 +549,7 @@ k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thr
     const double a00 = scr[0], a01 = scr[1], a02 = scr[2], a11 = scr[3], a12 = scr[4], a22 = scr[5];
     const double gdx = scr[6], gdy = scr[7], gdz = scr[8], sax = scr[9], say = scr[10], saz = scr[11];
     const int cnt = (int)scr[12];
+    const int lane_terms = (int)scr[13];
     float R[9];
     for (int i = 0; i < 9; i++) R[i] = 0.0f;
     int keep = 0;
@@ -546,7 +575,10 @@ k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thr
     if (ratio_reject) {
         decided = 1;                                       /* REJECT whatever the gradient is */
     } else if (d_conf == nullptr) {
-        const double gam = ((double)cnt + 3.0) * 5.9604644775390625e-08 * 1.001;
+        /* the reference's sequential sum is within (cnt + 3) 2^-24 sum|t| of the exact sum, the window sums' own f32
+         * accumulation (a lane's terms, then the six butterfly steps) within (lane_terms + 6) 2^-24 sum|t|, and sum|t|
+         * itself is short of the exact one by at most that relative amount (covered by the last factor) */
+        const double gam = ((double)cnt + (double)lane_terms + 12.0) * 5.9604644775390625e-08 * 1.002;
         const double ex = gam * sax, ey = gam * say, ez = gam * saz;
         const double del = sqrt(ex * ex + ey * ey + ez * ez);
         const double G = sqrt(gdx * gdx + gdy * gdy + gdz * gdz);
@@ -632,7 +664,7 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
     if (tabs) {
         const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
         hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, d_sigma, corner_thresh,
+                           (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, nlev, d_sigma, corner_thresh,
                            (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs);
         S3D_CHECK_LAUNCH();
     }
@@ -640,20 +672,20 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
         if (tabs && mode == 2) {
-            hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+            hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
                                d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
             S3D_CHECK_LAUNCH();
-            hipLaunchKernelGGL((k_orient_wave<4>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
-                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
+            hipLaunchKernelGGL((k_orient_wave<4>), dim3(n < 8192u ? n : 8192u), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag,
+                               d_center, c0, n, num, d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
         } else {
-            hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+            hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
                                d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
         }
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
                            d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
-        hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, num,
+        hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
                            d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
         S3D_CHECK_LAUNCH();
     }
