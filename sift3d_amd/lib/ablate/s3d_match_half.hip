@@ -180,12 +180,12 @@ extern "C" int s3d_k_nn_best2(const float* d_a, size_t a_stride, const int* d_a_
  * terms (<= 768 2^-24 |a||b| = 4.6e-5 |a||b|, the same bound as an f32 FMA chain) plus 2^-21 |a||b| from the split: inside
  * d = 1e-4 |a||b| + ... , so the candidate sets -- and with the exact f64 verification every result bit -- are unchanged. */
 #define NN_SCALE 256.0f
-/* Layout of the f16 copies: hi and lo halves of a row interleaved per k-step -- [row][k-step][hi 32 halves | lo 32 halves],
- * i.e. the 128 bytes a row contributes to one k-step (both panels) are ONE cache line, fetched once and used up at once.
- * With separate hi and lo arrays a k-step took the first 64 bytes of a line and the next k-step the second 64: by then
- * the line had left the L1 (two workgroups stream 64 KB per k-step through its 32 KB) and came from L2 a second time. */
-#define NN_PITCH (2 * NEL)           /* halves per row of a combined copy */
-#define NN_KOFF(e) ((((e) >> 5) << 6) + ((e) & 31))   /* element e of the hi part; the lo part sits 32 halves further */
+/* Row pitch of the f16 copies in halves.  (Rows 1536 bytes apart put the 16 rows a wave's load touches on every other
+ * 256-byte boundary; pitches of 1600, 1664 and 1792 bytes were timed against it -- no difference, profiles/
+ * r03_match_gemm_experiments.txt -- so the copies stay dense.) */
+#ifndef NN_PITCH
+#define NN_PITCH NEL
+#endif
 #if defined(S3D_EMU)
 typedef unsigned short nn_half;
 struct nn_h8 { nn_half v[8]; };
@@ -261,8 +261,8 @@ k_nn_split(const float *__restrict__ src, size_t stride, const int *__restrict__
     float x = 0.0f;
     if (r < n) x = src[(size_t)(sel ? (unsigned)sel[r] : r) * stride + e] * NN_SCALE;
     const nn_half h = nn_f2h(x);
-    hi[(size_t)r * NN_PITCH + NN_KOFF(e)] = h;
-    lo[(size_t)r * NN_PITCH + NN_KOFF(e)] = nn_f2h(x - nn_h2f(h));
+    hi[(size_t)r * NN_PITCH + e] = h;
+    lo[(size_t)r * NN_PITCH + e] = nn_f2h(x - nn_h2f(h));
 }
 
 /* squared norms in f64 (one wave per row), stored as f64 and f32; padding rows get a huge norm */
@@ -343,7 +343,7 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int c = t + 256 * u, row = c >> 2, q = c & 3;
-                stage[p][u] = *reinterpret_cast<const nn_h8 *>(gsrc[p] + (size_t)row * NN_PITCH + 2 * e0 + 8 * q);
+                stage[p][u] = *reinterpret_cast<const nn_h8 *>(gsrc[p] + (size_t)row * NN_PITCH + e0 + 8 * q);
             }
     };
     auto park = [&](int buf, const nn_h8 (&stage)[4][2]) {
@@ -423,7 +423,6 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
     };
     constexpr int NSTEP = NEL / GKH;
     static_assert(NEL % (2 * GKH) == 0, "the k loop is unrolled by two");
-    static_assert(GKH == 32, "NN_KOFF interleaves hi and lo per 32 halves");
 #if defined(NN_GEMM_CLOCKS)          /* profiling build: shader-clock and 100 MHz stamps of one workgroup in the middle of the grid */
     const long long ck0 = clock64(), wk0 = wall_clock64();
 #endif
@@ -759,8 +758,8 @@ extern "C" int s3d_k_nn_best2_fast(const float *d_a, size_t a_stride, const int 
     if (pool == nullptr) return 1;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
 #define NN_GET(var, type, slot, bytes) do { if (((var) = (type *)nn_get(pool, slot, bytes)) == nullptr) goto done; } while (0)
-    NN_GET(AH, nn_half, 0, sizeof(nn_half) * (size_t)NN_PITCH * napad); AL = AH + GKH;
-    NN_GET(BH, nn_half, 2, sizeof(nn_half) * (size_t)NN_PITCH * nbpad); BL = BH + GKH;
+    NN_GET(AH, nn_half, 0, sizeof(nn_half) * (size_t)NN_PITCH * napad); NN_GET(AL, nn_half, 1, sizeof(nn_half) * (size_t)NN_PITCH * napad);
+    NN_GET(BH, nn_half, 2, sizeof(nn_half) * (size_t)NN_PITCH * nbpad); NN_GET(BL, nn_half, 3, sizeof(nn_half) * (size_t)NN_PITCH * nbpad);
     NN_GET(a2f, float, 4, sizeof(float) * napad); NN_GET(b2f, float, 5, sizeof(float) * nbpad);
     NN_GET(a2d, double, 6, sizeof(double) * napad); NN_GET(b2d, double, 7, sizeof(double) * nbpad);
     NN_GET(S, float, 8, sizeof(float) * rows_chunk * nbpad);
@@ -881,8 +880,8 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     if (pool == nullptr) return 1;
 #define NN_TRY(x) do { if ((x) != hipSuccess) goto done; } while (0)
 #define NN_GET(var, type, slot, bytes) do { if (((var) = (type *)nn_get(pool, slot, bytes)) == nullptr) goto done; } while (0)
-    NN_GET(AH, nn_half, 0, sizeof(nn_half) * (size_t)NN_PITCH * napad); AL = AH + GKH;
-    NN_GET(BH, nn_half, 2, sizeof(nn_half) * (size_t)NN_PITCH * nbpad); BL = BH + GKH;
+    NN_GET(AH, nn_half, 0, sizeof(nn_half) * (size_t)NN_PITCH * napad); NN_GET(AL, nn_half, 1, sizeof(nn_half) * (size_t)NN_PITCH * napad);
+    NN_GET(BH, nn_half, 2, sizeof(nn_half) * (size_t)NN_PITCH * nbpad); NN_GET(BL, nn_half, 3, sizeof(nn_half) * (size_t)NN_PITCH * nbpad);
     NN_GET(a2f, float, 4, sizeof(float) * napad); NN_GET(b2f, float, 5, sizeof(float) * nbpad);
     NN_GET(a2d, double, 6, sizeof(double) * napad); NN_GET(b2d, double, 7, sizeof(double) * nbpad);
     NN_GET(S, float, 8, sizeof(float) * (size_t)napad * nbpad);
