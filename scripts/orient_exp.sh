@@ -1,0 +1,26 @@
+#!/bin/bash
+# GPU-box helper: kernel trace of detect (orientation mode 2: table walk + flagged) with the shipped library and with a variant
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"; mkdir -p gpurun_out
+export PYTHONDONTWRITEBYTECODE=1
+out=gpurun_out/orient_exp.txt
+: > $out
+for v in ${VARIANTS_O:-shipped goless}; do
+  lib=$R/sift3d_amd/lib/ablate/libsift3d_amd_$v.so
+  case "$v" in shipped*) lib=$R/sift3d_amd/lib/libsift3d_amd.so;; esac
+  case "$v" in shipped_g*) export S3D_ORI_GRID3=${v#shipped_g};; *) unset S3D_ORI_GRID3;; esac
+  echo "== $v" >> $out
+  ( cd /tmp && export TMPDIR=/tmp && S3D_ORI_MODE=${ORI_MODE:-2} SIFT3D_AMD_LIB=$lib timeout 300 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_oexp_$v" -o d -- python "$R/scripts/detect_ab.py" > "$R/gpurun_out/prof_oexp_$v.log" 2>&1 )
+  grep "detect min" gpurun_out/prof_oexp_$v.log >> $out
+  python - "$R/gpurun_out/prof_oexp_$v" >> $out <<'PY'
+import sqlite3, sys, re, glob, collections
+db = glob.glob(sys.argv[1] + "/*.db")[0]
+c = sqlite3.connect(db)
+d = collections.defaultdict(list)
+for name, s, e in c.execute("select name,start,end from kernels"):
+    d[re.sub(r"\(.*", "", name)[:36]].append((e - s) / 1e3)
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    if "orient" in k: print(f"  {k:38s} n={len(v):3d} avg {sum(v)/len(v):8.1f} min {min(v):8.1f} us")
+PY
+done
+cat $out

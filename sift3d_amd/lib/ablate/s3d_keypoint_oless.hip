@@ -394,7 +394,11 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
         const f4u ca = *(const f4u *)(p - 1);
         const f2u cb = *(const f2u *)(p + 3);
         const f4u yp = *(const f4u *)(p + nx), ym = *(const f4u *)(p - nx);
+#if defined(ORI_EXP_LESSLOAD)         /* timing experiment (wrong results): the z neighbours re-read the y neighbours' lines */
+        const f4u zp = *(const volatile f4u *)(p + nx), zm = *(const volatile f4u *)(p - nx);
+#else
         const f4u zp = *(const f4u *)(p + plane), zm = *(const f4u *)(p - (ptrdiff_t)plane);
+#endif
         const float cx[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
         const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
         const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
@@ -651,18 +655,13 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
     if (!d_scratch) return S3D_ERR;
     double *scr = (double *)d_scratch;
     s3d_ori_tab *tabs = (d_center == nullptr && d_tag != nullptr) ? (s3d_ori_tab *)d_tabs : nullptr;   /* per-level sigmas only */
-    /* diagnostics, read once: S3D_ORI_MODE=0 no tables; 1 (default) one kernel that replays or enumerates per candidate; 2 a
-     * table-walk kernel (fewer registers: more waves per SIMD) + the general kernel, on a fixed grid of waves, for what it
-     * flags.  Measured at 512^3, 119 965 candidates (profiles/r03_detect_tile3_oritab_variants.txt, r03_orient_experiments.txt):
-     * mode 0 1.46 ms; mode 1 ~1.35; mode 2 1.09 + 0.43-0.57 -- the table walk saves the enumeration but not the time: the
-     * kernel is bound neither by VALU issue (the f32 gradient sums, -15 % of a voxel's issue cycles, changed nothing) nor by
-     * L1 fill bandwidth (a third fewer distinct lines: -6 %) nor by workgroup launch rate (a fixed grid of 7-28 k waves
-     * walking the candidates: +10-20 %) but by each wave's chain of dependent load round trips, turn after turn. */
+    /* diagnostics, read once: S3D_ORI_MODE=0 no tables; 1 one kernel that replays or enumerates per candidate; 2 (default)
+     * a table-walk kernel (fewer registers: more waves per SIMD) + the general kernel for what it flags */
     static int env_mode = -1;
     if (env_mode < 0) {
         const char *e = getenv("S3D_ORI_MODE");
-        env_mode = e ? atoi(e) : 1;
-        if (env_mode < 0 || env_mode > 2) env_mode = 1;
+        env_mode = e ? atoi(e) : 2;
+        if (env_mode < 0 || env_mode > 2) env_mode = 2;
     }
     const int mode = g_orient_mode >= 0 ? g_orient_mode : env_mode;
     if (mode == 0) tabs = nullptr;
