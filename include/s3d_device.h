@@ -205,9 +205,10 @@ int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const u
                      const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
                      float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream stream);
 /* Test / profiling knob of the calling thread: how s3d_k_orient_tab uses the tables -- 0 not at all, 1 one kernel that
- * replays or enumerates per candidate (the default), 2 a table-walk kernel plus the general kernel for the candidates it
- * flags (fewer registers, more waves per SIMD; measured slower); anything else restores the default (or S3D_ORI_MODE). */
+ * replays or enumerates per candidate, 2 a table-walk kernel plus the general kernel for the candidates it flags; anything
+ * else restores the default (S3D_ORI_MODE, else 0: measured at 512^3, the tables do not pay -- profiles/r03_orient_experiments.txt). */
 void s3d_k_set_orient_mode(int mode);
+int s3d_k_orient_mode(void);                 /* what the calling thread's next s3d_k_orient_tab will do */
 /* Candidates are processed in chunks of S3D_ORIENT_CHUNK; the scratch holds one chunk's window sums. */
 #define S3D_ORIENT_CHUNK (1u << 20)
 #define S3D_ORIENT_SCRATCH_BYTES 128u

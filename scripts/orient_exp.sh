@@ -8,9 +8,10 @@ out=gpurun_out/orient_exp.txt
 for v in ${VARIANTS_O:-shipped goless}; do
   lib=$R/sift3d_amd/lib/ablate/libsift3d_amd_$v.so
   case "$v" in shipped*) lib=$R/sift3d_amd/lib/libsift3d_amd.so;; esac
-  case "$v" in shipped_g*) export S3D_ORI_GRID3=${v#shipped_g};; *) unset S3D_ORI_GRID3;; esac
+  m=${ORI_MODE:-2}
+  case "$v" in shipped_m*) m=${v#shipped_m};; esac
   echo "== $v" >> $out
-  ( cd /tmp && export TMPDIR=/tmp && S3D_ORI_MODE=${ORI_MODE:-2} SIFT3D_AMD_LIB=$lib timeout 300 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_oexp_$v" -o d -- python "$R/scripts/detect_ab.py" > "$R/gpurun_out/prof_oexp_$v.log" 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && S3D_ORI_MODE=$m SIFT3D_AMD_LIB=$lib timeout 300 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_oexp_$v" -o d -- python "$R/scripts/detect_ab.py" > "$R/gpurun_out/prof_oexp_$v.log" 2>&1 )
   grep "detect min" gpurun_out/prof_oexp_$v.log >> $out
   python - "$R/gpurun_out/prof_oexp_$v" >> $out <<'PY'
 import sqlite3, sys, re, glob, collections

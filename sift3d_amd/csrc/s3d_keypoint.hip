@@ -390,11 +390,17 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
     int cnt = 0;
     /* four x-consecutive voxels per lane and turn: one row decode and five wide unaligned loads (the level
      * buffers carry the slack, s3d_device.h) instead of four decodes and 24 dword loads */
-    auto accumulate = [&](const float *p, int nval, float w0, float w1, float w2, float w3) {
-        const f4u ca = *(const f4u *)(p - 1);
-        const f2u cb = *(const f2u *)(p + 3);
-        const f4u yp = *(const f4u *)(p + nx), ym = *(const f4u *)(p - nx);
-        const f4u zp = *(const f4u *)(p + plane), zm = *(const f4u *)(p - (ptrdiff_t)plane);
+    /* the six neighbour runs of a lane's four voxels (separate values, not a struct: a struct of under-aligned vectors
+     * went through scratch memory) */
+#define ORI_FETCH(p, ca, cb, yp, ym, zp, zm)                                              \
+    do {                                                                                  \
+        const float *p_ = (p);                                                            \
+        ca = *(const f4u *)(p_ - 1); cb = *(const f2u *)(p_ + 3);                         \
+        yp = *(const f4u *)(p_ + nx); ym = *(const f4u *)(p_ - nx);                       \
+        zp = *(const f4u *)(p_ + plane); zm = *(const f4u *)(p_ - (ptrdiff_t)plane);     \
+    } while (0)
+    auto accumulate = [&](const f4u &ca, const f2u &cb, const f4u &yp, const f4u &ym, const f4u &zp, const f4u &zm, int nval,
+                          float w0, float w1, float w2, float w3) {
         const float cx[6] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y};
         const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
         const float zpv[4] = {zp.x, zp.y, zp.z, zp.w}, zmv[4] = {zm.x, zm.y, zm.z, zm.w};
@@ -425,12 +431,23 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
         const int nt = T->n_turns;
         const float *pc = im + ((size_t)czi * plane + (size_t)cyi * nx + cxi);
         const s3d_ori_ent *E = T->ent + lane;
+        /* Three turns in flight: the neighbour runs of turn t + 1 are loaded (unconditionally: a lane without a chunk has
+         * offset 0, the centre) and the table entry of turn t + 2 is fetched before turn t is worked on -- a wave is a chain
+         * of dependent round trips otherwise, and that chain, not arithmetic or bandwidth, is what the kernel's time is
+         * (profiles/r03_orient_experiments.txt). */
         s3d_ori_ent e = E[0];
+        s3d_ori_ent e1 = E[(size_t)(nt > 1 ? 1 : 0) * 64];
+        f4u ca, yp, ym, zp, zm;
+        f2u cb;
+        ORI_FETCH(pc + e.off, ca, cb, yp, ym, zp, zm);
         for (int t = 0; t < nt; t++) {
-            s3d_ori_ent en = e;
-            if (t + 1 < nt) en = E[(size_t)(t + 1) * 64];
-            if (e.nval > 0) accumulate(pc + e.off, e.nval, e.w[0], e.w[1], e.w[2], e.w[3]);
-            e = en;
+            const s3d_ori_ent e2 = E[(size_t)(t + 2 < nt ? t + 2 : nt - 1) * 64];
+            f4u nca, nyp, nym, nzp, nzm;
+            f2u ncb;
+            ORI_FETCH(pc + e1.off, nca, ncb, nyp, nym, nzp, nzm);
+            if (e.nval > 0) accumulate(ca, cb, yp, ym, zp, zm, e.nval, e.w[0], e.w[1], e.w[2], e.w[3]);
+            e = e1; e1 = e2;
+            ca = nca; cb = ncb; yp = nyp; ym = nym; zp = nzp; zm = nzm;
         }
     } else if (PHASE != 3) {
     sweep(4, [&](bool valid, int x0, int y, int z, int nval) {
@@ -446,7 +463,10 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
             const int dxi = x0 + j - cxi;
             wv[j] = use_tab ? wtab[dxi * dxi + d2yz] : weight(dx * dx + dy * dy + dz * dz);
         }
-        accumulate(p, nval, wv[0], wv[1], wv[2], wv[3]);
+        f4u ca, yp, ym, zp, zm;
+        f2u cb;
+        ORI_FETCH(p, ca, cb, yp, ym, zp, zm);
+        accumulate(ca, cb, yp, ym, zp, zm, nval, wv[0], wv[1], wv[2], wv[3]);
     });
     }
     int lane_terms = cnt;
@@ -638,6 +658,17 @@ extern "C" size_t s3d_k_orient_scratch_bytes(uint32_t num)
 static thread_local int g_orient_mode = -1;                       /* test knob of the calling thread, see s3d_k_orient_tab */
 extern "C" void s3d_k_set_orient_mode(int mode) { g_orient_mode = mode >= 0 && mode <= 2 ? mode : -1; }
 
+extern "C" int s3d_k_orient_mode(void)
+{
+    static int env_mode = -1;
+    if (env_mode < 0) {
+        const char *e = getenv("S3D_ORI_MODE");
+        env_mode = e ? atoi(e) : 0;
+        if (env_mode < 0 || env_mode > 2) env_mode = 0;
+    }
+    return g_orient_mode >= 0 ? g_orient_mode : env_mode;
+}
+
 extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
 {
     return sizeof(s3d_ori_tab) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
@@ -651,20 +682,15 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
     if (!d_scratch) return S3D_ERR;
     double *scr = (double *)d_scratch;
     s3d_ori_tab *tabs = (d_center == nullptr && d_tag != nullptr) ? (s3d_ori_tab *)d_tabs : nullptr;   /* per-level sigmas only */
-    /* diagnostics, read once: S3D_ORI_MODE=0 no tables; 1 (default) one kernel that replays or enumerates per candidate; 2 a
+    /* S3D_ORI_MODE / s3d_k_set_orient_mode: 0 (default) no tables; 1 one kernel that replays or enumerates per candidate; 2 a
      * table-walk kernel (fewer registers: more waves per SIMD) + the general kernel, on a fixed grid of waves, for what it
      * flags.  Measured at 512^3, 119 965 candidates (profiles/r03_detect_tile3_oritab_variants.txt, r03_orient_experiments.txt):
      * mode 0 1.46 ms; mode 1 ~1.35; mode 2 1.09 + 0.43-0.57 -- the table walk saves the enumeration but not the time: the
      * kernel is bound neither by VALU issue (the f32 gradient sums, -15 % of a voxel's issue cycles, changed nothing) nor by
      * L1 fill bandwidth (a third fewer distinct lines: -6 %) nor by workgroup launch rate (a fixed grid of 7-28 k waves
-     * walking the candidates: +10-20 %) but by each wave's chain of dependent load round trips, turn after turn. */
-    static int env_mode = -1;
-    if (env_mode < 0) {
-        const char *e = getenv("S3D_ORI_MODE");
-        env_mode = e ? atoi(e) : 1;
-        if (env_mode < 0 || env_mode > 2) env_mode = 1;
-    }
-    const int mode = g_orient_mode >= 0 ? g_orient_mode : env_mode;
+     * walking the candidates: +10-20 %), and loading a turn ahead did not shorten it either (1.09 -> 1.06): the tables buy
+     * nothing end to end (detect 6.96 against 6.94 ms), so they stay an option. */
+    const int mode = s3d_k_orient_mode();
     if (mode == 0) tabs = nullptr;
     if (tabs) {
         const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
