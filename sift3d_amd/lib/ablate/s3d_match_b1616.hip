@@ -290,7 +290,7 @@ k_nn_norms(const float *__restrict__ src, size_t stride, const int *__restrict__
  * l & 31 at halves 8 (l >> 5) ..), the next step's global loads are in flight while the current one multiplies. */
 #define GKH 32                       /* halves of k per step */
 #ifndef GEMM_GM
-#define GEMM_GM 4u                   /* tiles per block of workgroups launched together: rows ... */
+#define GEMM_GM 8u                   /* tiles per block of co-resident workgroups: rows ... */
 #define GEMM_GN 32u                  /* ... and columns (a multiple of 8: one column group per XCD) */
 #endif
 #define GLD 40                       /* LDS row pitch in halves */
@@ -307,12 +307,11 @@ k_nn_gemm(const nn_half *__restrict__ Ah, const nn_half *__restrict__ Al, unsign
     __shared__ __attribute__((aligned(16))) nn_half sm[2][4][GT][GLD];   /* [buffer][A hi, A lo, B hi, B lo] */
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     /* Which tile this workgroup computes.  In launch order (x fastest) a row of tiles shares its A panel but streams the whole
-     * of B past every row.  Instead consecutive workgroups cover a block of GEMM_GM x GEMM_GN tiles, and because consecutive
-     * workgroup ids go to the eight XCDs round-robin, XCD k takes the GEMM_GN / 8 columns [4k, 4k + 4) of the block with all
-     * GEMM_GM rows: 4 A + 4 B panels of 393 KB (128 rows x 768 x (hi, lo) halves) = 3.1 MB, inside its 4 MB L2.  Once the
-     * kernel's pace was the operand stream from L2 (see NN_KOFF) this mattered: 8 x 32 blocks (12 panels, 4.7 MB per XCD)
-     * 6.80 ms for the whole match, 16 x 16 and 16 x 32 7.0, every shape whose panels fit the L2 (4 x 32, 4 x 16, 2 x 32, 2 x 16,
-     * 4 x 8) 6.46-6.60 (profiles/r03_match_gemm_experiments.txt). */
+     * of B past every row: 244 rows x 96 MB at 31 k x 31 k, and that operand traffic, not the matrix cores, set the pace.
+     * Instead the 256 workgroups that are resident together cover a block of GEMM_GM x GEMM_GN tiles (8 A panels + 32 B
+     * panels: 16 MB for 256 tiles instead of 96 MB for 244), and because consecutive workgroup ids go to the eight XCDs
+     * round-robin, XCD k takes the GEMM_GN / 8 columns [4k, 4k + 4) of the block with all GEMM_GM rows: 12 panels, under
+     * 5 MB, for its 32 tiles -- what its own L2 can hold. */
     unsigned tile_i, tile_j;
     {
         /* grid = (GEMM_GM * GEMM_GN workgroups of a block, blocks row-major): nn_gemm_grid */
