@@ -1,11 +1,12 @@
 #!/bin/bash
-# GPU-box helper: kernel trace of detect (orientation mode 2: table walk + flagged) with the shipped library and with a variant
+# GPU-box helper: kernel trace of detect per orientation mode (shipped_m<mode>) or with a variant library
+# (sift3d_amd/lib/ablate/libsift3d_amd_<name>.so from scripts/build_file_variants.py, mode ORI_MODE)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 out=gpurun_out/orient_exp.txt
 : > $out
-for v in ${VARIANTS_O:-shipped goless}; do
+for v in ${VARIANTS_O:-shipped_m0 shipped_m1 shipped_m2}; do
   lib=$R/sift3d_amd/lib/ablate/libsift3d_amd_$v.so
   case "$v" in shipped*) lib=$R/sift3d_amd/lib/libsift3d_amd.so;; esac
   m=${ORI_MODE:-2}
