@@ -42,7 +42,6 @@ int s3d_rt_sync(s3d_stream stream);
 int s3d_rt_sync_timeout(s3d_stream stream, double timeout_s);   /* 0 drained, 1 still busy after timeout_s, -1 error */
 int s3d_rt_stream_create(s3d_stream *stream);
 int s3d_rt_stream_create_nonblocking(s3d_stream *stream);   /* does not synchronise with the NULL stream */
-int s3d_rt_stream_create_cus(s3d_stream *stream, int cus);   /* non-blocking, its kernels confined to `cus` compute units */
 int s3d_rt_stream_destroy(s3d_stream stream);
 /* HIP events on `stream`, for timing the kernels where they run (bench.py) */
 int s3d_rt_event_create(void **ev);
@@ -210,16 +209,6 @@ int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const u
  * else restores the default (S3D_ORI_MODE, else 0: measured at 512^3, the tables do not pay -- profiles/r03_orient_experiments.txt). */
 void s3d_k_set_orient_mode(int mode);
 int s3d_k_orient_mode(void);                 /* what the calling thread's next s3d_k_orient_tab will do */
-/* The window sums of the first candidates of the list ahead of time -- [0, *d_num), a count still in device memory, by
- * `waves` waves that stride through them (a stream confined to part of the CUs runs this beside the coarse octaves'
- * filters) -- and the rest later: s3d_k_orient_rest(first = that count as the host then knows it) does the window sums
- * of [first, num) and the decisions of all.  Only when the list fits one chunk (s3d_k_orient_early_ok). */
-int s3d_k_orient_early_ok(uint32_t capacity);
-int s3d_k_orient_early(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag, const uint32_t *d_num,
-                       uint32_t capacity, const double *d_sigma, void *d_scratch, uint32_t waves, s3d_stream stream);
-int s3d_k_orient_rest(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag, uint32_t first, uint32_t num,
-                      const double *d_sigma, double corner_thresh, float *d_R, uint32_t *d_keep, void *d_scratch,
-                      s3d_stream stream);
 /* Candidates are processed in chunks of S3D_ORIENT_CHUNK; the scratch holds one chunk's window sums. */
 #define S3D_ORIENT_CHUNK (1u << 20)
 #define S3D_ORIENT_SCRATCH_BYTES 128u

@@ -109,12 +109,6 @@ typedef struct {
     s3d_stream ext_stream;
     void *oct_ev[S3D_MAX_OCTAVES];
     int extrema_enqueued;   /* build_gpyr_dev put the extrema pass on ext_stream; detect_dev collects it */
-    /* SIFT3D_AMD_EARLY_ORIENT=<CUs>: the orientation window sums of octave 0's candidates on a stream confined to that many
-     * CUs, beside the coarse octaves' filters (which keep the other CUs to themselves); d_count[6] = octave 0's count */
-    s3d_stream ori_stream;
-    int ori_stream_cus;
-    void *ev_o0, *ev_ori;
-    int orient_early_enqueued;
     /* pinned host staging that lives with the context (a fresh malloc of a few MB per call is an mmap plus a page fault
      * per 4 KB): [0] descriptor keys up, [1] keypoint coordinates down, [2] keypoint rotations down */
     void *h_stage[3];
@@ -187,10 +181,7 @@ static void ctx_free_all(s3d_ctx *c)
     for (int i = 0; i < S3D_MAX_OCTAVES; i++)
         if (c->oct_ev[i]) { s3d_rt_event_destroy(c->oct_ev[i]); c->oct_ev[i] = NULL; }
     if (c->ext_stream) { s3d_rt_stream_destroy(c->ext_stream); c->ext_stream = NULL; }
-    if (c->ori_stream) { s3d_rt_stream_destroy(c->ori_stream); c->ori_stream = NULL; }
-    if (c->ev_o0) { s3d_rt_event_destroy(c->ev_o0); c->ev_o0 = NULL; }
-    if (c->ev_ori) { s3d_rt_event_destroy(c->ev_ori); c->ev_ori = NULL; }
-    c->extrema_enqueued = c->orient_early_enqueued = 0;
+    c->extrema_enqueued = 0;
     for (int i = 0; i < 3; i++) {
         if (c->h_stage[i]) s3d_rt_host_free(c->h_stage[i]);
         c->h_stage[i] = NULL;
@@ -601,25 +592,12 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
     s3d_stream es = NULL;
     static int no_overlap = -1;                           /* diagnostics: S3D_NO_EXTREMA_OVERLAP=1, read once */
     if (no_overlap < 0) no_overlap = getenv("S3D_NO_EXTREMA_OVERLAP") != NULL;
-    int early_cus = 0;
-    c->extrema_enqueued = c->orient_early_enqueued = 0;
+    c->extrema_enqueued = 0;
     if (with_extrema && !no_overlap) {
-        const char *e = getenv("SIFT3D_AMD_EARLY_ORIENT");
         if (ctx_ensure_candidates(c, candidate_capacity(c))) return SIFT3D_FAILURE;
         if (!c->ext_stream) DEV(s3d_rt_stream_create_nonblocking(&c->ext_stream));
         es = c->ext_stream;
         DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), es));
-        if (e && atoi(e) > 0 && s3d_k_orient_early_ok(c->cand_cap)) early_cus = atoi(e);
-    }
-    if (early_cus) {
-        /* the orientation windows' sigmas: uploaded now, while the stream is empty (a copy from pageable memory queued
-         * behind kernels runs only once every stream has drained) */
-        for (int i = 0; i < g->num_octaves * L; i++) c->h_sigma[i] = ori_sig_fctr * g->levels[i].s;
-        DEV(s3d_rt_h2d(c->d_sigma, c->h_sigma, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
-        if (c->ori_stream && c->ori_stream_cus != early_cus) { s3d_rt_stream_destroy(c->ori_stream); c->ori_stream = NULL; }
-        if (!c->ori_stream) { DEV(s3d_rt_stream_create_cus(&c->ori_stream, early_cus)); c->ori_stream_cus = early_cus; }
-        if (!c->ev_o0) DEV(s3d_rt_event_create(&c->ev_o0));
-        if (!c->ev_ori) DEV(s3d_rt_event_create(&c->ev_ori));
     }
     unit_factors(units, 1.0, uf);
     if (c->in_src == NULL) API_FAIL("sift3d_amd: no input volume");
@@ -650,21 +628,6 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
             DEV(s3d_rt_event_record(c->oct_ev[o], c->stream));
             DEV(s3d_rt_stream_wait_event(es, c->oct_ev[o]));
             if (extrema_octave(sift3d, c, o, es)) return SIFT3D_FAILURE;
-            if (o == 0 && early_cus) {
-                /* octave 0's candidates are the head of the list: their count as of now, then their window sums on the
-                 * confined stream (the wait is enqueued right after the record: a wait issued after more work has been queued
-                 * on the event's stream would wait for that work too) */
-                s3d_pyramid_desc pd;
-                const char *w = getenv("SIFT3D_AMD_EARLY_ORIENT_WAVES");
-                fill_pyr_desc(g, c->d_level, &pd);
-                DEV(s3d_rt_d2d(c->d_count + 6, c->d_count, sizeof(uint32_t), es));
-                DEV(s3d_rt_event_record(c->ev_o0, es));
-                DEV(s3d_rt_stream_wait_event(c->ori_stream, c->ev_o0));
-                DEV(s3d_k_orient_early(&pd, c->d_cand_idx, c->d_cand_tag, c->d_count + 6, c->cand_cap, c->d_sigma, c->d_orient,
-                                       (uint32_t)(w && atoi(w) > 0 ? atoi(w) : early_cus * 16), c->ori_stream));
-                DEV(s3d_rt_event_record(c->ev_ori, c->ori_stream));
-                c->orient_early_enqueued = 1;
-            }
         }
         if (o != g->num_octaves - 1) {
             int ds = L - 1 - 2;                           /* downsample level index: max(s_end-2, first) */
@@ -684,17 +647,12 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
     const int L = g->num_levels;
     s3d_pyramid_desc pd;
     uint32_t counts[2] = {0, 0};
-    uint32_t count0 = 0;                                  /* candidates whose window sums an early pass has served */
     uint32_t cap = candidate_capacity(c);
     for (int attempt = 0; attempt < 2; attempt++) {
         s3d_stream es = c->stream;
         if (attempt == 0 && c->extrema_enqueued) {
             es = c->ext_stream;                           /* build_gpyr_dev enqueued the pass already */
         } else {
-            /* an early orientation pass of the overflowed attempt may still be reading the lists that are about to be
-             * freed and rebuilt */
-            if (c->orient_early_enqueued) DEV(s3d_rt_sync(c->ori_stream));
-            c->orient_early_enqueued = 0;
             if (ctx_ensure_candidates(c, cap)) return SIFT3D_FAILURE;
             DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), es));
             for (int o = 0; o < g->num_octaves; o++)
@@ -702,7 +660,6 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         }
         c->extrema_enqueued = 0;
         DEV(s3d_rt_d2h(counts, c->d_count, sizeof(uint32_t), es));
-        if (c->orient_early_enqueued) DEV(s3d_rt_d2h(&count0, c->d_count + 6, sizeof(uint32_t), es));
         DEV(s3d_rt_sync(es));
         if (counts[0] <= c->cand_cap) break;
         cap = counts[0] + 1024;                           /* candidate list overflowed: grow and redo */
@@ -717,15 +674,6 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
     fill_pyr_desc(g, c->d_level, &pd);
     {
         double *const sig = c->h_sigma;                   /* lives in the context: the copy below is asynchronous */
-        if (c->orient_early_enqueued) {
-            /* octave 0's window sums are done or under way on the confined stream (which also has the sigmas): the rest of
-             * the list, and the decisions for all, once it is through */
-            DEV(s3d_rt_stream_wait_event(c->stream, c->ev_ori));
-            DEV(s3d_k_orient_rest(&pd, c->d_cand_idx, c->d_cand_tag, count0, counts[0], c->d_sigma, sift3d->corner_thresh,
-                                  c->d_R, c->d_keep, c->d_orient, c->stream));
-            c->orient_early_enqueued = 0;
-            goto oriented;
-        }
         for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
         DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
         if (s3d_k_orient_mode() != 0 && c->oritab_bytes < s3d_k_orient_tab_bytes(&pd)) {
@@ -736,7 +684,6 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         }
         DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
                              c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_mode() != 0 ? c->d_oritab : NULL, c->stream));
-oriented:
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
                                c->d_Rk, c->d_count + 1, c->d_kscratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));

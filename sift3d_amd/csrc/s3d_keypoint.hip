@@ -547,31 +547,14 @@ __global__ void __launch_bounds__(64)
 k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
               const float *__restrict__ d_center, uint32_t cand0, uint32_t nchunk, uint32_t num, const double *__restrict__ d_sigma,
               double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
-              double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs, uint32_t slot0)
+              double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs)
 {
-    /* slot0: scratch slot of candidate cand0 (0, or the candidates of the chunk an early pass has already served) */
     if (PHASE == 4) {
         for (unsigned c = blockIdx.x; c < nchunk; c += gridDim.x)
-            orient_one<4>(pyr, d_idx, d_tag, d_center, cand0 + c, slot0 + c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, d_conf, tabs);
+            orient_one<4>(pyr, d_idx, d_tag, d_center, cand0 + c, c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, d_conf, tabs);
     } else {
-        orient_one<PHASE>(pyr, d_idx, d_tag, d_center, cand0 + blockIdx.x, slot0 + blockIdx.x, num, d_sigma, corner_thresh, d_scr,
-                          d_R, d_keep, d_conf, tabs);
-    }
-}
-
-/* The window sums of the candidates [0, *d_num) -- a count that is still in device memory when this is enqueued -- by a
- * fixed number of waves that stride through the list: for octave 0's candidates as soon as its extrema pass has counted
- * them, on a stream confined to part of the CUs, beside the coarse octaves' chain of short dependent kernels.  Scratch
- * slot = candidate index (the caller guarantees capacity <= one chunk). */
-__global__ void __launch_bounds__(64)
-k_orient_early(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag,
-               const uint32_t *__restrict__ d_num, uint32_t capacity, const double *__restrict__ d_sigma, double *__restrict__ d_scr)
-{
-    uint32_t num = *d_num;
-    if (num > capacity) num = capacity;                      /* an overflowed list is redone by the caller anyway */
-    for (uint32_t cand = blockIdx.x; cand < num; cand += gridDim.x) {
-        s3d_wave_lds_sync();                                 /* the previous candidate of this wave is done with the LDS tables */
-        orient_one<1>(pyr, d_idx, d_tag, nullptr, cand, cand, num, d_sigma, 0.0, d_scr, nullptr, nullptr, nullptr, nullptr);
+        orient_one<PHASE>(pyr, d_idx, d_tag, d_center, cand0 + blockIdx.x, blockIdx.x, num, d_sigma, corner_thresh, d_scr, d_R,
+                          d_keep, d_conf, tabs);
     }
 }
 
@@ -691,14 +674,12 @@ extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
     return sizeof(s3d_ori_tab) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
 }
 
-/* `first`: the window sums of the candidates [0, first) are in the scratch already (s3d_k_orient_early) */
-static int orient_run(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag, const float *d_center,
-                      uint32_t first, uint32_t num, const double *d_sigma, double corner_thresh, float *d_R, uint32_t *d_keep,
-                      double *d_conf, void *d_scratch, void *d_tabs, s3d_stream st)
+extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                                const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream st)
 {
     if (num == 0) return S3D_OK;
     if (!d_scratch) return S3D_ERR;
-    if (first > 0 && num > g_orient_chunk) S3D_FAIL("early orientation needs the candidates to fit one chunk");
     double *scr = (double *)d_scratch;
     s3d_ori_tab *tabs = (d_center == nullptr && d_tag != nullptr) ? (s3d_ori_tab *)d_tabs : nullptr;   /* per-level sigmas only */
     /* S3D_ORI_MODE / s3d_k_set_orient_mode: 0 (default) no tables; 1 one kernel that replays or enumerates per candidate; 2 a
@@ -715,67 +696,31 @@ static int orient_run(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const 
         const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
         hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, nlev, d_sigma, corner_thresh,
-                           (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs, 0u);
+                           (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs);
         S3D_CHECK_LAUNCH();
     }
     const uint32_t chunk = g_orient_chunk;
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
-        const uint32_t f = first > c0 ? (first - c0 < n ? first - c0 : n) : 0u;   /* candidates of this chunk that are done */
-        if (f < n) {
-            const uint32_t m = n - f;
-            if (tabs && mode == 2) {
-                hipLaunchKernelGGL((k_orient_wave<3>), dim3(m), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0 + f, m,
-                                   num, d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs, f);
-                S3D_CHECK_LAUNCH();
-                hipLaunchKernelGGL((k_orient_wave<4>), dim3(m < 8192u ? m : 8192u), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag,
-                                   d_center, c0 + f, m, num, d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr, f);
-            } else {
-                hipLaunchKernelGGL((k_orient_wave<1>), dim3(m), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0 + f, m,
-                                   num, d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs, f);
-            }
+        if (tabs && mode == 2) {
+            hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
+                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
             S3D_CHECK_LAUNCH();
+            hipLaunchKernelGGL((k_orient_wave<4>), dim3(n < 8192u ? n : 8192u), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag,
+                               d_center, c0, n, num, d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
+        } else {
+            hipLaunchKernelGGL((k_orient_wave<1>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
+                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
         }
+        S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
                            d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
-                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr, 0u);
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
         S3D_CHECK_LAUNCH();
     }
     return S3D_OK;
-}
-
-extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
-                                const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream st)
-{
-    return orient_run(pyr, d_idx, d_tag, d_center, 0u, num, d_sigma, corner_thresh, d_R, d_keep, d_conf, d_scratch, d_tabs, st);
-}
-
-/* Phase 1 ahead of time for the candidates [0, *d_num) (count in device memory, list capacity `capacity`, which must not
- * exceed the orientation chunk: s3d_k_orient_early_ok) by `waves` waves, then s3d_k_orient_rest with the host's copy of that
- * count once it is known. */
-extern "C" int s3d_k_orient_early_ok(uint32_t capacity) { return capacity <= g_orient_chunk; }
-
-extern "C" int s3d_k_orient_early(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
-                                  const uint32_t *d_num, uint32_t capacity, const double *d_sigma, void *d_scratch,
-                                  uint32_t waves, s3d_stream st)
-{
-    if (!d_scratch || capacity > g_orient_chunk) S3D_FAIL("early orientation: list larger than a chunk");
-    if (waves < 1) waves = 1;
-    hipLaunchKernelGGL(k_orient_early, dim3(waves), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_num, capacity, d_sigma,
-                       (double *)d_scratch);
-    S3D_CHECK_LAUNCH();
-    return S3D_OK;
-}
-
-extern "C" int s3d_k_orient_rest(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag, uint32_t first,
-                                 uint32_t num, const double *d_sigma, double corner_thresh, float *d_R, uint32_t *d_keep,
-                                 void *d_scratch, s3d_stream st)
-{
-    return orient_run(pyr, d_idx, d_tag, nullptr, first < num ? first : num, num, d_sigma, corner_thresh, d_R, d_keep, nullptr,
-                      d_scratch, nullptr, st);
 }
 
 extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,

@@ -89,28 +89,6 @@ extern "C" int s3d_rt_stream_create_nonblocking(s3d_stream *st)
     *st = (s3d_stream)s;
     return S3D_OK;
 }
-/* A non-blocking stream whose kernels may only use `cus` of the device's compute units (the mask's bits are dealt to the
- * XCDs round-robin and to an XCD's shader engines symmetrically, so the first `cus` bits give every XCD cus / 8 of its
- * CUs): work put here leaves the remaining CUs to whatever runs beside it.  cus <= 0 or >= all: an ordinary stream. */
-extern "C" int s3d_rt_stream_create_cus(s3d_stream *st, int cus)
-{
-#if defined(S3D_EMU)
-    (void)cus;
-    return s3d_rt_stream_create_nonblocking(st);
-#else
-    int dev = 0, ncu = 0;
-    S3D_HIP(hipGetDevice(&dev));
-    S3D_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus <= 0 || cus >= ncu || ncu > 1024) return s3d_rt_stream_create_nonblocking(st);
-    uint32_t mask[32];
-    memset(mask, 0, sizeof(mask));
-    for (int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t s;
-    S3D_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)((ncu + 31) / 32), mask));
-    *st = (s3d_stream)s;
-    return S3D_OK;
-#endif
-}
 extern "C" int s3d_rt_stream_destroy(s3d_stream st) { S3D_HIP(hipStreamDestroy((hipStream_t)st)); return S3D_OK; }
 extern "C" int s3d_rt_event_create(void **ev)
 {

@@ -52,15 +52,6 @@ def test_detect_describe_iso(emu, oracle):
     assert parity.check_detect_describe(emu, oracle, (32, 32, 32), (1, 1, 1), 40, seed=0) > 0
 
 
-def test_detect_early_orientation(emu, oracle, monkeypatch):
-    """SIFT3D_AMD_EARLY_ORIENT: octave 0's window sums enqueued as soon as its candidates are counted (device-side count,
-    strided waves), the rest and all decisions at the end -- same keypoints, same descriptors."""
-    monkeypatch.setenv("SIFT3D_AMD_EARLY_ORIENT", "192")
-    monkeypatch.setenv("SIFT3D_AMD_EARLY_ORIENT_WAVES", "5")
-    parity.check_detect_describe(emu, oracle, (40, 36, 32), (1, 1, 1), 120, 4, check_pyramid=False)
-    parity.check_detect_describe(emu, oracle, (32, 28, 40), (1, 1, 1.5), 80, 2, check_pyramid=False)
-
-
 def test_detect_describe_aniso(emu, oracle):
     assert parity.check_detect_describe(emu, oracle, (36, 32, 28), (1, 0.8, 2), 60, seed=3) > 0
 
