@@ -550,7 +550,7 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
  * rows.  Same voxels, same weights, same per-lane arithmetic as the general path; only the order in which the lanes' partial
  * sums are added differs (f64: ~1e-16 relative). */
 #define ORI_WIN_G 35                 /* rows of the extended grid per axis: 2 * 16 + 3 (a window radius below 16 voxels) */
-#define ORI_WIN_LDS 6144             /* floats of LDS a staged window may take (5960 at the default parameters' largest level): six workgroups per CU */
+#define ORI_WIN_LDS 8192             /* floats of LDS a staged window may take */
 __global__ void __launch_bounds__(64)
 k_orient_win_build(const s3d_ori_tab *__restrict__ tabs, s3d_ori_win *__restrict__ wins, int nlev, s3d_pyramid_desc pyr)
 {
@@ -763,6 +763,36 @@ k_orient_win(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uin
     }
 }
 
+/* compacted list of the flagged candidates of a chunk (d_keep == 3), in any order: list[0] = count, list[1..] = indices
+ * relative to cand0 */
+__global__ void __launch_bounds__(256)
+k_orient_flagged(const uint32_t *__restrict__ d_keep, uint32_t cand0, uint32_t n, uint32_t *__restrict__ list)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool f = i < n && d_keep[cand0 + i] == 3u;
+    const unsigned long long b = __ballot(f);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0 && b) base = atomicAdd(&list[0], (unsigned)__popcll(b));
+    base = (unsigned)__shfl((int)base, 0);
+    if (f) list[1 + base + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = i;
+}
+
+/* the general path (orient_one<1>) for the listed candidates, one wave each */
+__global__ void __launch_bounds__(64)
+k_orient_listed(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag, uint32_t cand0,
+                uint32_t num, const double *__restrict__ d_sigma, double corner_thresh, double *__restrict__ d_scr,
+                float *__restrict__ d_R, uint32_t *__restrict__ d_keep, const uint32_t *__restrict__ list, uint32_t slot0)
+{
+    const uint32_t count = list[0];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t c = list[1 + i];
+        s3d_wave_lds_sync();
+        orient_one<1>(pyr, d_idx, d_tag, nullptr, cand0 + c, slot0 + c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, nullptr,
+                      nullptr);
+    }
+}
+
 /* One wave per candidate (candidate cand0 + blockIdx.x of a chunk of nchunk); PHASE 4 -- the few candidates the table
  * walk flagged -- is a fixed grid of waves that each look through a stride of the chunk: a launch of one workgroup per
  * candidate that returns at once for nine in ten of them cost 0.43 ms at 120 k candidates. */
@@ -893,10 +923,11 @@ extern "C" int s3d_k_orient_mode(void)
     return g_orient_mode >= 0 ? g_orient_mode : env_mode;
 }
 
-/* d_tabs: the levels' window tables and their LDS-staging forms (mode 3) */
+/* d_tabs: the levels' window tables, their LDS-staging forms (mode 3), and the list of flagged candidates of a chunk */
 extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
 {
-    return (sizeof(s3d_ori_tab) + sizeof(s3d_ori_win)) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
+    return (sizeof(s3d_ori_tab) + sizeof(s3d_ori_win)) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels +
+           sizeof(uint32_t) * ((size_t)S3D_ORIENT_CHUNK + 1);
 }
 
 extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
@@ -919,9 +950,11 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
     if (mode == 3 && d_idx == nullptr) mode = 0;            /* the staged form takes its centres from the index list */
     if (mode == 0) tabs = nullptr;
     s3d_ori_win *wins = nullptr;
+    uint32_t *flagged = nullptr;
     if (tabs) {
         const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
         wins = reinterpret_cast<s3d_ori_win *>(tabs + nlev);
+        flagged = reinterpret_cast<uint32_t *>(wins + nlev);
         hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, nlev, d_sigma, corner_thresh,
                            (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs);
@@ -935,13 +968,15 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
         if (tabs && mode == 3) {
+            S3D_HIP(hipMemsetAsync(flagged, 0, sizeof(uint32_t), (hipStream_t)st));
             hipLaunchKernelGGL(k_orient_win, dim3(n), dim3(256), 0, (hipStream_t)st, *pyr, d_idx, d_tag, c0, num, d_sigma, scr, d_keep,
                                wins, 0u);
             S3D_CHECK_LAUNCH();
-            /* the flagged candidates on the general path: one workgroup per candidate that returns at once unless flagged
-             * (a compacted list of them served by a wave each took twice as long: 0.97 against 0.43 ms at 120 k candidates) */
-            hipLaunchKernelGGL((k_orient_wave<4>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
-                               d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
+            hipLaunchKernelGGL(k_orient_flagged, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, d_keep, c0, n, flagged);
+            S3D_CHECK_LAUNCH();
+            const uint32_t g4 = n / 2u + 1u;                   /* a wave per listed candidate (waves past the count return at once); more than half flagged: they loop */
+            hipLaunchKernelGGL(k_orient_listed, dim3(g4), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, c0,
+                               num, d_sigma, corner_thresh, scr, d_R, d_keep, flagged, 0u);
         } else if (tabs && mode == 2) {
             hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
                                d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
