@@ -584,32 +584,25 @@ k_orient_win_build(const s3d_ori_tab *__restrict__ tabs, s3d_ori_win *__restrict
         atomicMin(&rlo[(gz - 1) * G + gy], dx); atomicMax(&rhi[(gz - 1) * G + gy], dx + 3);
     }
     s3d_wave_lds_sync();
-    /* LDS offsets of the rows in grid order (z, y): 64 rows per step, a wave scan of their lengths (rounded up to whole
-     * float4 pieces, which is what the loader stores) and of their count */
-    {
-        int ofs_base = 0, row_base = 0;
-        for (int i0 = 0; i0 < G * G; i0 += 64) {
-            const int i = i0 + lane;
-            const bool has = i < G * G && rhi[i] >= rlo[i];
-            const int len = has ? (rhi[i] - rlo[i] + 1 + 3) & ~3 : 0;
-            int il = len, ic = has ? 1 : 0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int ul = __shfl(il, lane >= d ? lane - d : lane), uc = __shfl(ic, lane >= d ? lane - d : lane);
-                if (lane >= d) { il += ul; ic += uc; }
-            }
-            const int ofs = ofs_base + il - len, nrow = row_base + ic - (has ? 1 : 0);
-            if (i < G * G) rofs[i] = has ? ofs : -1;
-            if (has && nrow < S3D_ORI_WIN_ROWS) {
+    /* LDS offsets of the rows in grid order (z, y): one lane walks them -- a few hundred additions, once per level.  Row
+     * lengths are rounded up to a multiple of 4 floats (the loader stores whole float4 pieces). */
+    if (lane == 0) {
+        int ofs = 0, nrow = 0;
+        for (int i = 0; i < G * G; i++) {
+            rofs[i] = -1;
+            if (rhi[i] < rlo[i]) continue;
+            const int len = (rhi[i] - rlo[i] + 1 + 3) & ~3;
+            if (nrow < S3D_ORI_WIN_ROWS) {
                 const int gz = i / G, gy = i - gz * G;
                 W->rows[nrow].goff = (gz - R - 1) * plane + (gy - R - 1) * nx + rlo[i];
                 W->rows[nrow].loff = (unsigned short)ofs;
                 W->rows[nrow].len = (unsigned short)len;
             }
-            ofs_base += __shfl(il, 63);
-            row_base += __shfl(ic, 63);
+            rofs[i] = ofs;
+            ofs += len;
+            nrow++;
         }
-        if (lane == 0) { tot[0] = ofs_base; tot[1] = row_base; }
+        tot[0] = ofs; tot[1] = nrow;
     }
     s3d_wave_lds_sync();
     const bool fits = tot[0] <= ORI_WIN_LDS && tot[1] <= S3D_ORI_WIN_ROWS;
@@ -678,32 +671,15 @@ k_orient_win(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uin
     if (tid == 0) d_keep[cand] = ok ? 0u : 3u;
     if (!ok) return;
     const float *pc = im + ((size_t)czi * plane + (size_t)cyi * nx + cxi);
-    /* stage the rows: eight lanes per row, a float4 piece each, twelve rows per thread in flight -- first all their
-     * descriptors, then all their pieces, then the LDS stores (one row after the other was two dependent round trips per
-     * row: the whole workgroup stood through ~20 of them) */
+    /* stage the rows: eight lanes per row, a float4 piece each (rows are at most 32 + 4 floats long: two rounds at most) */
     {
-        const int nrows = W->n_rows, q4 = 4 * (tid & 7);
-        constexpr int NB = 12;
-        for (int r0 = tid >> 3; r0 < nrows; r0 += 32 * NB) {
-            int goff[NB], lofs[NB], len[NB];
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const int r = r0 + 32 * j;
-                const s3d_ori_row rr = W->rows[r < nrows ? r : nrows - 1];
-                goff[j] = rr.goff; lofs[j] = (int)rr.loff; len[j] = r < nrows ? (int)rr.len : 0;
+        const int nrows = W->n_rows;
+        for (int r = tid >> 3; r < nrows; r += 32) {
+            const int goff = W->rows[r].goff, loff = (int)W->rows[r].loff, len = (int)W->rows[r].len;
+            for (int q = 4 * (tid & 7); q < len; q += 32) {
+                const f4u v = *(const f4u *)(pc + goff + q);
+                *reinterpret_cast<float4 *>(&win[loff + q]) = make_float4(v.x, v.y, v.z, v.w);
             }
-            f4u v[NB];
-#pragma unroll
-            for (int j = 0; j < NB; j++) v[j] = *(const f4u *)(pc + goff[j] + (q4 < len[j] ? q4 : 0));
-#pragma unroll
-            for (int j = 0; j < NB; j++)
-                if (q4 < len[j]) *reinterpret_cast<float4 *>(&win[lofs[j] + q4]) = make_float4(v[j].x, v[j].y, v[j].z, v[j].w);
-#pragma unroll
-            for (int j = 0; j < NB; j++)                               /* rows longer than 32 floats (window radius >= 14) */
-                for (int q = q4 + 32; q < len[j]; q += 32) {
-                    const f4u u = *(const f4u *)(pc + goff[j] + q);
-                    *reinterpret_cast<float4 *>(&win[lofs[j] + q]) = make_float4(u.x, u.y, u.z, u.w);
-                }
         }
     }
     __syncthreads();
@@ -974,8 +950,8 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
             S3D_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_orient_flagged, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, d_keep, c0, n, flagged);
             S3D_CHECK_LAUNCH();
-            const uint32_t g4 = n / 2u + 1u;                   /* a wave per listed candidate (waves past the count return at once); more than half flagged: they loop */
-            hipLaunchKernelGGL(k_orient_listed, dim3(g4), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, c0,
+            const uint32_t g4 = n / 8u + 1u;
+            hipLaunchKernelGGL(k_orient_listed, dim3(g4 < 32768u ? g4 : 32768u), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, c0,
                                num, d_sigma, corner_thresh, scr, d_R, d_keep, flagged, 0u);
         } else if (tabs && mode == 2) {
             hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
