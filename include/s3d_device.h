@@ -200,16 +200,6 @@ typedef struct {
     int pad;
     s3d_ori_ent ent[S3D_ORI_TAB_TURNS * 64];
 } s3d_ori_tab;
-/* Mode 3 of s3d_k_orient_tab: the window staged once in LDS by a workgroup of four waves (k_orient_win); per level, which
- * rows to stage and where a chunk's five rows lie in LDS.  Built on the device from the s3d_ori_tab of the level. */
-#define S3D_ORI_WIN_ROWS 1232                /* 35 x 35 grid rows, rounded */
-typedef struct { int goff; unsigned short loff, len; } s3d_ori_row;        /* global offset from the centre, LDS offset, floats */
-typedef struct { unsigned short c, yp, ym, zp, zm, nval; float w[4]; int pad; } s3d_ori_went;
-typedef struct {
-    int n_turns, rb[6], n_rows, lds_floats, pad[7];
-    s3d_ori_row rows[S3D_ORI_WIN_ROWS];
-    s3d_ori_went ent[S3D_ORI_TAB_TURNS * 64];
-} s3d_ori_win;
 size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr);
 int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                      const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,

@@ -360,7 +360,6 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
                     const int d2yz = (y - cyi) * (y - cyi) + (z - czi) * (z - czi);
                     e.off = (z - czi) * (int)plane + (y - cyi) * nx + (x0 - cxi);
                     e.nval = nval;
-                    e.pad0 = (z - czi + 64) | ((y - cyi + 64) << 8) | ((x0 - cxi + 64) << 16);   /* for k_orient_win_build */
                     for (int j = 0; j < nval; j++) {
                         const int dxi = x0 + j - cxi;
                         e.w[j] = wtab[dxi * dxi + d2yz];
@@ -540,235 +539,6 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
     if (d_conf) d_conf[cand] = keep || conf > 0.0 ? conf : 0.0;
 }
 
-/* ---- the window staged in LDS (S3D_ORI_MODE 3) ------------------------------------------------------------------------
- * The table walk above still fetches every window voxel 5.5 times (a lane's four voxels take six neighbour runs out of
- * L1 / L2), and those loads are half of its time.  Here a workgroup of four waves serves one candidate: the rows the
- * ball touches (own voxels + the x, y, z neighbours its chunks read) are loaded ONCE, coalesced, into LDS, then the waves
- * share the level's turns (wave w takes turns w, w + 4, ..) and read their neighbour runs from LDS; the 13 sums of the
- * four waves are added in a fixed order.  Per level, k_orient_win_build derives from the level's window table
- * (s3d_ori_tab, PHASE 0) which rows to stage (global offset, LDS offset, length) and, per chunk, the LDS offsets of its five
- * rows.  Same voxels, same weights, same per-lane arithmetic as the general path; only the order in which the lanes' partial
- * sums are added differs (f64: ~1e-16 relative). */
-#define ORI_WIN_G 35                 /* rows of the extended grid per axis: 2 * 16 + 3 (a window radius below 16 voxels) */
-#define ORI_WIN_LDS 8192             /* floats of LDS a staged window may take */
-__global__ void __launch_bounds__(64)
-k_orient_win_build(const s3d_ori_tab *__restrict__ tabs, s3d_ori_win *__restrict__ wins, int nlev, s3d_pyramid_desc pyr)
-{
-    __shared__ int rlo[ORI_WIN_G * ORI_WIN_G], rhi[ORI_WIN_G * ORI_WIN_G];
-    __shared__ int rofs[ORI_WIN_G * ORI_WIN_G];
-    __shared__ int tot[2];
-    const int li = blockIdx.x, lane = threadIdx.x;
-    if (li >= nlev) return;
-    const s3d_ori_tab *T = tabs + li;
-    s3d_ori_win *W = wins + li;
-    const int nt = T->n_turns;
-    const int o = li / pyr.num_levels;
-    const int nx = pyr.dims[o][0], plane = nx * pyr.dims[o][1];
-    if (lane == 0) W->n_turns = 0;
-    if (nt <= 0) return;
-    const int R = -T->rb[0];
-    if (R < 1 || 2 * R + 3 > ORI_WIN_G || T->rb[1] != R || T->rb[2] != -R || T->rb[3] != R || T->rb[4] != -R || T->rb[5] != R) return;
-    const int G = 2 * R + 3;                                /* grid coordinate = offset + R + 1 */
-    for (int i = lane; i < G * G; i += 64) { rlo[i] = 1 << 20; rhi[i] = -(1 << 20); }
-    s3d_wave_lds_sync();
-    /* what every chunk reads: its own row from x0 - 1 to x0 + 4, its four neighbour rows from x0 to x0 + 3 */
-    for (int i = lane; i < nt * 64; i += 64) {
-        const s3d_ori_ent e = T->ent[i];
-        if (e.nval <= 0) continue;
-        const int dz = (e.pad0 & 255) - 64, dy = ((e.pad0 >> 8) & 255) - 64, dx = ((e.pad0 >> 16) & 255) - 64;
-        const int gy = dy + R + 1, gz = dz + R + 1;
-        atomicMin(&rlo[gz * G + gy], dx - 1); atomicMax(&rhi[gz * G + gy], dx + 4);
-        atomicMin(&rlo[gz * G + gy + 1], dx); atomicMax(&rhi[gz * G + gy + 1], dx + 3);
-        atomicMin(&rlo[gz * G + gy - 1], dx); atomicMax(&rhi[gz * G + gy - 1], dx + 3);
-        atomicMin(&rlo[(gz + 1) * G + gy], dx); atomicMax(&rhi[(gz + 1) * G + gy], dx + 3);
-        atomicMin(&rlo[(gz - 1) * G + gy], dx); atomicMax(&rhi[(gz - 1) * G + gy], dx + 3);
-    }
-    s3d_wave_lds_sync();
-    /* LDS offsets of the rows in grid order (z, y): one lane walks them -- a few hundred additions, once per level.  Row
-     * lengths are rounded up to a multiple of 4 floats (the loader stores whole float4 pieces). */
-    if (lane == 0) {
-        int ofs = 0, nrow = 0;
-        for (int i = 0; i < G * G; i++) {
-            rofs[i] = -1;
-            if (rhi[i] < rlo[i]) continue;
-            const int len = (rhi[i] - rlo[i] + 1 + 3) & ~3;
-            if (nrow < S3D_ORI_WIN_ROWS) {
-                const int gz = i / G, gy = i - gz * G;
-                W->rows[nrow].goff = (gz - R - 1) * plane + (gy - R - 1) * nx + rlo[i];
-                W->rows[nrow].loff = (unsigned short)ofs;
-                W->rows[nrow].len = (unsigned short)len;
-            }
-            rofs[i] = ofs;
-            ofs += len;
-            nrow++;
-        }
-        tot[0] = ofs; tot[1] = nrow;
-    }
-    s3d_wave_lds_sync();
-    const bool fits = tot[0] <= ORI_WIN_LDS && tot[1] <= S3D_ORI_WIN_ROWS;
-    for (int i = lane; i < nt * 64; i += 64) {
-        const s3d_ori_ent e = T->ent[i];
-        s3d_ori_went w;
-        w.c = w.yp = w.ym = w.zp = w.zm = 0; w.nval = 0; w.pad = 0;
-        w.w[0] = e.w[0]; w.w[1] = e.w[1]; w.w[2] = e.w[2]; w.w[3] = e.w[3];
-        if (e.nval > 0 && fits) {
-            const int dz = (e.pad0 & 255) - 64, dy = ((e.pad0 >> 8) & 255) - 64, dx = ((e.pad0 >> 16) & 255) - 64;
-            const int gy = dy + R + 1, gz = dz + R + 1;
-            auto at = [&](int row) { return (unsigned short)(rofs[row] + dx - rlo[row]); };
-            w.c = at(gz * G + gy); w.yp = at(gz * G + gy + 1); w.ym = at(gz * G + gy - 1);
-            w.zp = at((gz + 1) * G + gy); w.zm = at((gz - 1) * G + gy);
-            w.nval = (unsigned short)e.nval;
-        }
-        W->ent[i] = w;
-    }
-    if (lane == 0) {
-        for (int k = 0; k < 6; k++) W->rb[k] = T->rb[k];
-        W->n_rows = tot[1];
-        W->lds_floats = tot[0];
-        W->n_turns = fits ? nt : 0;
-    }
-}
-
-/* One workgroup of four waves per candidate; candidates whose window is not their level's table (clipped by a face, no
- * table) are flagged d_keep = 3 for the general path. */
-__global__ void __launch_bounds__(256)
-k_orient_win(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag, uint32_t cand0,
-             uint32_t num, const double *__restrict__ d_sigma, double *__restrict__ d_scr, uint32_t *__restrict__ d_keep,
-             const s3d_ori_win *__restrict__ wins, uint32_t slot0)
-{
-    __shared__ __attribute__((aligned(16))) float win[ORI_WIN_LDS];
-    __shared__ double part[4][12];
-    __shared__ int ipart[4][2];
-    const unsigned cand = cand0 + blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (cand >= num) return;
-    double *scr = d_scr + (size_t)(slot0 + blockIdx.x) * ORI_SCR;
-    const unsigned tag = d_tag[cand];
-    const int o = (int)(tag >> 8), k = (int)(tag & 255u);
-    const int li = o * pyr.num_levels + k;
-    const float *__restrict__ im = pyr.d_level[li];
-    const int nx = pyr.dims[o][0], ny = pyr.dims[o][1], nz = pyr.dims[o][2];
-    const float uxf = pyr.unitsf[o][0], uyf = pyr.unitsf[o][1], uzf = pyr.unitsf[o][2];
-    const unsigned plane = (unsigned)nx * (unsigned)ny;
-    const unsigned idx = d_idx[cand];
-    const int czi = (int)(idx / plane);
-    const int cyi = (int)((idx - (unsigned)czi * plane) / (unsigned)nx);
-    const int cxi = (int)(idx - (unsigned)czi * plane - (unsigned)cyi * (unsigned)nx);
-    const s3d_ori_win *W = wins + li;
-    const int nt = W->n_turns;
-    /* the level's table is this candidate's window iff its bounding box (the general path's, IM_LOOP_SPHERE_START's) is
-     * the table's, i.e. no clamp at a face of the volume is active */
-    bool ok = nt > 0;
-    if (ok) {
-        const double rad = d_sigma[li] * 3.0;
-        int xs, xe, ys, ye, zs, ze;
-        ori_bounds((float)cxi, rad, uxf, nx, &xs, &xe);
-        ori_bounds((float)cyi, rad, uyf, ny, &ys, &ye);
-        ori_bounds((float)czi, rad, uzf, nz, &zs, &ze);
-        ok = xs - cxi == W->rb[0] && xe - cxi == W->rb[1] && ys - cyi == W->rb[2] && ye - cyi == W->rb[3] &&
-             zs - czi == W->rb[4] && ze - czi == W->rb[5];
-    }
-    if (tid == 0) d_keep[cand] = ok ? 0u : 3u;
-    if (!ok) return;
-    const float *pc = im + ((size_t)czi * plane + (size_t)cyi * nx + cxi);
-    /* stage the rows: eight lanes per row, a float4 piece each (rows are at most 32 + 4 floats long: two rounds at most) */
-    {
-        const int nrows = W->n_rows;
-        for (int r = tid >> 3; r < nrows; r += 32) {
-            const int goff = W->rows[r].goff, loff = (int)W->rows[r].loff, len = (int)W->rows[r].len;
-            for (int q = 4 * (tid & 7); q < len; q += 32) {
-                const f4u v = *(const f4u *)(pc + goff + q);
-                *reinterpret_cast<float4 *>(&win[loff + q]) = make_float4(v.x, v.y, v.z, v.w);
-            }
-        }
-    }
-    __syncthreads();
-    const float iux = 1.0f / uxf, iuy = 1.0f / uyf, iuz = 1.0f / uzf;
-    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-    float gdx = 0, gdy = 0, gdz = 0, sax = 0, say = 0, saz = 0;
-    int cnt = 0;
-    for (int t = wave; t < nt; t += 4) {
-        const s3d_ori_went e = W->ent[(size_t)t * 64 + lane];
-        if (e.nval == 0) continue;
-        const float *c = win + e.c, *yp = win + e.yp, *ym = win + e.ym, *zp = win + e.zp, *zm = win + e.zm;
-        const float cx[6] = {c[-1], c[0], c[1], c[2], c[3], c[4]};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j >= (int)e.nval) break;
-            const float w = e.w[j];
-            const float gx = 0.5f * (cx[j + 2] - cx[j]) * iux;
-            const float gy = 0.5f * (yp[j] - ym[j]) * iuy;
-            const float gz = 0.5f * (zp[j] - zm[j]) * iuz;
-            const double gxd = (double)gx, gyd = (double)gy, gzd = (double)gz, wd = (double)w;
-            const double gxw = gxd * wd, gyw = gyd * wd, gzw = gzd * wd;
-            a00 = fma(gxw, gxd, a00); a01 = fma(gxw, gyd, a01); a02 = fma(gxw, gzd, a02);
-            a11 = fma(gyw, gyd, a11); a12 = fma(gyw, gzd, a12); a22 = fma(gzw, gzd, a22);
-            const float tx = gx * w, ty = gy * w, tz = gz * w;
-            gdx = gdx + tx; gdy = gdy + ty; gdz = gdz + tz;
-            sax = sax + fabsf(tx); say = say + fabsf(ty); saz = saz + fabsf(tz);
-            cnt++;
-        }
-    }
-    int lane_terms = cnt;
-    for (int m = 32; m >= 1; m >>= 1) {
-        a00 += __shfl_xor(a00, m); a01 += __shfl_xor(a01, m); a02 += __shfl_xor(a02, m);
-        a11 += __shfl_xor(a11, m); a12 += __shfl_xor(a12, m); a22 += __shfl_xor(a22, m);
-        gdx = gdx + __shfl_xor(gdx, m); gdy = gdy + __shfl_xor(gdy, m); gdz = gdz + __shfl_xor(gdz, m);
-        sax = sax + __shfl_xor(sax, m); say = say + __shfl_xor(say, m); saz = saz + __shfl_xor(saz, m);
-        cnt += __shfl_xor(cnt, m);
-        const int ot = __shfl_xor(lane_terms, m);
-        lane_terms = lane_terms > ot ? lane_terms : ot;
-    }
-    if (lane == 0) {
-        double *p = part[wave];
-        p[0] = a00; p[1] = a01; p[2] = a02; p[3] = a11; p[4] = a12; p[5] = a22;
-        p[6] = (double)gdx; p[7] = (double)gdy; p[8] = (double)gdz; p[9] = (double)sax; p[10] = (double)say; p[11] = (double)saz;
-        ipart[wave][0] = cnt; ipart[wave][1] = lane_terms;
-    }
-    __syncthreads();
-    if (tid < 12) {
-        /* the tensor in f64; the gradient terms are f32 sums of each wave, added here in f32 as one more level of the
-         * summation tree the decision's margin accounts for (lane_terms + 6 + 2 additions per component) */
-        if (tid < 6) scr[tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-        else scr[tid] = (double)((((float)part[0][tid] + (float)part[1][tid]) + (float)part[2][tid]) + (float)part[3][tid]);
-    } else if (tid == 12) {
-        scr[12] = (double)(ipart[0][0] + ipart[1][0] + ipart[2][0] + ipart[3][0]);
-        int mt = ipart[0][1];
-        for (int w = 1; w < 4; w++) mt = mt > ipart[w][1] ? mt : ipart[w][1];
-        scr[13] = (double)(mt + 4);                          /* + the cross-wave additions */
-    }
-}
-
-/* compacted list of the flagged candidates of a chunk (d_keep == 3), in any order: list[0] = count, list[1..] = indices
- * relative to cand0 */
-__global__ void __launch_bounds__(256)
-k_orient_flagged(const uint32_t *__restrict__ d_keep, uint32_t cand0, uint32_t n, uint32_t *__restrict__ list)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool f = i < n && d_keep[cand0 + i] == 3u;
-    const unsigned long long b = __ballot(f);
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == 0 && b) base = atomicAdd(&list[0], (unsigned)__popcll(b));
-    base = (unsigned)__shfl((int)base, 0);
-    if (f) list[1 + base + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = i;
-}
-
-/* the general path (orient_one<1>) for the listed candidates, one wave each */
-__global__ void __launch_bounds__(64)
-k_orient_listed(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const uint32_t *__restrict__ d_tag, uint32_t cand0,
-                uint32_t num, const double *__restrict__ d_sigma, double corner_thresh, double *__restrict__ d_scr,
-                float *__restrict__ d_R, uint32_t *__restrict__ d_keep, const uint32_t *__restrict__ list, uint32_t slot0)
-{
-    const uint32_t count = list[0];
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const uint32_t c = list[1 + i];
-        s3d_wave_lds_sync();
-        orient_one<1>(pyr, d_idx, d_tag, nullptr, cand0 + c, slot0 + c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, nullptr,
-                      nullptr);
-    }
-}
-
 /* One wave per candidate (candidate cand0 + blockIdx.x of a chunk of nchunk); PHASE 4 -- the few candidates the table
  * walk flagged -- is a fixed grid of waves that each look through a stride of the chunk: a launch of one workgroup per
  * candidate that returns at once for nine in ten of them cost 0.43 ms at 120 k candidates. */
@@ -886,7 +656,7 @@ extern "C" size_t s3d_k_orient_scratch_bytes(uint32_t num)
 }
 
 static thread_local int g_orient_mode = -1;                       /* test knob of the calling thread, see s3d_k_orient_tab */
-extern "C" void s3d_k_set_orient_mode(int mode) { g_orient_mode = mode >= 0 && mode <= 3 ? mode : -1; }
+extern "C" void s3d_k_set_orient_mode(int mode) { g_orient_mode = mode >= 0 && mode <= 2 ? mode : -1; }
 
 extern "C" int s3d_k_orient_mode(void)
 {
@@ -894,16 +664,14 @@ extern "C" int s3d_k_orient_mode(void)
     if (env_mode < 0) {
         const char *e = getenv("S3D_ORI_MODE");
         env_mode = e ? atoi(e) : 0;
-        if (env_mode < 0 || env_mode > 3) env_mode = 0;
+        if (env_mode < 0 || env_mode > 2) env_mode = 0;
     }
     return g_orient_mode >= 0 ? g_orient_mode : env_mode;
 }
 
-/* d_tabs: the levels' window tables, their LDS-staging forms (mode 3), and the list of flagged candidates of a chunk */
 extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
 {
-    return (sizeof(s3d_ori_tab) + sizeof(s3d_ori_win)) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels +
-           sizeof(uint32_t) * ((size_t)S3D_ORIENT_CHUNK + 1);
+    return sizeof(s3d_ori_tab) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
 }
 
 extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
@@ -922,38 +690,19 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
      * L1 fill bandwidth (a third fewer distinct lines: -6 %) nor by workgroup launch rate (a fixed grid of 7-28 k waves
      * walking the candidates: +10-20 %), and loading a turn ahead did not shorten it either (1.09 -> 1.06): the tables buy
      * nothing end to end (detect 6.96 against 6.94 ms), so they stay an option. */
-    int mode = s3d_k_orient_mode();
-    if (mode == 3 && d_idx == nullptr) mode = 0;            /* the staged form takes its centres from the index list */
+    const int mode = s3d_k_orient_mode();
     if (mode == 0) tabs = nullptr;
-    s3d_ori_win *wins = nullptr;
-    uint32_t *flagged = nullptr;
     if (tabs) {
         const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
-        wins = reinterpret_cast<s3d_ori_win *>(tabs + nlev);
-        flagged = reinterpret_cast<uint32_t *>(wins + nlev);
         hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, nlev, d_sigma, corner_thresh,
                            (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs);
         S3D_CHECK_LAUNCH();
-        if (mode == 3) {
-            hipLaunchKernelGGL(k_orient_win_build, dim3(nlev), dim3(64), 0, (hipStream_t)st, tabs, wins, (int)nlev, *pyr);
-            S3D_CHECK_LAUNCH();
-        }
     }
     const uint32_t chunk = g_orient_chunk;
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
-        if (tabs && mode == 3) {
-            S3D_HIP(hipMemsetAsync(flagged, 0, sizeof(uint32_t), (hipStream_t)st));
-            hipLaunchKernelGGL(k_orient_win, dim3(n), dim3(256), 0, (hipStream_t)st, *pyr, d_idx, d_tag, c0, num, d_sigma, scr, d_keep,
-                               wins, 0u);
-            S3D_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_orient_flagged, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, d_keep, c0, n, flagged);
-            S3D_CHECK_LAUNCH();
-            const uint32_t g4 = n / 8u + 1u;
-            hipLaunchKernelGGL(k_orient_listed, dim3(g4 < 32768u ? g4 : 32768u), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, c0,
-                               num, d_sigma, corner_thresh, scr, d_R, d_keep, flagged, 0u);
-        } else if (tabs && mode == 2) {
+        if (tabs && mode == 2) {
             hipLaunchKernelGGL((k_orient_wave<3>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
                                d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, tabs);
             S3D_CHECK_LAUNCH();

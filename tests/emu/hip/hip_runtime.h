@@ -277,7 +277,6 @@ static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
-static inline int atomicMin(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 static inline unsigned atomicExch(unsigned *p, unsigned v) { unsigned o = *p; *p = v; return o; }
 

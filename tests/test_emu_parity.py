@@ -82,24 +82,12 @@ def test_orientation_chunk_loop(emu, oracle):
     ((30, 28, 26), (2, 2, 2), (4.0, 5.0), True),               # octave 1: units 2, sigma in the same units
     ((32, 30, 28), (1, 1, 1.5), (2.0, 2.5), False),            # anisotropic: no tables, the general path serves all
 ])
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2])
 def test_orient_tables(emu, dims, units, sigmas, expect, mode):
     """Window sums replayed from the levels' tables (one kernel that decides per candidate / a table-walk kernel plus the
     general kernel for the rest) equal the sums every candidate enumerates for itself, bit for bit."""
     kept, replayed = parity.check_orient_tables(emu, dims, units, sigmas, 150, expect_tables=expect, mode=mode)
     assert kept > 0
-
-
-@pytest.mark.parametrize("mode", [1, 2, 3])
-def test_detect_with_orientation_tables(emu, oracle, mode):
-    """A whole detect + describe with the orientation window sums taken from the levels' tables (walked per wave, or with
-    the window staged in LDS): the keypoints are the oracle's."""
-    emu.sift.s3d_k_set_orient_mode.argtypes = [C.c_int]
-    emu.sift.s3d_k_set_orient_mode(mode)
-    try:
-        assert parity.check_detect_describe(emu, oracle, (40, 36, 32), (1, 1, 1), 120, 4, check_pyramid=False) > 0
-    finally:
-        emu.sift.s3d_k_set_orient_mode(-1)
 
 
 def test_raw_variants(emu, oracle):
