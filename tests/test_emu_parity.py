@@ -90,6 +90,18 @@ def test_orient_tables(emu, dims, units, sigmas, expect, mode):
     assert kept > 0
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_detect_with_orientation_tables(emu, oracle, mode):
+    """A whole detect + describe with the orientation window sums taken from the levels' tables: the keypoints are the
+    oracle's."""
+    emu.sift.s3d_k_set_orient_mode.argtypes = [C.c_int]
+    emu.sift.s3d_k_set_orient_mode(mode)
+    try:
+        assert parity.check_detect_describe(emu, oracle, (40, 36, 32), (1, 1, 1), 120, 4, check_pyramid=False) > 0
+    finally:
+        emu.sift.s3d_k_set_orient_mode(-1)
+
+
 def test_raw_variants(emu, oracle):
     parity.check_raw_variants(emu, oracle, (32, 32, 32), (1, 1, 1), 40)
 
