@@ -636,6 +636,10 @@ k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict_
 {
     __shared__ double ssd[NN_CAP];
     __shared__ int cidx[NN_CAP], sidx[NN_CAP];
+    /* the query row and four candidate rows at a time staged in LDS (pitch NEL + 4: the lanes' rows on different banks) */
+    constexpr int VG = 4, VP = NEL + 4;
+    __shared__ __attribute__((aligned(16))) float rowa[NEL];
+    __shared__ __attribute__((aligned(16))) float rowb[VG][VP];
     const unsigned i = blockIdx.x;
     if (i >= na) return;
     const int lane = threadIdx.x;
@@ -649,18 +653,46 @@ k_nn_verify(const float *__restrict__ a, size_t a_stride, const int *__restrict_
     const int mine = lane < n ? cand[(size_t)i * NN_CAP + lane] : 0x7fffffff;
     cidx[lane] = mine;
     __syncthreads();
-    if (lane < n) {
-        int rank = 0;
+    int rank = 0;
+    if (lane < n)
         for (int k = 0; k < n; k++) rank += cidx[k] < mine ? 1 : 0;
+    /* Rows come in through all 64 lanes (a 3 KB row is 12 loads of the wave instead of 768 loads of one lane -- read
+     * element by element by the two or three lanes that have a candidate, every cache line was a round trip of its own:
+     * 0.4 ms per direction at 31 k rows); each candidate's lane then adds its 768 squared differences out of LDS in the
+     * reference's order. */
+    {
         const float *pa = a + (size_t)(a_sel ? (unsigned)a_sel[i] : i) * a_stride;
-        const float *pb = b + (size_t)mine * b_stride;
-        double s = 0.0;
-        for (int e = 0; e < NEL; e++) {
-            const double diff = (double)pa[e] - (double)pb[e];
-            s += diff * diff;
+        for (int e = lane; e < NEL; e += 64) rowa[e] = pa[e];
+    }
+    for (int g0 = 0; g0 < n; g0 += VG) {
+        __syncthreads();                                    /* the previous group's sums are done with rowb */
+        for (int c = 0; c < VG && g0 + c < n; c++) {
+            const float *pb = b + (size_t)cidx[g0 + c] * b_stride;
+            for (int e = lane; e < NEL; e += 64) rowb[c][e] = pb[e];
         }
-        ssd[rank] = s;
-        sidx[rank] = mine;
+        __syncthreads();
+        if (lane >= g0 && lane < g0 + VG && lane < n) {
+            const float *rb = rowb[lane - g0];
+            double s = 0.0;
+            static_assert(NEL % 16 == 0 && VP % 4 == 0, "float4 reads of both rows");
+            for (int e = 0; e < NEL; e += 16) {             /* 16 elements' reads in flight, then their sum in order */
+                float4 qa[4], qb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    qa[u] = *reinterpret_cast<const float4 *>(&rowa[e + 4 * u]);
+                    qb[u] = *reinterpret_cast<const float4 *>(&rb[e + 4 * u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    double diff = (double)qa[u].x - (double)qb[u].x; s += diff * diff;
+                    diff = (double)qa[u].y - (double)qb[u].y; s += diff * diff;
+                    diff = (double)qa[u].z - (double)qb[u].z; s += diff * diff;
+                    diff = (double)qa[u].w - (double)qb[u].w; s += diff * diff;
+                }
+            }
+            ssd[rank] = s;
+            sidx[rank] = mine;
+        }
     }
     __syncthreads();
     if (lane == 0) {
@@ -824,15 +856,37 @@ done:
 
 /* threshold of every column: second smallest score over all 64-row blocks (partials from the GEMM epilogue) + the error
  * band */
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_nn_col_thr(const float *__restrict__ pm1, const float *__restrict__ pm2, unsigned nblk, unsigned nbpad, unsigned nb,
              const double *__restrict__ b2d, double a2max, float *__restrict__ thr)
 {
-    const unsigned j = blockIdx.x * 64u + threadIdx.x;
-    if (j >= nb) return;
+    /* 64 columns per workgroup, four waves that take every fourth 64-row block, eight blocks' minima in flight per step (one
+     * wave per 64 columns walking the blocks one at a time was 488 dependent round trips for two waves per CU: 0.24 ms) */
+    __shared__ float sm1[4][64], sm2[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned j = blockIdx.x * 64u + (unsigned)lane;          /* < nbpad: the block minima are stored for padded columns too */
     float m1 = 3.0e38f, m2 = 3.0e38f;
-    for (unsigned s = 0; s < nblk; s++) {
-        const float o1 = pm1[(size_t)s * nbpad + j], o2 = pm2[(size_t)s * nbpad + j];
+    for (unsigned s0 = (unsigned)w; s0 < nblk; s0 += 32) {
+        float o1[8], o2[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned sb = s0 + 4u * u;
+            const bool in = sb < nblk;
+            o1[u] = in ? pm1[(size_t)sb * nbpad + j] : 3.0e38f;
+            o2[u] = in ? pm2[(size_t)sb * nbpad + j] : 3.0e38f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float lo = m1 < o1[u] ? m1 : o1[u], hi = m1 < o1[u] ? o1[u] : m1, s2 = m2 < o2[u] ? m2 : o2[u];
+            m1 = lo;
+            m2 = hi < s2 ? hi : s2;
+        }
+    }
+    sm1[w][lane] = m1; sm2[w][lane] = m2;
+    __syncthreads();
+    if (w != 0 || j >= nb) return;
+    for (int k = 1; k < 4; k++) {                                  /* the two smallest of the four waves' pairs */
+        const float o1 = sm1[k][lane], o2 = sm2[k][lane];
         const float lo = m1 < o1 ? m1 : o1, hi = m1 < o1 ? o1 : m1, s2 = m2 < o2 ? m2 : o2;
         m1 = lo;
         m2 = hi < s2 ? hi : s2;
@@ -851,14 +905,27 @@ k_nn_col_cand(const float *__restrict__ S, const float *__restrict__ pm1, unsign
     if (j >= nb) return;
     const unsigned s0 = seg * blk_per_seg, s1 = s0 + blk_per_seg < nblk ? s0 + blk_per_seg : nblk;
     const float t = thr[j];
-    for (unsigned sb = s0; sb < s1; sb++) {
-        if (!(pm1[(size_t)sb * nbpad + j] <= t)) continue;
-        const unsigned i0 = sb * 64u, i1 = i0 + 64u < na ? i0 + 64u : na;
-        for (unsigned i = i0; i < i1; i++)
-            if (S[(size_t)i * nbpad + j] <= t) {
-                const int pos = atomicAdd(&count[j], 1);
-                if (pos < NN_CAP) cand[(size_t)j * NN_CAP + pos] = (int)i;
+    for (unsigned sc = s0; sc < s1; sc += 16) {
+        /* the block minima of 16 blocks together, then the rows of the blocks that can hold a candidate 16 at a time */
+        float p[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) p[u] = sc + u < s1 ? pm1[(size_t)(sc + u) * nbpad + j] : 3.0e38f;
+#pragma unroll 1
+        for (int u = 0; u < 16; u++) {
+            if (!(p[u] <= t)) continue;
+            const unsigned i0 = (sc + u) * 64u;
+            for (unsigned ib = i0; ib < i0 + 64u && ib < na; ib += 16) {
+                float v[16];
+#pragma unroll
+                for (int w = 0; w < 16; w++) v[w] = ib + w < na ? S[(size_t)(ib + w) * nbpad + j] : 3.0e38f;
+#pragma unroll
+                for (int w = 0; w < 16; w++)
+                    if (v[w] <= t) {
+                        const int pos = atomicAdd(&count[j], 1);
+                        if (pos < NN_CAP) cand[(size_t)j * NN_CAP + pos] = (int)(ib + w);
+                    }
             }
+        }
     }
 }
 
@@ -918,7 +985,7 @@ extern "C" int s3d_k_nn_match2_fast(const float *d_a, size_t a_stride, uint32_t 
     hipLaunchKernelGGL(k_nn_gemm, nn_gemm_grid(nbpad / GT, napad / GT), dim3(256), 0, st, AH, AL, 0u, BH, BL, nbpad, a2f, b2f, S, pm1, pm2,
                        rmin, napad / GT, nbpad / GT);
     hipLaunchKernelGGL(k_nn_rowscan, dim3(na), dim3(64), 0, st, S, rmin, nbpad, nb, 0u, na, a2d, b2max, candf, countf);
-    hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(64), 0, st, pm1, pm2, nblk, nbpad, nb, b2d, a2max, thr);
+    hipLaunchKernelGGL(k_nn_col_thr, dim3(nbpad / 64), dim3(256), 0, st, pm1, pm2, nblk, nbpad, nb, b2d, a2max, thr);
     hipLaunchKernelGGL(k_nn_col_cand, dim3(nbpad / 64, NN_SEG), dim3(64), 0, st, S, pm1, nbpad, nb, na, blk_per_seg, nblk, thr, candb,
                        countb);
     hipLaunchKernelGGL(k_nn_verify, dim3(na), dim3(64), 0, st, d_a, a_stride, (const int *)nullptr, na, d_b, b_stride, candf,
