@@ -593,10 +593,18 @@ def main():
     if rank == 0 and K and not args.no_match:
         # row f1, outside the timed region: SIFT3D_nn_match of this volume's K descriptors against themselves
         # (device resident; the cost does not depend on the data: 2 exhaustive K x K f64 SSD passes)
+        # The first call of a process allocates the matcher's device scratch (4.3 bytes per pair: 4 GB here; 10-130 ms
+        # depending on the box): reported apart, the figure is the better of the next two calls.
         t0 = time.perf_counter()
         m = dev.nn_match(d_desc.value, K, d_desc.value, K, 0.8, stride=776)   # records laid out like SIFT3D_Descriptor
-        t_match = time.perf_counter() - t0
-        result["config"]["match"] = {"pairs": K * K, "ms": round(t_match * 1e3, 2), "self_matches": int((m == np.arange(K)).sum()),
+        t_first = time.perf_counter() - t0
+        t_match = float("inf")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            m = dev.nn_match(d_desc.value, K, d_desc.value, K, 0.8, stride=776)
+            t_match = min(t_match, time.perf_counter() - t0)
+        result["config"]["match"] = {"pairs": K * K, "ms": round(t_match * 1e3, 2), "first_call_ms": round(t_first * 1e3, 2),
+                                     "self_matches": int((m == np.arange(K)).sum()),
                                      "Gpairs_per_s": round(2.0 * K * K / t_match / 1e9, 1),
                                      "method": "f32 screening of all pairs (forward and backward pass) + exact f64 verification "
                                                "of the candidates; indices bit-identical to the exhaustive f64 search"}
