@@ -110,6 +110,12 @@ void s3d_k_gauss_set_mode(int mode);
  * Per calling thread.  s3d_k_gauss_tile3_launches: how many such launches the calling thread has made (tests). */
 void s3d_k_gauss_set_tile3(long max_voxels);
 long s3d_k_gauss_tile3_launches(void);
+/* The table-driven axis passes (s3d_gauss_tab.hip: any tap spacing, any row length; chosen by the library for volumes
+ * above 64^3 wherever the unit-spacing and dyadic kernels do not apply).  Outputs per marching chunk, the number of such
+ * passes the calling thread has launched (tests), and the release of the tap tables of every device. */
+void s3d_k_gauss_tab_set_chunk(int chunk);
+long s3d_k_gauss_tab_launches(void);
+void s3d_k_tap_tables_release(void);
 int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz,
                        int nc, const float uf[3], const float *taps, int width, int path,
                        s3d_stream stream);

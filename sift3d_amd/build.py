@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "lib", "obj")
 INC = os.path.join(ROOT, "include")
 
-HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
+HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_gauss_tab.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
                "s3d_dense.hip", "s3d_match.hip", "s3d_resample.hip", "s3d_rccl.hip"]
 C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c", "host/s3d_host_draw.c", "host/s3d_host_slab.c"]
 BIN = os.path.join(HERE, "bin")
@@ -27,7 +27,9 @@ CLI_PROGRAMS = ["kpSift3D", "denseSift3D", "regSift3D"]
 # Per-file extra flags.  s3d_keypoint.hip: the SLP vectoriser pairs scalar f32 operations into v_pk_* instructions, which on
 # gfx950 cost 4.4 cycles per wave64 against 2.8 for a scalar f32 op (scripts/ubench_valu.hip) and need register shuffles
 # and s_nops around them: a net loss for the VALU-bound descriptor kernel.
-EXTRA_HIP_FLAGS = {"s3d_keypoint.hip": ["-fno-slp-vectorize"]}
+# s3d_gauss_tab.hip: its packed operations are written out (s3d_f2); what the vectoriser adds on top pairs values of
+# different taps and pays for it in register moves and s_nops.
+EXTRA_HIP_FLAGS = {"s3d_keypoint.hip": ["-fno-slp-vectorize"], "s3d_gauss_tab.hip": ["-fno-slp-vectorize"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}"]

@@ -48,4 +48,24 @@ __device__ __forceinline__ void s3d_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* four floats at any dword-aligned address: rows and planes of volumes whose row length is not a multiple of 4 start
+ * anywhere, and global_load_dwordx4 / global_store_dwordx4 only need dword alignment */
+#if defined(__clang__)
+typedef float s3d_f4u __attribute__((ext_vector_type(4), aligned(4)));
+#else                                      /* the g++ emulator build of the test suite */
+struct s3d_f4u { float x, y, z, w; };
+#endif
+/* two floats for explicitly packed arithmetic (v_pk_mul_f32 / v_pk_add_f32: element-wise, every element rounded like the
+ * scalar operation); elements by index */
+#if defined(__clang__)
+typedef float s3d_f2 __attribute__((ext_vector_type(2)));
+#else
+typedef float s3d_f2 __attribute__((vector_size(8)));
+#endif
+
+/* dynamically sized LDS of a kernel (the size is the launch's third parameter) */
+#ifndef S3D_DYN_LDS
+#define S3D_DYN_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 static inline unsigned s3d_div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

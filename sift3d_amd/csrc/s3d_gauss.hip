@@ -467,6 +467,12 @@ static bool launch_z_ring(int hw, const float *src, float *dst, size_t plane4, i
 
 static thread_local int g_no_dyadic = 0;      /* profiling / test knob of the calling thread: force the generic kernel */
 static thread_local int g_force_z_ring = 0;   /* test knob: the marching z kernel whatever the size of its grid */
+static thread_local int g_force_tab = 0;      /* test knob: the table-driven passes (s3d_gauss_tab.hip) whatever the size of the volume */
+static thread_local int g_no_tab = 0;         /* profiling knob: never the table-driven passes */
+
+/* s3d_gauss_tab.hip: 0 done, 1 not eligible, -1 error */
+extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
+                                   const float *taps, int width, float uf, int uhw, s3d_stream stream);
 
 static int check_taps(const float *taps, int width, S3dTaps *out)
 {
@@ -515,6 +521,14 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
             S3D_CHECK_LAUNCH();
             return S3D_OK;
         }
+    }
+    /* any other spacing, any row length: the table-driven passes -- where the volume gives their marching waves enough to do
+     * (a pass over 32^3 voxels is a handful of waves walking the volume; the plain kernels below take a few us there) */
+    if (nc == 1 && !g_no_dyadic && !g_no_tab &&
+        (g_force_tab || (size_t)nx * ny * (size_t)(z1 - z0) > (size_t)64 * 64 * 64)) {
+        const int r = s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, axis, z0, z1, taps, width, uf, uhw, st);
+        if (r < 0) return S3D_ERR;
+        if (r == 0) return S3D_OK;
     }
     if (nc == 1 && !g_no_dyadic) {
         bool done = false;
@@ -1048,13 +1062,16 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
 static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk().  Per calling thread. */
 
 /* profiling / test knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
- * bit 1 = no dyadic-spacing specialisation of the generic axis pass; bit 2 = k_conv_z_ring also where its grid would not
- * fill the GPU (tests reach it on small volumes) */
+ * bit 1 = no specialisation of the generic axis pass at all (k_conv_axis only); bit 2 = k_conv_z_ring also where its grid
+ * would not fill the GPU (tests reach it on small volumes); bit 3 = the table-driven passes (s3d_gauss_tab.hip) also on
+ * small volumes (tests); bit 4 = never the table-driven passes (A/B runs) */
 extern "C" void s3d_k_gauss_set_mode(int mode)
 {
     g_gauss_mode = mode & 1;
     g_no_dyadic = (mode >> 1) & 1;
     g_force_z_ring = (mode >> 2) & 1;
+    g_force_tab = (mode >> 3) & 1;
+    g_no_tab = (mode >> 4) & 1;
 }
 
 /* tuning knobs for profiling runs (rows / planes per marching chunk) */

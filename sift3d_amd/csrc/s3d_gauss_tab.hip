@@ -1,0 +1,381 @@
+/* s3d_gauss_tab.hip -- one axis pass of the separable filter for ANY tap spacing and ANY row length at streaming speed
+ * (apply_Sep_FIR_filter imutil/imutil.c:3459-3544, convolve_sep_gen imutil/imutil.c:2274-2393).
+ *
+ * The reference places its taps `uf = unit / units[dim]` voxels apart and interpolates linearly between the two
+ * voxels around every tap position (imutil.c:2286-2328, mirrored boundary :2355-2393).  Which two voxels, and with
+ * which weight, depends on the position ALONG THE FILTERED AXIS only -- not on the other two coordinates -- but it does
+ * depend on that position in a way no closed form captures: the interior loop carries a running float coordinate
+ * (coord -= step; ...; coord += step) whose rounding drifts with the magnitude of p.  So the coordinate loop is run
+ * once per position, by k_tap_table (one thread per position, verbatim the loop of k_conv_axis), into a table
+ * (lo, frac) per (position, tap) that lives in HBM for as long as the process does (a few hundred KB per distinct
+ * (n, hw, uf); a pyramid has a few dozen).  The passes then contain no coordinate arithmetic at all:
+ *
+ *   k_conv_march_tab  y or z pass.  One wave = 64 float4 columns (256 consecutive floats of the row / plane; the row
+ *                     length need not be a multiple of 4: loads and stores are dword aligned and the last column is
+ *                     clamped onto the end) marching along the axis.  Source rows enter a ring of W = 2*uhw+3 rows in
+ *                     LDS exactly once, D rows ahead through registers; the taps of output p read the ring at byte
+ *                     offsets that come out of the table through the SCALAR cache (they are wave uniform), as do
+ *                     frac and 1-frac.  Per output row: 1 global load, 1 store, 2 ds_read_b128 + 20 VALU per tap.
+ *   k_conv_x_tab      x pass.  One wave = 64 consecutive outputs of a row, marching over rows.  The (lo, frac) of a
+ *                     lane's x are loaded once into registers; every row is staged in LDS twice, the second copy one
+ *                     float to the left, so that the pair (src[lo], src[lo+1]) is one 8-byte aligned ds_read_b64 whatever
+ *                     the parity of lo (256 B/clk instead of the 128 of ds_read2_b32); the second copy starts 32 banks
+ *                     after the first, so even and odd lanes never meet in a bank.
+ *
+ * Same taps, same order, same expression per element as k_conv_axis: bit-identical to it and to the reference.
+ * This file MUST be compiled with -ffp-contract=off. */
+#include "s3d_common.h"
+
+#include <mutex>
+
+#define TAB_MAX_HW 9
+#define TAB_MAX_UHW 30                    /* ring of 2*uhw+3 <= 63 rows (63 KB of LDS), x segment of 64+2*uhw+3 <= 128 floats */
+
+/* ---- the table -------------------------------------------------------------------------------------------------
+ * march layout (p-major, all wave uniform -> scalar loads): m[p*4*NT + k]        = ring byte offset of row lo     (lo % W) * 1024
+ *                                                           m[p*4*NT + NT + k]   = ring byte offset of row lo + 1
+ *                                                           m[p*4*NT + 2NT + k]  = frac (float bits)
+ *                                                           m[p*4*NT + 3NT + k]  = 1 - frac (float bits)
+ * x layout (tap-major, coalesced per-lane loads):           xlo[k*n + p] = lo ; xfr[k*n + p] = frac (float bits)
+ * bad: set when a tap of some position leaves [max(0, p-uhw-1), min(n-1, p+uhw+1)] -- what the ring / the staged segment
+ * hold for position p.  Cannot happen for the spacings the reference's own arithmetic produces (see the header); a table
+ * with the flag set is never used (the caller takes k_conv_axis). */
+__global__ void __launch_bounds__(64)
+k_tap_table(int *__restrict__ m, int *__restrict__ xlo, int *__restrict__ xfr, int *__restrict__ bad, int n, int hw, float uf,
+            int uhw, int W)
+{
+    const int p = (int)(blockIdx.x * 64u + threadIdx.x);
+    if (p >= n) return;
+    const int NT = 2 * hw + 1;
+    const int dim_end = n - 1;
+    const int lo_min = p - uhw - 1 > 0 ? p - uhw - 1 : 0, hi_max = p + uhw + 1 < n - 1 ? p + uhw + 1 : n - 1;
+    const bool interior = p >= uhw && p <= n - 2 - uhw;
+    float run = (float)p;
+    int *row = m + (size_t)p * (size_t)(4 * NT);
+    int flag = 0;
+    for (int d = -hw; d <= hw; d++) {
+        const float step = (float)d * uf;
+        float coord;
+        if (interior) {                                    /* imutil.c:2311-2328: the coordinate is carried along */
+            run = run - step;
+            coord = run;
+            run = run + step;
+        } else {                                           /* imutil.c:2355-2393 */
+            coord = (float)p - step;
+            if ((int)coord < 0)
+                coord = -coord;
+            else if ((int)coord >= dim_end)
+                coord = 2.0f * (float)dim_end - coord - 0.1f;
+        }
+        const int lo = (int)coord;
+        const float frac = coord - (float)lo;
+        const int k = d + hw;
+        if (lo < lo_min || lo + 1 > hi_max) { flag = 1; continue; }
+        row[k] = (lo % W) * 1024;
+        row[NT + k] = ((lo + 1) % W) * 1024;
+        row[2 * NT + k] = __float_as_int(frac);
+        row[3 * NT + k] = __float_as_int(1.0f - frac);
+        xlo[(size_t)k * n + p] = lo;
+        xfr[(size_t)k * n + p] = __float_as_int(frac);
+    }
+    if (flag) atomicMax(bad, 1);
+}
+
+struct TapTab {
+    int dev, n, hw, uhw, W;
+    unsigned uf_bits;
+    int *d_m, *d_xlo, *d_xfr;                              /* nullptr: unusable (flag set or allocation failed) */
+};
+
+#define TAB_CACHE 256
+static TapTab g_tab[TAB_CACHE];
+static int g_ntab = 0;
+static std::mutex g_tab_lock;
+
+/* The table of (n, hw, uf) on the current device; built (and waited for) the first time it is asked for, so that any
+ * stream may use it afterwards.  nullptr: not available -- the caller takes another kernel. */
+static const TapTab *tap_table(int n, int hw, float uf, int uhw)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    unsigned ub;
+    memcpy(&ub, &uf, 4);
+    std::lock_guard<std::mutex> guard(g_tab_lock);
+    for (int i = 0; i < g_ntab; i++)
+        if (g_tab[i].dev == dev && g_tab[i].n == n && g_tab[i].hw == hw && g_tab[i].uf_bits == ub)
+            return g_tab[i].d_m ? &g_tab[i] : nullptr;
+    if (g_ntab == TAB_CACHE) return nullptr;               /* more distinct passes than any pyramid has: no new tables */
+    TapTab t;
+    t.dev = dev; t.n = n; t.hw = hw; t.uhw = uhw; t.W = 2 * uhw + 3; t.uf_bits = ub;
+    t.d_m = t.d_xlo = t.d_xfr = nullptr;
+    const int NT = 2 * hw + 1;
+    const size_t words = (size_t)n * NT;
+    int *blk = nullptr;
+    /* one allocation: flag | march table | xlo | xfr */
+    if (hipMalloc((void **)&blk, sizeof(int) * (4 + 6 * words)) == hipSuccess) {
+        int bad = 1;
+        hipStream_t st = nullptr;
+        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMemsetAsync(blk, 0, sizeof(int) * 4, st) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_tap_table, dim3(s3d_div_up((size_t)n, 64)), dim3(64), 0, st, blk + 4, blk + 4 + 4 * words,
+                               blk + 4 + 5 * words, blk, n, hw, uf, uhw, t.W);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipMemcpyAsync(&bad, blk, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if (st) hipStreamDestroy(st);
+        if (ok && bad == 0) {
+            t.d_m = blk + 4; t.d_xlo = blk + 4 + 4 * words; t.d_xfr = blk + 4 + 5 * words;
+        } else {
+            hipFree(blk);
+        }
+    }
+    g_tab[g_ntab] = t;
+    return g_tab[g_ntab++].d_m ? &g_tab[g_ntab - 1] : nullptr;
+}
+
+/* device memory held by the tables of every device goes back (called with the last context of the process) */
+extern "C" void s3d_k_tap_tables_release(void)
+{
+    std::lock_guard<std::mutex> guard(g_tab_lock);
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int i = 0; i < g_ntab; i++)
+        if (g_tab[i].d_m && hipSetDevice(g_tab[i].dev) == hipSuccess) hipFree(g_tab[i].d_m - 4);
+    if (have) hipSetDevice(cur);
+    g_ntab = 0;
+}
+
+/* ---- marching pass (y or z) --------------------------------------------------------------------------------------- */
+template <int HW, int D>
+__global__ void __launch_bounds__(64)
+k_conv_march_tab(const float *__restrict__ src, float *__restrict__ dst, unsigned ncol4, size_t nflat, size_t stride,
+                 size_t bstride, int p_begin, int p_end, int chunk, int rmin, int rmax, int W, int A,
+                 const int *__restrict__ tab, S3dTaps taps)
+{
+    constexpr int NT = 2 * HW + 1;
+    S3D_DYN_LDS(float4, ring);                             /* W rows of 64 float4 */
+    const int lane = threadIdx.x;
+    const size_t col = (size_t)blockIdx.x * 64 + (size_t)lane;
+    size_t off = (col < ncol4 ? col : (size_t)ncol4 - 1) * 4;
+    if (off + 4 > nflat) off = nflat - 4;                  /* last column of a ragged extent: clamped onto the end (overlaps) */
+    const float *base = src + (size_t)blockIdx.z * bstride + off;
+    float *out = dst + (size_t)blockIdx.z * bstride + off;
+    const int p0 = p_begin + (int)blockIdx.y * chunk;
+    const int p1 = p0 + chunk < p_end ? p0 + chunk : p_end;
+    if (p0 >= p1) return;
+    auto rowof = [&](int p) { const int r = p + A; return r < rmax ? r : rmax; };   /* newest row the ring holds at output p */
+    auto ld = [&](int r) -> s3d_f4u { return *reinterpret_cast<const s3d_f4u *>(base + (size_t)r * stride); };
+    auto put = [&](int slot, const s3d_f4u &v) { ring[slot * 64 + lane] = make_float4(v.x, v.y, v.z, v.w); };
+
+    /* prologue: rows [max(rmin, R - W + 1), R] of the first output, eight loads in flight at a time */
+    int rcur = rowof(p0);
+    {
+        int r = rcur - W + 1;
+        if (r < rmin) r = rmin;
+        for (; r <= rcur; r += 8) {
+            s3d_f4u t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = ld(r + j < rcur ? r + j : rcur);
+#pragma unroll
+            for (int j = 0; j < 8; j++) put((r + j < rcur ? r + j : rcur) % W, t[j]);
+        }
+    }
+    int slot = rcur % W;
+    s3d_f4u q[D];                                          /* rows of outputs p+1 .. p+D, in flight */
+#pragma unroll
+    for (int d = 0; d < D; d++) q[d] = ld(rowof(p0 + 1 + d));
+    const char *ringb = reinterpret_cast<const char *>(ring) + lane * 16;
+    /* one output row; then the row the next output adds goes into the ring (none once the ring has reached rmax: the same
+     * row goes to the same slot again) and its register takes the load of the row D outputs on.  The march is unrolled D
+     * times so that the queue is indexed statically: shifting it through register moves would make every step wait for
+     * the load it has just issued. */
+    auto step = [&](int p, s3d_f4u &qu) {
+        const int *row = tab + (size_t)p * (size_t)(4 * NT);
+        s3d_f2 lo2 = {0.0f, 0.0f}, hi2 = {0.0f, 0.0f};   /* (x, y) and (z, w) of the output: packed f32 operations */
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const float4 a = *reinterpret_cast<const float4 *>(ringb + row[k]);
+            const float4 b = *reinterpret_cast<const float4 *>(ringb + row[NT + k]);
+            const float frac = __int_as_float(row[2 * NT + k]), om = __int_as_float(row[3 * NT + k]);
+            const float tap = taps.t[k];
+            const s3d_f2 alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+            lo2 = lo2 + tap * (om * alo + frac * blo);
+            hi2 = hi2 + tap * (om * ahi + frac * bhi);
+        }
+        {   /* lanes past the last column sit on the last column (clamped above) and store the same values again: no branch
+             * around the store, so the wait counts of the loads around it stay exact */
+            s3d_f4u o;
+            o.x = lo2[0]; o.y = lo2[1]; o.z = hi2[0]; o.w = hi2[1];
+            *reinterpret_cast<s3d_f4u *>(out + (size_t)p * stride) = o;
+        }
+        const int rnext = rowof(p + 1);
+        if (rnext != rcur) {
+            rcur = rnext;
+            slot = slot + 1 == W ? 0 : slot + 1;
+        }
+        put(slot, qu);
+        qu = ld(rowof(p + 1 + D));
+    };
+    int p = p0;
+    for (; p + D <= p1; p += D) {                          /* straight-line groups: the wait counts come out exact */
+#pragma unroll
+        for (int u = 0; u < D; u++) step(p + u, q[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++)
+        if (p + u < p1) step(p + u, q[u]);
+}
+
+/* ---- x pass -------------------------------------------------------------------------------------------------------- */
+#define XT_LINE 160                       /* dwords per staged copy: >= 64 + 2*TAB_MAX_UHW + 3, and = 32 (mod 64) */
+template <int HW, int D>
+__global__ void __launch_bounds__(64)
+k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, size_t row_begin, size_t row_end,
+             unsigned rows_per_wave, int uhw, const int *__restrict__ xlo, const int *__restrict__ xfr, S3dTaps taps)
+{
+    constexpr int NT = 2 * HW + 1;
+    __shared__ __attribute__((aligned(16))) float line[2 * XT_LINE];   /* [0, XT_LINE): seg[i] ; [XT_LINE, ..): seg[i + 1] */
+    const int lane = threadIdx.x;
+    const int xs = (int)blockIdx.x * 64;
+    const int x = xs + lane;
+    const int xc = x < nx ? x : nx - 1;
+    const int g0 = xs - uhw - 1;                           /* source index of segment slot 0 */
+    /* the wave's taps touch slots [0, 64 + 2*uhw + 3) <= 127 */
+    int addr[NT];
+    float fr[NT], om[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = xlo[(size_t)k * nx + xc] - g0;       /* 0 <= i, i + 1 < L (k_tap_table checked it) */
+        addr[k] = (i & 1) ? (XT_LINE + i - 1) * 4 : i * 4;
+        fr[k] = __int_as_float(xfr[(size_t)k * nx + xc]);
+        om[k] = 1.0f - fr[k];
+    }
+    auto clampx = [&](int i) { return i < 0 ? 0 : (i > nx - 1 ? nx - 1 : i); };
+    const int i0 = clampx(g0 + lane), i1 = clampx(g0 + 64 + lane);
+    const int slot1 = lane >= 1 ? XT_LINE + lane - 1 : 2 * XT_LINE - 1;
+    const size_t r0 = row_begin + (size_t)blockIdx.y * rows_per_wave;
+    const size_t r1 = r0 + rows_per_wave < row_end ? r0 + rows_per_wave : row_end;
+    if (r0 >= r1) return;
+    struct Raw { float v0, v1; };
+    auto load_row = [&](size_t r) -> Raw {                 /* unconditional, clamped: a prefetch must not sit under a branch */
+        const float *row = src + (r < r1 ? r : r1 - 1) * (size_t)nx;
+        Raw q;
+        q.v0 = row[i0];
+        q.v1 = row[i1];
+        return q;
+    };
+    Raw q[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) q[d] = load_row(r0 + d);
+    const char *lineb = reinterpret_cast<const char *>(line);
+    auto step = [&](size_t r, Raw &qu) {                   /* unrolled D times: the queue is indexed statically (see the march) */
+        /* four unconditional stores: slots no tap reads (64 + lane >= L; lane 0's copy-2 slot, parked in the last dword)
+         * take clamped, valid values -- a branch here would cost the loads around it their exact wait counts */
+        line[lane] = qu.v0;
+        line[slot1] = qu.v0;
+        line[64 + lane] = qu.v1;
+        line[XT_LINE + 63 + lane] = qu.v1;
+        qu = load_row(r + D);
+        s3d_wave_lds_sync();
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const float2 ab = *reinterpret_cast<const float2 *>(lineb + addr[k]);
+            acc = acc + taps.t[k] * (om[k] * ab.x + fr[k] * ab.y);
+        }
+        s3d_wave_lds_sync();                               /* the next row's staging must not overtake these reads */
+        dst[r * (size_t)nx + xc] = acc;                    /* lanes past the row end repeat the last voxel's store */
+    };
+    size_t r = r0;
+    for (; r + D <= r1; r += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) step(r + u, q[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++)
+        if (r + u < r1) step(r + u, q[u]);
+}
+
+/* ---- dispatch ------------------------------------------------------------------------------------------------------ */
+static thread_local int g_chunk_tab = 128;                 /* outputs per marching chunk (target) */
+static thread_local long g_tab_launches = 0;
+extern "C" void s3d_k_gauss_tab_set_chunk(int chunk) { if (chunk >= 8) g_chunk_tab = chunk; }
+extern "C" long s3d_k_gauss_tab_launches(void) { return g_tab_launches; }   /* passes the calling thread has launched (tests) */
+
+/* Outputs per marching chunk: every chunk re-reads the W - 1 rows before its first output, so long chunks -- but a grid
+ * that leaves CUs idle costs more than re-reads out of L2: halve while the launch has fewer than 2048 waves and a chunk
+ * still is twice the ring. */
+static int pick_chunk(int nout, int W, size_t waves_per_chunk)
+{
+    int nch = (int)s3d_div_up((size_t)nout, g_chunk_tab);
+    int chunk = (nout + nch - 1) / nch;
+    while (waves_per_chunk * (size_t)s3d_div_up((size_t)nout, chunk) < 2048 && chunk / 2 >= 2 * W) chunk = (chunk + 1) / 2;
+    return chunk;
+}
+
+template <int HW>
+static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int ny, int nz, int axis, int z0, int z1,
+                      const S3dTaps &taps, hipStream_t st)
+{
+    constexpr int D = 4;
+    const size_t plane = (size_t)nx * ny;
+    if (axis == 0) {
+        const size_t rb = (size_t)ny * z0, re = (size_t)ny * z1, nrows = re - rb;
+        const unsigned strips = s3d_div_up((size_t)nx, 64);
+        /* enough waves for 256 CUs x ~8, but rows enough per wave to pay for the 2*NT table loads of its lanes */
+        unsigned rpw = 256;
+        while (rpw > 32 && (size_t)strips * s3d_div_up(nrows, rpw) < 4096) rpw >>= 1;
+        if (s3d_div_up(nrows, rpw) > 65535u) rpw = s3d_div_up(nrows, 65535);   /* very tall volumes: more rows per wave */
+        hipLaunchKernelGGL((k_conv_x_tab<HW, D>), dim3(strips, s3d_div_up(nrows, rpw)), dim3(64), 0, st, src, dst, nx, rb, re,
+                           rpw, t->uhw, t->d_xlo, t->d_xfr, taps);
+        S3D_CHECK_LAUNCH();
+        return S3D_OK;
+    }
+    const size_t lds = (size_t)t->W * 1024;
+    const int A = t->uhw + 1;
+    if (axis == 1) {
+        const int chunk = pick_chunk(ny, t->W, (size_t)s3d_div_up(s3d_div_up((size_t)nx, 4), 64) * (size_t)(z1 - z0));
+        hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up((size_t)nx, 4), 64), s3d_div_up(ny, chunk), z1 - z0),
+                           dim3(64), lds, st, src + plane * z0, dst + plane * z0, s3d_div_up((size_t)nx, 4), (size_t)nx,
+                           (size_t)nx, plane, 0, ny, chunk, 0, ny - 1, t->W, A, t->d_m, taps);
+        S3D_CHECK_LAUNCH();
+        return S3D_OK;
+    }
+    const int nzo = z1 - z0;
+    const int chunk = pick_chunk(nzo, t->W, s3d_div_up(s3d_div_up(plane, 4), 64));
+    const int rmin = z0 - t->uhw - 1 > 0 ? z0 - t->uhw - 1 : 0, rmax = z1 + t->uhw < nz - 1 ? z1 + t->uhw : nz - 1;
+    hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up(plane, 4), 64), s3d_div_up(nzo, chunk), 1), dim3(64),
+                       lds, st, src, dst, s3d_div_up(plane, 4), plane, plane, (size_t)0, z0, z1, chunk, rmin, rmax, t->W, A,
+                       t->d_m, taps);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+/* One axis pass over the planes [z0, z1) of a single-channel volume.  0: done; 1: not eligible (nothing launched; the
+ * caller takes another kernel); -1: error. */
+extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
+                                   const float *taps, int width, float uf, int uhw, s3d_stream stream)
+{
+    const int hw = width / 2;
+    const int dims[3] = {nx, ny, nz};
+    if (hw < 1 || hw > TAB_MAX_HW || uhw < 1 || uhw > TAB_MAX_UHW || uhw >= dims[axis] - 1) return 1;
+    if (nx > (1 << 22) || ny > (1 << 22) || nz > (1 << 22)) return 1;
+    if (axis == 1 && (nx < 4 || z1 - z0 > 65535)) return 1;
+    if (axis == 2 && (size_t)nx * ny < 4) return 1;
+    const TapTab *t = tap_table(dims[axis], hw, uf, uhw);
+    if (!t) return 1;
+    S3dTaps tp;
+    memset(&tp, 0, sizeof(tp));
+    memcpy(tp.t, taps, sizeof(float) * width);
+    hipStream_t st = (hipStream_t)stream;
+    g_tab_launches++;
+    switch (hw) {
+#define S3D_TB(H) case H: return launch_tab<H>(t, d_src, d_dst, nx, ny, nz, axis, z0, z1, tp, st);
+    S3D_TB(1) S3D_TB(2) S3D_TB(3) S3D_TB(4) S3D_TB(5) S3D_TB(6) S3D_TB(7) S3D_TB(8) S3D_TB(9)
+#undef S3D_TB
+    default: break;
+    }
+    return 1;
+}

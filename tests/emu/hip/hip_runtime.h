@@ -223,6 +223,10 @@ inline void wave_gather(const void *mine, size_t bytes, void *all)
 
 }  // namespace emu
 
+/* dynamic LDS: one block runs at a time, so one process-wide buffer of the hardware's size serves every launch */
+namespace emu { inline void *dyn_lds() { static long double buf[160 * 1024 / sizeof(long double)]; return buf; } }
+#define S3D_DYN_LDS(T, name) T *name = reinterpret_cast<T *>(emu::dyn_lds())
+
 #define threadIdx (emu::S().threadIdx)
 #define blockIdx (emu::S().blockIdx)
 #define blockDim (emu::S().blockDim)

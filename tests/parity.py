@@ -590,6 +590,55 @@ def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
             dev.free(p)
 
 
+def check_sep_fir_tab(lib, oracle, dims, units, sigmas, splits=(), chunk=None):
+    """The table-driven axis passes (s3d_gauss_tab.hip: any tap spacing, any row length) against the oracle, whole volumes
+    and Z-slab plane ranges, bit for bit; mode 8 makes the library take them on volumes this small, the launch counter
+    says that they are what ran.  Scratch poisoned with NaN so that a plane the range arithmetic forgets shows up."""
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    vol = np.random.default_rng(1).standard_normal((nz, ny, nx)).astype(np.float32)
+    uf = np.array([np.float32(1.0 / u) for u in units], np.float32)
+    L.s3d_k_sep_fir_slab.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    L.s3d_k_gauss_set_tile3.argtypes = [C.c_long]
+    L.s3d_k_gauss_tab_launches.restype = C.c_long
+    L.s3d_k_gauss_tab_set_chunk.argtypes = [C.c_int]
+    d_src, d_a, d_b, d_t = dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes)
+    try:
+        L.s3d_k_gauss_set_tile3(0)
+        L.s3d_k_gauss_set_mode(8)
+        if chunk:
+            L.s3d_k_gauss_tab_set_chunk(chunk)
+        for sigma in sigmas:
+            taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)
+            want = oracle.sep_fir(vol, taps, units, 1.0)
+            n0 = L.s3d_k_gauss_tab_launches()
+            L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+            L.s3d_rt_memset(C.c_void_p(d_a), 0xFF, vol.nbytes, None)
+            dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps, path=1)
+            ran = L.s3d_k_gauss_tab_launches() - n0
+            full = dev.download(d_a, vol.shape)
+            nd = nbitdiff(full, want)
+            assert nd == 0, f"dims {dims} units {units} sigma {sigma} (width {taps.size}): {nd} of {full.size} elements differ"
+            assert ran == 3, f"dims {dims} units {units} sigma {sigma}: {ran} of the 3 passes were table-driven"
+            for z0, z1 in splits:
+                L.s3d_rt_memset(C.c_void_p(d_t), 0xFF, vol.nbytes, None)
+                L.s3d_rt_memset(C.c_void_p(d_b), 0xFF, vol.nbytes, None)
+                assert L.s3d_k_sep_fir_slab(d_src, d_b, d_t, nx, ny, nz, z0, z1, uf.ctypes.data, taps.ctypes.data,
+                                            taps.size, None) == 0
+                got = dev.download(d_b, vol.shape)[z0:z1]
+                nd = nbitdiff(got, full[z0:z1])
+                assert nd == 0, f"slab [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
+        return ran
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+        L.s3d_k_gauss_set_tile3(-1)
+        L.s3d_k_gauss_tab_set_chunk(128)
+        for p in (d_src, d_a, d_b, d_t):
+            dev.free(p)
+
+
 def check_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits=()):
     """k_gauss3_tile (the three passes of one application in one launch, for small volumes) against the oracle and
     against the three separate passes, whole volumes and Z-slab plane ranges, bit for bit; the launch counter says that

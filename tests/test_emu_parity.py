@@ -189,6 +189,22 @@ def test_sep_fir_tile3(emu, oracle, dims, units, sigmas, splits):
     parity.check_sep_fir_tile3(emu, oracle, dims, units, sigmas, splits)
 
 
+TAB_CASES = [
+    ((21, 19, 17), (1, 1, 1), S3, [(0, 9), (9, 17)], None),                # unit spacing, ragged rows: all three passes
+    ((70, 23, 18), (0.7, 0.7, 1.5), S3 + (2.6,), [(3, 11)], 8),            # taps 1.43 voxels apart in plane, 2/3 along z; two x strips
+    ((37, 41, 29), (1, 0.8, 2), S3, [(0, 14), (14, 29)], None),            # in-plane spacing differs per axis
+    ((23, 19, 40), (2, 2, 2), S3, [(10, 30)], 16),                         # octave 1 of a ragged volume (dyadic, no float4 rows)
+    ((19, 23, 33), (0.5, 1.3, 4), (0.973294, 1.22627), [(0, 33)], None),   # taps two voxels apart along x, a quarter along z
+    ((130, 9, 7), (1.5, 1, 1), S3[:2], [], None),                          # three x strips, the last one two voxels wide
+]
+
+
+@pytest.mark.parametrize("dims,units,sigmas,splits,chunk", TAB_CASES)
+def test_sep_fir_tab(emu, oracle, dims, units, sigmas, splits, chunk):
+    """The table-driven passes for any tap spacing and row length: bit-identical to the oracle, whole volumes and slabs."""
+    assert parity.check_sep_fir_tab(emu, oracle, dims, units, sigmas, splits, chunk) >= 1
+
+
 @pytest.mark.parametrize("dims,zero", [((32, 28, 24), False), ((24, 24, 20), True)])
 def test_sep_fir_div(emu, oracle, dims, zero):
     """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit."""
