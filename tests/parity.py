@@ -639,6 +639,74 @@ def check_sep_fir_tab(lib, oracle, dims, units, sigmas, splits=(), chunk=None):
             dev.free(p)
 
 
+def check_sep_fir_tab_vs_plain(lib, dims, units, sigmas):
+    """Full-size volumes: one filter application by whatever the library picks (the table-driven passes wherever the
+    unit-spacing / dyadic kernels do not apply) against the per-element kernel (mode 2), bit for bit."""
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    vol = np.random.default_rng(2).standard_normal((nz, ny, nx)).astype(np.float32)
+    uf = np.array([np.float32(1.0 / u) for u in units], np.float32)
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    L.s3d_k_gauss_tab_launches.restype = C.c_long
+    d_src, d_a, d_t = dev.upload(vol), dev.malloc(vol.nbytes), dev.malloc(vol.nbytes)
+    g = abi.Gauss_filter()
+    try:
+        for sigma in sigmas:
+            assert lib.imutil.init_Gauss_filter(C.byref(g), sigma, 3) == 0
+            taps = np.ctypeslib.as_array(g.f.kernel, shape=(g.f.width,)).copy()
+            lib.imutil.cleanup_Gauss_filter(C.byref(g))
+            out = []
+            for mode in (0, 2):
+                L.s3d_k_gauss_set_mode(mode)
+                n0 = L.s3d_k_gauss_tab_launches()
+                L.s3d_rt_memset(C.c_void_p(d_a), 0xFF, vol.nbytes, None)
+                dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
+                out.append(dev.download(d_a, vol.shape))
+                ran = L.s3d_k_gauss_tab_launches() - n0
+                assert (ran >= 1) == (mode == 0), f"mode {mode}: {ran} table-driven passes"
+            nd = nbitdiff(out[0], out[1])
+            assert nd == 0, f"dims {dims} units {units} sigma {sigma}: {nd} of {out[0].size} elements differ"
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+        for p in (d_src, d_a, d_t):
+            dev.free(p)
+
+
+def check_detect_modes_agree(lib, dims, units, modes=(0, 2), seed=0):
+    """SIFT3D_detect_keypoints on a device-resident synthetic volume under two kernel selections: identical keypoints."""
+    from sift3d_amd import synth
+    dev = dev_of(lib)
+    L = dev.L
+    nx, ny, nz = dims
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    vol = synth.blobs(nx, ny, nz, synth.default_nblobs(nx, ny, nz), seed)
+    d_vol = dev.upload(vol)
+    res = []
+    try:
+        for mode in modes:
+            L.s3d_k_gauss_set_mode(mode)
+            s = abi.SIFT3D()
+            assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+            kp = abi.Keypoint_store()
+            lib.sift.init_Keypoint_store(C.byref(kp))
+            rc = lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), nx, ny, nz,
+                                                          C.c_double(units[0]), C.c_double(units[1]), C.c_double(units[2]),
+                                                          C.byref(kp))
+            assert rc == 0
+            res.append(lib.keypoints_to_numpy(kp))
+            lib.sift.cleanup_Keypoint_store(C.byref(kp))
+            lib.sift.cleanup_SIFT3D(C.byref(s))
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+        dev.free(d_vol)
+    (ca, sa, Ra), (cb, sb, Rb) = res
+    assert ca.shape == cb.shape, f"{ca.shape[0]} vs {cb.shape[0]} keypoints"
+    assert (ca == cb).all() and (sa == sb).all(), "keypoint coordinates / levels differ"
+    assert nbitdiff(Ra, Rb) == 0, "orientations differ"
+    return ca.shape[0]
+
+
 def check_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits=()):
     """k_gauss3_tile (the three passes of one application in one launch, for small volumes) against the oracle and
     against the three separate passes, whole volumes and Z-slab plane ranges, bit for bit; the launch counter says that

@@ -619,3 +619,38 @@ def test_extrema_runmax(lib):
     """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form."""
     d = (128, 96, 80)
     parity.check_extrema_runmax(lib, d, [(0, d[2]), (0, d[2] // 2), (d[2] // 2 - 3, d[2])])
+
+
+S3T = (0.7, 0.973294, 1.94659)                                        # widths 5, 7, 13
+
+
+@pytest.mark.parametrize("dims,units,sigmas,splits,chunk", [
+    ((21, 19, 17), (1, 1, 1), S3T, [(0, 9), (9, 17)], None),               # unit spacing, ragged rows
+    ((70, 23, 18), (0.7, 0.7, 1.5), S3T + (2.6,), [(3, 11)], 8),           # taps 1.43 voxels apart in plane, 2/3 along z
+    ((37, 41, 29), (1, 0.8, 2), S3T, [(0, 14), (14, 29)], None),
+    ((23, 19, 40), (2, 2, 2), S3T, [(10, 30)], 16),                        # octave 1 of a ragged volume
+    ((19, 23, 33), (0.5, 1.3, 4), (0.973294, 1.22627), [(0, 33)], None),
+    ((130, 9, 7), (1.5, 1, 1), S3T[:2], [], None),
+    ((203, 181, 97), (0.7, 0.7, 1.5), (1.22627, 2.45255), [(40, 97)], None),   # several chunks, strips and waves per axis
+    ((255, 254, 120), (1, 1, 1), (0.538701, 2.45255), [(0, 60)], None),        # ragged unit spacing at a size that fills the GPU
+])
+def test_sep_fir_tab(lib, oracle, dims, units, sigmas, splits, chunk):
+    """The table-driven axis passes (any tap spacing, any row length): bit-identical to the oracle, whole volumes and slabs."""
+    assert parity.check_sep_fir_tab(lib, oracle, dims, units, sigmas, splits, chunk) == 3
+
+
+@pytest.mark.parametrize("dims,units", [((512, 512, 300), (0.7, 0.7, 1.5)), ((511, 509, 303), (1, 1, 1)),
+                                        ((510, 508, 200), (1, 0.8, 2)), ((384, 400, 256), (0.5, 1.3, 4))])
+def test_sep_fir_tab_full_size(lib, dims, units):
+    """At sizes the CPU oracle does not finish in seconds: the table-driven passes (what the library picks by itself) equal
+    the per-element kernel k_conv_axis (mode 2: no specialisation at all; pinned to the oracle and the reference's goldens
+    by the tests above) bit for bit, for the narrowest and the widest filter of the default bank."""
+    parity.check_sep_fir_tab_vs_plain(lib, dims, units, (0.538701, 2.45255))
+
+
+@pytest.mark.parametrize("dims,units", [((512, 512, 300), (0.7, 0.7, 1.5)), ((511, 509, 303), (1, 1, 1))])
+def test_detect_full_size_any_spacing(lib, dims, units):
+    """A whole detect on an anisotropic / ragged volume at full size: with the table-driven passes and the plain per-element
+    kernels the same keypoints come out (coordinates, level, orientation bits)."""
+    k = parity.check_detect_modes_agree(lib, dims, units, modes=(0, 2))
+    assert k > 1000
