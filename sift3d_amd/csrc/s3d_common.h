@@ -48,6 +48,24 @@ __device__ __forceinline__ void s3d_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* LDS hand-off between the waves of a workgroup whose global loads must stay in flight: __syncthreads() carries a
+ * workgroup-scope fence over ALL address spaces (s_waitcnt vmcnt(0): every prefetched row would be waited for at every
+ * barrier); here the fences name the LDS only (s_waitcnt lgkmcnt(0) + s_barrier). */
+#ifndef S3D_BLOCK_LDS_SYNC
+__device__ __forceinline__ void s3d_block_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
+/* a wave-uniform value the compiler cannot see to be uniform (derived from threadIdx): to a scalar register, so that what
+ * is indexed with it is loaded through the scalar cache */
+#ifndef S3D_UNIFORM
+#define S3D_UNIFORM(x) (__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
+
 /* four floats at any dword-aligned address: rows and planes of volumes whose row length is not a multiple of 4 start
  * anywhere, and global_load_dwordx4 / global_store_dwordx4 only need dword alignment */
 #if defined(__clang__)

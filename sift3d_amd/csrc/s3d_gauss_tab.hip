@@ -29,13 +29,16 @@
 #include <mutex>
 
 #define TAB_MAX_HW 9
-#define TAB_MAX_UHW 30                    /* ring of 2*uhw+3 <= 63 rows (63 KB of LDS), x segment of 64+2*uhw+3 <= 128 floats */
+#define TAB_MW 4                          /* waves of a marching workgroup (they share a ring) */
+#define TAB_MAX_UHW 26                    /* ring of 2*uhw+2+2*TAB_MW <= 62 rows (62 KB of LDS), x segment of 64+2*uhw+3 <= 128 floats */
 
 /* ---- the table -------------------------------------------------------------------------------------------------
- * march layout (p-major, all wave uniform -> scalar loads): m[p*4*NT + k]        = ring byte offset of row lo     (lo % W) * 1024
- *                                                           m[p*4*NT + NT + k]   = ring byte offset of row lo + 1
- *                                                           m[p*4*NT + 2NT + k]  = frac (float bits)
- *                                                           m[p*4*NT + 3NT + k]  = 1 - frac (float bits)
+ * march layout (p-major, TS = 4*NT + 1 words per position, all wave uniform -> scalar loads):
+ *                                                           m[p*TS + k]        = ring byte offset of row lo     (lo % W) * 1024
+ *                                                           m[p*TS + NT + k]   = ring byte offset of row lo + 1
+ *                                                           m[p*TS + 2NT + k]  = frac (float bits)
+ *                                                           m[p*TS + 3NT + k]  = 1 - frac (float bits)
+ *                                                           m[p*TS + 4NT]      = 1 iff every frac of the position is 0
  * x layout (tap-major, coalesced per-lane loads):           xlo[k*n + p] = lo ; xfr[k*n + p] = frac (float bits)
  * bad: set when a tap of some position leaves [max(0, p-uhw-1), min(n-1, p+uhw+1)] -- what the ring / the staged segment
  * hold for position p.  Cannot happen for the spacings the reference's own arithmetic produces (see the header); a table
@@ -51,8 +54,8 @@ k_tap_table(int *__restrict__ m, int *__restrict__ xlo, int *__restrict__ xfr, i
     const int lo_min = p - uhw - 1 > 0 ? p - uhw - 1 : 0, hi_max = p + uhw + 1 < n - 1 ? p + uhw + 1 : n - 1;
     const bool interior = p >= uhw && p <= n - 2 - uhw;
     float run = (float)p;
-    int *row = m + (size_t)p * (size_t)(4 * NT);
-    int flag = 0;
+    int *row = m + (size_t)p * (size_t)(4 * NT + 1);
+    int flag = 0, allzero = 1;
     for (int d = -hw; d <= hw; d++) {
         const float step = (float)d * uf;
         float coord;
@@ -75,9 +78,11 @@ k_tap_table(int *__restrict__ m, int *__restrict__ xlo, int *__restrict__ xfr, i
         row[NT + k] = ((lo + 1) % W) * 1024;
         row[2 * NT + k] = __float_as_int(frac);
         row[3 * NT + k] = __float_as_int(1.0f - frac);
+        if (frac != 0.0f) allzero = 0;
         xlo[(size_t)k * n + p] = lo;
         xfr[(size_t)k * n + p] = __float_as_int(frac);
     }
+    row[4 * NT] = allzero;
     if (flag) atomicMax(bad, 1);
 }
 
@@ -106,27 +111,27 @@ static const TapTab *tap_table(int n, int hw, float uf, int uhw)
             return g_tab[i].d_m ? &g_tab[i] : nullptr;
     if (g_ntab == TAB_CACHE) return nullptr;               /* more distinct passes than any pyramid has: no new tables */
     TapTab t;
-    t.dev = dev; t.n = n; t.hw = hw; t.uhw = uhw; t.W = 2 * uhw + 3; t.uf_bits = ub;
+    t.dev = dev; t.n = n; t.hw = hw; t.uhw = uhw; t.W = 2 * uhw + 2 + 2 * TAB_MW; t.uf_bits = ub;
     t.d_m = t.d_xlo = t.d_xfr = nullptr;
     const int NT = 2 * hw + 1;
-    const size_t words = (size_t)n * NT;
+    const size_t words = (size_t)n * NT, mwords = (size_t)n * (4 * NT + 1);
     int *blk = nullptr;
     /* one allocation: flag | march table | xlo | xfr */
-    if (hipMalloc((void **)&blk, sizeof(int) * (4 + 6 * words)) == hipSuccess) {
+    if (hipMalloc((void **)&blk, sizeof(int) * (4 + mwords + 2 * words)) == hipSuccess) {
         int bad = 1;
         hipStream_t st = nullptr;
         bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipMemsetAsync(blk, 0, sizeof(int) * 4, st) == hipSuccess;
         if (ok) {
-            hipLaunchKernelGGL(k_tap_table, dim3(s3d_div_up((size_t)n, 64)), dim3(64), 0, st, blk + 4, blk + 4 + 4 * words,
-                               blk + 4 + 5 * words, blk, n, hw, uf, uhw, t.W);
+            hipLaunchKernelGGL(k_tap_table, dim3(s3d_div_up((size_t)n, 64)), dim3(64), 0, st, blk + 4, blk + 4 + mwords,
+                               blk + 4 + mwords + words, blk, n, hw, uf, uhw, t.W);
             ok = hipGetLastError() == hipSuccess;
         }
         ok = ok && hipMemcpyAsync(&bad, blk, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
         if (st) hipStreamDestroy(st);
         if (ok && bad == 0) {
-            t.d_m = blk + 4; t.d_xlo = blk + 4 + 4 * words; t.d_xfr = blk + 4 + 5 * words;
+            t.d_m = blk + 4; t.d_xlo = blk + 4 + mwords; t.d_xfr = blk + 4 + mwords + words;
         } else {
             hipFree(blk);
         }
@@ -147,16 +152,23 @@ extern "C" void s3d_k_tap_tables_release(void)
     g_ntab = 0;
 }
 
-/* ---- marching pass (y or z) --------------------------------------------------------------------------------------- */
+/* ---- marching pass (y or z) ---------------------------------------------------------------------------------------
+ * A workgroup is MW waves on the SAME 64 float4 columns; output rows are dealt to them round-robin (group g = rows
+ * p0 + MW*g .. + MW-1, wave w takes row p0 + MW*g + w) and they share one ring.  A ring per wave (W = 2*uhw+3 KB each) left
+ * a CU with 5 waves at uhw = 12 -- one per SIMD, nothing to cover an LDS round trip or a dependent VALU chain with: the
+ * 0.7-mm in-plane passes ran at 1/3 of the VALU rate.  Shared, the ring costs 2*uhw + 2 + 2*MW rows per MW waves (16-20
+ * waves per CU at the widest filters).  One barrier per group: after its output a wave stores the source row it has had
+ * in flight for D groups -- row R_g + 1 + w, R_g = newest row of group g -- into the slot of a row no wave of group g
+ * reads (that is what the second MW of the ring size buys), then waits for the other waves' rows. */
 template <int HW, int D>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * TAB_MW)
 k_conv_march_tab(const float *__restrict__ src, float *__restrict__ dst, unsigned ncol4, size_t nflat, size_t stride,
                  size_t bstride, int p_begin, int p_end, int chunk, int rmin, int rmax, int W, int A,
                  const int *__restrict__ tab, S3dTaps taps)
 {
-    constexpr int NT = 2 * HW + 1;
+    constexpr int NT = 2 * HW + 1, MW = TAB_MW, TS = 4 * NT + 1;
     S3D_DYN_LDS(float4, ring);                             /* W rows of 64 float4 */
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = S3D_UNIFORM(threadIdx.x >> 6);
     const size_t col = (size_t)blockIdx.x * 64 + (size_t)lane;
     size_t off = (col < ncol4 ? col : (size_t)ncol4 - 1) * 4;
     if (off + 4 > nflat) off = nflat - 4;                  /* last column of a ragged extent: clamped onto the end (overlaps) */
@@ -165,67 +177,89 @@ k_conv_march_tab(const float *__restrict__ src, float *__restrict__ dst, unsigne
     const int p0 = p_begin + (int)blockIdx.y * chunk;
     const int p1 = p0 + chunk < p_end ? p0 + chunk : p_end;
     if (p0 >= p1) return;
-    auto rowof = [&](int p) { const int r = p + A; return r < rmax ? r : rmax; };   /* newest row the ring holds at output p */
-    auto ld = [&](int r) -> s3d_f4u { return *reinterpret_cast<const s3d_f4u *>(base + (size_t)r * stride); };
+    auto ld = [&](int r) -> s3d_f4u { return *reinterpret_cast<const s3d_f4u *>(base + (size_t)(r < rmax ? r : rmax) * stride); };
     auto put = [&](int slot, const s3d_f4u &v) { ring[slot * 64 + lane] = make_float4(v.x, v.y, v.z, v.w); };
 
-    /* prologue: rows [max(rmin, R - W + 1), R] of the first output, eight loads in flight at a time */
-    int rcur = rowof(p0);
+    /* prologue: rows [max(rmin, R0 - W + 1), R0], R0 = newest row of group 0, dealt to the waves, eight loads in flight */
+    const int R0 = p0 + MW - 1 + A < rmax ? p0 + MW - 1 + A : rmax;
     {
-        int r = rcur - W + 1;
+        int r = R0 - W + 1;
         if (r < rmin) r = rmin;
-        for (; r <= rcur; r += 8) {
+        for (r += w; r <= R0; r += 8 * MW) {
             s3d_f4u t[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) t[j] = ld(r + j < rcur ? r + j : rcur);
+            for (int j = 0; j < 8; j++) t[j] = ld(r + MW * j < R0 ? r + MW * j : R0);
 #pragma unroll
-            for (int j = 0; j < 8; j++) put((r + j < rcur ? r + j : rcur) % W, t[j]);
+            for (int j = 0; j < 8; j++) put((r + MW * j < R0 ? r + MW * j : R0) % W, t[j]);
         }
     }
-    int slot = rcur % W;
-    s3d_f4u q[D];                                          /* rows of outputs p+1 .. p+D, in flight */
+    /* this wave's rows: R0 + 1 + w, then MW further per group; rows past rmax are rmax again (same slot, same values) */
+    int rins = p0 + MW - 1 + A + 1 + w;                    /* unclamped */
+    int slot = rins % W;
+    const int slot_max = rmax % W;
+    s3d_f4u q[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) q[d] = ld(rowof(p0 + 1 + d));
+    for (int d = 0; d < D; d++) q[d] = ld(rins + MW * d);
     const char *ringb = reinterpret_cast<const char *>(ring) + lane * 16;
-    /* one output row; then the row the next output adds goes into the ring (none once the ring has reached rmax: the same
-     * row goes to the same slot again) and its register takes the load of the row D outputs on.  The march is unrolled D
-     * times so that the queue is indexed statically: shifting it through register moves would make every step wait for
-     * the load it has just issued. */
-    auto step = [&](int p, s3d_f4u &qu) {
-        const int *row = tab + (size_t)p * (size_t)(4 * NT);
+    s3d_block_lds_sync();
+    /* one group: this wave's output row, its source row into the ring, its register reloaded with the row D groups on.
+     * The march is unrolled D times so that the queue is indexed statically: shifting it through register moves would make
+     * every step wait for the load it has just issued. */
+    auto output = [&](int p) {
+        const int *row = tab + (size_t)p * (size_t)TS;
         s3d_f2 lo2 = {0.0f, 0.0f}, hi2 = {0.0f, 0.0f};   /* (x, y) and (z, w) of the output: packed f32 operations */
+        if (row[4 * NT]) {
+            /* every tap of this row sits on a voxel (frac == 0: unit spacing away from the mirrored ends): the sample is
+             * src[lo] -- the reference's 1.0f * src[lo] + 0.0f * src[lo + 1] up to the sign of a zero, which cannot
+             * reach the sum (it starts at +0) */
 #pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const float4 a = *reinterpret_cast<const float4 *>(ringb + row[k]);
-            const float4 b = *reinterpret_cast<const float4 *>(ringb + row[NT + k]);
-            const float frac = __int_as_float(row[2 * NT + k]), om = __int_as_float(row[3 * NT + k]);
-            const float tap = taps.t[k];
-            const s3d_f2 alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
-            lo2 = lo2 + tap * (om * alo + frac * blo);
-            hi2 = hi2 + tap * (om * ahi + frac * bhi);
+            for (int k = 0; k < NT; k++) {
+                const float4 a = *reinterpret_cast<const float4 *>(ringb + row[k]);
+                const float tap = taps.t[k];
+                const s3d_f2 alo = {a.x, a.y}, ahi = {a.z, a.w};
+                lo2 = lo2 + tap * alo;
+                hi2 = hi2 + tap * ahi;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const float4 a = *reinterpret_cast<const float4 *>(ringb + row[k]);
+                const float4 b = *reinterpret_cast<const float4 *>(ringb + row[NT + k]);
+                const float frac = __int_as_float(row[2 * NT + k]), om = __int_as_float(row[3 * NT + k]);
+                const float tap = taps.t[k];
+                const s3d_f2 alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+                lo2 = lo2 + tap * (om * alo + frac * blo);
+                hi2 = hi2 + tap * (om * ahi + frac * bhi);
+            }
         }
-        {   /* lanes past the last column sit on the last column (clamped above) and store the same values again: no branch
-             * around the store, so the wait counts of the loads around it stay exact */
-            s3d_f4u o;
-            o.x = lo2[0]; o.y = lo2[1]; o.z = hi2[0]; o.w = hi2[1];
-            *reinterpret_cast<s3d_f4u *>(out + (size_t)p * stride) = o;
-        }
-        const int rnext = rowof(p + 1);
-        if (rnext != rcur) {
-            rcur = rnext;
-            slot = slot + 1 == W ? 0 : slot + 1;
-        }
-        put(slot, qu);
-        qu = ld(rowof(p + 1 + D));
+        /* lanes past the last column sit on the last column (clamped above) and store the same values again: no branch
+         * around the store, so the wait counts of the loads around it stay exact */
+        s3d_f4u o;
+        o.x = lo2[0]; o.y = lo2[1]; o.z = hi2[0]; o.w = hi2[1];
+        *reinterpret_cast<s3d_f4u *>(out + (size_t)p * stride) = o;
     };
-    int p = p0;
-    for (; p + D <= p1; p += D) {                          /* straight-line groups: the wait counts come out exact */
+    auto insert = [&](s3d_f4u &qu) {
+        put(rins <= rmax ? slot : slot_max, qu);
+        rins += MW;
+        slot += MW;
+        if (slot >= W) slot -= W;
+        qu = ld(rins + MW * (D - 1));
+        s3d_block_lds_sync();
+    };
+    int pb = p0;                                           /* first row of the group; the same in every wave (barriers) */
+    for (; pb + MW * D <= p1; pb += MW * D) {              /* D full groups, straight-line: the wait counts come out exact */
 #pragma unroll
-        for (int u = 0; u < D; u++) step(p + u, q[u]);
+        for (int u = 0; u < D; u++) {
+            output(pb + MW * u + w);
+            insert(q[u]);
+        }
     }
 #pragma unroll
     for (int u = 0; u < D; u++)
-        if (p + u < p1) step(p + u, q[u]);
+        if (pb + MW * u < p1) {
+            if (pb + MW * u + w < p1) output(pb + MW * u + w);
+            insert(q[u]);
+        }
 }
 
 /* ---- x pass -------------------------------------------------------------------------------------------------------- */
@@ -252,6 +286,10 @@ k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, siz
         fr[k] = __int_as_float(xfr[(size_t)k * nx + xc]);
         om[k] = 1.0f - fr[k];
     }
+    bool zero = true;
+#pragma unroll
+    for (int k = 0; k < NT; k++) zero = zero && fr[k] == 0.0f;
+    const bool allzero = __ballot(zero ? 0 : 1) == 0ull;   /* wave uniform */
     auto clampx = [&](int i) { return i < 0 ? 0 : (i > nx - 1 ? nx - 1 : i); };
     const int i0 = clampx(g0 + lane), i1 = clampx(g0 + 64 + lane);
     const int slot1 = lane >= 1 ? XT_LINE + lane - 1 : 2 * XT_LINE - 1;
@@ -280,10 +318,15 @@ k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, siz
         qu = load_row(r + D);
         s3d_wave_lds_sync();
         float acc = 0.0f;
+        if (allzero) {                                     /* every tap of every lane sits on a voxel: see the march */
 #pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const float2 ab = *reinterpret_cast<const float2 *>(lineb + addr[k]);
-            acc = acc + taps.t[k] * (om[k] * ab.x + fr[k] * ab.y);
+            for (int k = 0; k < NT; k++) acc = acc + taps.t[k] * *reinterpret_cast<const float *>(lineb + addr[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const float2 ab = *reinterpret_cast<const float2 *>(lineb + addr[k]);
+                acc = acc + taps.t[k] * (om[k] * ab.x + fr[k] * ab.y);
+            }
         }
         s3d_wave_lds_sync();                               /* the next row's staging must not overtake these reads */
         dst[r * (size_t)nx + xc] = acc;                    /* lanes past the row end repeat the last voxel's store */
@@ -338,7 +381,7 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
     if (axis == 1) {
         const int chunk = pick_chunk(ny, t->W, (size_t)s3d_div_up(s3d_div_up((size_t)nx, 4), 64) * (size_t)(z1 - z0));
         hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up((size_t)nx, 4), 64), s3d_div_up(ny, chunk), z1 - z0),
-                           dim3(64), lds, st, src + plane * z0, dst + plane * z0, s3d_div_up((size_t)nx, 4), (size_t)nx,
+                           dim3(64 * TAB_MW), lds, st, src + plane * z0, dst + plane * z0, s3d_div_up((size_t)nx, 4), (size_t)nx,
                            (size_t)nx, plane, 0, ny, chunk, 0, ny - 1, t->W, A, t->d_m, taps);
         S3D_CHECK_LAUNCH();
         return S3D_OK;
@@ -346,8 +389,8 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
     const int nzo = z1 - z0;
     const int chunk = pick_chunk(nzo, t->W, s3d_div_up(s3d_div_up(plane, 4), 64));
     const int rmin = z0 - t->uhw - 1 > 0 ? z0 - t->uhw - 1 : 0, rmax = z1 + t->uhw < nz - 1 ? z1 + t->uhw : nz - 1;
-    hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up(plane, 4), 64), s3d_div_up(nzo, chunk), 1), dim3(64),
-                       lds, st, src, dst, s3d_div_up(plane, 4), plane, plane, (size_t)0, z0, z1, chunk, rmin, rmax, t->W, A,
+    hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up(plane, 4), 64), s3d_div_up(nzo, chunk), 1),
+                       dim3(64 * TAB_MW), lds, st, src, dst, s3d_div_up(plane, 4), plane, plane, (size_t)0, z0, z1, chunk, rmin, rmax, t->W, A,
                        t->d_m, taps);
     S3D_CHECK_LAUNCH();
     return S3D_OK;

@@ -227,6 +227,10 @@ inline void wave_gather(const void *mine, size_t bytes, void *all)
 namespace emu { inline void *dyn_lds() { static long double buf[160 * 1024 / sizeof(long double)]; return buf; } }
 #define S3D_DYN_LDS(T, name) T *name = reinterpret_cast<T *>(emu::dyn_lds())
 
+#define S3D_UNIFORM(x) ((int)(x))
+#define S3D_BLOCK_LDS_SYNC 1
+static inline void s3d_block_lds_sync() { emu::yield_to_sched(1); }
+
 #define threadIdx (emu::S().threadIdx)
 #define blockIdx (emu::S().blockIdx)
 #define blockDim (emu::S().blockDim)
