@@ -89,8 +89,9 @@ int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny
 int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0,
                        int z1, const float uf[3], const float *taps, int width, s3d_stream stream);
 /* im_scale (imutil.c:1977) folded into the filter that follows it: dst planes [z0, z1) = filter(src / *d_div), every
- * source voxel divided as it is loaded (*d_div == 0: not divided), so the scaled image is never written.  Only for the
- * configurations the fused kernels take -- s3d_k_sep_fir_div_eligible() != 0 -- and an error otherwise. */
+ * source voxel divided as it is loaded (*d_div == 0: not divided), so the scaled image is never written.  For the
+ * configurations the fused unit-spacing kernels take and those whose x pass is table-driven (any spacing, any row
+ * length, volumes above 64^3) -- s3d_k_sep_fir_div_eligible() != 0 -- and an error otherwise. */
 int s3d_k_sep_fir_div_eligible(int nx, int ny, int nz, const float uf[3], int width);
 int s3d_k_sep_fir_div(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
                       const float uf[3], const float *taps, int width, const float *d_div, s3d_stream stream);

@@ -548,7 +548,7 @@ static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es
     if (nkp <= S3D_FUSED_KP_MAX) {
         unsigned long long *bits[S3D_FUSED_KP_MAX];
         for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
-        /* three keypoint levels, nx % 4 == 0: the DoG maxima come out of the extrema pass itself (running lower bound,
+        /* three keypoint levels: the DoG maxima come out of the extrema pass itself (running lower bound,
          * then the exact thresholds on the survivors) instead of a pass of their own over four levels */
         fused = s3d_k_extrema_fused_runmax((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz,
                                            sift3d->peak_thresh, c->d_red + 1, bits, es);

@@ -597,7 +597,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
             const s3d_lev *L = &sl->lev[o * nl];
             if (zb <= za) continue;          /* only in a replicated octave with fewer planes than ranks: no collectives there */
             const size_t nwords = ((size_t)(zb - za) * pe + 63) / 64;
-            const int fused = nkp == 3 && (nxo & 3) == 0;   /* all keypoint levels in one pass (s3d_k_extrema_fused) */
+            const int fused = nkp == 3 && nxo >= 4;         /* all keypoint levels in one pass (s3d_k_extrema_fused) */
             if (fused) {
                 const float *l6[6];
                 unsigned long long *bits[3];

@@ -90,7 +90,10 @@ struct ExtArgs {
  * exact maxima of the voxels the launch covered -- k_extrema_refilter then clears the survivors below the exact
  * threshold.  Saves the separate pass over four GSS levels that k_dogmax3 is (16 of the 40 B/voxel of an octave's
  * extrema step). */
-template <int NKP, bool RUNMAX>
+/* RAGGED: rows of any length >= 4.  The four voxels of a thread are consecutive in memory but may straddle a row end (then
+ * each gets its own coordinates for the interior test; memory neighbours are still idx +- 1 for every tested voxel), the
+ * loads are dword aligned, and the one thread at the end of a level whose four would leave it takes its voxels one by one. */
+template <int NKP, bool RUNMAX, bool RAGGED>
 __global__ void __launch_bounds__(256)
 k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
                 const float *__restrict__ d_dogmax /* [NKP], per keypoint level */, unsigned *__restrict__ d_runmax)
@@ -111,15 +114,31 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
     float d[NKP + 2][4];                                   /* DoG centres, level k: L(k) - L(k+1) */
 #pragma unroll
     for (int k = 0; k < NKP + 2; k++) d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.0f;
-    if (idx < n) {                                         /* n - idx0 is a multiple of 4 (nx % 4 == 0) */
-        float4 c[NKP + 3];
+    if (!RAGGED || idx + 4u <= n) {
+        if (idx < n) {                                     /* !RAGGED: n - idx0 is a multiple of 4 (nx % 4 == 0) */
+            float c[NKP + 3][4];
 #pragma unroll
-        for (int k = 0; k < NKP + 3; k++) c[k] = *reinterpret_cast<const float4 *>(a.l[k] + idx);
+            for (int k = 0; k < NKP + 3; k++) {
+                if (RAGGED) {
+                    const s3d_f4u v = *reinterpret_cast<const s3d_f4u *>(a.l[k] + idx);
+                    c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.l[k] + idx);
+                    c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
+                }
+            }
 #pragma unroll
-        for (int k = 0; k < NKP + 2; k++) {
-            d[k][0] = c[k].x - c[k + 1].x; d[k][1] = c[k].y - c[k + 1].y;
-            d[k][2] = c[k].z - c[k + 1].z; d[k][3] = c[k].w - c[k + 1].w;
+            for (int k = 0; k < NKP + 2; k++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[k][j] = c[k][j] - c[k + 1][j];
         }
+    } else if (idx < n) {                                  /* RAGGED: the last, partial group of the range */
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (idx + (unsigned)j < n) {
+#pragma unroll
+                for (int k = 0; k < NKP + 2; k++) d[k][j] = a.l[k][idx + j] - a.l[k + 1][idx + j];
+            }
     }
     /* x neighbours of the thread's end voxels: the neighbouring lanes hold them as the last / first DoG value of
      * their float4s; only the two end lanes of a wave load them (12 dword loads per thread used to be a third
@@ -136,21 +155,35 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
         const unsigned y = rem / nx;
         const unsigned x = rem - y * nx;
         row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
+        bool inner[4];                                     /* voxel j may be an extremum: not on a face of the level */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned xj = x + (unsigned)j;
+            if (!RAGGED) {
+                inner[j] = row_ok && xj >= 1 && xj + 2 <= nx;
+            } else {                                       /* past the row end: the next row (nx >= 4: at most once), maybe the next plane */
+                unsigned yj = y, zj = z;
+                if (xj >= nx) {
+                    xj -= nx;
+                    if (++yj == ny) { yj = 0; zj++; }
+                }
+                inner[j] = xj >= 1 && xj + 2 <= nx && yj >= 1 && yj + 2 <= ny && zj >= 1 && zj + 2 <= nz;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NKP; s++) {
             const float thr = (float)(peak * (double)(RUNMAX ? seen[s] : d_dogmax[s]));   /* sift.c:1169 */
             const float *l1 = a.l[s + 1], *l2 = a.l[s + 2];
             float left = 0.0f, right = 0.0f;              /* idx-1 / idx+4 stay inside the level for every tested voxel */
-            if (row_ok && x >= 1) left = lane > 0 ? from_lo[s] : l1[idx - 1] - l2[idx - 1];
-            if (row_ok && x + 5 <= nx) right = lane < 63 ? from_hi[s] : l1[idx + 4] - l2[idx + 4];
+            if (inner[0]) left = lane > 0 ? from_lo[s] : l1[idx - 1] - l2[idx - 1];
+            if (inner[3]) right = lane < 63 ? from_hi[s] : l1[idx + 4] - l2[idx + 4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const unsigned xj = x + (unsigned)j;
                 const float v = d[s + 1][j];
                 const float pv = d[s][j], nv = d[s + 2][j];
                 const float xm = j == 0 ? left : d[s + 1][j - 1];
                 const float xp = j == 3 ? right : d[s + 1][j + 1];
-                const bool live = row_ok && (v > thr || v < -thr) && xj >= 1 && xj + 2 <= nx;
+                const bool live = inner[j] && (v > thr || v < -thr);
                 if (live && v > pv && v > nv && v > xm && v > xp) pmax |= 1u << (4 * s + j);
                 if (live && v < pv && v < nv && v < xm && v < xp) pmin |= 1u << (4 * s + j);
             }
@@ -234,28 +267,33 @@ k_extrema_refilter(ExtArgs<NKP> a, unsigned idx0, size_t nwords, double peak, co
 
 /* Keypoint levels s = 0 .. nkp-1 of one octave at once.  d_levels: nkp+3 GSS levels starting at L(s-1) of
  * the first keypoint level; d_dogmax: nkp maxima (max|DoG| of each keypoint level); d_bits: nkp bitmaps.
- * Returns 1 without doing anything when not eligible (nx % 4 != 0, nkp not instantiated). */
+ * Returns 1 without doing anything when not eligible (nx < 4, nkp not instantiated). */
 static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
                                 double peak_thresh, const float *d_dogmax, unsigned *d_runmax,
                                 unsigned long long *const *d_bits, s3d_stream st)
 {
     const size_t n = (size_t)nx * ny * nz, plane = (size_t)nx * ny;
-    if (nkp != 3 || (nx & 3)) return 1;
+    if (nkp != 3 || nx < 4) return 1;
     if (nx < 1 || ny < 1 || nz < 1 || n >= 0xFFFFFF00ull) S3D_FAIL("level too large for 32-bit voxel indices");
     if (z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad slab");
     ExtArgs<3> a;
     for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];
     for (int k = 0; k < 3; k++) a.bits[k] = d_bits[k];
     a.thr_scale_unused = 0.0f;
-    const dim3 grid(s3d_div_up(plane * (size_t)(z1 - z0) / 4, 256));
-    if (d_runmax)
-        hipLaunchKernelGGL((k_extrema_fused<3, true>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, (unsigned)ny,
-                           (unsigned)nz, (unsigned)(plane * z0), (unsigned)(plane * z1), peak_thresh, (const float *)nullptr,
-                           d_runmax);
-    else
-        hipLaunchKernelGGL((k_extrema_fused<3, false>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, (unsigned)ny,
-                           (unsigned)nz, (unsigned)(plane * z0), (unsigned)(plane * z1), peak_thresh, d_dogmax,
-                           (unsigned *)nullptr);
+    bool ragged = (nx & 3) != 0;
+    for (int k = 0; k < 6; k++) ragged = ragged || (((uintptr_t)d_levels[k]) & 15) != 0;
+    const dim3 grid(s3d_div_up(s3d_div_up(plane * (size_t)(z1 - z0), 4), 256));
+    const unsigned i0 = (unsigned)(plane * z0), i1 = (unsigned)(plane * z1);
+#define S3D_EXF(RM, RG, DM, RX) hipLaunchKernelGGL((k_extrema_fused<3, RM, RG>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, \
+                                                   (unsigned)ny, (unsigned)nz, i0, i1, peak_thresh, DM, RX)
+    if (d_runmax) {
+        if (ragged) S3D_EXF(true, true, (const float *)nullptr, d_runmax);
+        else S3D_EXF(true, false, (const float *)nullptr, d_runmax);
+    } else {
+        if (ragged) S3D_EXF(false, true, d_dogmax, (unsigned *)nullptr);
+        else S3D_EXF(false, false, d_dogmax, (unsigned *)nullptr);
+    }
+#undef S3D_EXF
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
@@ -276,7 +314,7 @@ extern "C" int s3d_k_extrema_fused_runmax(const float *const *d_levels, int nkp,
                                           double peak_thresh, float *d_dogmax, unsigned long long *const *d_bits,
                                           s3d_stream st)
 {
-    if (nkp != 3 || (nx & 3)) return 1;
+    if (nkp != 3 || nx < 4) return 1;
     S3D_HIP(hipMemsetAsync(d_dogmax, 0, 3 * sizeof(float), (hipStream_t)st));
     return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, nullptr, (unsigned *)d_dogmax, d_bits, st);
 }
@@ -286,7 +324,7 @@ extern "C" int s3d_k_extrema_refilter(const float *const *d_levels, int nkp, int
                                       s3d_stream st)
 {
     const size_t plane = (size_t)nx * ny;
-    if (nkp != 3 || (nx & 3)) S3D_FAIL("not eligible");
+    if (nkp != 3 || nx < 4) S3D_FAIL("not eligible");
     if (z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad slab");
     ExtArgs<3> a;
     for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];

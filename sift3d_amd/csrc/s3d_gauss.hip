@@ -472,7 +472,8 @@ static thread_local int g_no_tab = 0;         /* profiling knob: never the table
 
 /* s3d_gauss_tab.hip: 0 done, 1 not eligible, -1 error */
 extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
-                                   const float *taps, int width, float uf, int uhw, s3d_stream stream);
+                                   const float *taps, int width, float uf, int uhw, const float *d_div, s3d_stream stream);
+extern "C" int s3d_k_conv_x_tab_available(int nx, int ny, int nz, int width, float uf, int uhw);
 
 static int check_taps(const float *taps, int width, S3dTaps *out)
 {
@@ -484,7 +485,7 @@ static int check_taps(const float *taps, int width, S3dTaps *out)
 
 /* one axis pass over the planes [z0, z1) of a volume addressed by global z (z0 = 0, z1 = nz: all) */
 static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int nz, int nc, int axis, int z0, int z1,
-                           const float *taps, int width, float uf, s3d_stream st)
+                           const float *taps, int width, float uf, s3d_stream st, const float *d_div = nullptr)
 {
     S3dTaps t;
     if (check_taps(taps, width, &t)) return S3D_ERR;
@@ -497,6 +498,12 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
     /* the reference indexes out of bounds here; refuse instead */
     if (uhw >= dims[axis] - 1) S3D_FAIL("image too small for this filter along the axis");
     if (d_src == d_dst) S3D_FAIL("in-place axis pass is not supported");
+    if (d_div) {                                          /* only the table-driven x pass divides on load */
+        const int r = nc == 1 && axis == 0 ? s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, 0, z0, z1, taps, width, uf, uhw, d_div, st) : 1;
+        if (r == 0) return S3D_OK;
+        if (r > 0) s3d_rt_set_error(__func__, "no dividing pass for this configuration");
+        return S3D_ERR;
+    }
     const size_t ib = strides[2] * (size_t)z0, ie = strides[2] * (size_t)z1;
     const bool vec4 = axis != 0 && (strides[1] & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15);
     if (nc == 1 && !g_no_dyadic && vec4) {
@@ -526,7 +533,7 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
      * (a pass over 32^3 voxels is a handful of waves walking the volume; the plain kernels below take a few us there) */
     if (nc == 1 && !g_no_dyadic && !g_no_tab &&
         (g_force_tab || (size_t)nx * ny * (size_t)(z1 - z0) > (size_t)64 * 64 * 64)) {
-        const int r = s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, axis, z0, z1, taps, width, uf, uhw, st);
+        const int r = s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, axis, z0, z1, taps, width, uf, uhw, nullptr, st);
         if (r < 0) return S3D_ERR;
         if (r == 0) return S3D_OK;
     }
@@ -1499,12 +1506,23 @@ extern "C" int s3d_k_sep_fir_slab(const float *d_src, float *d_dst, float *d_tmp
     return S3D_OK;
 }
 
-/* dst = filter(src / *d_div) for the configurations the fused kernels take (single channel, unit tap spacing, nx % 4 == 0):
- * im_scale folded into the first filter of the pyramid.  s3d_k_sep_fir_div_eligible() says whether this call is available;
- * callers scale explicitly (s3d_k_scale_div) otherwise. */
+/* dst = filter(src / *d_div): im_scale folded into the first filter of the pyramid.  Available (s3d_k_sep_fir_div_eligible)
+ * for the configurations the fused unit-spacing kernels take and for those whose x pass is table-driven (any tap spacing,
+ * any row length; volumes above 64^3); callers scale explicitly (s3d_k_scale_div) otherwise. */
+static int div_by_x_tab(int nx, int ny, int nz, const float uf[3], int width)
+{
+    if (width < 1 || width > S3D_MAX_TAPS || !(width & 1) || g_no_dyadic || g_no_tab) return 0;
+    if (!g_force_tab && (size_t)nx * ny * (size_t)nz <= (size_t)64 * 64 * 64) return 0;
+    const int hw = width / 2;
+    const int uhw[3] = {(int)ceilf((float)hw * uf[0]), (int)ceilf((float)hw * uf[1]), (int)ceilf((float)hw * uf[2])};
+    if (uhw[0] >= nx - 1 || uhw[1] >= ny - 1 || uhw[2] >= nz - 1) return 0;
+    return s3d_k_conv_x_tab_available(nx, ny, nz, width, uf[0], uhw[0]);
+}
+
 extern "C" int s3d_k_sep_fir_div_eligible(int nx, int ny, int nz, const float uf[3], int width)
 {
-    return width >= 1 && width <= S3D_MAX_TAPS && (width & 1) && fast_eligible(nx, ny, nz, 1, uf, width);
+    if (!(width >= 1 && width <= S3D_MAX_TAPS && (width & 1))) return 0;
+    return fast_eligible(nx, ny, nz, 1, uf, width) || div_by_x_tab(nx, ny, nz, uf, width);
 }
 
 extern "C" int s3d_k_sep_fir_div(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
@@ -1514,8 +1532,16 @@ extern "C" int s3d_k_sep_fir_div(const float *d_src, float *d_dst, float *d_tmp,
     if (check_taps(taps, width, &t)) return S3D_ERR;
     if (nx < 1 || ny < 1 || nz < 1 || z0 < 0 || z1 > nz || z0 >= z1 || d_div == nullptr) S3D_FAIL("bad arguments");
     if (d_tmp == d_src || d_tmp == d_dst) S3D_FAIL("scratch must not alias src/dst");
-    if (!fast_eligible(nx, ny, nz, 1, uf, width)) S3D_FAIL("configuration not eligible for the fused scale + filter");
-    return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, width / 2, t, (hipStream_t)stream, d_div);
+    if (fast_eligible(nx, ny, nz, 1, uf, width))
+        return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, width / 2, t, (hipStream_t)stream, d_div);
+    if (!div_by_x_tab(nx, ny, nz, uf, width)) S3D_FAIL("configuration not eligible for the fused scale + filter");
+    /* the three passes of s3d_k_sep_fir_slab, the x pass dividing as it loads */
+    const int h = (int)ceilf((float)(width / 2) * uf[2]) + 1;
+    const int za = z0 - h > 0 ? z0 - h : 0, zb = z1 + h < nz ? z1 + h : nz;
+    if (conv_axis_range(d_src, d_dst, nx, ny, nz, 1, 0, za, zb, taps, width, uf[0], stream, d_div)) return S3D_ERR;
+    if (conv_axis_range(d_dst, d_tmp, nx, ny, nz, 1, 1, za, zb, taps, width, uf[1], stream)) return S3D_ERR;
+    if (conv_axis_range(d_tmp, d_dst, nx, ny, nz, 1, 2, z0, z1, taps, width, uf[2], stream)) return S3D_ERR;
+    return S3D_OK;
 }
 
 extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,

@@ -262,17 +262,33 @@ k_conv_march_tab(const float *__restrict__ src, float *__restrict__ dst, unsigne
         }
 }
 
+struct S3dTrue { static constexpr bool value = true; };
+struct S3dFalse { static constexpr bool value = false; };
+
 /* ---- x pass -------------------------------------------------------------------------------------------------------- */
 #define XT_LINE 160                       /* dwords per staged copy: >= 64 + 2*TAB_MAX_UHW + 3, and = 32 (mod 64) */
-template <int HW, int D>
+/* DIV: every source voxel is divided by *d_div as it is loaded (im_scale, imutil.c:1977: samp / max, the same IEEE division; an
+ * all-zero image -- maximum 0 -- is left alone): the first filter of a pyramid reads the caller's volume directly. */
+template <int HW, int D, bool DIV>
 __global__ void __launch_bounds__(64)
 k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, size_t row_begin, size_t row_end,
-             unsigned rows_per_wave, int uhw, const int *__restrict__ xlo, const int *__restrict__ xfr, S3dTaps taps)
+             unsigned rows_per_wave, unsigned nstrips, int uhw, const int *__restrict__ xlo, const int *__restrict__ xfr,
+             S3dTaps taps, const float *__restrict__ d_div)
 {
+    float div = 1.0f;
+    if (DIV) {
+        div = *d_div;
+        if (div == 0.0f) div = 1.0f;
+    }
     constexpr int NT = 2 * HW + 1;
     __shared__ __attribute__((aligned(16))) float line[2 * XT_LINE];   /* [0, XT_LINE): seg[i] ; [XT_LINE, ..): seg[i + 1] */
     const int lane = threadIdx.x;
-    const int xs = (int)blockIdx.x * 64;
+    /* Workgroups go to the XCDs round-robin (block b on XCD b % 8) and every strip shares the cache lines of its halo with
+     * its neighbours: with the strips of a row spread over the XCDs those lines came out of HBM once per L2 that wanted them
+     * (1.5x - 2x the row).  Here XCD c takes the row chunks c, c + 8, ... and, one after the other, all strips of each. */
+    const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+    const unsigned chunk_id = xcd + 8u * (j / nstrips);
+    const int xs = (int)(j % nstrips) * 64;
     const int x = xs + lane;
     const int xc = x < nx ? x : nx - 1;
     const int g0 = xs - uhw - 1;                           /* source index of segment slot 0 */
@@ -293,52 +309,68 @@ k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, siz
     auto clampx = [&](int i) { return i < 0 ? 0 : (i > nx - 1 ? nx - 1 : i); };
     const int i0 = clampx(g0 + lane), i1 = clampx(g0 + 64 + lane);
     const int slot1 = lane >= 1 ? XT_LINE + lane - 1 : 2 * XT_LINE - 1;
-    const size_t r0 = row_begin + (size_t)blockIdx.y * rows_per_wave;
+    const size_t r0 = row_begin + (size_t)chunk_id * rows_per_wave;
     const size_t r1 = r0 + rows_per_wave < row_end ? r0 + rows_per_wave : row_end;
     if (r0 >= r1) return;
     struct Raw { float v0, v1; };
-    auto load_row = [&](size_t r) -> Raw {                 /* unconditional, clamped: a prefetch must not sit under a branch */
-        const float *row = src + (r < r1 ? r : r1 - 1) * (size_t)nx;
+    /* the row pointers advance by additions (a 64-bit product per row is a dozen scalar instructions of the ~40 a row of a
+     * narrow filter costs); loads past the last row of the wave stay on it: unconditional, a prefetch must not sit under a branch */
+    const float *pld = src + r0 * (size_t)nx;
+    size_t rld = r0;
+    auto load_row = [&]() -> Raw {
         Raw q;
-        q.v0 = row[i0];
-        q.v1 = row[i1];
+        q.v0 = pld[i0];
+        q.v1 = pld[i1];
+        if (DIV) {
+            q.v0 = q.v0 / div;
+            q.v1 = q.v1 / div;
+        }
+        if (rld + 1 < r1) pld += nx;
+        rld++;
         return q;
     };
     Raw q[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) q[d] = load_row(r0 + d);
+    for (int d = 0; d < D; d++) q[d] = load_row();
     const char *lineb = reinterpret_cast<const char *>(line);
-    auto step = [&](size_t r, Raw &qu) {                   /* unrolled D times: the queue is indexed statically (see the march) */
-        /* four unconditional stores: slots no tap reads (64 + lane >= L; lane 0's copy-2 slot, parked in the last dword)
-         * take clamped, valid values -- a branch here would cost the loads around it their exact wait counts */
-        line[lane] = qu.v0;
-        line[slot1] = qu.v0;
-        line[64 + lane] = qu.v1;
-        line[XT_LINE + 63 + lane] = qu.v1;
-        qu = load_row(r + D);
-        s3d_wave_lds_sync();
-        float acc = 0.0f;
-        if (allzero) {                                     /* every tap of every lane sits on a voxel: see the march */
+    float *pst = dst + r0 * (size_t)nx + xc;               /* lanes past the row end repeat the last voxel's store */
+    /* ZERO: every tap of every lane sits on a voxel (see the march); decided once per wave, so the row loop has no branch */
+    auto march = [&](auto ZERO) {
+        auto step = [&](Raw &qu) {                         /* unrolled D times: the queue is indexed statically (see the march) */
+            /* four unconditional stores: slots no tap reads (64 + lane >= L; lane 0's copy-2 slot, parked in the last dword)
+             * take clamped, valid values -- a branch here would cost the loads around it their exact wait counts */
+            line[lane] = qu.v0;
+            line[slot1] = qu.v0;
+            line[64 + lane] = qu.v1;
+            line[XT_LINE + 63 + lane] = qu.v1;
+            qu = load_row();
+            s3d_wave_lds_sync();
+            float acc = 0.0f;
+            if (decltype(ZERO)::value) {
 #pragma unroll
-            for (int k = 0; k < NT; k++) acc = acc + taps.t[k] * *reinterpret_cast<const float *>(lineb + addr[k]);
-        } else {
+                for (int k = 0; k < NT; k++) acc = acc + taps.t[k] * *reinterpret_cast<const float *>(lineb + addr[k]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < NT; k++) {
-                const float2 ab = *reinterpret_cast<const float2 *>(lineb + addr[k]);
-                acc = acc + taps.t[k] * (om[k] * ab.x + fr[k] * ab.y);
+                for (int k = 0; k < NT; k++) {
+                    const float2 ab = *reinterpret_cast<const float2 *>(lineb + addr[k]);
+                    acc = acc + taps.t[k] * (om[k] * ab.x + fr[k] * ab.y);
+                }
             }
+            s3d_wave_lds_sync();                           /* the next row's staging must not overtake these reads */
+            *pst = acc;
+            pst += nx;
+        };
+        size_t r = r0;
+        for (; r + D <= r1; r += D) {
+#pragma unroll
+            for (int u = 0; u < D; u++) step(q[u]);
         }
-        s3d_wave_lds_sync();                               /* the next row's staging must not overtake these reads */
-        dst[r * (size_t)nx + xc] = acc;                    /* lanes past the row end repeat the last voxel's store */
+#pragma unroll
+        for (int u = 0; u < D; u++)
+            if (r + u < r1) step(q[u]);
     };
-    size_t r = r0;
-    for (; r + D <= r1; r += D) {
-#pragma unroll
-        for (int u = 0; u < D; u++) step(r + u, q[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < D; u++)
-        if (r + u < r1) step(r + u, q[u]);
+    if (allzero) march(S3dTrue());
+    else march(S3dFalse());
 }
 
 /* ---- dispatch ------------------------------------------------------------------------------------------------------ */
@@ -360,7 +392,7 @@ static int pick_chunk(int nout, int W, size_t waves_per_chunk)
 
 template <int HW>
 static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int ny, int nz, int axis, int z0, int z1,
-                      const S3dTaps &taps, hipStream_t st)
+                      const S3dTaps &taps, hipStream_t st, const float *d_div)
 {
     constexpr int D = 4;
     const size_t plane = (size_t)nx * ny;
@@ -370,9 +402,16 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
         /* enough waves for 256 CUs x ~8, but rows enough per wave to pay for the 2*NT table loads of its lanes */
         unsigned rpw = 256;
         while (rpw > 32 && (size_t)strips * s3d_div_up(nrows, rpw) < 4096) rpw >>= 1;
-        if (s3d_div_up(nrows, rpw) > 65535u) rpw = s3d_div_up(nrows, 65535);   /* very tall volumes: more rows per wave */
-        hipLaunchKernelGGL((k_conv_x_tab<HW, D>), dim3(strips, s3d_div_up(nrows, rpw)), dim3(64), 0, st, src, dst, nx, rb, re,
-                           rpw, t->uhw, t->d_xlo, t->d_xfr, taps);
+        /* chunks rounded up to a multiple of 8 (one per XCD and round; the surplus workgroups find no rows and leave) */
+        const size_t nchunks = ((size_t)s3d_div_up(nrows, rpw) + 7) & ~(size_t)7;
+        if (nchunks * strips > 0x7fffffffull) return 1;
+        const dim3 grid((unsigned)(nchunks * strips));
+        if (d_div)
+            hipLaunchKernelGGL((k_conv_x_tab<HW, D, true>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
+                               t->d_xlo, t->d_xfr, taps, d_div);
+        else
+            hipLaunchKernelGGL((k_conv_x_tab<HW, D, false>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
+                               t->d_xlo, t->d_xfr, taps, (const float *)nullptr);
         S3D_CHECK_LAUNCH();
         return S3D_OK;
     }
@@ -398,15 +437,30 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
 
 /* One axis pass over the planes [z0, z1) of a single-channel volume.  0: done; 1: not eligible (nothing launched; the
  * caller takes another kernel); -1: error. */
+static int tab_eligible(int nx, int ny, int nz, int axis, int z0, int z1, int hw, int uhw)
+{
+    const int dims[3] = {nx, ny, nz};
+    if (hw < 1 || hw > TAB_MAX_HW || uhw < 1 || uhw > TAB_MAX_UHW || uhw >= dims[axis] - 1) return 0;
+    if (nx > (1 << 22) || ny > (1 << 22) || nz > (1 << 22)) return 0;
+    if (axis == 1 && (nx < 4 || z1 - z0 > 65535)) return 0;
+    if (axis == 2 && (size_t)nx * ny < 4) return 0;
+    return 1;
+}
+
+/* 1: the x pass of this configuration is available from here (its table exists or could be built now) */
+extern "C" int s3d_k_conv_x_tab_available(int nx, int ny, int nz, int width, float uf, int uhw)
+{
+    if (!(width & 1) || !tab_eligible(nx, ny, nz, 0, 0, nz, width / 2, uhw)) return 0;
+    return tap_table(nx, width / 2, uf, uhw) != nullptr;
+}
+
+/* d_div != NULL (axis 0 only): the source is divided by *d_div as it is loaded */
 extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
-                                   const float *taps, int width, float uf, int uhw, s3d_stream stream)
+                                   const float *taps, int width, float uf, int uhw, const float *d_div, s3d_stream stream)
 {
     const int hw = width / 2;
     const int dims[3] = {nx, ny, nz};
-    if (hw < 1 || hw > TAB_MAX_HW || uhw < 1 || uhw > TAB_MAX_UHW || uhw >= dims[axis] - 1) return 1;
-    if (nx > (1 << 22) || ny > (1 << 22) || nz > (1 << 22)) return 1;
-    if (axis == 1 && (nx < 4 || z1 - z0 > 65535)) return 1;
-    if (axis == 2 && (size_t)nx * ny < 4) return 1;
+    if (!tab_eligible(nx, ny, nz, axis, z0, z1, hw, uhw) || (d_div && axis != 0)) return 1;
     const TapTab *t = tap_table(dims[axis], hw, uf, uhw);
     if (!t) return 1;
     S3dTaps tp;
@@ -415,7 +469,7 @@ extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int
     hipStream_t st = (hipStream_t)stream;
     g_tab_launches++;
     switch (hw) {
-#define S3D_TB(H) case H: return launch_tab<H>(t, d_src, d_dst, nx, ny, nz, axis, z0, z1, tp, st);
+#define S3D_TB(H) case H: return launch_tab<H>(t, d_src, d_dst, nx, ny, nz, axis, z0, z1, tp, st, d_div);
     S3D_TB(1) S3D_TB(2) S3D_TB(3) S3D_TB(4) S3D_TB(5) S3D_TB(6) S3D_TB(7) S3D_TB(8) S3D_TB(9)
 #undef S3D_TB
     default: break;

@@ -181,23 +181,29 @@ __global__ void __launch_bounds__(256) k_decimate2(const float *__restrict__ src
     dst[((size_t)z * my + y) * mx + x] = src[((size_t)(2 * z) * ny + 2 * y) * nx + 2 * x];
 }
 
-/* The same for nx % 8 == 0: a thread turns two aligned float4 loads (8 consecutive source voxels) into one float4
- * store, a workgroup takes DEC_ROWS destination rows.  One voxel per thread and one row per workgroup (above) spent the
- * octave 0 -> 1 step of a 512^3 pyramid, 65 536 workgroups of 256 scalar loads, at 0.17 of the HBM rate. */
+/* The same, four destination voxels per thread: two 16-byte loads (8 consecutive source voxels) -> one 16-byte store, a
+ * workgroup takes DEC_ROWS destination rows.  Rows of any length >= 4 destination voxels: loads and stores are dword
+ * aligned and the last quad of a row is clamped onto its end (it repeats voxels of the quad before it).  One voxel per
+ * thread and one row per workgroup (above) spent the octave 0 -> 1 step of a 512^3 pyramid, 65 536 workgroups of 256 scalar
+ * loads, at 0.17 of the HBM rate. */
 #define DEC_ROWS 4
-__global__ void __launch_bounds__(256) k_decimate2_v4(const float *__restrict__ src, int nx, int ny, int mq /* mx / 4 */,
-                                                      int my, int mz, float *__restrict__ dst)
+__global__ void __launch_bounds__(256) k_decimate2_v4(const float *__restrict__ src, int nx, int ny, int mx, int my, int mz,
+                                                      float *__restrict__ dst)
 {
     const int tpr = 256 / DEC_ROWS;                                  /* threads along x per row */
     const int q0 = threadIdx.x % tpr;
     const long row = (long)blockIdx.x * DEC_ROWS + threadIdx.x / tpr;    /* destination row = z * my + y */
     if (row >= (long)my * mz) return;
     const int z = (int)(row / my), y = (int)(row - (long)z * my);
-    const float4 *s = reinterpret_cast<const float4 *>(src + ((size_t)(2 * z) * ny + 2 * y) * nx);
-    float4 *d = reinterpret_cast<float4 *>(dst + (size_t)row * mq * 4);
+    const float *s = src + ((size_t)(2 * z) * ny + 2 * y) * nx;
+    float *d = dst + (size_t)row * mx;
+    const int mq = (mx + 3) / 4;
     for (int q = q0; q < mq; q += tpr) {
-        const float4 a = s[2 * q], b = s[2 * q + 1];
-        d[q] = make_float4(a.x, a.z, b.x, b.z);
+        const int x = 4 * q + 4 <= mx ? 4 * q : mx - 4;
+        const s3d_f4u a = *reinterpret_cast<const s3d_f4u *>(s + 2 * x), b = *reinterpret_cast<const s3d_f4u *>(s + 2 * x + 4);
+        s3d_f4u o;
+        o.x = a.x; o.y = a.z; o.z = b.x; o.w = b.z;
+        *reinterpret_cast<s3d_f4u *>(d + x) = o;
     }
 }
 
@@ -205,10 +211,10 @@ extern "C" int s3d_k_decimate2(const float *d_src, int nx, int ny, int nz, float
 {
     const int mx = nx / 2, my = ny / 2, mz = nz / 2;
     if (mx < 1 || my < 1 || mz < 1) S3D_FAIL("volume too small to decimate");
-    if ((nx & 7) == 0 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0) {
+    if (mx >= 4) {
         const long rows = (long)my * mz;
         hipLaunchKernelGGL(k_decimate2_v4, dim3((unsigned)((rows + DEC_ROWS - 1) / DEC_ROWS)), dim3(256), 0, (hipStream_t)st,
-                           d_src, nx, ny, mx / 4, my, mz, d_dst);
+                           d_src, nx, ny, mx, my, mz, d_dst);
         S3D_CHECK_LAUNCH();
         return S3D_OK;
     }

@@ -466,8 +466,8 @@ def check_extrema_runmax(lib, dims, ranges, seed=3):
     nwords = (n + 63) // 64
     d_bits = [dev.malloc(nwords * 8) for _ in range(6)]
     d_max = dev.malloc(64)
+    d_ref = dev.malloc(nwords * 8)
     P6 = (C.c_void_p * 6)(*d_lv)
-    P4 = (C.c_void_p * 4)(*d_lv[1:5])
     Ba = (C.c_void_p * 3)(*d_bits[:3])
     Bb = (C.c_void_p * 3)(*d_bits[3:])
     L.s3d_k_dogmax3.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -481,9 +481,21 @@ def check_extrema_runmax(lib, dims, ranges, seed=3):
                 L.s3d_rt_memset(C.c_void_p(b), 0, nwords * 8, None)
             # the reference order of things: maxima of the planes in the range, then the thresholded extrema
             plane = nx * ny
-            Q4 = (C.c_void_p * 4)(*[p + 4 * plane * z0 for p in d_lv[1:5]])
-            assert L.s3d_k_dogmax3(Q4, plane * (z1 - z0), d_max, None) == 0
-            want_max = dev.download(d_max, (3,))
+            want_max = np.array([np.abs(levels[k + 1][z0:z1] - levels[k + 2][z0:z1]).max() for k in range(3)], np.float32)
+            if (plane * z0) % 4 == 0:
+                Q4 = (C.c_void_p * 4)(*[p + 4 * plane * z0 for p in d_lv[1:5]])
+                assert L.s3d_k_dogmax3(Q4, plane * (z1 - z0), d_max, None) == 0
+                assert nbitdiff(dev.download(d_max, (3,)), want_max) == 0
+            else:
+                L.s3d_rt_h2d(C.c_void_p(d_max), want_max.ctypes.data_as(C.c_void_p), 12, None)
+                dev.sync()
+            # the per-level kernel (one level per launch, one voxel per thread): the pinned form
+            L.s3d_k_extrema_slab.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+            ref_bits = []
+            for k in range(3):
+                assert L.s3d_k_extrema_slab(d_lv[k], d_lv[k + 1], d_lv[k + 2], d_lv[k + 3], nx, ny, nz, z0, z1, 0.1,
+                                            d_max + 4 * k, d_ref, None) == 0
+                ref_bits.append(dev.download(d_ref, (nwords * 2,)).view(np.uint64)[:(plane * (z1 - z0) + 63) // 64].copy())
             assert L.s3d_k_extrema_fused(P6, 3, nx, ny, nz, z0, z1, 0.1, d_max, Ba, None) == 0
             assert L.s3d_k_extrema_fused_runmax(P6, 3, nx, ny, nz, z0, z1, 0.1, d_max, Bb, None) == 0
             got_max = dev.download(d_max, (3,))
@@ -496,15 +508,16 @@ def check_extrema_runmax(lib, dims, ranges, seed=3):
                 a = dev.download(d_bits[k], (nwords * 2,)).view(np.uint64)[:nw]
                 b = dev.download(d_bits[3 + k], (nwords * 2,)).view(np.uint64)[:nw]
                 assert np.array_equal(a, b), f"planes [{z0},{z1}) level {k}: {int((a != b).sum())} bitmap words differ"
+                assert np.array_equal(a, ref_bits[k]), f"planes [{z0},{z1}) level {k}: fused and per-level bitmaps differ"
                 total += int(np.unpackbits(a.view(np.uint8)).sum())
             assert total > 0
             del w0
     finally:
-        for p in d_lv + d_bits + [d_max]:
+        for p in d_lv + d_bits + [d_max, d_ref]:
             dev.free(p)
 
 
-def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False):
+def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False, units=(1, 1, 1), mode=0):
     """s3d_k_sep_fir_div (im_scale folded into the loads of the first filter) against the explicit sequence maximum ->
     s3d_k_scale_div -> filter, bit for bit, whole volume and plane ranges; an all-zero volume stays all zero (the reference
     does not divide by a zero maximum)."""
@@ -514,7 +527,9 @@ def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False):
     vol = np.random.default_rng(5).standard_normal((nz, ny, nx)).astype(np.float32) * np.float32(37.5)
     if zero:
         vol[:] = 0
-    uf = np.ones(3, np.float32)
+    uf = np.array([np.float32(1.0 / u) for u in units], np.float32)
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    L.s3d_k_gauss_set_tile3.argtypes = [C.c_long]
     L.s3d_k_sep_fir_div.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.s3d_k_sep_fir_div_eligible.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int]
     L.s3d_k_absmax.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -523,6 +538,9 @@ def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False):
                                   dev.malloc(vol.nbytes))
     d_max = dev.malloc(64)
     try:
+        L.s3d_k_gauss_set_mode(mode)                       # 8: the table-driven passes also on small volumes
+        if mode:
+            L.s3d_k_gauss_set_tile3(0)
         assert L.s3d_k_absmax(d_src, vol.size, d_max, None) == 0
         assert L.s3d_k_scale_div(d_sc, vol.size, d_max, None) == 0
         scaled = dev.download(d_sc, vol.shape)
@@ -541,11 +559,17 @@ def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False):
                 got = dev.download(d_b, vol.shape)[z0:z1]
                 nd = nbitdiff(got, want[z0:z1])
                 assert nd == 0, f"planes [{z0},{z1}) sigma {sigma} (width {taps.size}): {nd} elements differ"
-        # not eligible: the caller has to scale explicitly, and the call says so
-        bad = np.array([1.0, 1.0, 0.5], np.float32)
-        assert L.s3d_k_sep_fir_div_eligible(nx, ny, nz, bad.ctypes.data, 5) == 0
-        assert L.s3d_k_sep_fir_div_eligible(nx + 1, ny, nz, uf.ctypes.data, 5) == 0
+        # not eligible (small volumes off the unit-spacing kernels' grid): the caller has to scale explicitly, and the
+        # call says so
+        if mode == 0 and vol.size <= 64 ** 3:
+            bad = np.array([1.0, 1.0, 0.5], np.float32)
+            assert L.s3d_k_sep_fir_div_eligible(nx, ny, nz, bad.ctypes.data, 5) == 0
+            assert L.s3d_k_sep_fir_div_eligible(nx + 1, ny, nz, uf.ctypes.data, 5) == 0
+            assert L.s3d_k_sep_fir_div(d_src, d_b, d_t, nx, ny, nz, 0, nz, bad.ctypes.data, taps.ctypes.data, taps.size,
+                                       d_max, None) != 0
     finally:
+        L.s3d_k_gauss_set_mode(0)
+        L.s3d_k_gauss_set_tile3(-1)
         for p in (d_src, d_sc, d_a, d_b, d_t, d_max):
             dev.free(p)
 

@@ -205,13 +205,18 @@ def test_sep_fir_tab(emu, oracle, dims, units, sigmas, splits, chunk):
     assert parity.check_sep_fir_tab(emu, oracle, dims, units, sigmas, splits, chunk) >= 1
 
 
-@pytest.mark.parametrize("dims,zero", [((32, 28, 24), False), ((24, 24, 20), True)])
-def test_sep_fir_div(emu, oracle, dims, zero):
-    """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit."""
-    parity.check_sep_fir_div(emu, oracle, dims, (0.973294, 1.94659), [(0, 7), (5, dims[2] - 3), (dims[2] - 6, dims[2])], zero=zero)
+@pytest.mark.parametrize("dims,zero,units,mode", [((32, 28, 24), False, (1, 1, 1), 0), ((24, 24, 20), True, (1, 1, 1), 0),
+                                                  ((31, 27, 24), False, (1, 1, 1), 8), ((70, 20, 22), False, (0.7, 0.7, 1.5), 8),
+                                                  ((25, 24, 20), True, (1, 0.8, 2), 8)])
+def test_sep_fir_div(emu, oracle, dims, zero, units, mode):
+    """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit: in the
+    fused unit-spacing kernels and (mode 8) in the table-driven x pass of any other configuration."""
+    parity.check_sep_fir_div(emu, oracle, dims, (0.973294, 1.94659), [(0, 7), (5, dims[2] - 3), (dims[2] - 6, dims[2])], zero=zero,
+                             units=units, mode=mode)
 
 
-def test_extrema_runmax(emu):
-    """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form."""
-    d = (32, 20, 18)
+@pytest.mark.parametrize("d", [(32, 20, 18), (31, 21, 18), (30, 19, 17), (5, 9, 11)])
+def test_extrema_runmax(emu, d):
+    """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form = the
+    per-level kernel; rows of any length (the four voxels of a thread straddle row ends, dword-aligned loads)."""
     parity.check_extrema_runmax(emu, d, [(0, d[2]), (0, d[2] // 2), (d[2] // 2 - 3, d[2])])

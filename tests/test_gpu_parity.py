@@ -118,6 +118,9 @@ def test_detect_describe_golden(lib, name):
     ((128, 128, 128), (1, 1, 1), 2000, 0),      # the survey's 491-keypoint anchor
     ((256, 256, 256), (1, 1, 1), 16000, 2),     # 4 octaves, ~3900 keypoints: every level bit for bit, all descriptors
     ((192, 160, 128), (1, 1, 1.5), 6000, 7),    # anisotropic slices: fused in-plane passes + generic z pass
+    ((161, 150, 93), (0.7, 0.7, 1.5), 2500, 8),  # 0.7-mm pixels, thick slices, ragged rows: table-driven passes on octave 0,
+                                                 # ragged extrema / decimation, scale folded into the x pass
+    ((131, 127, 90), (1, 1, 1), 1500, 9),        # unit voxels, rows of odd length
 ])
 def test_detect_describe_vs_oracle(lib, oracle, dims, units, nblobs, seed):
     k = parity.check_detect_describe(lib, oracle, dims, units, nblobs, seed)
@@ -609,15 +612,20 @@ def test_orient_tables(lib, dims, units, sigmas, expect, mode):
     assert kept > 0
 
 
-@pytest.mark.parametrize("dims,zero", [((64, 52, 48), False), ((512, 40, 36), False), ((24, 24, 20), True)])
-def test_sep_fir_div(lib, oracle, dims, zero):
+@pytest.mark.parametrize("dims,zero,units,mode", [((64, 52, 48), False, (1, 1, 1), 0), ((512, 40, 36), False, (1, 1, 1), 0),
+                                                  ((24, 24, 20), True, (1, 1, 1), 0), ((31, 27, 24), False, (1, 1, 1), 8),
+                                                  ((70, 20, 22), False, (0.7, 0.7, 1.5), 8), ((25, 24, 20), True, (1, 0.8, 2), 8),
+                                                  ((255, 130, 90), False, (0.7, 0.7, 1.5), 0)])
+def test_sep_fir_div(lib, oracle, dims, zero, units, mode):
     """im_scale folded into the first filter of the pyramid (s3d_k_sep_fir_div) equals scale-then-filter bit for bit."""
-    parity.check_sep_fir_div(lib, oracle, dims, (0.973294, 1.94659), [(0, 7), (5, dims[2] - 3), (dims[2] - 6, dims[2])], zero=zero)
+    parity.check_sep_fir_div(lib, oracle, dims, (0.973294, 1.94659), [(0, 7), (5, dims[2] - 3), (dims[2] - 6, dims[2])], zero=zero,
+                             units=units, mode=mode)
 
 
-def test_extrema_runmax(lib):
-    """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form."""
-    d = (128, 96, 80)
+@pytest.mark.parametrize("d", [(128, 96, 80), (127, 97, 80), (126, 95, 81), (5, 9, 11)])
+def test_extrema_runmax(lib, d):
+    """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form = the
+    per-level kernel; rows of any length (the four voxels of a thread straddle row ends, dword-aligned loads)."""
     parity.check_extrema_runmax(lib, d, [(0, d[2]), (0, d[2] // 2), (d[2] // 2 - 3, d[2])])
 
 
