@@ -79,8 +79,26 @@ template <int NKP>
 struct ExtArgs {
     const float *l[NKP + 3];              /* L(s-1) .. L(s+NKP+1), s = first keypoint level */
     unsigned long long *bits[NKP];        /* one bitmap per keypoint level */
-    float thr_scale_unused;
+    unsigned long long plane_magic, nx_magic;   /* i / plane = (i * plane_magic) >> plane_shift for every i < 2^32 (host: div_magic) */
+    unsigned plane_shift, nx_shift;
 };
+
+/* m, s with floor(i / d) == (i * m) >> s for every 32-bit i: s = 32 + ceil(log2 d), m = ceil(2^s / d) < 2^33 (Granlund &
+ * Montgomery); the product needs 65 bits at most -- the kernels' i are below 2^32 - 256 and d >= 4 here, so m < 2^32 + ...
+ * is checked instead of assumed */
+static bool div_magic(unsigned d, unsigned long long *m, unsigned *s)
+{
+    if (d == 0) return false;
+    unsigned l = 0;
+    while ((1ull << l) < d) l++;
+    const unsigned sh = 32 + l;
+    const unsigned __int128 one = (unsigned __int128)1 << sh;
+    const unsigned __int128 mm = (one + d - 1) / d;
+    if (mm >> 32 > 1) return false;                        /* keep i * m inside 64 bits for i < 2^31, see below */
+    *m = (unsigned long long)mm;
+    *s = sh;
+    return true;
+}
 
 /* RUNMAX: the DoG maxima are not known yet.  d_runmax[s] (bit patterns of non-negative floats, zeroed before the launch)
  * is a running maximum of |DoG(s)| over the workgroups that have finished so far: whatever a workgroup reads there is a
@@ -92,69 +110,102 @@ struct ExtArgs {
  * extrema step). */
 /* RAGGED: rows of any length >= 4.  The four voxels of a thread are consecutive in memory but may straddle a row end (then
  * each gets its own coordinates for the interior test; memory neighbours are still idx +- 1 for every tested voxel), the
- * loads are dword aligned, and the one thread at the end of a level whose four would leave it takes its voxels one by one. */
+ * loads are dword aligned, and the one thread at the end of a level whose four would leave it takes its voxels one by one.
+ *
+ * What was measured on the way from 0.90 to 0.72 ms per 512^3 octave (profiles/r04_extrema_ablation.txt; same box per
+ * comparison): the six 16-byte loads of a thread are unconditional, from an address clamped into the range (under
+ * `if (idx < n)` they are waited for where the branches join); the x neighbours of a wave's two end lanes (voxel idx - 1
+ * of lane 0, idx + 4 of lane 63) are ONE load per level issued by those two lanes only -- as a load per lane they cost the
+ * texture addresser as much as 16-byte loads (0.84 ms with four per thread, 0.67 with none and no second phase),
+ * through the scalar cache (wave-uniform addresses) they miss it every time (0.89); the running maxima are read after
+ * the streaming loads have been issued (0.78 -> 0.72); the two integer divisions per quad are multiplications by
+ * reciprocals and the eight comparisons per voxel v_max3 / v_min3 forms (VALU was half busy; nothing measurable).  A
+ * software-pipelined loop over four tiles per workgroup (loads of tile t + 1 in flight through the dependent gathers of
+ * tile t) was built and was slower than one tile per workgroup at 8 waves per SIMD (0.84 vs 0.74). */
 template <int NKP, bool RUNMAX, bool RAGGED>
 __global__ void __launch_bounds__(256)
 k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
                 const float *__restrict__ d_dogmax /* [NKP], per keypoint level */, unsigned *__restrict__ d_runmax)
 {
-    float seen[NKP];                                       /* RUNMAX: the bound this workgroup works with */
-#pragma unroll
-    for (int s = 0; s < NKP; s++) seen[s] = RUNMAX ? __uint_as_float(__atomic_load_n(&d_runmax[s], __ATOMIC_RELAXED)) : 0.0f;
     /* voxels idx0 + 4*g .. +3 ; a wave covers 256 consecutive voxels = 4 bitmap words */
     const unsigned g = blockIdx.x * 256u + threadIdx.x;
     const unsigned idx = idx0 + 4u * g;
     const int lane = threadIdx.x & 63;
     const unsigned plane = nx * ny;
+    /* the wave's end neighbours: DoG(s) of the voxel before its first and after its last (clamped into the range: a
+     * clamped one belongs to a voxel on a face of the level, which is not tested) */
+    float edge_lo[NKP], edge_hi[NKP];
+    {
+        /* one load per level serves both ends: lane 0 fetches voxel idx - 1, lane 63 voxel idx + 4 (clamped into the range:
+         * a clamped one belongs to a voxel on a face of the level, which is not tested) */
+        unsigned ie = lane == 0 ? (idx > 0u ? idx - 1u : 0u) : idx + 4u;
+        if (ie >= n) ie = n - 1u;
+        float e[NKP + 1];
+#pragma unroll
+        for (int k = 0; k < NKP + 1; k++) e[k] = 0.0f;
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int k = 0; k < NKP + 1; k++) e[k] = a.l[k + 1][ie];
+        }
+#pragma unroll
+        for (int s = 0; s < NKP; s++) edge_lo[s] = edge_hi[s] = e[s] - e[s + 1];
+    }
     /* phase 1 (streaming, no dependent loads): everything that can be decided from this thread's own
-     * float4s and its two x-neighbours -- peak threshold, the two scale neighbours, the two x neighbours.
+     * quads and its two x-neighbours -- peak threshold, the two scale neighbours, the two x neighbours.
      * Survivors (~1 %) are remembered as bits s*4+j of pmax / pmin. */
     unsigned pmax = 0u, pmin = 0u;
-    bool row_ok = false;
     float d[NKP + 2][4];                                   /* DoG centres, level k: L(k) - L(k+1) */
+    {
+        /* the quads of all levels: unconditional loads from an address clamped into the range (a load under `if (idx < n)`
+         * is waited for where the branches join; threads past the range, and the one quad that straddles its end,
+         * discard what they loaded) */
+        const unsigned il = idx + 4u <= n ? idx : n - 4u;      /* n - idx0 >= 4 (host) */
+        float c[NKP + 3][4];
 #pragma unroll
-    for (int k = 0; k < NKP + 2; k++) d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.0f;
-    if (!RAGGED || idx + 4u <= n) {
-        if (idx < n) {                                     /* !RAGGED: n - idx0 is a multiple of 4 (nx % 4 == 0) */
-            float c[NKP + 3][4];
-#pragma unroll
-            for (int k = 0; k < NKP + 3; k++) {
-                if (RAGGED) {
-                    const s3d_f4u v = *reinterpret_cast<const s3d_f4u *>(a.l[k] + idx);
-                    c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
-                } else {
-                    const float4 v = *reinterpret_cast<const float4 *>(a.l[k] + idx);
-                    c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
-                }
+        for (int k = 0; k < NKP + 3; k++) {
+            if (RAGGED) {
+                const s3d_f4u v = *reinterpret_cast<const s3d_f4u *>(a.l[k] + il);
+                c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>(a.l[k] + il);
+                c[k][0] = v.x; c[k][1] = v.y; c[k][2] = v.z; c[k][3] = v.w;
             }
-#pragma unroll
-            for (int k = 0; k < NKP + 2; k++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) d[k][j] = c[k][j] - c[k + 1][j];
         }
-    } else if (idx < n) {                                  /* RAGGED: the last, partial group of the range */
+        const bool whole = idx + 4u <= n;                  /* !RAGGED: n - idx0 is a multiple of 4, so idx < n means whole */
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-            if (idx + (unsigned)j < n) {
+        for (int k = 0; k < NKP + 2; k++)
 #pragma unroll
-                for (int k = 0; k < NKP + 2; k++) d[k][j] = a.l[k][idx + j] - a.l[k + 1][idx + j];
-            }
+            for (int j = 0; j < 4; j++) d[k][j] = whole ? c[k][j] - c[k + 1][j] : 0.0f;
+        if (RAGGED && !whole && idx < n) {                 /* the last, partial quad of the range: one thread per launch */
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (idx + (unsigned)j < n) {
+#pragma unroll
+                    for (int k = 0; k < NKP + 2; k++) d[k][j] = a.l[k][idx + j] - a.l[k + 1][idx + j];
+                }
+        }
     }
+    float seen[NKP];                                       /* RUNMAX: the bound this workgroup works with (read behind the streaming loads) */
+#pragma unroll
+    for (int s = 0; s < NKP; s++) seen[s] = RUNMAX ? __uint_as_float(__atomic_load_n(&d_runmax[s], __ATOMIC_RELAXED)) : 0.0f;
     /* x neighbours of the thread's end voxels: the neighbouring lanes hold them as the last / first DoG value of
-     * their float4s; only the two end lanes of a wave load them (12 dword loads per thread used to be a third
-     * of the kernel's memory instructions).  All lanes take part in the exchange. */
+     * their quads.  All lanes take part in the exchange. */
     float from_lo[NKP], from_hi[NKP];
 #pragma unroll
     for (int s = 0; s < NKP; s++) {
         from_lo[s] = __shfl_up(d[s + 1][3], 1);
         from_hi[s] = __shfl_down(d[s + 1][0], 1);
+        if (lane == 0) from_lo[s] = edge_lo[s];
+        if (lane == 63) from_hi[s] = edge_hi[s];
     }
     if (idx < n) {
-        const unsigned z = idx / plane;
+        /* idx / plane and rem / nx by multiplication with the rounded-up reciprocal (exact for every idx < 2^31, see
+         * div_magic) -- a 32-bit integer division is ~40 instructions, and there were two per quad */
+        const unsigned z = (unsigned)(((unsigned long long)idx * a.plane_magic) >> a.plane_shift);
         const unsigned rem = idx - z * plane;
-        const unsigned y = rem / nx;
+        const unsigned y = (unsigned)(((unsigned long long)rem * a.nx_magic) >> a.nx_shift);
         const unsigned x = rem - y * nx;
-        row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
+        const bool row_ok = y >= 1 && y + 2 <= ny && z >= 1 && z + 2 <= nz;
         bool inner[4];                                     /* voxel j may be an extremum: not on a face of the level */
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -173,19 +224,18 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
 #pragma unroll
         for (int s = 0; s < NKP; s++) {
             const float thr = (float)(peak * (double)(RUNMAX ? seen[s] : d_dogmax[s]));   /* sift.c:1169 */
-            const float *l1 = a.l[s + 1], *l2 = a.l[s + 2];
-            float left = 0.0f, right = 0.0f;              /* idx-1 / idx+4 stay inside the level for every tested voxel */
-            if (inner[0]) left = lane > 0 ? from_lo[s] : l1[idx - 1] - l2[idx - 1];
-            if (inner[3]) right = lane < 63 ? from_hi[s] : l1[idx + 4] - l2[idx + 4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float v = d[s + 1][j];
                 const float pv = d[s][j], nv = d[s + 2][j];
-                const float xm = j == 0 ? left : d[s + 1][j - 1];
-                const float xp = j == 3 ? right : d[s + 1][j + 1];
-                const bool live = inner[j] && (v > thr || v < -thr);
-                if (live && v > pv && v > nv && v > xm && v > xp) pmax |= 1u << (4 * s + j);
-                if (live && v < pv && v < nv && v < xm && v < xp) pmin |= 1u << (4 * s + j);
+                const float xm = j == 0 ? from_lo[s] : d[s + 1][j - 1];   /* idx-1 / idx+4 stay inside the level for every tested voxel */
+                const float xp = j == 3 ? from_hi[s] : d[s + 1][j + 1];
+                /* strictly above (below) every neighbour <=> above their maximum (below their minimum): the same
+                 * comparisons on the same values, in v_max3 / v_min3 form */
+                const bool live = inner[j] && fabsf(v) > thr;
+                const float hi4 = fmaxf(fmaxf(fmaxf(pv, nv), xm), xp), lo4 = fminf(fminf(fminf(pv, nv), xm), xp);
+                if (live && v > hi4) pmax |= 1u << (4 * s + j);
+                if (live && v < lo4) pmin |= 1u << (4 * s + j);
             }
         }
     }
@@ -226,13 +276,10 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
             if (m > seen[s]) atomicMax(&d_runmax[s], __float_as_uint(m));     /* rare once the bound has settled */
         }
     }
-    unsigned nib[NKP];
-#pragma unroll
-    for (int s = 0; s < NKP; s++) nib[s] = (res >> (4 * s)) & 15u;
     /* lanes 16w .. 16w+15 hold the 16 nibbles of word w: OR them together inside each 16-lane row */
 #pragma unroll
     for (int s = 0; s < NKP; s++) {
-        unsigned long long w = (unsigned long long)nib[s] << (4 * (lane & 15));
+        unsigned long long w = (unsigned long long)((res >> (4 * s)) & 15u) << (4 * (lane & 15));
         w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4); w |= __shfl_xor(w, 8);
         const unsigned word = (4u * g) >> 6;
         if ((lane & 15) == 0 && 4u * g < ((n - idx0 + 63u) & ~63u)) a.bits[s][word] = w;
@@ -279,9 +326,12 @@ static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, i
     ExtArgs<3> a;
     for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];
     for (int k = 0; k < 3; k++) a.bits[k] = d_bits[k];
-    a.thr_scale_unused = 0.0f;
+    /* i * m < 2^64 needs i < 2^64 / m: m < 2^33, so every i < 2^31 is safe; larger levels take the per-level kernel */
+    if (n >= 0x7FFFFF00ull || !div_magic((unsigned)plane, &a.plane_magic, &a.plane_shift) ||
+        !div_magic((unsigned)nx, &a.nx_magic, &a.nx_shift)) return 1;
     bool ragged = (nx & 3) != 0;
     for (int k = 0; k < 6; k++) ragged = ragged || (((uintptr_t)d_levels[k]) & 15) != 0;
+    if (plane * (size_t)(z1 - z0) < 4) return 1;
     const dim3 grid(s3d_div_up(s3d_div_up(plane * (size_t)(z1 - z0), 4), 256));
     const unsigned i0 = (unsigned)(plane * z0), i1 = (unsigned)(plane * z1);
 #define S3D_EXF(RM, RG, DM, RX) hipLaunchKernelGGL((k_extrema_fused<3, RM, RG>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, \
@@ -329,7 +379,7 @@ extern "C" int s3d_k_extrema_refilter(const float *const *d_levels, int nkp, int
     ExtArgs<3> a;
     for (int k = 0; k < 6; k++) a.l[k] = d_levels[k];
     for (int k = 0; k < 3; k++) a.bits[k] = d_bits[k];
-    a.thr_scale_unused = 0.0f;
+    a.plane_magic = a.nx_magic = 0; a.plane_shift = a.nx_shift = 0;
     const size_t nwords = (plane * (size_t)(z1 - z0) + 63) / 64;
     hipLaunchKernelGGL((k_extrema_refilter<3>), dim3(s3d_div_up(nwords, 256)), dim3(256), 0, (hipStream_t)st, a,
                        (unsigned)(plane * z0), nwords, peak_thresh, d_dogmax);
