@@ -73,14 +73,14 @@ def passes():
         dev.free(d_src); dev.free(d_dst)
 
 
-def detects():
+def detects(modes=(0, 16)):
     cases = [((512, 512, 512), (1.0, 1.0, 1.0)), ((512, 512, 300), (0.7, 0.7, 1.5)), ((512, 512, 512), (1.0, 0.8, 2.0)),
              ((512, 512, 512), (1.0, 1.0, 1.5)), ((511, 509, 303), (1.0, 1.0, 1.0)), ((510, 510, 510), (1.0, 1.0, 1.0))]
     for dims, units in cases:
         nx, ny, nz = dims
         vol = synth.blobs(nx, ny, nz, synth.default_nblobs(nx, ny, nz), 0)
         d_vol = dev.upload(vol)
-        for mode in (0, 16):
+        for mode in modes:
             L.s3d_k_gauss_set_mode(mode)
             s = abi.SIFT3D(); lib.sift.init_SIFT3D(C.byref(s))
             kp = abi.Keypoint_store(); lib.sift.init_Keypoint_store(C.byref(kp))
@@ -103,4 +103,4 @@ if __name__ == "__main__":
     if "passes" in what:
         passes()
     if "detects" in what:
-        detects()
+        detects(tuple(int(m) for m in os.environ.get("MODES", "0,16").split(",")))

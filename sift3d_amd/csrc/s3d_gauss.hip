@@ -365,108 +365,8 @@ static bool launch_dyadic(int hw, const float *src, float *dst, size_t ib, size_
     }
 }
 
-/* Generic tap spacing along z (anisotropic slices: uz / ux is not a power of two), four x-consecutive voxels per
- * lane.  k_conv_axis_v4 loads 2*(2*HW+1) float4 per output straight from memory -- 34 for HW = 8, against 14
- * distinct planes -- and ran at the L2's pace (0.97 ms per 512^3 pass, 5x the unit-spacing z pass).  Here one wave
- * owns 64 float4 columns and marches along z through a chunk of 64 planes: every source plane is read from
- * memory once into a ring of W = 2*uhw+4 plane rows in LDS (a lane only ever touches its own column: no
- * barriers), and the taps read the ring.  The tap coordinates depend on z alone: lane l evaluates the
- * reference's coordinate loop (incl. its interior drift and the mirror rules, as k_conv_axis) for plane zb + l
- * once, in the prologue, and the march broadcasts plane i's (frac, ring rows) out of lane i's registers with
- * v_readlane.  Same taps, order and expression per element: bit-identical to k_conv_axis.  Measured at 512^3,
- * HW = 8, taps 2/3 plane apart: 0.68 ms against 0.97 ms; ~390 instructions per 256-voxel output row at 2.5 waves
- * per SIMD (16 KB of ring per wave) is what is left -- prefetching the plane loads two outputs ahead, or reading
- * each ring row once and sliding an (a, b) pair on wave-uniform branches, measured no faster. */
-__device__ __forceinline__ int s3d_readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ float s3d_readlane_f(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-template <int HW, int WCAP>
-__global__ void __launch_bounds__(64)
-k_conv_z_ring(const float *__restrict__ src, float *__restrict__ dst, size_t plane4, int nz, int z0, int z1, float uf,
-              int uhw, int W, S3dTaps taps)
-{
-    __shared__ float4 ring[WCAP * 64];
-    const int lane = threadIdx.x;
-    const size_t col = (size_t)blockIdx.x * 64 + (size_t)lane;
-    const bool colok = col < plane4;
-    const size_t c = colok ? col : plane4 - 1;             /* loads stay inside the plane; the store is predicated */
-    const int zb = z0 + (int)blockIdx.y * 64;
-    const int ze = zb + 64 < z1 ? zb + 64 : z1;
-    if (zb >= ze) return;
-    /* prologue: the taps of plane zb + lane */
-    const int p = zb + lane < ze ? zb + lane : ze - 1;
-    const int dim_end = nz - 1;
-    float fr[2 * HW + 1];
-    int oa[2 * HW + 1], ob[2 * HW + 1];
-    int nlo = 0x7fffffff, nhi = -1;
-    {
-        const bool interior = p >= uhw && p <= nz - 2 - uhw;
-        float run = (float)p;
-#pragma unroll
-        for (int d = -HW; d <= HW; d++) {
-            const float step = (float)d * uf;
-            float coord;
-            if (interior) {
-                run = run - step;
-                coord = run;
-                run = run + step;
-            } else {
-                coord = (float)p - step;
-                if ((int)coord < 0)
-                    coord = -coord;
-                else if ((int)coord >= dim_end)
-                    coord = 2.0f * (float)dim_end - coord - 0.1f;
-            }
-            const int lo = (int)coord;
-            fr[d + HW] = coord - (float)lo;
-            oa[d + HW] = (lo % W) * 64;
-            ob[d + HW] = ((lo + 1) % W) * 64;
-            nlo = nlo < lo ? nlo : lo;
-            nhi = nhi > lo + 1 ? nhi : lo + 1;
-        }
-    }
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 *d4 = reinterpret_cast<float4 *>(dst);
-    int loaded = s3d_readlane_i(nlo, 0) - 1;               /* highest source plane in the ring */
-    for (int i = 0; i < ze - zb; i++) {
-        const int need = s3d_readlane_i(nhi, i);
-        while (loaded < need) {
-            ++loaded;
-            ring[(loaded % W) * 64 + lane] = s4[c + (size_t)loaded * plane4];
-        }
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int k = 0; k < 2 * HW + 1; k++) {
-            const float frac = s3d_readlane_f(fr[k], i);
-            const float4 a = ring[s3d_readlane_i(oa[k], i) + lane], b = ring[s3d_readlane_i(ob[k], i) + lane];
-            const float tap = taps.t[k];
-            acc.x = acc.x + tap * ((1.0f - frac) * a.x + frac * b.x);
-            acc.y = acc.y + tap * ((1.0f - frac) * a.y + frac * b.y);
-            acc.z = acc.z + tap * ((1.0f - frac) * a.z + frac * b.z);
-            acc.w = acc.w + tap * ((1.0f - frac) * a.w + frac * b.w);
-        }
-        if (colok) d4[col + (size_t)(zb + i) * plane4] = acc;
-    }
-}
-
-template <int WCAP>
-static bool launch_z_ring(int hw, const float *src, float *dst, size_t plane4, int nz, int z0, int z1, float uf, int uhw,
-                          int W, const S3dTaps &t, hipStream_t st)
-{
-    const dim3 grid(s3d_div_up(plane4, 64), s3d_div_up((size_t)(z1 - z0), 64)), block(64);
-    switch (hw) {
-#define S3D_ZR(H) case H: hipLaunchKernelGGL((k_conv_z_ring<H, WCAP>), grid, block, 0, st, src, dst, plane4, nz, z0, z1, uf, uhw, W, t); return true;
-    S3D_ZR(1) S3D_ZR(2) S3D_ZR(3) S3D_ZR(4) S3D_ZR(5) S3D_ZR(6) S3D_ZR(7) S3D_ZR(8) S3D_ZR(9)
-#undef S3D_ZR
-    default: return false;
-    }
-}
-
 static thread_local int g_no_dyadic = 0;      /* profiling / test knob of the calling thread: force the generic kernel */
-static thread_local int g_force_z_ring = 0;   /* test knob: the marching z kernel whatever the size of its grid */
+static thread_local int g_tab_over_dyadic = 0; /* A/B knob: the table-driven march also where the dyadic y / z kernels apply */
 static thread_local int g_force_tab = 0;      /* test knob: the table-driven passes (s3d_gauss_tab.hip) whatever the size of the volume */
 static thread_local int g_no_tab = 0;         /* profiling knob: never the table-driven passes */
 
@@ -506,7 +406,10 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
     }
     const size_t ib = strides[2] * (size_t)z0, ie = strides[2] * (size_t)z1;
     const bool vec4 = axis != 0 && (strides[1] & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15);
-    if (nc == 1 && !g_no_dyadic && vec4) {
+    /* dyadic spacing along y / z: the register kernels below -- except on large volumes (an anisotropic octave 0 whose slice
+     * spacing is 2, 4: the table-driven march is 20-25 % faster at 512^3 and level with them at 256^3) */
+    const bool big = (size_t)nx * ny * (size_t)(z1 - z0) >= ((size_t)1 << 25) && !g_no_tab;
+    if (nc == 1 && !g_no_dyadic && vec4 && !g_tab_over_dyadic && !big) {
         bool done = false;
         const size_t sa4 = strides[axis] / 4;
         if (uf == 0.5f) done = launch_dyadic_v4<1>(hw, d_src, d_dst, ib / 4, ie / 4, sa4, dims[axis], t, (hipStream_t)st);
@@ -542,19 +445,6 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
         if (uf == 0.5f) done = launch_dyadic<1>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
         else if (uf == 0.25f) done = launch_dyadic<2>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
         else if (uf == 0.125f) done = launch_dyadic<3>(hw, d_src, d_dst, ib, ie, strides[axis], dims[axis], t, (hipStream_t)st);
-        if (done) {
-            S3D_CHECK_LAUNCH();
-            return S3D_OK;
-        }
-    }
-    /* the marching z kernel only where its grid (a wave per 64 float4 columns and 64 planes) fills the GPU: on the small
-     * octaves of a pyramid it is a handful of waves walking the volume (26-49 us at 32^3 where the plain kernel takes 6) */
-    if (vec4 && !g_no_dyadic && axis == 2 && nc == 1 &&
-        (g_force_z_ring || s3d_div_up(strides[2] / 4, 64) * (size_t)s3d_div_up((size_t)(z1 - z0), 64) >= 512)) {
-        const int W = 2 * uhw + 4;
-        bool done = false;
-        if (W <= 16) done = launch_z_ring<16>(hw, d_src, d_dst, strides[2] / 4, nz, z0, z1, uf, uhw, W, t, (hipStream_t)st);
-        else if (W <= 32) done = launch_z_ring<32>(hw, d_src, d_dst, strides[2] / 4, nz, z0, z1, uf, uhw, W, t, (hipStream_t)st);
         if (done) {
             S3D_CHECK_LAUNCH();
             return S3D_OK;
@@ -1069,14 +959,15 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
 static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk().  Per calling thread. */
 
 /* profiling / test knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
- * bit 1 = no specialisation of the generic axis pass at all (k_conv_axis only); bit 2 = k_conv_z_ring also where its grid
- * would not fill the GPU (tests reach it on small volumes); bit 3 = the table-driven passes (s3d_gauss_tab.hip) also on
- * small volumes (tests); bit 4 = never the table-driven passes (A/B runs) */
+ * bit 1 = no specialisation of the generic axis pass at all (k_conv_axis only); bit 2 = unused (was: the per-wave LDS-ring z
+ * kernel of round 3, superseded by the table-driven march); bit 3 = the table-driven passes (s3d_gauss_tab.hip) also on
+ * small volumes (tests); bit 4 = never the table-driven passes (A/B runs); bit 5 = the table-driven march also where the
+ * dyadic y / z kernels apply (A/B runs) */
 extern "C" void s3d_k_gauss_set_mode(int mode)
 {
     g_gauss_mode = mode & 1;
     g_no_dyadic = (mode >> 1) & 1;
-    g_force_z_ring = (mode >> 2) & 1;
+    g_tab_over_dyadic = (mode >> 5) & 1;
     g_force_tab = (mode >> 3) & 1;
     g_no_tab = (mode >> 4) & 1;
 }

@@ -588,11 +588,10 @@ def check_sep_fir_slab(lib, oracle, dims, units, sigmas, splits):
     L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
     L.s3d_k_gauss_set_tile3.argtypes = [C.c_long]
     try:
-        # mode 4: the marching z kernel (k_conv_z_ring) also on volumes whose grid would not fill the GPU -- the library
-        # picks it by grid size, these volumes are small.  The one-launch tile kernel would take volumes this small
+        # mode 8: the table-driven passes (s3d_gauss_tab.hip) also on volumes this small -- the library takes them above 64^3.  The one-launch tile kernel would take volumes this small
         # before any of the pass kernels: off here, check_sep_fir_tile3 is its test.
         L.s3d_k_gauss_set_tile3(0)
-        for mode in (0, 4):
+        for mode in (0, 8):
             L.s3d_k_gauss_set_mode(mode)
             for sigma in sigmas:
                 taps = np.ascontiguousarray(oracle.gauss_taps(sigma), np.float32)

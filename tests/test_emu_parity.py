@@ -29,8 +29,8 @@ def emu():
     ((20, 18, 16), (2, 2, 2), 1, 2.45255, 1.0),        # octave-1 spacing (half-voxel taps)
     ((19, 23, 18), (1, 0.7, 2), 1, 1.54501, 1.0),      # anisotropic (non-dyadic: coordinate drift)
     ((12, 13, 11), (1, 1, 2), 3, 1.22627, -1.0),       # multi-channel, unit = -1
-    ((24, 20, 70), (1, 1, 1.5), 1, 2.45255, 1.0),      # LDS-ring z pass (generic spacing), two z chunks, ragged columns
-    ((20, 24, 40), (1, 1, 0.7), 1, 1.54501, 1.0),      # the same with taps 1.43 planes apart (32-row ring)
+    ((24, 20, 70), (1, 1, 1.5), 1, 2.45255, 1.0),      # generic z spacing (2/3 plane), integral hw * uf
+    ((20, 24, 40), (1, 1, 0.7), 1, 1.54501, 1.0),      # taps 1.43 planes apart
 ])
 def test_sep_fir_api(emu, oracle, dims, units, nc, sigma, unit):
     parity.check_sep_fir_api(emu, oracle, dims, units, nc, sigma, unit)

@@ -79,7 +79,7 @@ def test_loopback_ranks_equal_single_gpu(hip, world, dims, nblobs, seed, o_shard
 
 
 def test_loopback_anisotropic_slices(hip):
-    """units (1, 1, 1.5): the z pass of the slabs runs with fractional taps (k_conv_z_ring where the grid is large enough) and a wider halo."""
+    """units (1, 1, 1.5): the z pass of the slabs runs with fractional taps (the table-driven march above 64^3) and a wider halo."""
     vol = synth.blobs(80, 72, 256, 1500, 9)
     want = single_gpu(hip, vol, (1, 1, 1.5))
     out = loopback(hip.sift, 2, vol, (1, 1, 1.5))
