@@ -106,6 +106,11 @@ typedef struct {
 int sift3d_amd_slab_create(sift3d_amd_slab **out, const SIFT3D *params, const sift3d_amd_transport *t, int nx,
                            int ny, int nz, double ux, double uy, double uz, void *hip_stream);
 void sift3d_amd_slab_destroy(sift3d_amd_slab *sl);
+/* The plan of rank `rank` of a `world`-way job WITHOUT a device (no transport, no allocation): z0/z1, o_shard, halo,
+ * num_octaves/levels and device_bytes = what sift3d_amd_slab_create would allocate; the other fields are 0.  Fails with
+ * the message of the real call where that would refuse the decomposition (slabs thinner than a descriptor window). */
+int sift3d_amd_slab_plan(const SIFT3D *params, int world, int rank, int nx, int ny, int nz, double ux, double uy, double uz,
+                         sift3d_amd_slab_info *info);
 int sift3d_amd_slab_get_info(const sift3d_amd_slab *sl, sift3d_amd_slab_info *info);
 
 /* SIFT3D_detect_keypoints for this rank's slab: `vol` = base slices [z0, z1) (x fastest, nx*ny*(z1-z0) floats),
@@ -125,7 +130,8 @@ int sift3d_amd_slab_owner(const sift3d_amd_slab *sl, const Keypoint *key);
 /* Seconds a rank waits for its stream (i.e. for its peers) before it aborts its transport and fails: environment
  * variable SIFT3D_SLAB_TIMEOUT_S, default 120, 0 = wait for ever. */
 
-/* TEST HOOK: the next time rank `rank` passes point `where` it fails as if an allocation / copy had failed there
+/* TEST HOOK, present only in the TESTING build of the library (-DS3D_TESTING: lib/libsift3d_amd_testing.so and the
+ * emulator build of the test suite): the next time rank `rank` passes point `where` it fails as if an allocation / copy had failed there
  * (1: slab_create, 2: detect before any collective, 3: detect inside the pyramid after the first halo exchange,
  * 4: detect before the candidate lists are sized, 5: describe).  One shot; rank < 0 disarms. */
 void sift3d_amd_slab_test_inject(int rank, int where);

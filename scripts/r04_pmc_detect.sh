@@ -8,7 +8,7 @@ P3="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MI
 i=0; dbs=""
 for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  S3D_NO_EXTREMA_OVERLAP=1 DIMS=$DIMS UNITS=$UNITS REPS=2 timeout 300 rocprofv3 --pmc $P --kernel-trace -d "$R/gpurun_out/${TAG}_pmc$i" -o pmc -- python "$R/scripts/detect_one.py" > "$R/gpurun_out/${TAG}_pmc$i.log" 2>&1
+  SIFT3D_AMD_LIB=$R/sift3d_amd/lib/libsift3d_amd_testing.so S3D_NO_EXTREMA_OVERLAP=1 DIMS=$DIMS UNITS=$UNITS REPS=2 timeout 300 rocprofv3 --pmc $P --kernel-trace -d "$R/gpurun_out/${TAG}_pmc$i" -o pmc -- python "$R/scripts/detect_one.py" > "$R/gpurun_out/${TAG}_pmc$i.log" 2>&1
   f=$(find "$R/gpurun_out/${TAG}_pmc$i" -name "*.db" | head -1); [ -n "$f" ] && dbs="$dbs $f"
 done
 python "$R/scripts/pmc_summary.py" $dbs > "$R/gpurun_out/${TAG}_pmc_detect.md" 2>&1

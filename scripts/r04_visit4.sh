@@ -13,6 +13,6 @@ run() {  # tag dims units
   rm -rf gpurun_out/tr_$1
 }
 run unit512 512,512,512 1,1,1
-S3D_NO_EXTREMA_OVERLAP=1 run unit512_serial 512,512,512 1,1,1
+SIFT3D_AMD_LIB=$R/sift3d_amd/lib/libsift3d_amd_testing.so S3D_NO_EXTREMA_OVERLAP=1 run unit512_serial 512,512,512 1,1,1
 timeout 600 python scripts/tab_time.py detects > gpurun_out/v4_tab_detects.txt 2>&1; echo "exit $?" >> gpurun_out/v4_tab_detects.txt
 grep "mode  0" gpurun_out/v4_tab_detects.txt

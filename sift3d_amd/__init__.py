@@ -38,6 +38,24 @@ def load() -> "abi.Sift3dLib":
     return lib
 
 
+_cdll_testing = None
+
+
+def load_testing() -> "abi.Sift3dLib":
+    """The TESTING build of the library (lib/libsift3d_amd_testing.so: the product's objects with the diagnostic
+    switches and the failure-injection hook of csrc/host/s3d_host.h compiled in).  For the few tests that need them."""
+    global _cdll_testing
+    from .device import bind_extensions
+    if _cdll_testing is None:
+        path = _os.path.join(_HERE, "lib", "libsift3d_amd_testing.so")
+        if not _os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -m sift3d_amd.build`")
+        _cdll_testing = _C.CDLL(path)
+    lib = abi.Sift3dLib(_cdll_testing, None, "sift3d_amd (testing build)")
+    bind_extensions(lib.sift)
+    return lib
+
+
 def load_device() -> "device.DeviceLib":
     """The flat device C-ABI (s3d_rt_* / s3d_k_*) of include/s3d_device.h."""
     from .device import DeviceLib

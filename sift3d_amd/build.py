@@ -51,6 +51,12 @@ def _run(cmd):
         raise RuntimeError("build failed: " + cmd[-1])
 
 
+# Sources with diagnostic switches / test hooks behind -DS3D_TESTING (csrc/host/s3d_host.h): compiled a second time for
+# lib/libsift3d_amd_testing.so, which differs from the product library in these objects only.  The product library has
+# neither sift3d_amd_slab_test_inject nor the S3D_* environment switches.
+TESTING_SOURCES = ["s3d_gauss.hip", "s3d_keypoint.hip", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_slab.c"]
+
+
 def build(verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(INC, h) for h in os.listdir(INC)] + \
@@ -78,6 +84,24 @@ def build(verbose: bool = False) -> str:
         # -Bsymbolic: the library's own calls to init_im & co bind to itself even if another libimutil
         # (e.g. the reference oracle in a test process) is loaded.
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", out, *objs, "-lm", "-lz",
+              "-lpthread", "-ldl"])
+    # the TESTING variant: the same objects, TESTING_SOURCES recompiled with -DS3D_TESTING
+    tobjs = list(objs)
+    for s in TESTING_SOURCES:
+        src = os.path.join(CSRC, s)
+        base = os.path.basename(s).rsplit(".", 1)[0]
+        o = os.path.join(OBJ, base + ".testing.o")
+        if _newer(src, o, headers):
+            if verbose:
+                print("testing build:", s)
+            if s.endswith(".hip"):
+                _run([HIPCC, *HIP_FLAGS, *EXTRA_HIP_FLAGS.get(s, []), "-DS3D_TESTING", "-c", src, "-o", o])
+            else:
+                _run(["gcc", *C_FLAGS, "-DS3D_TESTING", "-c", src, "-o", o])
+        tobjs[tobjs.index(os.path.join(OBJ, base + ".o"))] = o
+    tout = os.path.join(LIB, "libsift3d_amd_testing.so")
+    if any(_newer(o, tout) for o in tobjs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", tout, *tobjs, "-lm", "-lz",
               "-lpthread", "-ldl"])
     synth = os.path.join(LIB, "libs3d_synth.so")
     ssrc = os.path.join(CSRC, "synth.c")

@@ -35,4 +35,14 @@ int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descr
 int s3d_mgpu_info(const struct s3d_mgpu *m, int r, void *info);
 void s3d_mgpu_free(struct s3d_mgpu *m);
 
+/* Diagnostic switches (ablation, A/B and failure-injection aids of the test suite) exist only in the TESTING build of the
+ * library (-DS3D_TESTING: lib/libsift3d_amd_testing.so, tests/emu); the product build compiles them out -- S3D_DIAG_ENV is
+ * then a constant NULL and the branches behind it disappear.  The runtime switches the product does read are listed in
+ * INTEGRATION.md. */
+#if defined(S3D_TESTING)
+#define S3D_DIAG_ENV(name) getenv(name)
+#else
+#define S3D_DIAG_ENV(name) ((const char *)0)
+#endif
+
 #endif

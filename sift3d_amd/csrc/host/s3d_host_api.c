@@ -591,7 +591,7 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
     double units[3] = {sift3d->im.ux, sift3d->im.uy, sift3d->im.uz};
     s3d_stream es = NULL;
     static int no_overlap = -1;                           /* diagnostics: S3D_NO_EXTREMA_OVERLAP=1, read once */
-    if (no_overlap < 0) no_overlap = getenv("S3D_NO_EXTREMA_OVERLAP") != NULL;
+    if (no_overlap < 0) no_overlap = S3D_DIAG_ENV("S3D_NO_EXTREMA_OVERLAP") != NULL;
     c->extrema_enqueued = 0;
     if (with_extrema && !no_overlap) {
         if (ctx_ensure_candidates(c, candidate_capacity(c))) return SIFT3D_FAILURE;

@@ -83,7 +83,7 @@ static int s3d_ratio_reject(double ssd_best, double ssd_nearest, float nn_thresh
 static int s3d_best2(const float *d_a, size_t a_stride, const int *d_a_sel, uint32_t na, const float *d_b, size_t b_stride,
                      uint32_t nb, double *d_best, double *d_second, int *d_idx, void *stream)
 {
-    if (getenv("S3D_NN_EXHAUSTIVE") == NULL) {
+    if (S3D_DIAG_ENV("S3D_NN_EXHAUSTIVE") == NULL) {
         const int rc = s3d_k_nn_best2_fast(d_a, a_stride, d_a_sel, na, d_b, b_stride, nb, d_best, d_second, d_idx, stream);
         if (rc <= 0) return rc;
     }
@@ -113,7 +113,7 @@ int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const fl
         goto done;
 
     /* both directions from one score matrix when it fits (s3d_k_nn_match2_fast); otherwise pass by pass below */
-    if (getenv("S3D_NN_EXHAUSTIVE") == NULL && getenv("S3D_NN_TWO_PASS") == NULL) {
+    if (S3D_DIAG_ENV("S3D_NN_EXHAUSTIVE") == NULL && S3D_DIAG_ENV("S3D_NN_TWO_PASS") == NULL) {
         const size_t m = (size_t)nb;
         double *d_b2 = NULL, *h_b2 = (double *)malloc(2 * m * sizeof(double));
         int *d_bi = NULL, *h_bi = (int *)malloc(m * sizeof(int));
@@ -122,7 +122,7 @@ int sift3d_amd_nn_match_dev(const float *d_a, size_t a_stride, long na, const fl
             s3d_rt_malloc((void **)&d_bi, m * sizeof(int)) == 0) {
             fast = s3d_k_nn_match2_fast(d_a, a_stride, (uint32_t)na, d_b, b_stride, (uint32_t)nb, d_best, d_best + n, d_idx,
                                         d_b2, d_b2 + m, d_bi, stream);
-            if (getenv("S3D_NN_DEBUG")) S3D_MSG("SIFT3D_nn_match: one-matrix screening returned %d (%s)\n", fast, s3d_rt_last_error());
+            if (S3D_DIAG_ENV("S3D_NN_DEBUG")) S3D_MSG("SIFT3D_nn_match: one-matrix screening returned %d (%s)\n", fast, s3d_rt_last_error());
             if (fast == 0 &&
                 (s3d_rt_d2h(h_best, d_best, 2 * n * sizeof(double), stream) || s3d_rt_d2h(h_idx, d_idx, n * sizeof(int), stream) ||
                  s3d_rt_d2h(h_b2, d_b2, 2 * m * sizeof(double), stream) || s3d_rt_d2h(h_bi, d_bi, m * sizeof(int), stream) ||

@@ -52,7 +52,9 @@ static double slab_timeout_s(void)
     return t;
 }
 
-/* test hook (sift3d_amd_slab_test_inject): one-shot failure of rank g_inject_rank at point g_inject_where */
+/* test hook (sift3d_amd_slab_test_inject): one-shot failure of rank g_inject_rank at point g_inject_where.  TESTING
+ * build only; the product library has neither the symbol nor the checks. */
+#if defined(S3D_TESTING)
 static volatile int g_inject_rank = -1, g_inject_where = 0;
 void sift3d_amd_slab_test_inject(int rank, int where) { g_inject_where = where; g_inject_rank = rank; }
 static int injected(int rank, int where)
@@ -65,6 +67,9 @@ static int injected(int rank, int where)
     do {                                                                                                          \
         if (injected((sl)->t.rank, (where))) SLAB_FAIL("sift3d_amd slab: injected failure %d on rank %d", (where), (sl)->t.rank); \
     } while (0)
+#else
+#define INJECT(sl, where) ((void)0)
+#endif
 
 static double now_ms(void)
 {
@@ -90,6 +95,7 @@ struct sift3d_amd_slab {
     sift3d_amd_transport t;
     s3d_stream cs, ms;              /* compute stream; transfer stream of the deferred halo planes */
     int own_cs;
+    int dry;                        /* planning only (sift3d_amd_slab_plan): no device call, allocations are counted */
     void *ev_ready, *ev_done;
     int pending;                    /* deferred halo transfers in flight on ms */
     SIFT3D plan;                    /* host-side plan: pyramid metadata, filter bank, thresholds */
@@ -183,8 +189,10 @@ static int slab_sync(sift3d_amd_slab *sl)
 static int dmalloc(sift3d_amd_slab *sl, void *pp, size_t bytes, int zero)
 {
     void **p = (void **)pp;
-    DEV(s3d_rt_malloc(p, bytes));
-    if (zero) DEV(s3d_rt_memset(*p, 0, bytes, sl->cs));
+    if (!sl->dry) {
+        DEV(s3d_rt_malloc(p, bytes));
+        if (zero) DEV(s3d_rt_memset(*p, 0, bytes, sl->cs));
+    }
     sl->device_bytes += (double)bytes;
     return SIFT3D_SUCCESS;
 }
@@ -259,6 +267,12 @@ static int plan_partition(sift3d_amd_slab *sl)
 void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
 {
     if (sl == NULL) return;
+    if (sl->dry) {                                       /* nothing on a device */
+        cleanup_SIFT3D(&sl->plan);
+        free(sl->bounds);
+        free(sl);
+        return;
+    }
     s3d_rt_sync(sl->cs);
     if (sl->ms) s3d_rt_sync(sl->ms);
     for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&sl->lev[i].base);
@@ -305,14 +319,16 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
     }
     if (plan_partition(sl)) return SIFT3D_FAILURE;
 
-    if (hip_stream) sl->cs = (s3d_stream)hip_stream;
-    else { DEV(s3d_rt_stream_create(&sl->cs)); sl->own_cs = 1; }
-    DEV(s3d_rt_stream_create(&sl->ms));
-    DEV(s3d_rt_event_create(&sl->ev_ready));
-    DEV(s3d_rt_event_create(&sl->ev_done));
-    if (G > 1) {
-        DEV(s3d_rt_event_create(&sl->ev_reach));
-        for (int i = 0; i < 2 * SLAB_MAX_OPS; i++) DEV(s3d_rt_event_create(&sl->ev_op[i]));
+    if (!sl->dry) {
+        if (hip_stream) sl->cs = (s3d_stream)hip_stream;
+        else { DEV(s3d_rt_stream_create(&sl->cs)); sl->own_cs = 1; }
+        DEV(s3d_rt_stream_create(&sl->ms));
+        DEV(s3d_rt_event_create(&sl->ev_ready));
+        DEV(s3d_rt_event_create(&sl->ev_done));
+        if (G > 1) {
+            DEV(s3d_rt_event_create(&sl->ev_reach));
+            for (int i = 0; i < 2 * SLAB_MAX_OPS; i++) DEV(s3d_rt_event_create(&sl->ev_op[i]));
+        }
     }
     INJECT(sl, 1);
 
@@ -359,6 +375,7 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
         dmalloc(sl, &sl->d_red, 16 * sizeof(float), 1) || dmalloc(sl, &sl->d_count, 8 * sizeof(uint32_t), 1) ||
         dmalloc(sl, &sl->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS, 0))
         return SIFT3D_FAILURE;
+    if (sl->dry) return dmalloc(sl, &sl->d_mesh, sizeof(float) * S3D_MESH_FLOATS, 0);
     {
         float mesh[S3D_MESH_FLOATS];
         s3d_mesh_table(mesh);
@@ -399,6 +416,27 @@ int sift3d_amd_slab_create(sift3d_amd_slab **out, const SIFT3D *params, const si
     }
     *out = sl;
     return SIFT3D_SUCCESS;
+}
+
+/* The plan of rank `rank` of a `world`-way job without touching a device: partition, halo, sharded octaves and the bytes
+ * sift3d_amd_slab_create would allocate (the candidate and descriptor lists a detect sizes later are not in it).  Fails,
+ * with the message of the real call, where that would refuse the decomposition. */
+int sift3d_amd_slab_plan(const SIFT3D *params, int world, int rank, int nx, int ny, int nz, double ux, double uy, double uz,
+                         sift3d_amd_slab_info *info)
+{
+    sift3d_amd_slab *sl;
+    int rc;
+    if (params == NULL || info == NULL || world < 1 || rank < 0 || rank >= world || nx < 1 || ny < 1 || nz < 1)
+        SLAB_FAIL("sift3d_amd_slab_plan: bad arguments");
+    if ((sl = (sift3d_amd_slab *)calloc(1, sizeof(*sl))) == NULL) SLAB_FAIL("sift3d_amd_slab_plan: out of memory");
+    sl->dry = 1;
+    sl->t.world = world; sl->t.rank = rank;
+    sl->nx = nx; sl->ny = ny; sl->nz = nz;
+    sl->units[0] = ux; sl->units[1] = uy; sl->units[2] = uz;
+    rc = slab_build(sl, params, NULL);
+    if (rc == SIFT3D_SUCCESS) rc = sift3d_amd_slab_get_info(sl, info);
+    sift3d_amd_slab_destroy(sl);
+    return rc;
 }
 
 int sift3d_amd_slab_get_info(const sift3d_amd_slab *sl, sift3d_amd_slab_info *info)
@@ -443,7 +481,7 @@ static int exchange_halo(sift3d_amd_slab *sl, const s3d_lev *lv, int o, int h, i
     const int z0 = sl->part[o][0], z1 = sl->part[o][1];
     /* S3D_SLAB_NO_DEFER=1: every halo plane ordered with the compute stream, one communicator in use (debugging aid) */
     static int no_defer = -1;
-    if (no_defer < 0) { const char *e = getenv("S3D_SLAB_NO_DEFER"); no_defer = e && atoi(e) ? 1 : 0; }
+    if (no_defer < 0) { const char *e = S3D_DIAG_ENV("S3D_SLAB_NO_DEFER"); no_defer = e && atoi(e) ? 1 : 0; }
     const int n = (now <= 0 || now >= h || no_defer) ? h : now;
     const size_t pb = lv->pe * sizeof(float);
     const int sides = (sl->t.rank > 0) + (sl->t.rank < sl->t.world - 1);

@@ -1305,13 +1305,17 @@ k_gauss3_tile(const float *__restrict__ src, float *__restrict__ dst, G3Geom g, 
     }
 }
 
-/* volumes up to this many output voxels take the tile kernel (0: never).  Per calling thread; the initial value comes
- * from the environment (S3D_TILE3_MAX) once per process, for profiling runs. */
+/* volumes up to this many output voxels take the tile kernel (0: never).  Per calling thread; in the TESTING build the
+ * initial value comes from the environment (S3D_TILE3_MAX) once per process, for profiling runs. */
 static long tile3_default()
 {
     static long v = -1;
     if (v < 0) {
+#if defined(S3D_TESTING)
         const char *e = getenv("S3D_TILE3_MAX");
+#else
+        const char *e = nullptr;
+#endif
         v = e ? atol(e) : 64L * 64L * 64L;
         if (v < 0) v = 0;
     }

@@ -662,7 +662,11 @@ extern "C" int s3d_k_orient_mode(void)
 {
     static int env_mode = -1;
     if (env_mode < 0) {
+#if defined(S3D_TESTING)
         const char *e = getenv("S3D_ORI_MODE");
+#else
+        const char *e = nullptr;
+#endif
         env_mode = e ? atoi(e) : 0;
         if (env_mode < 0 || env_mode > 2) env_mode = 0;
     }

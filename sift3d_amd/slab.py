@@ -82,8 +82,9 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.s3d_rt_sync.argtypes = [_vp]
     L.s3d_rt_last_error.restype = C.c_char_p
     L.sift3d_amd_last_error.restype = C.c_char_p
-    L.sift3d_amd_slab_test_inject.argtypes = [C.c_int, C.c_int]
-    L.sift3d_amd_slab_test_inject.restype = None
+    if hasattr(L, "sift3d_amd_slab_test_inject"):          # the TESTING build of the library only
+        L.sift3d_amd_slab_test_inject.argtypes = [C.c_int, C.c_int]
+        L.sift3d_amd_slab_test_inject.restype = None
     if hasattr(L, "sift3d_amd_rccl_unique_id"):          # absent from builds without the RCCL transport
         L.sift3d_amd_rccl_unique_id.argtypes = [C.c_char_p]
         L.sift3d_amd_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int, P(Transport)]

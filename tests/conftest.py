@@ -39,3 +39,10 @@ def hip():
     """The product library through the reference's C API (fails loudly when not built / no GPU)."""
     import sift3d_amd
     return sift3d_amd.load()
+
+
+@pytest.fixture(scope="session")
+def hip_testing():
+    """The TESTING build of the product library (diagnostic switches and the failure-injection hook compiled in)."""
+    import sift3d_amd
+    return sift3d_amd.load_testing()

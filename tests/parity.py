@@ -380,7 +380,7 @@ def check_describe_window(lib, oracle, dims, units, nblobs, seed):
     return len(xyzos), int(cnt.sum())
 
 
-def check_nn_match_duplicates(lib, oracle, thr=0.8):
+def check_nn_match_duplicates(lib, oracle, thr=0.8, knobs=True):
     """More than 64 exact duplicates of one descriptor in the second set: the screened matcher must hand the pass to
     the exhaustive kernel (candidate overflow) and still return the oracle's matches."""
     from tests.util import rand_desc
@@ -389,7 +389,7 @@ def check_nn_match_duplicates(lib, oracle, thr=0.8):
     want = oracle.nn_match(d1, d2, thr)
     rc, got, _ = nn_match_api(lib, d1, d2, thr)
     assert rc == 0 and np.array_equal(got, want)
-    for knob in ("S3D_NN_EXHAUSTIVE", "S3D_NN_TWO_PASS"):   # the exhaustive kernel / the pass-by-pass screened form
+    for knob in ("S3D_NN_EXHAUSTIVE", "S3D_NN_TWO_PASS") if knobs else ():   # the exhaustive kernel / the pass-by-pass screened form (TESTING build)
         os.environ[knob] = "1"
         try:
             rc, got, _ = nn_match_api(lib, d1, d2, thr)

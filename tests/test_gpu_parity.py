@@ -18,6 +18,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def libt(hip_testing):
+    from sift3d_amd.device import DeviceLib
+    assert DeviceLib(hip_testing.sift).device_count() >= 1
+    return hip_testing
+
+
+@pytest.fixture(scope="module")
 def lib(hip):
     dev = parity.dev_of(hip)
     assert dev.device_count() >= 1, "no HIP device: the HIP path has no CPU fallback"
@@ -237,17 +244,19 @@ def test_nn_match_vs_oracle(lib, oracle, n1, seed, thr):
     assert parity.check_nn_match(lib, oracle, n1, seed, thr) > 0
 
 
-def test_nn_match_pass_by_pass(lib, oracle):
-    """The screened matcher in its pass-by-pass form (used when the score matrix exceeds the budget)."""
+def test_nn_match_pass_by_pass(libt, oracle):
+    """The screened matcher in its pass-by-pass form (used when the score matrix exceeds the budget).  The switch that
+    forces it exists in the TESTING build of the library only."""
     os.environ["S3D_NN_TWO_PASS"] = "1"
     try:
-        assert parity.check_nn_match(lib, oracle, 3001, 4, 0.7) > 0
+        assert parity.check_nn_match(libt, oracle, 3001, 4, 0.7) > 0
     finally:
         del os.environ["S3D_NN_TWO_PASS"]
 
 
-def test_nn_match_candidate_overflow(lib, oracle):
-    assert parity.check_nn_match_duplicates(lib, oracle) >= 3
+def test_nn_match_candidate_overflow(lib, libt, oracle):
+    assert parity.check_nn_match_duplicates(lib, oracle, knobs=False) >= 3
+    assert parity.check_nn_match_duplicates(libt, oracle) >= 3
 
 
 def test_nn_match_unnormalised_stores(lib, oracle):
@@ -257,11 +266,11 @@ def test_nn_match_unnormalised_stores(lib, oracle):
 
 
 @pytest.mark.parametrize("n1,seed", [(3001, 4), (1000, 3)])
-def test_nn_match_exhaustive_kernel(lib, oracle, n1, seed):
-    """The exhaustive f64 kernel (the fallback of the screened matcher) on its own."""
+def test_nn_match_exhaustive_kernel(libt, oracle, n1, seed):
+    """The exhaustive f64 kernel (the fallback of the screened matcher) on its own (TESTING build: the switch)."""
     os.environ["S3D_NN_EXHAUSTIVE"] = "1"
     try:
-        assert parity.check_nn_match(lib, oracle, n1, seed, 0.8) > 0
+        assert parity.check_nn_match(libt, oracle, n1, seed, 0.8) > 0
     finally:
         del os.environ["S3D_NN_EXHAUSTIVE"]
 

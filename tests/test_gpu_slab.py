@@ -160,11 +160,12 @@ def test_rccl_transport_with_a_world_of_one(hip):
     dev.free(d_b)
 
 
-def test_failed_rank_does_not_hang_on_the_device(hip):
+def test_failed_rank_does_not_hang_on_the_device(hip_testing):
     """The abort path on real streams (loop-back ranks sharing this GPU): rank 1 fails in the middle of the pyramid, after
     the first halo exchange, with kernels and copies of both ranks in flight.  SIFT3D_detect_keypoints must come back with
     SIFT3D_FAILURE (pytest-timeout / the driver's limit is the no-hang assertion), and the same struct must then produce the
-    single-GPU result.  The same for a failure inside a describe."""
+    single-GPU result.  The same for a failure inside a describe.  (TESTING build of the library: the injection hook.)"""
+    hip = hip_testing
     L = S.bind(hip.sift)
     vol = synth.blobs(96, 80, 192, 1400, 5)
     want = single_gpu(hip, vol)
