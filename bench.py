@@ -13,13 +13,15 @@ A step = one pass of the hot path over one synthetic volume that is ALREADY RESI
 SIFT3D_detect_keypoints (copy + scale + 36 Gaussian applications + extrema + orientation; the small
 keypoint list is downloaded because the API returns it) followed by SIFT3D_extract_descriptors for
 every keypoint with the descriptors left in HBM.  At N = 1 the workload is BASELINE.json configs[1]:
-512^3 float32, "blobs+noise" generator, 128 000 blobs (31 207 keypoints).  At N > 1 the workload is ONE
-512 x 512 x (512*N) volume sharded by Z-slab over the N GPUs by the host-C driver of
-include/sift3d_amd_slab.h (csrc/host/s3d_host_slab.c): 512 slices per GPU (weak scaling), halo planes exchanged
-with ncclSend/ncclRecv between Z-neighbours, ncclAllReduce(max) for the scale and peak thresholds, ncclAllGather
-for the seed of the replicated coarse octaves; BASELINE configs[3] (one 1024^3 volume in
-nz/N-slice slabs) rides along untimed as config.strong_1024, or is the timed workload with --strong.
-`--replicas` runs one independent volume per rank instead; `--loopback R` runs R slab ranks on ONE GPU (diagnostic).
+512^3 float32, "blobs+noise" generator, 128 000 blobs (31 207 keypoints).  At N > 1 the workload is BASELINE
+configs[3], the one north_star quotes its multi-GPU figure on: ONE 1024^3 volume sharded by Z-slab over the N GPUs
+("scaling": "strong": the work is fixed, nz/N slices per GPU) by the host-C driver of include/sift3d_amd_slab.h
+(csrc/host/s3d_host_slab.c): halo planes exchanged with ncclSend/ncclRecv between Z-neighbours, ncclAllReduce(max)
+for the scale and peak thresholds, ncclAllGather for the seed of the replicated coarse octaves (SURVEY.md section
+8e).  The weak-scaling volume (512 x 512 x 512*N, 512 slices per GPU) rides along untimed as config.weak_512xN, or is
+the timed workload with --weak.  `--dry` prints the plan of such a job (partition, halo, sharded octaves, HBM per rank) for
+N = 2, 4, 8 without touching a device.  `--replicas` runs one independent volume per rank instead; `--loopback R` runs
+R slab ranks on ONE GPU (diagnostic).
 
 One JSON line on stdout (rank 0).  Besides the driver's contract it carries
   roofline      the fused X+Y Gaussian kernel at 512^3 (dominant kernel of the north-star Gaussian),
@@ -132,7 +134,7 @@ def _cpu_baseline_worker(sample_n):
                                 f"{dt:.1f} s, {threads} OpenMP threads)"}), flush=True)
 
 
-def cpu_baseline(sample_n=160):
+def cpu_baseline(sample_n=160, timeout=600):
     """The CPU leg runs in a child process with a bounded OpenMP team: the reference calls LAPACK from
     inside its OpenMP loops and the OpenBLAS bundled with scipy aborts beyond 128 caller threads (this
     box has 256 hardware threads); OPENBLAS_NUM_THREADS=1 as in BASELINE.md."""
@@ -140,7 +142,7 @@ def cpu_baseline(sample_n=160):
     threads = min(os.cpu_count() or 1, 64)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1")
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(sample_n)], env=env,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=timeout)
     for line in reversed(r.stdout.strip().splitlines()):
         if line.startswith("{"):
             return json.loads(line)
@@ -239,13 +241,80 @@ def slab_result(args, per_rank, extra, dims, world, tname, rccl):
         cfg["rccl_ranks"], cfg["rccl_version"] = rccl       # what the communicator itself reports (ncclCommCount, ncclGetVersion)
     result = {"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": world,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-              "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+              "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
               "dtype": "f32", "data": "synthetic", "config": cfg}
     if extra is not None:
-        _, c3 = slab_summary(extra, (1024, 1024, 1024), 2, world, tname)
-        c3["workload"] = f"BASELINE configs[3]: one 1024^3 volume, Z-slabs of {extra[0]['slices']} slices on {world} GPUs"
-        result["config"]["strong_1024"] = c3
+        edims, ekey = extra_job(args, world)
+        _, c3 = slab_summary(extra, edims, 2, world, tname)
+        c3["workload"] = (f"one {edims[0]}x{edims[1]}x{edims[2]} volume, Z-slabs of {extra[0]['slices']} slices on {world} GPUs "
+                          f"({'BASELINE configs[3], strong scaling' if args.weak else 'weak scaling: 512 slices per GPU'}); 2 steps, untimed extra")
+        result["config"][ekey] = c3
     return result
+
+
+def timed_dims(args, world):
+    """The timed N > 1 workload: BASELINE configs[3] (one --strong-size^3 volume, strong scaling) unless --weak."""
+    n = args.size
+    return (n, n, n * world) if args.weak else (args.strong_size,) * 3
+
+
+def extra_job(args, world):
+    """The other decomposition, run for two untimed steps after the timed region."""
+    n = args.size
+    return ((args.strong_size,) * 3, "strong_1024") if args.weak else ((n, n, n * world), "weak_512xN")
+
+
+def dry_plan(L, dims, world, params=None):
+    """Plans of all ranks of a `world`-way Z-slab job on a dims volume (sift3d_amd_slab_plan: no device).  Raises
+    RuntimeError with the library's message where the real call would refuse the decomposition."""
+    from sift3d_amd import slab as S
+    s = S.make_params(L, params)
+    L.sift3d_amd_slab_plan.argtypes = [C.POINTER(abi.SIFT3D)] + [C.c_int] * 5 + [C.c_double] * 3 + [C.POINTER(S.SlabInfo)]
+    L.sift3d_amd_slab_last_error.restype = C.c_char_p
+    out = []
+    try:
+        for r in range(world):
+            inf = S.SlabInfo()
+            if L.sift3d_amd_slab_plan(C.byref(s), world, r, dims[0], dims[1], dims[2], 1.0, 1.0, 1.0, C.byref(inf)) != 0:
+                raise RuntimeError((L.sift3d_amd_slab_last_error() or b"").decode())
+            out.append(inf)
+    finally:
+        L.cleanup_SIFT3D(C.byref(s))
+    plane = dims[0] * dims[1] * 4
+    return {"volume": list(dims), "ranks": world,
+            "slices_per_rank": [int(i.z1 - i.z0) for i in out], "z_bounds": [int(out[0].z0)] + [int(i.z1) for i in out],
+            "sharded_octaves": int(out[0].o_shard) + 1, "octaves": int(out[0].num_octaves), "halo_planes": int(out[0].halo),
+            # planes a rank holds per sharded octave-0 level: its slices plus the halo on each interior side
+            "halo_overhead_octave0": round(2.0 * out[0].halo / max(1, min(int(i.z1 - i.z0) for i in out)), 3),
+            "halo_MiB_per_level_and_side_octave0": round(out[0].halo * plane / 2**20, 1),
+            "HBM_GiB_per_rank": [round(i.device_bytes / 2**30, 2) for i in out],
+            "fits_288_GB": all(i.device_bytes < 0.9 * 288e9 for i in out)}
+
+
+def dry_run(args):
+    """--dry: validate the decomposition of the N > 1 workloads without a device.  One JSON line."""
+    from sift3d_amd import slab as S
+    L = S.bind(sift3d_amd.cdll())
+    worlds = [args.gpus] if args.gpus > 1 else [2, 4, 8]
+    out = {"dry": True, "metric": METRIC, "plans": {}}
+    for N in worlds:
+        entry = {}
+        for key, dims in (("strong", (args.strong_size,) * 3), ("weak", (args.size, args.size, args.size * N))):
+            try:
+                entry[key] = dry_plan(L, dims, N, bench_params())
+            except RuntimeError as e:
+                entry[key] = {"volume": list(dims), "ranks": N, "refused": str(e)}
+        entry["timed"] = "weak" if args.weak else "strong"
+        entry["command"] = (f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {N} --master-addr 127.0.0.1 --master-port P "
+                            f"bench.py --gpus {N} --steps K --warmup W" + (" --weak" if args.weak else ""))
+        out["plans"][str(N)] = entry
+    # what a decomposition that cannot work says (slabs thinner than a descriptor window)
+    try:
+        dry_plan(L, (64, 64, 64), 8, bench_params())
+        out["refusal_example"] = None
+    except RuntimeError as e:
+        out["refusal_example"] = {"volume": [64, 64, 64], "ranks": 8, "refused": str(e)}
+    print(json.dumps(out), flush=True)
 
 
 def run_inprocess(args, dev):
@@ -262,7 +331,7 @@ def run_inprocess(args, dev):
         log(f"bench.py: --gpus {N} requested, {ndev} GPU(s) visible: refusing to benchmark fewer GPUs than asked for")
         raise SystemExit(2)
     n = args.size
-    dims = (args.strong_size,) * 3 if args.strong else (n, n, n * N)
+    dims = timed_dims(args, N)
     try:
         tr = S.rccl_all_transports(L, N)
         rccl = S.rccl_info(L, tr[0])
@@ -313,8 +382,8 @@ def run_inprocess(args, dev):
 
     per_rank = run(dims, args.steps, args.warmup, "timed")
     extra = None
-    if not args.no_match and not args.strong and N in (2, 4, 8, 16) and n >= 512:
-        extra = run((1024, 1024, 1024), 2, 1, "configs[3]")
+    if not args.no_match and N in (2, 4, 8, 16) and n >= 512:
+        extra = run(extra_job(args, N)[0], 2, 1, extra_job(args, N)[1])
     result = slab_result(args, per_rank, extra, dims, N, tname, rccl)
     dev.check(dev.L.s3d_rt_set_device(0), "set_device")
     if not args.no_roofline:
@@ -326,9 +395,9 @@ def run_inprocess(args, dev):
 
 def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
     """N > 1 under torchrun: one rank per GPU, the C Z-slab driver over RCCL (ncclSend/ncclRecv halos).  Timed
-    workload: ONE n x n x (n*N) volume, n slices per GPU (weak scaling; --strong: one --strong-size^3 volume, nz/N
-    slices per GPU).  After the timed region, unless --no-match: BASELINE configs[3] as named -- one 1024^3 volume in
-    nz/N-slice slabs (config.strong_1024)."""
+    workload: BASELINE configs[3] -- ONE --strong-size^3 volume (1024^3), nz/N slices per GPU, strong scaling (--weak: one
+    n x n x (n*N) volume, n slices per GPU).  After the timed region, unless --no-match: the other of the two for two
+    untimed steps (config.weak_512xN / config.strong_1024)."""
     import torch
     from sift3d_amd import slab as S
     L = sift3d_amd.cdll()
@@ -374,11 +443,11 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
             os._exit(3)
 
     n = args.size
-    dims = (args.strong_size,) * 3 if args.strong else (n, n, n * world)
+    dims = timed_dims(args, world)
     per_rank = gather(job(dims, args.steps, args.warmup, "timed"))
     extra = None
-    if not args.no_match and not args.strong and world in (2, 4, 8, 16) and n >= 512:
-        extra = gather(job((1024, 1024, 1024), 2, 1, "configs[3]"))
+    if not args.no_match and world in (2, 4, 8, 16) and n >= 512:
+        extra = gather(job(extra_job(args, world)[0], 2, 1, extra_job(args, world)[1]))
     if rank == 0:
         result = slab_result(args, per_rank, extra, dims, world, tname, rccl)
         if not args.no_roofline:
@@ -400,7 +469,7 @@ def run_loopback(args, dev):
     L = sift3d_amd.cdll()
     R = args.loopback
     n = args.size
-    dims = (args.strong_size,) * 3 if args.strong else (n, n, n * R)
+    dims = timed_dims(args, R)
     tr = S.loopback_transports(L, R)
     bar = threading.Barrier(R)
 
@@ -418,7 +487,7 @@ def run_loopback(args, dev):
     nvox = float(dims[0]) * dims[1] * dims[2]
     print(json.dumps({"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                      "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                      "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic", "config": cfg}), flush=True)
 
 
@@ -448,14 +517,25 @@ def add_roofline(result, dev, n):
     # HIP-event time.  `frac` credits the fusion (two algorithmic passes for one read and one write of the volume);
     # `physical_frac` is the DRAM-side rate against the same 8 TB/s -- the guide's float4-copy ceiling is 6.29 TB/s.
     phys = traffic / (worst["xy_ms"] * 1e-3) / 1e9 if traffic else None
-    result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+    # `frac`: one whole filter application (x, y and z passes: SURVEY 8(d)'s 24 algorithmic B/voxel) of the slowest width over
+    # the HIP-event time of its two kernels -- the figure north_star's ">= 70 % of the HBM roofline" is about.  Beside it:
+    # kernel_frac (the fused X+Y kernel alone on its 16 algorithmic B/voxel: two passes for one read and one write, so it can
+    # exceed what a copy could) and physical_frac (the PMC bytes of that kernel over the same time: what the DRAM side
+    # actually moved, against 8 TB/s; the guide's float4-copy ceiling is 6.29 TB/s).
+    slow = min(apps, key=lambda a: a["app_GBs"])
+    result["roofline"] = {"bound": "hbm", "achieved": slow["app_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(slow["app_GBs"] / HBM_PEAK_GBS, 4),
+                          "basis": f"one Gaussian application, width {slow['width']} (the slowest of the default bank): 24 algorithmic "
+                                   f"B/voxel x {int(nv)} voxels over xy {slow['xy_ms']} ms + z {slow['z_ms']} ms",
+                          "kernel_GBs": round(ach, 1), "kernel_frac": round(ach / HBM_PEAK_GBS, 4),
+                          "traffic": traffic, "traffic_source": traffic_source,
                           "physical_GBs": round(phys, 1) if phys else None,
                           "physical_frac": round(phys / HBM_PEAK_GBS, 4) if phys else None,
                           "physical_frac_of_copy_ceiling": round(phys / 6290.0, 4) if phys else None,
                           "time_source": f"HIP events on the launch stream inside this run (s3d_k_gauss_set_events), mean of 5 launches: "
-                                         f"{worst['xy_ms']} ms; the rocprofv3 --kernel-trace --stats average of the same kernel is kept in "
-                                         f"profiles/ (per round: r03_*_kernel_stats.md) and is a few per cent shorter (no event overhead)",
+                                         f"k_gauss_xy<{worst['width'] // 2}> {worst['xy_ms']} ms; the rocprofv3 --kernel-trace --stats average "
+                                         f"of the same kernel is kept in profiles/ (per round: rNN_*_kernel_stats.md) and was 8-9 % shorter in "
+                                         f"round 3 (281.8 vs 307.3 us: the events bracket launch gaps as well)",
                           "kernel": f"k_gauss_xy<{worst['width'] // 2}> (fused X+Y pass, width {worst['width']}): "
                                     f"16 algorithmic B/voxel x {int(nv)} voxels per launch"}
     result["config"]["gauss_apps"] = apps
@@ -473,15 +553,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="skip the untimed extras after the timed steps (matcher, descriptor-kernel statistics, host-buffer API, dense 256^3, anisotropic and two-volume configurations)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--strong", action="store_true",
-                    help="N > 1 (or --loopback): one --strong-size^3 volume split into nz/N-slice slabs instead of n slices per GPU")
-    ap.add_argument("--strong-size", type=int, default=1024, help="edge of the --strong volume (1024 = BASELINE configs[3])")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1 (or --loopback): time the weak-scaling volume (n x n x n*N, n slices per GPU) instead of BASELINE "
+                         "configs[3] (one --strong-size^3 volume in nz/N-slice slabs, the default)")
+    ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling is the default")
+    ap.add_argument("--strong-size", type=int, default=1024, help="edge of the strong-scaling volume (1024 = BASELINE configs[3])")
+    ap.add_argument("--dry", action="store_true",
+                    help="no device: print the Z-slab plan (partition, halo, sharded octaves, HBM per rank) of the N > 1 jobs for "
+                         "N = 2, 4, 8 (or --gpus N), and what a refused decomposition says")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the reference on BASELINE configs[1] itself (512^3: ~6.5 minutes on 64 cores) instead of quoting "
+                         "profiles/r03_cpu_baseline_512.json")
     ap.add_argument("--loopback", type=int, default=0,
                     help="diagnostic on one GPU: R Z-slab ranks as host threads sharing the device (loop-back transport)")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one independent volume per rank instead of the Z-slab decomposition")
     args = ap.parse_args()
 
+    if args.dry:
+        dry_run(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -762,6 +853,42 @@ def main():
             dev.free(d_vol2)
             lib.sift.cleanup_SIFT3D(C.byref(s4))
         lib.sift.cleanup_SIFT3D(C.byref(s3))
+    if rank == 0 and not args.no_match:
+        # Off the unit-voxel, multiple-of-four grid (outside the timed region): a 0.7 x 0.7 x 1.5 mm volume (clinical CT
+        # spacing: taps 1.43 voxels apart in plane, 2/3 along z -- every pass table-driven, s3d_gauss_tab.hip) and a volume
+        # whose rows are 511 voxels long.  ratio_to_unit = detect time per voxel over the unit-voxel 512^3 detect of this run.
+        unit_ps = t_detect / float(n) ** 3 * 1e12
+        for key, dims, units in (("aniso_0.7x0.7x1.5", (512, 512, 300), (0.7, 0.7, 1.5)), ("odd_511", (511, 509, 303), (1.0, 1.0, 1.0))):
+            ex, ey, ez = dims
+            evol = synth.blobs(ex, ey, ez, synth.default_nblobs(ex, ey, ez), 0)
+            d_e = dev.upload(evol)
+            se = abi.SIFT3D()
+            assert lib.sift.init_SIFT3D(C.byref(se)) == 0
+            kpe = abi.Keypoint_store()
+            lib.sift.init_Keypoint_store(C.byref(kpe))
+            de = C.c_void_p()
+            te = []
+            for _ in range(4):
+                dev.sync()
+                t0 = time.perf_counter()
+                rc = lib.sift.sift3d_amd_detect_keypoints_dev(C.byref(se), C.c_void_p(d_e), ex, ey, ez, *units, C.byref(kpe))
+                dev.sync()
+                t1 = time.perf_counter()
+                if rc == 0 and kpe.slab.num:
+                    rc = lib.sift.sift3d_amd_extract_descriptors_dev(C.byref(se), C.byref(kpe), C.byref(de))
+                dev.sync()
+                te.append((t1 - t0, time.perf_counter() - t1))
+                if rc != 0:
+                    raise SystemExit(f"{key} failed: " + lib.sift.sift3d_amd_last_error().decode())
+            det = min(t[0] for t in te[1:])
+            ps = det / (float(ex) * ey * ez) * 1e12
+            result["config"][key] = {"dims": list(dims), "units": list(units), "detect_ms": round(det * 1e3, 2),
+                                     "describe_ms": round(min(t[1] for t in te[1:]) * 1e3, 2), "keypoints": int(kpe.slab.num),
+                                     "detect_ps_per_voxel": round(ps, 1), "unit_voxel_detect_ps_per_voxel": round(unit_ps, 1),
+                                     "ratio_to_unit": round(ps / unit_ps, 3)}
+            dev.free(d_e)
+            lib.sift.cleanup_Keypoint_store(C.byref(kpe))
+            lib.sift.cleanup_SIFT3D(C.byref(se))
     if rank == 0 and not args.no_roofline:
         add_roofline(result, dev, n)
     if rank == 0 and not args.no_cpu_baseline:
@@ -773,11 +900,18 @@ def main():
         # The in-run sample above is bounded (160^3: ~12 s).  The same reference build on BASELINE configs[1] ITSELF -- the
         # 512^3 volume this line's `value` is quoted on -- was timed once on an MI355X box's host cores (6.4 minutes; SURVEY
         # 8d): quoted here with its provenance, not re-measured per run.
-        try:
-            full = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_baseline_512.json")))
-            result["cpu_baseline"]["configs1_512"] = {k: full[k] for k in ("value", "unit", "cores", "kind", "sample", "provenance")}
-        except Exception:
-            pass
+        if args.cpu_baseline_full:
+            try:
+                result["cpu_baseline"]["configs1_512"] = dict(cpu_baseline(512, timeout=1500), quoted=False)
+            except Exception as e:
+                result["cpu_baseline"]["configs1_512"] = {"value": None, "quoted": False, "sample": f"failed: {e}"}
+        else:
+            try:
+                full = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_baseline_512.json")))
+                result["cpu_baseline"]["configs1_512"] = dict({k: full[k] for k in ("value", "unit", "cores", "kind", "sample", "provenance")},
+                                                              quoted=True)     # not timed in this run: --cpu-baseline-full does that
+            except Exception:
+                pass
     if rank == 0:
         print(json.dumps(result), flush=True)
     dev.free(d_vol)

@@ -111,6 +111,8 @@ void sift3d_amd_slab_destroy(sift3d_amd_slab *sl);
  * the message of the real call where that would refuse the decomposition (slabs thinner than a descriptor window). */
 int sift3d_amd_slab_plan(const SIFT3D *params, int world, int rank, int nx, int ny, int nz, double ux, double uy, double uz,
                          sift3d_amd_slab_info *info);
+/* message of the last sift3d_amd_slab_* failure on the calling thread (also printed through SIFT3D_ERR when it happens) */
+const char *sift3d_amd_slab_last_error(void);
 int sift3d_amd_slab_get_info(const sift3d_amd_slab *sl, sift3d_amd_slab_info *info);
 
 /* SIFT3D_detect_keypoints for this rank's slab: `vol` = base slices [z0, z1) (x fastest, nx*ny*(z1-z0) floats),

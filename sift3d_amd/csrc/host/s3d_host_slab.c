@@ -29,6 +29,7 @@
 #define SLAB_MAX_OPS 96          /* timed transport operations per detect (2 sharded octaves x 6 levels + all-reduces: ~25) */
 
 static __thread char g_slab_err[512];
+const char *sift3d_amd_slab_last_error(void) { return g_slab_err; }   /* of the calling thread */
 #define SLAB_FAIL(...)                                           \
     do {                                                         \
         snprintf(g_slab_err, sizeof(g_slab_err), __VA_ARGS__);   \

@@ -65,10 +65,13 @@ def _bench(args, env):
 
 
 def test_bench_gpus_n_without_a_launcher(emu):
-    p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "2"})
+    """`python bench.py --gpus 2`: strong scaling on ONE --strong-size^3 volume is what is timed (BASELINE configs[3] at
+    full size); the JSON carries the per-rank transport figures."""
+    p = _bench(["--gpus", "2", "--strong-size", "64"], {"S3D_EMU_DEVICES": "2"})
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     cfg = rec["config"]
+    assert rec["scaling"] == "strong" and "64x64x64" in cfg["workload"] and cfg["slices_per_rank"] == [32, 32]
     assert rec["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and "rccl_version" in cfg
     assert len(cfg["keypoints_per_rank"]) == 2 and sum(cfg["keypoints_per_rank"]) == cfg["keypoints"] > 0
     assert len(cfg["halo_wait_ms_per_rank"]) == 2 and len(cfg["comm_ms_per_rank"]) == 2
@@ -82,19 +85,46 @@ def test_bench_without_rccl_falls_back_and_says_so(emu):
              S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_PRELOAD"):
         e.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "32", "--steps", "1", "--warmup", "0",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--weak", "--size", "32", "--steps", "1", "--warmup", "0",
                         "--no-roofline", "--no-cpu-baseline", "--no-match"], capture_output=True, text=True, timeout=900, env=e)
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
-    assert rec["n_gpus"] == 2 and "RCCL did NOT initialise" in rec["config"]["parallelism"] and "rccl_ranks" not in rec["config"]
+    assert rec["scaling"] == "weak" and rec["n_gpus"] == 2 and "RCCL did NOT initialise" in rec["config"]["parallelism"] and "rccl_ranks" not in rec["config"]
     assert "falling back" in p.stderr
 
 
 def test_bench_refuses_to_benchmark_fewer_gpus_than_asked(emu):
-    p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "1"})
+    p = _bench(["--gpus", "2", "--weak"], {"S3D_EMU_DEVICES": "1"})
     assert p.returncode == 2 and "{" not in p.stdout and "refusing" in p.stderr
-    p = _bench(["--gpus", "2"], {"S3D_EMU_DEVICES": "2", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    p = _bench(["--gpus", "2", "--weak"], {"S3D_EMU_DEVICES": "2", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode == 2 and "{" not in p.stdout and "WORLD_SIZE=1" in p.stderr
+
+
+def test_bench_dry_run_plans_without_a_device():
+    """`python bench.py --dry`: the product library (no device in this container), N = 2, 4, 8: partition, halo, HBM per rank
+    of the strong (1024^3, timed by default) and weak (512 x 512 x 512 N) jobs; a decomposition that cannot work says why."""
+    e = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SIFT3D_AMD_LIB", "S3D_BENCH_PARAMS"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry"], capture_output=True, text=True, timeout=300, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["dry"] is True and sorted(rec["plans"]) == ["2", "4", "8"]
+    for N in (2, 4, 8):
+        pl = rec["plans"][str(N)]
+        assert pl["timed"] == "strong" and f"--nproc-per-node {N}" in pl["command"] and f"--gpus {N}" in pl["command"]
+        st, wk = pl["strong"], pl["weak"]
+        assert st["volume"] == [1024, 1024, 1024] and st["slices_per_rank"] == [1024 // N] * N and st["z_bounds"][-1] == 1024
+        assert wk["volume"] == [512, 512, 512 * N] and wk["slices_per_rank"] == [512] * N
+        assert st["halo_planes"] == 39 and min(st["slices_per_rank"]) >= st["halo_planes"]
+        assert 1 <= st["sharded_octaves"] <= st["octaves"] == 8 and st["fits_288_GB"] and max(st["HBM_GiB_per_rank"]) < 64
+    assert rec["plans"]["8"]["strong"]["sharded_octaves"] == 2                     # slabs of 128, 64 slices; octaves >= 2 replicated
+    assert "thinner than the descriptor halo" in rec["refusal_example"]["refused"]
+    # a job that cannot be decomposed: refused in the plan, not at run time
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", "--gpus", "16", "--strong-size", "256"],
+                       capture_output=True, text=True, timeout=300, env=e)
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert "refused" in rec["plans"]["16"]["strong"] and "refused" not in rec["plans"]["16"]["weak"]
 
 
 def _plain(emu, vol, n, balance):
