@@ -14,7 +14,7 @@ from sift3d_amd import build as b   # noqa: E402
 b.build()
 out_dir = os.path.join(b.LIB, "ablate")
 os.makedirs(out_dir, exist_ok=True)
-objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and f != sys.argv[1] + ".o"]
+objs = [os.path.join(b.OBJ, f) for f in os.listdir(b.OBJ) if f.endswith(".o") and not f.endswith(".testing.o") and f != sys.argv[1] + ".o"]
 FILE = sys.argv[1]
 for spec in sys.argv[2:]:
     name, rev = spec.split("=", 1)

@@ -665,74 +665,127 @@ k_conv_x_mc(const float *__restrict__ src, float *__restrict__ dst, int nx, int 
 
 /* Dense-descriptor front end fused with the x pass of its 12-channel blur.  The barycentric image
  * (sift.c:2412-2441: three weights per voxel into the channels of the hit face's vertices, zero elsewhere
- * and on the volume's border) is never written to HBM: a block computes it for 64 voxels of one x-row plus
- * HW neighbours on either side into LDS and convolves from there.  Same arithmetic, same order as
- * k_dense_bary followed by k_conv_x_mc, so the result is bit-identical; saves 2 x 48 B/voxel of traffic. */
-#define BX_SEG 64
+ * and on the volume's border) is never written to HBM: a workgroup computes the EXTENDED row E of a tile -- E[c] = voxel -c
+ * (c < 0), voxel c (c <= nx-2), (1-f_j) voxel[nx-2-j] + f_j voxel[nx-1-j] (c = nx-1+j; imutil.c:2378-2380) -- into LDS,
+ * twelve channels per position, and every output is the plain sum of taps over it: no boundary case is left in the
+ * convolution.  Same arithmetic, same order as k_dense_bary followed by k_conv_x_mc: bit-identical; saves 2 x 48 B/voxel.
+ *
+ * Round 4 form.  A workgroup of BX_THREADS = 768 threads (one per output float4 of a row tile) owns a tile of BX_TILE = 256
+ * voxels of a row and walks down BX_ROWS rows with it: the mesh table is loaded once per workgroup (round 3: once per 64
+ * voxels), every thread below tile + 2 HW runs the face search of its position per row (two for the HW + 1 blended
+ * positions beyond the row's end), the slots are double buffered so that a row costs one barrier, and the gradient loads
+ * of the next row are in flight through the convolution of this one.  What was measured on the way (256^3,
+ * profiles/r04_dense_experiments.txt): round 3 (a 192-thread workgroup per 64 voxels, the row ends in a rolled loop of
+ * mirror / blend cases inside the row waves) 619 us; this tiling with the same boundary loop 563; a sparse form (16-byte
+ * records, three multiply-adds per tap into LDS accumulators) 384 for the interior alone but 650-980 with any of three ways
+ * of doing the row ends beside it; this form 520-580 at 320 ... 768 threads.  The kernel issues 150 M VALU wave instructions
+ * per launch (19 taps x 12 channels, unfused) = 0.25 ms at 4 clk each and waits the other half of its time
+ * (SQ_WAIT_ANY 65 % of the wave cycles); the target of 250 us was not reached. */
+#define BX_TILE 256
+#define BX_THREADS 768
+#define BX_ROWS 8
 template <int HW>
-__global__ void __launch_bounds__(BX_SEG * 3)
+__global__ void __launch_bounds__(BX_THREADS)
 k_bary_x_mc(const float *__restrict__ sm, float *__restrict__ dst, int nx, int ny, int nz, float iux, float iuy,
             float iuz, const float *__restrict__ d_mesh, S3dTaps taps, EdgeFrac ef)
 {
-    constexpr int W = 2 * HW + 1, NST = BX_SEG + 2 * HW;
+    constexpr int W = 2 * HW + 1, NST = BX_TILE + 2 * HW;
+    static_assert(NST <= BX_THREADS, "one position of the extended row per thread");
     __shared__ float mesh[S3D_MESH_FLOATS];
-    __shared__ __attribute__((aligned(16))) float st[NST * S3D_NVERT];
+    __shared__ __attribute__((aligned(16))) float st[2][NST * S3D_NVERT];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * BX_SEG, y = blockIdx.y, z = blockIdx.z;
-    for (int i = tid; i < S3D_MESH_FLOATS; i += BX_SEG * 3) mesh[i] = d_mesh[i];
-    for (int i = tid; i < NST * S3D_NVERT; i += BX_SEG * 3) st[i] = 0.0f;
-    __syncthreads();
-    /* stage voxels x0-HW .. x0+BX_SEG-1+HW (slot s <-> voxel x0-HW+s) */
+    const int x0 = blockIdx.x * BX_TILE, z = blockIdx.z;
+    const int y0 = blockIdx.y * BX_ROWS, y1 = y0 + BX_ROWS < ny ? y0 + BX_ROWS : ny;
+    for (int i = tid; i < S3D_MESH_FLOATS; i += BX_THREADS) mesh[i] = d_mesh[i];
     const size_t plane = (size_t)nx * ny;
-    if (tid < NST) {
-        const int x = x0 - HW + tid;
-        if (x >= 1 && x <= nx - 2 && y >= 1 && y <= ny - 2 && z >= 1 && z <= nz - 2) {
-            const float *p = sm + ((size_t)z * plane + (size_t)y * nx + x);
+    const bool zin = z >= 1 && z <= nz - 2;
+    const int zl = z < 1 ? 1 : (z > nz - 2 ? nz - 2 : z);
+    /* stage 1: position c = x0 - HW + tid of the extended row (slot tid): voxel xa, and voxel xb as well where the position
+     * is a blend.  Loads are unconditional from a clamped, valid address (a prefetch under a branch is waited for at the
+     * join). */
+    int c = x0 - HW + tid;
+    if (c < 0) c = -c;
+    const bool blend = tid < NST && c >= nx - 1 && c - (nx - 1) <= HW;
+    const int jb = blend ? c - (nx - 1) : 0;
+    const int xa = blend ? nx - 2 - jb : c, xb = blend ? nx - 1 - jb : 1;
+    const bool used = tid < NST && (c <= nx - 2 || blend);  /* positions beyond nx - 1 + HW are read by no valid output */
+    auto clampx = [&](int x) { return x < 1 ? 1 : (x > nx - 2 ? nx - 2 : x); };
+    const int xal = clampx(xa), xbl = clampx(xb);
+    struct Grad { float xm, xp, ym, yp, zm, zp; };
+    auto load = [&](int y, int xl) -> Grad {
+        const int yl = y < 1 ? 1 : (y > ny - 2 ? ny - 2 : y);
+        const float *p = sm + ((size_t)zl * plane + (size_t)yl * nx + xl);
+        Grad g;
+        g.xm = p[-1]; g.xp = p[1]; g.ym = p[-nx]; g.yp = p[nx]; g.zm = p[-(ptrdiff_t)plane]; g.zp = p[plane];
+        return g;
+    };
+    /* the twelve channels of voxel xv into h (zero outside the interior and where the gradient is flat) */
+    auto voxel = [&](const Grad &q, int xv, int y, float *h) {
+#pragma unroll
+        for (int k = 0; k < S3D_NVERT; k++) h[k] = 0.0f;
+        if (zin && xv >= 1 && xv <= nx - 2 && y >= 1 && y <= ny - 2) {
             V3 g;
-            g.x = 0.5f * (p[1] - p[-1]);
-            g.y = 0.5f * (p[nx] - p[-nx]);
-            g.z = 0.5f * (p[plane] - p[-(ptrdiff_t)plane]);
+            g.x = 0.5f * (q.xp - q.xm);
+            g.y = 0.5f * (q.yp - q.ym);
+            g.z = 0.5f * (q.zp - q.zm);
             g.x = g.x * iux; g.y = g.y * iuy; g.z = g.z * iuz;
             V3 bary;
             const int face = s3d_icos_bin_fast(mesh, g, &bary);
             if (face >= 0) {
-                float *t = st + tid * S3D_NVERT;
-                t[__float_as_int(S3D_MESH_AT(mesh, face, 13))] = bary.x;
-                t[__float_as_int(S3D_MESH_AT(mesh, face, 14))] = bary.y;
-                t[__float_as_int(S3D_MESH_AT(mesh, face, 15))] = bary.z;
-            }
-        }
-    }
-    __syncthreads();
-    const int v = tid / 3, cq = (tid - 3 * v) * 4;            /* voxel of the segment, channel quad */
-    const int x = x0 + v;
-    if (x >= nx) return;
-    auto slot = [&](int c) { return *reinterpret_cast<const float4 *>(st + (c - x0 + HW) * S3D_NVERT + cq); };
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (x >= HW && x + HW <= nx - 2) {
+                const int v0 = __float_as_int(S3D_MESH_AT(mesh, face, 13)), v1 = __float_as_int(S3D_MESH_AT(mesh, face, 14)),
+                          v2 = __float_as_int(S3D_MESH_AT(mesh, face, 15));
 #pragma unroll
-        for (int k = 0; k < W; k++) {
-            const float4 s = slot(x + HW - k);
-            const float t = taps.t[k];
-            acc.x = acc.x + t * s.x; acc.y = acc.y + t * s.y; acc.z = acc.z + t * s.z; acc.w = acc.w + t * s.w;
-        }
-    } else {
-#pragma unroll 1
-        for (int k = 0; k < W; k++) {
-            int c = x + HW - k;
-            if (c < 0) c = -c;
-            float4 s;
-            if (c <= nx - 2) {
-                s = slot(c);
-            } else {
-                const int j = c - (nx - 1);
-                s = blend4(slot(nx - 2 - j), slot(nx - 1 - j), ef.f[j]);
+                for (int k = 0; k < S3D_NVERT; k++) h[k] = k == v0 ? bary.x : (k == v1 ? bary.y : (k == v2 ? bary.z : 0.0f));
             }
-            const float t = taps.t[k];
-            acc.x = acc.x + t * s.x; acc.y = acc.y + t * s.y; acc.z = acc.z + t * s.z; acc.w = acc.w + t * s.w;
         }
+    };
+    auto stage = [&](const Grad &qa, const Grad &qb, int y, float *slots) {
+        if (!used) return;
+        float h[S3D_NVERT];
+        voxel(qa, xa, y, h);
+        if (blend) {                                       /* a handful of threads of the row's last tile */
+            float g[S3D_NVERT];
+            voxel(qb, xb, y, g);
+            const float f = ef.f[jb], om = 1.0f - f;
+#pragma unroll
+            for (int k = 0; k < S3D_NVERT; k++) h[k] = om * h[k] + f * g[k];
+        }
+        float4 *t4 = reinterpret_cast<float4 *>(slots + tid * S3D_NVERT);
+        t4[0] = make_float4(h[0], h[1], h[2], h[3]);
+        t4[1] = make_float4(h[4], h[5], h[6], h[7]);
+        t4[2] = make_float4(h[8], h[9], h[10], h[11]);
+    };
+    Grad ca = load(y0, xal), cb = load(y0, xbl);
+    __syncthreads();                                       /* the mesh table */
+    stage(ca, cb, y0, st[0]);
+    if (y0 + 1 < y1) { ca = load(y0 + 1, xal); cb = load(y0 + 1, xbl); }
+    __syncthreads();
+    for (int y = y0; y < y1; y++) {
+        const float *slots = st[(y - y0) & 1];
+        /* stage 1 of the next row into the other buffer (its loads were issued a row ago), then this row's outputs */
+        Grad na = ca, nb = cb;
+        if (y + 1 < y1) {
+            stage(ca, cb, y + 1, st[(y + 1 - y0) & 1]);
+            if (y + 2 < y1) { na = load(y + 2, xal); nb = load(y + 2, xbl); }
+        }
+        /* stage 2: output float4 o = 3 * voxel + channel quad, BX_TILE * 3 of them over the workgroup's threads; the slot of
+         * E[x + HW - k] is v + 2 HW - k */
+        float *drow = dst + ((size_t)z * plane + (size_t)y * nx + x0) * S3D_NVERT;
+        const int nout = (nx - x0 < BX_TILE ? nx - x0 : BX_TILE) * 3;
+        for (int o = tid; o < nout; o += BX_THREADS) {
+            const float4 *sl = reinterpret_cast<const float4 *>(slots) + o + 3 * 2 * HW;
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const float4 s4 = sl[-3 * k];
+                const float t = taps.t[k];
+                acc.x = acc.x + t * s4.x; acc.y = acc.y + t * s4.y; acc.z = acc.z + t * s4.z; acc.w = acc.w + t * s4.w;
+            }
+            reinterpret_cast<float4 *>(drow)[o] = acc;
+        }
+        ca = na; cb = nb;
+        __syncthreads();                                   /* the next row's slots are complete; this row's have been read */
     }
-    *reinterpret_cast<float4 *>(dst + ((size_t)z * plane + (size_t)y * nx + x) * S3D_NVERT + cq) = acc;
 }
 
 /* ---- fused X+Y pass ----------------------------------------------------------------------------- */
@@ -1139,8 +1192,8 @@ static int launch_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, i
     EdgeFrac ex, ey, ez;
     if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
     const size_t nxc = (size_t)nx * S3D_NVERT;
-    hipLaunchKernelGGL((k_bary_x_mc<HW>), dim3(s3d_div_up(nx, BX_SEG), ny, nz), dim3(BX_SEG * 3), 0, st, d_smooth, d_dst,
-                       nx, ny, nz, 1.0f / unitsf[0], 1.0f / unitsf[1], 1.0f / unitsf[2], d_mesh, t, ex);
+    hipLaunchKernelGGL((k_bary_x_mc<HW>), dim3(s3d_div_up(nx, BX_TILE), s3d_div_up(ny, BX_ROWS), nz), dim3(BX_THREADS), 0, st,
+                       d_smooth, d_dst, nx, ny, nz, 1.0f / unitsf[0], 1.0f / unitsf[1], 1.0f / unitsf[2], d_mesh, t, ex);
     S3D_CHECK_LAUNCH();
     const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
     const int cz = (nz + (int)s3d_div_up(nz, g_chunk_z) - 1) / (int)s3d_div_up(nz, g_chunk_z);

@@ -56,8 +56,9 @@ def test_detect_describe_aniso(emu, oracle):
     assert parity.check_detect_describe(emu, oracle, (36, 32, 28), (1, 0.8, 2), 60, seed=3) > 0
 
 
-def test_dense(emu, oracle):
-    parity.check_dense(emu, oracle, (14, 13, 12), (1, 1, 2))
+@pytest.mark.parametrize("dims", [(14, 13, 12), (44, 12, 11)])   # rows shorter than / longer than two filter half widths (interior outputs)
+def test_dense(emu, oracle, dims):
+    parity.check_dense(emu, oracle, dims, (1, 1, 2))
 
 
 def test_dense_rotate(emu, oracle):
