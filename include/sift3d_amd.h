@@ -377,6 +377,19 @@ int init_Mat_rm_p(Mat_rm *const mat, const void *const p, const int num_rows, co
                   const Mat_rm_type type, const int set_zero);           /* imutil.c:655 */
 int eigen_Mat_rm(Mat_rm *A, Mat_rm *Q, Mat_rm *L);                       /* imutil.c:2992 (Jacobi instead of LAPACK dsyevd) */
 int transpose_Mat_rm(const Mat_rm *const src, Mat_rm *const dst);        /* imutil.c:3338 */
+/* the small public helpers beside the hot path (csrc/host/s3d_host_mat.c): host C, no LAPACK */
+int identity_Mat_rm(const int n, Mat_rm *const mat);                                             /* imutil.c:934 */
+int mul_Mat_rm(const Mat_rm *const mat_in1, const Mat_rm *const mat_in2, Mat_rm *const mat_out); /* imutil.c:2923 */
+int solve_Mat_rm(const Mat_rm *const A, const Mat_rm *const B, const double limit, Mat_rm *const X);   /* imutil.c:3089 (LU; SIFT3D_SINGULAR below `limit`, < 0: 100 eps) */
+int solve_Mat_rm_ls(const Mat_rm *const A, const Mat_rm *const B, Mat_rm *const X);              /* imutil.c:3207 (min-norm least squares, Jacobi SVD instead of dgelss) */
+int det_symm_Mat_rm(Mat_rm *mat, void *det);                                                     /* imutil.c:3389 (the reference's value: the SUM of the eigenvalues) */
+int apply_tform_Mat_rm(const void *const tform, const Mat_rm *const mat_in, Mat_rm *const mat_out);   /* imutil.c:2733 */
+int im_permute(const Image *const src, const int dim1, const int dim2, Image *const dst);        /* imutil.c:2476 */
+int im_upsample_2x(const Image *const src, Image *const dst);                                    /* imutil.c:1685 */
+int im_restride(const Image *const src, const size_t *const strides, Image *const dst);          /* imutil.c:2537 */
+int draw_grid(Image *grid, int nx, int ny, int nz, int spacing, int line_width);                 /* imutil.c:973 */
+int trace_Mat_rm(Mat_rm *mat, void *trace);                                                      /* imutil.c:3301 */
+int print_Mat_rm(const Mat_rm *const mat);                                                       /* imutil.c:803 */
 /* Defaults the reference exports as data (its regSift3D prints them: cli/regSift3D.c:83-84) */
 extern const double SIFT3D_nn_thresh_default;                            /* reg.h:20, reg.c:24 */
 extern const double SIFT3D_err_thresh_default;                           /* imutil.h:33, imutil.c:102 */

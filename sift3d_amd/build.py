@@ -21,7 +21,7 @@ INC = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["s3d_rt.hip", "s3d_image.hip", "s3d_gauss.hip", "s3d_gauss_tab.hip", "s3d_extrema.hip", "s3d_keypoint.hip",
                "s3d_dense.hip", "s3d_match.hip", "s3d_resample.hip", "s3d_rccl.hip"]
-C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c", "host/s3d_host_draw.c", "host/s3d_host_slab.c"]
+C_SOURCES = ["host/s3d_host_util.c", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_io.c", "host/s3d_host_cli.c", "host/s3d_host_reg.c", "host/s3d_host_draw.c", "host/s3d_host_slab.c", "host/s3d_host_mat.c"]
 BIN = os.path.join(HERE, "bin")
 CLI_PROGRAMS = ["kpSift3D", "denseSift3D", "regSift3D"]
 # Per-file extra flags.  s3d_keypoint.hip: the SLP vectoriser pairs scalar f32 operations into v_pk_* instructions, which on

@@ -16,7 +16,7 @@ for f in s3d_rt s3d_image s3d_gauss s3d_gauss_tab s3d_extrema s3d_keypoint s3d_d
     g++ $CXXFLAGS -x c++ -c "$CSRC/$f.hip" -o "$OBJ/$f.o"
   fi
 done
-for f in s3d_host_util s3d_host_api s3d_host_match s3d_host_io s3d_host_cli s3d_host_reg s3d_host_draw s3d_host_slab; do
+for f in s3d_host_util s3d_host_api s3d_host_match s3d_host_io s3d_host_cli s3d_host_reg s3d_host_draw s3d_host_slab s3d_host_mat; do
   gcc -DS3D_TESTING -std=gnu11 -O1 -g -fPIC -ffp-contract=off -I"$ROOT/include" -I"$CSRC/host" -pthread -c "$CSRC/host/$f.c" -o "$OBJ/$f.o"
 done
 g++ -shared -fPIC -Wl,-Bsymbolic -o "$HERE/libsift3d_emu.so" "$OBJ"/*.o -lm -lpthread -lz -ldl

