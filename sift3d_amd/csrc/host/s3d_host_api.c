@@ -198,15 +198,24 @@ static void ctx_release(int handle)
     c = g_ctx[handle - 1];
     g_ctx[handle - 1] = NULL;
     for (int i = 0; i < S3D_MAX_CTX; i++) live += g_ctx[i] != NULL;
+    /* The matcher's scratch (score matrix and operand copies, up to ~9 GiB at 31 k x 31 k) and the tap tables of the
+     * table-driven filter passes are kept per device between calls.  They belong to no SIFT3D struct, so they go when
+     * the last one does -- decided and done under the registry lock, so that a context created meanwhile cannot have what
+     * it has just allocated taken away: a process that is done with its structs gets the memory back, one that works in a
+     * loop keeps a struct alive anyway. */
+    if (c && live == 0) {                               /* the last one: its streams drained first, then the shared pools */
+        s3d_mgpu_free(c->mgpu);
+        ctx_free_all(c);
+        free(c);
+        c = NULL;
+        s3d_k_nn_release_scratch();
+        s3d_k_tap_tables_release();
+    }
     pthread_mutex_unlock(&g_ctx_lock);
     if (c) {
         s3d_mgpu_free(c->mgpu);
         ctx_free_all(c);
         free(c);
-        /* The matcher's scratch (score matrix and operand copies, up to ~9 GiB at 31 k x 31 k) is kept per device between
-         * calls.  It belongs to no SIFT3D struct, so it goes when the last one does: a process that is done with its
-         * structs gets the memory back, one that matches in a loop keeps a struct alive anyway. */
-        if (live == 0) s3d_k_nn_release_scratch();
     }
 }
 

@@ -27,6 +27,7 @@
 
 #define DESC_REC_FLOATS (sizeof(SIFT3D_Descriptor) / sizeof(float)) /* 776 */
 #define SLAB_MAX_OPS 96          /* timed transport operations per detect (2 sharded octaves x 6 levels + all-reduces: ~25) */
+#define SLAB_MAX_WAITS 16       /* waits for the deferred halo lane per detect that are timed (finish_halos calls with planes pending) */
 
 static __thread char g_slab_err[512];
 const char *sift3d_amd_slab_last_error(void) { return g_slab_err; }   /* of the calling thread */
@@ -139,8 +140,9 @@ struct sift3d_amd_slab {
     double halo_bytes, device_bytes, detect_ms, describe_ms, comm_ms, halo_wait_ms;
     /* GPU-side timing of the transport operations of a detect: event pairs around every operation ordered with the
      * compute stream, and the moment the compute stream starts to wait for the deferred lane */
-    void *ev_op[2 * SLAB_MAX_OPS], *ev_reach;
-    int n_ops, have_reach;
+    void *ev_op[2 * SLAB_MAX_OPS];
+    void *ev_wait[2 * SLAB_MAX_WAITS];  /* (compute stream reaches the wait, deferred lane done) per finish_halos of a detect */
+    int n_ops, n_waits;
 };
 
 /* A transport operation that is ordered with the compute stream, bracketed by a pair of events: what the stream spends
@@ -167,8 +169,11 @@ static void collect_comm_times(sift3d_amd_slab *sl)
     sl->comm_ms = sl->halo_wait_ms = 0.0;
     for (int i = 0; i < sl->n_ops; i++)
         if (s3d_rt_event_elapsed_ms(sl->ev_op[2 * i], sl->ev_op[2 * i + 1], &ms) == 0) sl->comm_ms += (double)ms;
-    if (sl->have_reach && s3d_rt_event_elapsed_ms(sl->ev_reach, sl->ev_done, &ms) == 0 && ms > 0.0f) sl->halo_wait_ms = (double)ms;
-    sl->n_ops = sl->have_reach = 0;
+    /* every finish_halos of the detect that found planes pending has its own pair: the wait of each one counts (one pair,
+     * overwritten per call, reported the last wait only) */
+    for (int i = 0; i < sl->n_waits; i++)
+        if (s3d_rt_event_elapsed_ms(sl->ev_wait[2 * i], sl->ev_wait[2 * i + 1], &ms) == 0 && ms > 0.0f) sl->halo_wait_ms += (double)ms;
+    sl->n_ops = sl->n_waits = 0;
 }
 
 /* Drain the compute stream -- which, with more than one rank, means: wait for the peers.  Not for ever: past the
@@ -285,7 +290,8 @@ void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
     if (sl->h_keys) s3d_rt_host_free(sl->h_keys);
     for (int i = 0; i < 2 * SLAB_MAX_OPS; i++)
         if (sl->ev_op[i]) s3d_rt_event_destroy(sl->ev_op[i]);
-    if (sl->ev_reach) s3d_rt_event_destroy(sl->ev_reach);
+    for (int i = 0; i < 2 * SLAB_MAX_WAITS; i++)
+        if (sl->ev_wait[i]) s3d_rt_event_destroy(sl->ev_wait[i]);
     if (sl->ev_ready) s3d_rt_event_destroy(sl->ev_ready);
     if (sl->ev_done) s3d_rt_event_destroy(sl->ev_done);
     if (sl->ms) s3d_rt_stream_destroy(sl->ms);
@@ -327,8 +333,8 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
         DEV(s3d_rt_event_create(&sl->ev_ready));
         DEV(s3d_rt_event_create(&sl->ev_done));
         if (G > 1) {
-            DEV(s3d_rt_event_create(&sl->ev_reach));
             for (int i = 0; i < 2 * SLAB_MAX_OPS; i++) DEV(s3d_rt_event_create(&sl->ev_op[i]));
+            for (int i = 0; i < 2 * SLAB_MAX_WAITS; i++) DEV(s3d_rt_event_create(&sl->ev_wait[i]));
         }
     }
     INJECT(sl, 1);
@@ -503,10 +509,11 @@ static int exchange_halo(sift3d_amd_slab *sl, const s3d_lev *lv, int o, int h, i
 static int finish_halos(sift3d_amd_slab *sl)
 {
     if (sl->pending) {
-        DEV(s3d_rt_event_record(sl->ev_reach, sl->cs));         /* from here on the compute stream waits for lane 1 */
-        sl->have_reach = 1;
-        DEV(s3d_rt_event_record(sl->ev_done, sl->ms));
-        DEV(s3d_rt_stream_wait_event(sl->cs, sl->ev_done));
+        /* pair i of this detect (beyond SLAB_MAX_WAITS calls the last pair is reused: those waits go uncounted) */
+        const int i = sl->n_waits < SLAB_MAX_WAITS ? sl->n_waits++ : SLAB_MAX_WAITS - 1;
+        DEV(s3d_rt_event_record(sl->ev_wait[2 * i], sl->cs));   /* from here on the compute stream waits for lane 1 */
+        DEV(s3d_rt_event_record(sl->ev_wait[2 * i + 1], sl->ms));
+        DEV(s3d_rt_stream_wait_event(sl->cs, sl->ev_wait[2 * i + 1]));
         sl->pending = 0;
     }
     return SIFT3D_SUCCESS;
@@ -705,7 +712,7 @@ int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device,
     if (rc != SIFT3D_SUCCESS && sl->t.world > 1) {
         if (sl->t.abort) sl->t.abort(sl->t.self);
         sl->pending = 0;
-        sl->n_ops = sl->have_reach = 0;
+        sl->n_ops = sl->n_waits = 0;
     }
     return rc;
 }
@@ -719,7 +726,7 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
     if (vol == NULL) SLAB_FAIL("sift3d_amd_slab_detect: no volume");
     INJECT(sl, 2);
     sl->halo_bytes = 0.0;
-    sl->n_ops = sl->have_reach = 0;
+    sl->n_ops = sl->n_waits = 0;
     if (on_device) DEV(s3d_rt_d2d(own, vol, n_local * sizeof(float), sl->cs));
     else DEV(s3d_rt_h2d(own, vol, n_local * sizeof(float), sl->cs));
     /* im_scale with the global maximum (sift.c:903, imutil.c:1977-1991) */
@@ -1487,6 +1494,18 @@ int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descr
         }
     }
     balance_describe(m, kp, owner);
+    /* a keypoint whose window the rank it went to does not hold (a caller-supplied scale, a level that only receives a
+     * filter's halo) is an input error: say so here -- inside a rank it would abort every transport and the pyramids with it */
+    for (size_t i = 0; i < num; i++) {
+        const Keypoint *k = kp->buf + i;
+        const Pyramid *g = &m->sl[0]->plan.gpyr;
+        if (!rank_holds_window(m->sl[owner[i]], k, k->o - g->first_octave, k->s - g->first_level)) {
+            const int r = owner[i];
+            free(owner);
+            SLAB_FAIL("sift3d_amd: the descriptor window of keypoint %zu (o=%d, s=%d) reaches beyond the planes rank %d holds", i,
+                      k->o, k->s, r);
+        }
+    }
     for (size_t i = 0; i < num; i++) cnt[owner[i]]++;
     sel = (size_t *)malloc((num + 1) * sizeof(size_t));
     fill = (size_t *)calloc(256, sizeof(size_t));

@@ -926,11 +926,7 @@ struct DwShared {
     uint32_t nkey[2][(sizeof(s3d_desc_key) + 3) / 4];   /* ... and its record, fetched while the current one is worked on */
 };
 
-#if defined(S3D_EMU)
-#define DW_SHARED_DECL static DwShared dw_smem_obj; DwShared &sm = dw_smem_obj
-#else
-#define DW_SHARED_DECL extern __shared__ unsigned long long dw_smem_raw[]; DwShared &sm = *reinterpret_cast<DwShared *>(dw_smem_raw)
-#endif
+#define DW_SHARED_DECL S3D_DYN_LDS(unsigned long long, dw_smem_raw); DwShared &sm = *reinterpret_cast<DwShared *>(dw_smem_raw)
 
 /* s3d_expf with the exp2 table passed in (LDS) */
 __device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long *__restrict__ tab)
@@ -953,11 +949,7 @@ __device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long 
     return (float)(y * s);
 }
 
-#if defined(S3D_EMU)
-#define DW_UNIFORM(x) (x)
-#else
-#define DW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))   /* a workgroup-uniform value: to an SGPR */
-#endif
+#define DW_UNIFORM(x) ((uint32_t)S3D_UNIFORM(x))            /* a workgroup-uniform value: to an SGPR */
 
 #if defined(S3D_EMU)
 #define DW_RCP(x) (1.0f / (x))
@@ -977,10 +969,12 @@ __device__ __forceinline__ float s3d_expf_tab(float x, const unsigned long long 
  * face (the discontinuous part, see s3d_math.h) is unchanged: a 1e-6 error cannot carry a sample across the 2e-5 margin.
  * Straight-line code: *safe tells the caller whether the result stands or the sequential search has to decide (the four
  * voxels of a chunk run this back to back so that the scheduler can interleave them; the rare searches follow). */
-#if defined(S3D_EMU) || defined(DW_NO_FMA)
+#if defined(DW_NO_FMA)
 #define DW_FMAF(a, b, c) ((a) * (b) + (c))                 /* -ffp-contract=off: two roundings */
 #else
-#define DW_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))     /* one v_fma_f32 where only a continuous quantity is formed */
+#define DW_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))     /* one v_fma_f32 where only a continuous quantity is formed (the emulator
+                                                             * build of the test suite: libm's fmaf -- the same single rounding, so
+                                                             * the CPU tests run the arithmetic, and the resolve() path, that ships) */
 #endif
 __device__ __forceinline__ int dw_face_fast(const float *__restrict__ mesh, const float *__restrict__ fcn, V3 g, V3 *bary, bool *safe)
 {
@@ -1168,7 +1162,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
-#if !defined(DW_NO_FMA) && !defined(S3D_EMU)
+#if !defined(DW_NO_FMA)
         /* The rotated gradient only feeds continuous quantities here (|grad|, barycentric weights) and a face choice that
          * is accepted with a 2e-5 margin: fused forms (1e-7 relative) are as good.  Whatever DECIDES near a boundary --
          * a sample close to a face edge, |grad|^2 close to the floor -- is redone by resolve() on the reference's
@@ -1194,7 +1188,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         v.safe = (safe && !floor_unsure) || !(live || (valid && floor_unsure));
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
         v.vbx = vbx; v.vby = vby; v.vbz = vbz;
-#if !defined(DW_NO_FMA) && !defined(S3D_EMU)
+#if !defined(DW_NO_FMA)
         v.gx = gx; v.gy = gy; v.gz = gz;
 #else
         v.gx = gr.x; v.gy = gr.y; v.gz = gr.z;
@@ -1205,7 +1199,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     auto resolve = [&](DwVox &v) {
         if (v.safe) return;
         V3 bary = v3(0.0f, 0.0f, 0.0f);
-#if !defined(DW_NO_FMA) && !defined(S3D_EMU)
+#if !defined(DW_NO_FMA)
         const float rx = g.r00 * v.gx + g.r01 * v.gy + g.r02 * v.gz;
         const float ry = g.r10 * v.gx + g.r11 * v.gy + g.r12 * v.gz;
         const float rz = g.r20 * v.gx + g.r21 * v.gy + g.r22 * v.gz;

@@ -740,17 +740,24 @@ static NnPool *nn_pool_lock(void)
     return &g_nn_pool[dev];
 }
 
+/* every device's pool (the scratch of a match that ran while another device was current stays on that device otherwise) */
 extern "C" void s3d_k_nn_release_scratch(void)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NN_DEVS) return;
-    pthread_mutex_lock(&g_nn_locks[dev]);
-    for (int k = 0; k < NN_SLOTS; k++) {
-        if (g_nn_pool[dev].p[k]) (void)hipFree(g_nn_pool[dev].p[k]);
-        g_nn_pool[dev].p[k] = nullptr;
-        g_nn_pool[dev].cap[k] = 0;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < NN_DEVS; dev++) {
+        pthread_mutex_lock(&g_nn_locks[dev]);
+        bool any = false;
+        for (int k = 0; k < NN_SLOTS; k++) any = any || g_nn_pool[dev].p[k] != nullptr;
+        if (any && hipSetDevice(dev) == hipSuccess)
+            for (int k = 0; k < NN_SLOTS; k++) {
+                if (g_nn_pool[dev].p[k]) (void)hipFree(g_nn_pool[dev].p[k]);
+                g_nn_pool[dev].p[k] = nullptr;
+                g_nn_pool[dev].cap[k] = 0;
+            }
+        pthread_mutex_unlock(&g_nn_locks[dev]);
     }
-    pthread_mutex_unlock(&g_nn_locks[dev]);
+    if (have) (void)hipSetDevice(cur);
 }
 
 /* The f16 hi / lo split (every element x 2^8: hi = f16, lo = f16 of the remainder) stays inside the error band of the

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include <rccl/rccl.h>
 
@@ -93,9 +94,21 @@ struct Rank {
     hipStream_t hs;          /* stream of the host-side gathers */
     pthread_mutex_t lock;    /* abort vs destroy */
     volatile int aborted;
+    int inflight;            /* rank-side calls between their look at `aborted` and their return (atomic) */
+};
+
+/* A rank-side call announces itself BEFORE it looks at `aborted`, and an abort (another thread: a failed rank takes every
+ * transport of its job down) raises the flag and then gives announced calls a moment to get into RCCL or out again before
+ * it aborts the communicators: a call can no longer pass the check, lose the CPU, and hand RCCL a communicator that has
+ * been freed in the meantime.  A call that is INSIDE RCCL when the abort comes is what ncclCommAbort is for. */
+struct InFlight {
+    Rank *me;
+    explicit InFlight(Rank *r) : me(r) { __atomic_add_fetch(&me->inflight, 1, __ATOMIC_SEQ_CST); }
+    ~InFlight() { __atomic_sub_fetch(&me->inflight, 1, __ATOMIC_SEQ_CST); }
 };
 
 #define S3D_ALIVE(me)                                                                      \
+    InFlight inflight_guard_(const_cast<Rank *>(me));                                      \
     do {                                                                                   \
         if ((me)->aborted) { s3d_rt_set_error("rccl transport", "aborted"); return S3D_ERR; } \
     } while (0)
@@ -150,18 +163,34 @@ int stage_wait(Rank *me)
 /* host lists (keypoint records, a few MB; descriptor records when a caller gathers them): through HBM, so that the
  * one fabric serves everything; piecewise through the fixed staging (every rank passes the same `bytes`, so every rank
  * makes the same number of pieces) */
+void rc_abort(void *self);
+
+/* one piece of rc_allgather_host: everything it enqueues on the gather stream */
+int gather_piece(Rank *me, const void *send, void *recv, size_t bytes, size_t off, size_t nb)
+{
+    char *d_all = me->d_stage, *d_mine = d_all + STAGE_PIECE * (size_t)me->world;
+    S3D_ALIVE(me);
+    S3D_HIP(hipMemcpyAsync(d_mine, (const char *)send + off, nb, hipMemcpyHostToDevice, me->hs));
+    S3D_NCCL(g_api.AllGather(d_mine, d_all, nb, ncclUint8, me->comm[0], me->hs));
+    for (int r = 0; r < me->world; r++)
+        S3D_HIP(hipMemcpyAsync((char *)recv + (size_t)r * bytes + off, d_all + (size_t)r * nb, nb, hipMemcpyDeviceToHost, me->hs));
+    return stage_wait(me);
+}
+
 int rc_allgather_host(void *self, const void *send, void *recv, size_t bytes)
 {
     Rank *me = (Rank *)self;
-    char *d_all = me->d_stage, *d_mine = d_all + STAGE_PIECE * (size_t)me->world;
     for (size_t off = 0; off < bytes; off += STAGE_PIECE) {
         const size_t nb = bytes - off < STAGE_PIECE ? bytes - off : STAGE_PIECE;
-        S3D_ALIVE(me);
-        S3D_HIP(hipMemcpyAsync(d_mine, (const char *)send + off, nb, hipMemcpyHostToDevice, me->hs));
-        S3D_NCCL(g_api.AllGather(d_mine, d_all, nb, ncclUint8, me->comm[0], me->hs));
-        for (int r = 0; r < me->world; r++)
-            S3D_HIP(hipMemcpyAsync((char *)recv + (size_t)r * bytes + off, d_all + (size_t)r * nb, nb, hipMemcpyDeviceToHost, me->hs));
-        if (stage_wait(me)) return S3D_ERR;
+        if (gather_piece(me, send, recv, bytes, off, nb)) {
+            /* A time-out or an error leaves the all-gather and the copies into the CALLER's buffer queued; the caller frees
+             * that buffer as soon as this returns.  The rank gives up its transport (include/sift3d_amd_slab.h: a rank whose
+             * wait exceeds SIFT3D_SLAB_TIMEOUT_S aborts its own transport) -- the aborted all-gather returns -- and the
+             * gather stream is drained before anybody may touch `recv` again. */
+            rc_abort(me);
+            (void)hipStreamSynchronize(me->hs);
+            return S3D_ERR;
+        }
     }
     return S3D_OK;
 }
@@ -174,6 +203,13 @@ void rc_abort(void *self)
     pthread_mutex_lock(&me->lock);
     if (!me->aborted) {
         me->aborted = 1;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        /* calls that announced themselves before the flag went up: into RCCL or out again (bounded: one that is blocked
+         * INSIDE RCCL stays in flight until the abort below releases it) */
+        for (int spin = 0; spin < 2000 && __atomic_load_n(&me->inflight, __ATOMIC_SEQ_CST) > 0; spin++) {
+            struct timespec ts = {0, 50000};
+            nanosleep(&ts, nullptr);
+        }
         for (int l = 0; l < 2; l++)
             if (me->comm[l]) { g_api.CommAbort(me->comm[l]); me->comm[l] = nullptr; }
     }
@@ -256,8 +292,9 @@ extern "C" int sift3d_amd_rccl_create(const unsigned char id[SIFT3D_AMD_RCCL_ID_
     if (r == ncclSuccess) {
         ncclUniqueId *all = (ncclUniqueId *)malloc(sizeof(u2) * (size_t)world);
         if (all == nullptr || rc_allgather_host(me, &u2, all, sizeof(u2))) {
+            rc_abort(me);                 /* (rc_allgather_host has aborted and drained already when it is what failed) */
+            (void)hipStreamSynchronize(me->hs);
             free(all);
-            rc_abort(me);
             rc_destroy(me);
             return S3D_ERR;
         }
