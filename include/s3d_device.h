@@ -196,7 +196,7 @@ int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint3
                  void *d_scratch /* s3d_k_orient_scratch_bytes(num) bytes */, s3d_stream stream);
 /* The same with the levels' window tables: d_tabs = s3d_k_orient_tab_bytes(pyr) bytes of device memory the call fills
  * (one launch, a wave per level) and the window sums then replay -- the window of a candidate with an integer centre
- * away from the faces of the volume, in a level with equal power-of-two units, is a property of its level (which
+ * away from the faces of the volume is a property of its level, whatever the units are (which
  * voxels, in which order, with which weights), so the row intervals, scans and weights need not be redone per
  * candidate.  Same results, bit for bit; d_tabs == NULL is s3d_k_orient. */
 #define S3D_ORI_TAB_TURNS 128                /* turns of 64 lanes a table holds (default parameters: 11-27) */
@@ -208,6 +208,9 @@ typedef struct {
     s3d_ori_ent ent[S3D_ORI_TAB_TURNS * 64];
 } s3d_ori_tab;
 size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr);
+/* Nonzero when s3d_k_orient_tab will use d_tabs for this pyramid: the knob below asks for it, or the levels' units are not
+ * one power of two (no per-wave weight table: the replayed weights then save an expf per window voxel). */
+int s3d_k_orient_wants_tab(const s3d_pyramid_desc *pyr);
 int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                      const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
                      float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream stream);

@@ -685,14 +685,14 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
         double *const sig = c->h_sigma;                   /* lives in the context: the copy below is asynchronous */
         for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
         DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
-        if (s3d_k_orient_mode() != 0 && c->oritab_bytes < s3d_k_orient_tab_bytes(&pd)) {
+        if (s3d_k_orient_wants_tab(&pd) && c->oritab_bytes < s3d_k_orient_tab_bytes(&pd)) {
             dfree(&c->d_oritab);
             c->oritab_bytes = 0;
             DEV(s3d_rt_malloc(&c->d_oritab, s3d_k_orient_tab_bytes(&pd)));
             c->oritab_bytes = s3d_k_orient_tab_bytes(&pd);
         }
         DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
-                             c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_mode() != 0 ? c->d_oritab : NULL, c->stream));
+                             c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_wants_tab(&pd) ? c->d_oritab : NULL, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
                                c->d_Rk, c->d_count + 1, c->d_kscratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));

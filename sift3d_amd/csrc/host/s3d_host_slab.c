@@ -755,14 +755,14 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
             sl->orient_bytes = need;
         }
     }
-    if (s3d_k_orient_mode() != 0 && sl->oritab_bytes < s3d_k_orient_tab_bytes(&sl->pd)) {
+    if (s3d_k_orient_wants_tab(&sl->pd) && sl->oritab_bytes < s3d_k_orient_tab_bytes(&sl->pd)) {
         dfree(&sl->d_oritab);
         sl->oritab_bytes = 0;
         if (dmalloc(sl, &sl->d_oritab, s3d_k_orient_tab_bytes(&sl->pd), 0)) return SIFT3D_FAILURE;
         sl->oritab_bytes = s3d_k_orient_tab_bytes(&sl->pd);
     }
     DEV(s3d_k_orient_tab(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, NULL, ncand, sl->d_sigma, sl->plan.corner_thresh, sl->d_R,
-                         sl->d_keep, NULL, sl->d_orient, s3d_k_orient_mode() != 0 ? sl->d_oritab : NULL, sl->cs));
+                         sl->d_keep, NULL, sl->d_orient, s3d_k_orient_wants_tab(&sl->pd) ? sl->d_oritab : NULL, sl->cs));
     DEV(s3d_k_compact_keys(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, sl->d_R, sl->d_keep, ncand, sl->d_xyzos, sl->d_Rk,
                            sl->d_count + 1, sl->d_kscratch, sl->cs));
     DEV(s3d_rt_d2h(sl->h_counts + 1, sl->d_count + 1, sizeof(uint32_t), sl->cs));

@@ -157,8 +157,8 @@ __device__ __forceinline__ int orient_finish(const float vr[2][3], float gwx, fl
 }
 
 /* PHASE 0 builds, PHASE 1 replays the window table of a level (s3d_ori_tab): for a candidate with an integer centre
- * away from the volume's faces, in a level with equal power-of-two units -- every detected candidate of a unit-voxel
- * volume but the few near a face -- the window is the SAME set of voxel offsets, visited in the SAME order by the same
+ * away from the volume's faces -- every detected candidate but the few near a face, whatever the units -- the window
+ * is the SAME set of voxel offsets, visited in the SAME order by the same
  * lanes, with the SAME weights, whatever the candidate: row intervals, scans, look-ups and the weight table are level
  * properties.  PHASE 0 (one wave per level) runs the sweep below once for a stand-in centre and records what every lane
  * does in every turn; PHASE 1 checks that the candidate's own bounding box (relative to its centre) is the table's and
@@ -241,16 +241,17 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
     const int cxi = (int)vcx, cyi = (int)vcy, czi = (int)vcz;
     const bool use_tab = uxf == uyf && uxf == uzf && um == 0.5f && (float)cxi == vcx && (float)cyi == vcy &&
                          (float)czi == vcz && rad2 / (double)u2 < (double)(ORI_WTAB - 2);
+    /* The level's window table (PHASE 0 fills, 1 / 3 replay) needs less than the weight table does: with an integer
+     * centre the offsets (float)x - vcx are the same exact integers for every candidate, so dx, dy, dz, the squared
+     * distance, the end tests of the rows and the weights are the same floats WHATEVER the units are -- anisotropic
+     * levels replay weights that PHASE 0 computed with the general path's own expression. */
+    const bool tab_ok = (float)cxi == vcx && (float)cyi == vcy && (float)czi == vcz;
     /* PHASE 1: does the level's window table describe this candidate's window? */
     bool replay = false;
-    if ((PHASE == 1 || PHASE == 3) && tabs != nullptr && d_center == nullptr && use_tab) {
+    if ((PHASE == 1 || PHASE == 3) && tabs != nullptr && d_center == nullptr && tab_ok) {
         const s3d_ori_tab *T = tabs + li;
         replay = T->n_turns > 0 && xs - cxi == T->rb[0] && xe - cxi == T->rb[1] && ys - cyi == T->rb[2] &&
                  ye - cyi == T->rb[3] && zs - czi == T->rb[4] && ze - czi == T->rb[5];
-    }
-    if (PHASE == 0 && !use_tab) {                          /* no table for this level: the general path serves it */
-        if (lane == 0) tabs[li].n_turns = 0;
-        return;
     }
     if (PHASE == 3) {                                      /* table walk only; PHASE 4 takes what is flagged here */
         if (lane == 0) d_keep[cand] = replay ? 0u : 3u;
@@ -358,11 +359,13 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
                 e.w[0] = e.w[1] = e.w[2] = e.w[3] = 0.0f;
                 if (valid) {
                     const int d2yz = (y - cyi) * (y - cyi) + (z - czi) * (z - czi);
+                    const float dy = ((float)y - vcy) * uyf, dz = ((float)z - vcz) * uzf;
                     e.off = (z - czi) * (int)plane + (y - cyi) * nx + (x0 - cxi);
                     e.nval = nval;
                     for (int j = 0; j < nval; j++) {
                         const int dxi = x0 + j - cxi;
-                        e.w[j] = wtab[dxi * dxi + d2yz];
+                        const float dx = ((float)(x0 + j) - vcx) * uxf;
+                        e.w[j] = use_tab ? wtab[dxi * dxi + d2yz] : weight(dx * dx + dy * dy + dz * dz);
                     }
                 }
                 T->ent[turn * 64 + lane] = e;
@@ -673,6 +676,14 @@ extern "C" int s3d_k_orient_mode(void)
     return g_orient_mode >= 0 ? g_orient_mode : env_mode;
 }
 
+extern "C" int s3d_k_orient_wants_tab(const s3d_pyramid_desc *pyr)
+{
+    if (s3d_k_orient_mode() != 0) return 1;
+    int ipow;
+    const float ux = pyr->unitsf[0][0], uy = pyr->unitsf[0][1], uz = pyr->unitsf[0][2];
+    return !(ux == uy && ux == uz && frexpf(ux, &ipow) == 0.5f);
+}
+
 extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
 {
     return sizeof(s3d_ori_tab) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
@@ -694,7 +705,11 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
      * L1 fill bandwidth (a third fewer distinct lines: -6 %) nor by workgroup launch rate (a fixed grid of 7-28 k waves
      * walking the candidates: +10-20 %), and loading a turn ahead did not shorten it either (1.09 -> 1.06): the tables buy
      * nothing end to end (detect 6.96 against 6.94 ms), so they stay an option. */
-    const int mode = s3d_k_orient_mode();
+    int mode = s3d_k_orient_mode();
+    /* Levels without the per-wave weight table (units that are not one power of two: the weight is an expf per voxel, a
+     * third of the general path's instructions) do gain from the window tables: 1.75 -> ~1.2 ms at 512 x 512 x 300 voxels
+     * of 0.7 x 0.7 x 1.5. */
+    if (mode == 0 && tabs && s3d_k_orient_wants_tab(pyr)) mode = 1;
     if (mode == 0) tabs = nullptr;
     if (tabs) {
         const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);

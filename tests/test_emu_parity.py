@@ -81,7 +81,8 @@ def test_orientation_chunk_loop(emu, oracle):
 @pytest.mark.parametrize("dims,units,sigmas,expect", [
     ((40, 36, 34), (1, 1, 1), (2.0, 2.5, 3.2), True),          # the detector's case: unit voxels
     ((30, 28, 26), (2, 2, 2), (4.0, 5.0), True),               # octave 1: units 2, sigma in the same units
-    ((32, 30, 28), (1, 1, 1.5), (2.0, 2.5), False),            # anisotropic: no tables, the general path serves all
+    ((32, 30, 28), (1, 1, 1.5), (2.0, 2.5), True),             # anisotropic: tables whose weights are the general path's expf
+    ((36, 34, 24), (0.7, 0.7, 1.5), (1.6, 2.0), True),         # units that are no power of two on any axis
 ])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_orient_tables(emu, dims, units, sigmas, expect, mode):

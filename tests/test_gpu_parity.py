@@ -612,7 +612,8 @@ def test_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits):
 @pytest.mark.parametrize("dims,units,sigmas,expect", [
     ((96, 88, 80), (1, 1, 1), (2.0159, 2.5398, 3.2), True),
     ((64, 60, 56), (2, 2, 2), (4.0317, 5.0797, 6.4), True),
-    ((48, 40, 44), (1, 1, 1.5), (2.0, 2.5), False),
+    ((48, 40, 44), (1, 1, 1.5), (2.0, 2.5), True),
+    ((72, 64, 40), (0.7, 0.7, 1.5), (1.6, 2.0159, 2.5398), True),
 ])
 def test_orient_tables(lib, dims, units, sigmas, expect, mode):
     """Orientation window sums replayed from the levels' tables equal the sums every candidate enumerates for itself, bit
