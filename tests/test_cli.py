@@ -87,7 +87,7 @@ def test_kpSift3D_emulated(progs, oracle, tmp_path, emu_env):
 
 @pytest.mark.gpu
 def test_kpSift3D_end_to_end(progs, oracle, tmp_path):
-    _kp_end_to_end(progs, oracle, tmp_path, (64, 56, 48), 220, 11, 20, None)
+    _kp_end_to_end(progs, oracle, tmp_path, (128, 128, 128), 2600, 11, 200, None)      # the size of the reference's own example volumes
 
 
 def _kp_end_to_end(progs, oracle, tmp_path, dims, nblobs, seed, min_kp, env):
