@@ -707,14 +707,23 @@ def main():
         st = np.zeros((K, 2), np.uint32)
         assert lib.sift.sift3d_amd_describe_window_stats(C.byref(s), C.byref(kp), st.ctypes.data_as(C.POINTER(C.c_uint))) == 0
         wv = int(st[:, 0].astype(np.int64).sum())
+        described, redone = C.c_ulonglong(0), C.c_ulonglong(0)
+        try:                                     # how often the histogram grid of a keypoint had to be redone
+            L = lib.sift
+            L.s3d_k_describe_redo_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+            if L.s3d_k_describe_redo_stats(C.byref(described), C.byref(redone), 0) != 0:
+                described, redone = C.c_ulonglong(0), C.c_ulonglong(0)
+        except AttributeError:
+            pass
         result["config"]["describe_kernel"] = {
             "window_voxels": wv, "lds_atomics_per_window_voxel": 24,
             "Gvox_window_per_s": round(wv / t_describe / 1e9, 1),
             "G_lds_atomic_lane_ops_per_s": round(24.0 * wv / t_describe / 1e9, 1),
-            "lds_data_path_floor_ms": round(24.0 * (wv / 64.0) * 6.4 / 256.0 / 2.4e9 * 1e3, 2),
-            "bound": "VALU issue (about 243 instructions per window voxel, 45 of them f64) for everything but the trilinear "
-                     "back end, whose 24 conflict-free ds_add_u64 per voxel (6.4 clk per wave and CU: lds_data_path_floor_ms) "
-                     "bound it; not HBM, not MFMA -- DESIGN.md section 4, profiles/r02_describe_ablations.txt"}
+            "lds_data_path_floor_ms": round(24.0 * (wv / 64.0) * 4.2 / 256.0 / 2.4e9 * 1e3, 2),
+            "windows_described_since_start": int(described.value), "windows_described_twice": int(redone.value),
+            "bound": "VALU issue (about 245 instructions per window voxel, 45 of them f64) and the LDS pipe (24 conflict-free "
+                     "ds_add_u32 per voxel into 32 bank-private copies, 4.2 clk per wave and CU: lds_data_path_floor_ms) overlap "
+                     "imperfectly; not HBM, not MFMA -- DESIGN.md section 4, profiles/r04_describe_field32.txt"}
     if rank == 0 and not args.no_match:
         # BASELINE configs[0] flavour, outside the timed region: the kpSift3D program on a 128^3 NIfTI-1 volume
         # (.nii.gz in, keypoint and descriptor CSVs out) -- process start, HIP initialisation, zlib and CSV

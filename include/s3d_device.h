@@ -258,6 +258,12 @@ int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint
                    const float *d_mesh, float *d_out, size_t out_stride /* floats, >= 768 */,
                    uint32_t *d_work, s3d_stream stream);
 
+/* The descriptor kernel sets the grid of a keypoint's fixed-point histogram from a sampled estimate of the window's
+ * gradient mass and proves afterwards that no 32-bit field wrapped; a keypoint whose proof fails is described again
+ * with the grid of its measured mass.  *described / *redone: how many windows the current device has described / has
+ * described twice since the counters were last reset (reset != 0 clears them). */
+int s3d_k_describe_redo_stats(unsigned long long *described, unsigned long long *redone, int reset);
+
 /* Test / diagnostics aid: d_stats[2i] = number of voxels the descriptor window of keypoint i accepts, d_stats[2i+1] = a
  * checksum of their coordinates, produced by the descriptor kernel's own window enumeration. */
 int s3d_k_describe_window_stats(const s3d_pyramid_desc *pyr, const s3d_desc_key *d_keys, uint32_t num,

@@ -919,6 +919,7 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
 #define DW_TMAX 2048                      /* entries of the weight table (squared voxel distances 0 .. DW_TMAX-1) */
 #define DW_CMAP 16384                     /* chunks of a round that get a direct chunk -> row entry (the rest: binary search) */
 #endif
+#define DW_NFIELD (2 * DW_NCOPY)           /* 32-bit histogram fields per bin: one per lane of a half wave */
 #define DW_WAVES (DW_THREADS / 64)
 #define DW_HIST_WORDS (S3D_DESC_NUMEL * DW_NCOPY)
 #define DW_NOUT ((S3D_DESC_NUMEL + DW_THREADS - 1) / DW_THREADS)   /* histogram bins a thread finalises */
@@ -936,6 +937,9 @@ struct DwShared {
     unsigned short seg_len[DW_THREADS];
     unsigned short chunk_row[DW_CMAP];    /* row (thread index of the round) that chunk c belongs to */
     int wave_tot[DW_WAVES];
+    unsigned long long copy_units[DW_NFIELD];   /* per histogram copy: an upper bound of what any of its fields can hold (the proof) */
+    float est_part[DW_WAVES];
+    unsigned proof_over, proof_fine;      /* a copy's bound exceeds the field / some copy's bound shows the grid is as fine as intended */
     unsigned win_chk, win_vox;
     unsigned next[2];                     /* the keypoint this workgroup takes next (claimed one keypoint ahead) */
     uint32_t nkey[2][(sizeof(s3d_desc_key) + 3) / 4];   /* ... and its record, fetched while the current one is worked on */
@@ -1032,6 +1036,22 @@ __device__ __forceinline__ double dw_block_sum(double v, double *part, int tid)
     return r;
 }
 
+/* Sum over the wave, for code that runs BEFORE the window of a keypoint: __shfl_xor's index vectors are pure functions of
+ * the lane id, so the optimiser shares them with the sums after the window and keeps them in registers across it; here
+ * they are formed from an opaque copy of the lane id at the point of use. */
+__device__ __forceinline__ float dw_wave_sum_early(float v, int lane_opaque)
+{
+#if defined(S3D_EMU)
+    (void)lane_opaque;
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+#else
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = v + __int_as_float(__builtin_amdgcn_ds_bpermute((lane_opaque ^ m) << 2, __float_as_int(v)));
+#endif
+    return v;
+}
+
 /* A value the optimiser cannot see through: address arithmetic derived from it is redone where it is used instead of
  * being hoisted out of the persistent keypoint loop and held (or spilled) across the whole chunk loop. */
 __device__ __forceinline__ int dw_opaque(int x)
@@ -1041,6 +1061,10 @@ __device__ __forceinline__ int dw_opaque(int x)
 #endif
     return x;
 }
+
+/* how often the grid had to be redone: [0] windows described, [1] windows described twice (per device, since the last
+ * s3d_k_describe_redo_stats call that asked for a reset) */
+__device__ unsigned long long g_dw_stat[2];
 
 template <bool COUNT_ONLY>
 __global__ void __launch_bounds__(DW_THREADS)
@@ -1126,24 +1150,117 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     const bool use_tab = !COUNT_ONLY && g.uxf == g.uyf && g.uxf == g.uzf && um == 0.5f && (float)cxi == key.cx &&
                          (float)cyi == key.cy && (float)czi == key.cz && g.rad2 / u2 < (float)(DW_TMAX - 348);   /* + 6 r + 9 for the chunk's last voxel stays below DW_TMAX */
 
-    /* fixed-point grid 2^-f of the histogram (see (2) above): a contribution is bounded by the gradient bound 2^bexp
-     * (level voxels are bounded by 1 -- scaled input, convex filters -- so a central difference is <= 1/u per axis) */
-    int bexp;
-    (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);
-    int head = 1;
-    {
-        const unsigned long long per_copy = (unsigned long long)(wx > 0 ? wx : 1) * (unsigned)(wy > 0 ? wy : 1) * (unsigned)(wz > 0 ? wz : 1) / DW_NCOPY + 4096ull;
-        while ((1ull << head) < per_copy) head++;
-    }
-    const int fbits = (int)DW_UNIFORM(47 - bexp - head);      /* frexp leaves bexp in a vector register: back to scalar */
-    const double Mfix = ldexp(1.5, 52 - fbits);
-    const double unscale = ldexp(1.0, -fbits);
+    /* fixed-point grid of the histogram (see (2) above): 2^-f / fs, set from the window's measured gradient mass further
+     * down (dw_scale) and proved sufficient after the fact */
+    int fbits = 0;
+    float fscale = 1.0f;
+    double Mfix = 0.0;
 
     const int tz = dw_opaque(tid);
+    /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
+    const float slab_hi = 4.0f / g.binf - g.half;
+    const float a0 = g.r00 * g.uxf, a1 = g.r10 * g.uxf, a2 = g.r20 * g.uxf;
+    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
+    /* A1: the accepted interval [lo, hi] of bounding-box row r = by + wy * bz; false: none */
+    auto row_span = [&](int r, int *plo, int *phi, int *pby, int *pbz) -> bool {
+        int by;
+        const int bz = fdiv_small(r, wy, inv_wy, &by);
+        const int y = g.ys + by, z = g.zs + bz;
+        const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
+        const float s2 = g.rad2 - dy * dy - dz * dz;
+        const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) / g.uxf;
+        float lo_f = s2 < -1e-3f * g.rad2 ? 1.0f : -chord, hi_f = s2 < -1e-3f * g.rad2 ? -1.0f : chord;
+        const float c0 = g.r01 * dy + g.r02 * dz, c1 = g.r11 * dy + g.r12 * dz, c2 = g.r21 * dy + g.r22 * dz;
+        const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (fabsf(av[i]) > 1e-6f) {                      /* else: left to the exact tests below */
+                const float t0 = (-g.half - cv[i]) / av[i], t1 = (slab_hi - cv[i]) / av[i];
+                lo_f = fmaxf(lo_f, fminf(t0, t1));
+                hi_f = fminf(hi_f, fmaxf(t0, t1));
+            }
+        int lo = (int)ceilf(g.cx + lo_f - 1e-3f), hi = (int)floorf(g.cx + hi_f + 1e-3f);
+        lo = lo > g.xs ? lo : g.xs;
+        hi = hi < xe ? hi : xe;
+        auto inside = [&](int x) {
+            float sq, vx, vy, vz;
+            return desc_window(g, x, y, z, &sq, &vx, &vy, &vz);
+        };
+        while (lo <= hi && !inside(lo)) lo++;
+        while (lo <= hi && !inside(hi)) hi--;
+        if (lo > hi) return false;
+        while (lo > g.xs && inside(lo - 1)) lo--;
+        while (hi < xe && inside(hi + 1)) hi++;
+        *plo = lo; *phi = hi; *pby = by; *pbz = bz;
+        return true;
+    };
+
+
+    /* ---- the scale of the fixed-point grid (dw_scale) ----------------------------------------------------------------
+     * The histogram fields are 32 bits wide (ds_add_u32: 4.2 clk of the LDS pipe per wave against 6.4 for ds_add_u64, and
+     * twice the copies in the same 96 KB), so the grid has to fit the keypoint: fine enough for the 1e-4 contract,
+     * coarse enough that no field can wrap.  Both are statements about the window's gradient mass T = sum |w grad| (a
+     * voxel spreads exactly its |w grad| over its 24 contributions): a field of copy k holds at most T_k, the mass of the
+     * voxels that the lanes of copy k worked on, and the bins' rounding noise relative to the descriptor's norm is
+     * ~ sqrt(contributions per bin) * grid / |h|, with |h| ~ T / 20.  So: (1) T is estimated from one voxel at a
+     * pseudo-random place in each of up to 512 rows spread over the window (loads issued here, consumed after the
+     * histogram has been cleared); (2) grid = 1.15 T_est / 32 * 1.35 / 2^32, i.e. ~1e-11 T -- the contract needs
+     * < 9e-11 T at three sigma for a bin of 4000 contributions; (3) every lane sums the mass it sends, and after the window
+     * the per-copy sums PROVE that no field wrapped (T_k / grid + rounding slack < 2^32 - 2^21; the 2^21 are kept for
+     * fields whose sum is negative: barycentric weights down to -1.2e-6 are accepted, sift.c:50).  If the proof fails, or
+     * the estimate was so far off that the grid came out more than 8x coarser than intended, the keypoint is redone with
+     * the grid that its measured T_k asks for (s3d_k_describe_redo_stats counts them). */
+    int floose;
+    {
+        int bexp, head = 1;
+        (void)frexpf(sqrtf(iux * iux + iuy * iuy + iuz * iuz) * 1.0001f, &bexp);
+        const unsigned long long per_copy = (unsigned long long)(wx > 0 ? wx : 1) * (unsigned)(wy > 0 ? wy : 1) * (unsigned)(wz > 0 ? wz : 1) / DW_NFIELD + 4096ull;
+        while ((1ull << head) < per_copy) head++;
+        floose = (int)DW_UNIFORM(31 - bexp - head);           /* frexp leaves bexp in a vector register: to a scalar one */
+    }
+    const double flimit = 4294967296.0 - 2097152.0;
+    const double fgoal = flimit / 1.35;
+    auto set_scale = [&](double tk) {                         /* tk: the largest per-copy mass expected, unscaled */
+        int f;
+        float fs = 1.0f;
+        if (tk > 0.0) {
+            const double S = fgoal / (tk > 1e-280 ? tk : 1e-280);
+            int e;
+            const double mant = frexp(S, &e);                 /* S = mant 2^e, mant in [0.5, 1) */
+            f = e - 1;
+            fs = (float)(2.0 * mant);
+            if (f > 100) { f = 100; fs = 1.0f; }
+            if (f < -60) { f = -60; fs = 1.0f; }
+        } else {
+            /* no gradient seen: the grid that cannot wrap whatever the window holds (floose: level voxels are bounded by 1 --
+             * scaled input, convex filters -- so a central difference is <= 1/u per axis); the proof then finds it coarse */
+            f = floose;
+        }
+        fbits = (int)DW_UNIFORM(f);                           /* scalar registers: they live across the whole window */
+        fscale = __uint_as_float(DW_UNIFORM(__float_as_uint(fs)));
+        Mfix = ldexp(1.5, 52 - fbits);
+    };
+    /* (1) the sample of this thread: six neighbours of one accepted voxel */
+    const int nsamp = COUNT_ONLY ? 0 : (nrows < DW_THREADS / 2 ? nrows : DW_THREADS / 2);
+    float sp_xm = 0.0f, sp_xp = 0.0f, sp_ym = 0.0f, sp_yp = 0.0f, sp_zm = 0.0f, sp_zp = 0.0f;
+    int sp_x = 0, sp_y = 0, sp_z = 0, sp_len = 0;
+    if (tz < nsamp) {
+        int lo = 0, hi = 0, by = 0, bz = 0;
+        const int r = (int)(((long long)tz * nrows) / (nsamp > 0 ? nsamp : 1));
+        if (row_span(r, &lo, &hi, &by, &bz)) {
+            sp_len = hi - lo + 1;
+            sp_x = lo + (int)(((((unsigned)r * 2654435761u) >> 16) * (unsigned)sp_len) >> 16);
+            sp_y = g.ys + by; sp_z = g.zs + bz;
+            const float *p = im + ((size_t)sp_z * plane + (size_t)sp_y * nx + sp_x);
+            sp_xm = p[-1]; sp_xp = p[1]; sp_ym = p[-nx]; sp_yp = p[nx]; sp_zm = p[-(ptrdiff_t)plane]; sp_zp = p[plane];
+        }
+    }
+
     for (int i = tz; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
-    if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; }
+    if (tz < DW_NFIELD) sm.copy_units[tz] = 0ull;
+    if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; sm.proof_over = 0; sm.proof_fine = 0; }
     __syncthreads();
-    /* the next keypoint's record: loaded now (one word per lane of the first wave), parked in LDS after the chunk loop */
+    /* the next keypoint's record: loaded now (one word per lane of the first wave), parked in LDS further down */
     constexpr int KEY_WORDS = (int)((sizeof(s3d_desc_key) + 3) / 4);
     uint32_t nkey_word = 0;
     {
@@ -1159,8 +1276,36 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         }
         __syncthreads();
     }
+    if (!COUNT_ONLY) {
+        /* (1) continued: the row's mass from its sample, the window's from the rows */
+        float est = 0.0f;
+        if (sp_len > 0) {
+            float w;
+            if (use_tab) {
+                const int dxi = sp_x - cxi, dyi = sp_y - cyi, dzi = sp_z - czi;
+                w = sm.wtab[dxi * dxi + dyi * dyi + dzi * dzi];
+            } else {
+                const float dx = ((float)sp_x - g.cx) * g.uxf, dy = ((float)sp_y - g.cy) * g.uyf, dz = ((float)sp_z - g.cz) * g.uzf;
+                w = s3d_expf_tab((float)((double)(-0.5f * (dx * dx + dy * dy + dz * dz)) * inv_sig2), sm.etab);
+            }
+            const float gx = 0.5f * (sp_xp - sp_xm) * iux, gy = 0.5f * (sp_yp - sp_ym) * iuy, gz = 0.5f * (sp_zp - sp_zm) * iuz;
+            est = w * DW_SQRT(gx * gx + gy * gy + gz * gz) * (float)sp_len;
+        }
+        est = dw_wave_sum_early(est, dw_opaque(lane));
+        if (lane == 0) sm.est_part[tz >> 6] = est;
+    }
+    /* the next keypoint's record has arrived by now (the samples were requested before it): park it (slot (turn + 1) & 1
+     * was last read at the top of the previous turn) instead of carrying it through the window in a register */
+    if (tz < KEY_WORDS) sm.nkey[(turn + 1) & 1][tz] = nkey_word;
+    if (!COUNT_ONLY) {
+        __syncthreads();
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < DW_WAVES; w++) tsum = tsum + sm.est_part[w];
+        set_scale(1.15 * (double)tsum * (double)nrows / (double)(nsamp > 0 ? nsamp : 1) / (double)DW_NFIELD);
+    }
 
-    const unsigned copy8 = (unsigned)(lane & (DW_NCOPY - 1)) * 8u;
+    const unsigned copy8 = (unsigned)(lane & (DW_NFIELD - 1)) * 4u;
     char *const hbase = reinterpret_cast<char *>(sm.hist);
 
     /* cell coordinates advance linearly along x: vb(x + 1) = vb(x) + (R^T e_x) ux binf.  They only feed the trilinear
@@ -1171,6 +1316,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
      * operations of a wave complete in order, and a table read queued behind 24 atomics waits for all of them.
      * front: cell coordinates vb, window weight w, central differences (x2) -> face and the three vertex magnitudes. */
     struct DwVox { float m0, m1, m2, vbx, vby, vbz, gx, gy, gz; int face; bool safe; };
+    float mass = 0.0f;                                        /* |w grad| of the voxels this lane has sent to its histogram copy */
     auto front = [&](bool valid, float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
         DwVox v;
         gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
@@ -1198,7 +1344,8 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         bool safe;
         const int face = dw_face_fast(sm.mesh, sm.fcn, gr, &bary, &safe);
         const bool live = valid && !((double)gg < S3D_BARY_EPS_D);       /* icos_hist_bin's floor on |grad|^2, sift.c:1655 */
-        const float mag = DW_SQRT(gg);
+        const float mag = DW_SQRT(gg) * fscale;
+        mass = mass + (valid ? mag : 0.0f);                      /* (resolve() may move it by an ulp: the proof allows 1e-4) */
         v.face = live ? face : -1;
         v.safe = (safe && !floor_unsure) || !(live || (valid && floor_unsure));
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
@@ -1222,7 +1369,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const float rx = v.gx, ry = v.gy, rz = v.gz;
 #endif
         v.face = s3d_icos_bin(sm.mesh, v3(rx, ry, rz), &bary);           /* -1 below the floor on |grad|^2 */
-        const float mag = DW_SQRT(rx * rx + ry * ry + rz * rz);
+        const float mag = DW_SQRT(rx * rx + ry * ry + rz * rz) * fscale;
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
     };
     /* back: the trilinear spread over 8 cells x 3 vertices */
@@ -1249,9 +1396,9 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                     const double wc = wxy * wzs[iz];
                     constexpr int DCB = S3D_NVERT * DW_NCOPY * 8;
                     const int dc = (ix + 4 * iy + 16 * iz) * DCB;                          /* compile-time byte offset */
-                    atomicAdd(reinterpret_cast<unsigned long long *>(p0 + dc), (unsigned long long)__double_as_longlong(fma(m0, wc, Mfix)));
-                    atomicAdd(reinterpret_cast<unsigned long long *>(p1 + dc), (unsigned long long)__double_as_longlong(fma(m1, wc, Mfix)));
-                    atomicAdd(reinterpret_cast<unsigned long long *>(p2 + dc), (unsigned long long)__double_as_longlong(fma(m2, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned *>(p0 + dc), (unsigned)__double_as_longlong(fma(m0, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned *>(p1 + dc), (unsigned)__double_as_longlong(fma(m1, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned *>(p2 + dc), (unsigned)__double_as_longlong(fma(m2, wc, Mfix)));
                 }
             }
     };
@@ -1307,44 +1454,16 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         return L;
     };
 
-    /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
-    const float slab_hi = 4.0f / g.binf - g.half;
-    const float a0 = g.r00 * g.uxf, a1 = g.r10 * g.uxf, a2 = g.r20 * g.uxf;
-    const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
+    for (int attempt = 0; ; attempt++) {
+    unsigned turns = 0;                                       /* chunks a thread has taken at most, over the rounds */
     for (int r0 = 0; r0 < nrows; r0 += DW_THREADS) {
         /* ---- A1: this thread's row ---- */
         int len = 0;
         unsigned first = 0;
         const int tr = dw_opaque(tid), ln = tr & 63;        /* this round's own copy: see dw_opaque */
         if (r0 + tr < nrows) {
-            int by;
-            const int bz = fdiv_small(r0 + tr, wy, inv_wy, &by);
-            const int y = g.ys + by, z = g.zs + bz;
-            const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
-            const float s2 = g.rad2 - dy * dy - dz * dz;
-            const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) / g.uxf;
-            float lo_f = s2 < -1e-3f * g.rad2 ? 1.0f : -chord, hi_f = s2 < -1e-3f * g.rad2 ? -1.0f : chord;
-            const float c0 = g.r01 * dy + g.r02 * dz, c1 = g.r11 * dy + g.r12 * dz, c2 = g.r21 * dy + g.r22 * dz;
-            const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2};
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-                if (fabsf(av[i]) > 1e-6f) {                      /* else: left to the exact tests below */
-                    const float t0 = (-g.half - cv[i]) / av[i], t1 = (slab_hi - cv[i]) / av[i];
-                    lo_f = fmaxf(lo_f, fminf(t0, t1));
-                    hi_f = fminf(hi_f, fmaxf(t0, t1));
-                }
-            int lo = (int)ceilf(g.cx + lo_f - 1e-3f), hi = (int)floorf(g.cx + hi_f + 1e-3f);
-            lo = lo > g.xs ? lo : g.xs;
-            hi = hi < xe ? hi : xe;
-            auto inside = [&](int x) {
-                float sq, vx, vy, vz;
-                return desc_window(g, x, y, z, &sq, &vx, &vy, &vz);
-            };
-            while (lo <= hi && !inside(lo)) lo++;
-            while (lo <= hi && !inside(hi)) hi--;
-            if (lo <= hi) {
-                while (lo > g.xs && inside(lo - 1)) lo--;
-                while (hi < xe && inside(hi + 1)) hi++;
+            int lo = 0, hi = 0, by = 0, bz = 0;
+            if (row_span(r0 + tr, &lo, &hi, &by, &bz)) {
                 len = hi - lo + 1;
                 first = (unsigned)(lo - g.xs) | ((unsigned)by << 10) | ((unsigned)bz << 20);
             }
@@ -1365,9 +1484,6 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         sm.seg_len[tr] = (unsigned short)len;
         sm.seg_off[tr] = before + incl - nchunk;
         if (tr == DW_THREADS - 1) sm.seg_off[DW_THREADS] = before + incl;
-        /* the next keypoint's record has arrived by now: park it (slot (turn + 1) & 1 was last read at the top of the
-         * previous turn) instead of carrying it through the chunk loop in a register */
-        if (r0 == 0 && tr < KEY_WORDS) sm.nkey[(turn + 1) & 1][tr] = nkey_word;
         {   /* chunk -> row map: every row enters itself for its own chunks (ten dependent LDS reads of a binary search per
              * chunk become one) */
             const int c0 = before + incl - nchunk;
@@ -1375,6 +1491,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         }
         __syncthreads();
         const int total = sm.seg_off[DW_THREADS];
+        turns += DW_UNIFORM((unsigned)total / DW_THREADS + 1u);
         /* ---- B: one chunk per thread and turn; the next chunk's look-up and loads are issued before this chunk's
          * atomics (they would otherwise queue behind them) ---- */
         if (COUNT_ONLY) {                                           /* test aid: count + checksum of the window set */
@@ -1416,25 +1533,45 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
          * wave reaches only once it has finished this round's chunks; waves that run out of chunks early start on the next
          * round's row intervals instead of waiting. */
     }
-    __syncthreads();                                          /* all histogram atomics (and the window counters) are in */
+    if (COUNT_ONLY) break;
+    if (tid == 0 && attempt == 0) atomicAdd(&g_dw_stat[0], 1ull);
+    /* (3) the proof.  Copy k = lanes k and k + 32 of every wave; a contribution is rounded to the grid (<= 1/2 each, 24 per
+     * voxel, <= 4 turns voxels per lane), a lane's float sum is short by < 1e-5 of itself. */
+    {
+        const int lp = dw_opaque(lane);
+#if defined(S3D_EMU)
+        const float m2 = mass + __shfl_xor(mass, 32);
+#else
+        const float m2 = mass + __int_as_float(__builtin_amdgcn_ds_bpermute((lp ^ 32) << 2, __float_as_int(mass)));
+#endif
+        if (lp < DW_NFIELD) {
+            double d = ldexp((double)m2, fbits) * 1.0001 + 96.0 * (double)turns;
+            if (!(d < 1e18)) d = 1e18;
+            atomicAdd(&sm.copy_units[lp], (unsigned long long)d);
+        }
+    }
+    __syncthreads();                                          /* ... and all histogram atomics are in */
     const int tm = dw_opaque(tid);
-    if (nrows <= 0 && tm < KEY_WORDS) sm.nkey[(turn + 1) & 1][tm] = nkey_word;     /* no round ran */
-    if (COUNT_ONLY) {
-        if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
-        __syncthreads();                                      /* before the next keypoint clears the counters */
-    } else {
-    /* merge the copies (48-bit two's complement integers: order free), then normalise / clamp / normalise */
+    if (tm < DW_NFIELD) {
+        const double u = (double)sm.copy_units[tm];
+        if (!(u < flimit)) sm.proof_over = 1u;
+        if (u >= fgoal / 8.0) sm.proof_fine = 1u;
+    }
+    /* merge the copies (integers: order free; a field at the very top of the range is a small negative sum), then
+     * normalise / clamp / normalise */
     double ss = 0.0;
     float v[DW_NOUT];
+    const double unscale = ldexp(1.0, -fbits) / (double)fscale;
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++) {
         const int b = tm + q * DW_THREADS;
         v[q] = 0.0f;
         if (b < S3D_DESC_NUMEL) {
             long long acc = 0;
-            for (int w = 0; w < DW_NCOPY; w++) {
-                const unsigned long long raw = sm.hist[b * DW_NCOPY + ((w + b) & (DW_NCOPY - 1))];
-                acc += (long long)(raw << 16) >> 16;                  /* sign-extend the low 48 bits */
+            const unsigned *h32 = reinterpret_cast<const unsigned *>(sm.hist);
+            for (int w = 0; w < DW_NFIELD; w++) {
+                const unsigned h = h32[b * DW_NFIELD + ((w + b) & (DW_NFIELD - 1))];
+                acc += h >= 0xffe00000u ? (long long)h - 4294967296ll : (long long)h;
             }
             v[q] = (float)((double)acc * unscale);
             ss += (double)v[q] * (double)v[q];
@@ -1442,6 +1579,23 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     }
     const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
     double norm = sqrt(dw_block_sum(ss, sm.part, tm)) + 2.220446049250313e-16; /* + DBL_EPSILON */
+    /* (the barriers of the sum lie between the flags' writers and these reads) */
+    const bool over = DW_UNIFORM(sm.proof_over) != 0u, fine = DW_UNIFORM(sm.proof_fine) != 0u;
+    if (attempt < 2 && (over || !(fine || attempt > 0 || fbits >= 100))) {
+        /* redo with the grid of the measured mass */
+        if (tid == 0 && attempt == 0) atomicAdd(&g_dw_stat[1], 1ull);
+        double umax = 0.0;
+        for (int k = 0; k < DW_NFIELD; k++) umax = fmax(umax, (double)sm.copy_units[k]);
+        const double tk = ldexp(umax, -fbits) / (double)fscale;
+        __syncthreads();                                      /* every thread has read the bounds and the flags */
+        set_scale(1.02 * tk);
+        mass = 0.0f;
+        for (int i = tm; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
+        if (tm < DW_NFIELD) sm.copy_units[tm] = 0ull;
+        if (tid == 0) { sm.proof_over = 0; sm.proof_fine = 0; }
+        __syncthreads();
+        continue;
+    }
     float inv = (float)(1.0 / norm);
     ss = 0.0;
 #pragma unroll
@@ -1455,6 +1609,12 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++)
         if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tm + q * DW_THREADS] = v[q] * inv;
+    break;
+    }
+    if (COUNT_ONLY) {
+        __syncthreads();                                      /* the window counters are in */
+        if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
+        __syncthreads();                                      /* before the next keypoint clears the counters */
     }
     /* every barrier above lies between thread 0's claim and this read; the slot alternates so that the next turn's claim
      * cannot overtake a slow reader */
@@ -1520,5 +1680,18 @@ extern "C" int s3d_k_describe(const s3d_pyramid_desc *pyr, const s3d_desc_key *d
     hipLaunchKernelGGL((k_describe_wg<false>), dim3(grid), dim3(DW_THREADS), sizeof(DwShared), (hipStream_t)st, *pyr, d_keys, num,
                        d_mesh, d_out, out_stride, (uint32_t *)nullptr, d_work);
     S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+extern "C" int s3d_k_describe_redo_stats(unsigned long long *described, unsigned long long *redone, int reset)
+{
+    unsigned long long h[2] = {0, 0};
+    S3D_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dw_stat), sizeof(h)));
+    if (described) *described = h[0];
+    if (redone) *redone = h[1];
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        S3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_stat), z, sizeof(z)));
+    }
     return S3D_OK;
 }

@@ -293,6 +293,10 @@ static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1);
 static inline hipError_t hipFree(void *p) { free(p); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return 0; }
+/* __device__ variables are plain globals here */
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipMemcpyFromSymbol(void *d, const void *sym, size_t n) { memmove(d, sym, n); return 0; }
+static inline hipError_t hipMemcpyToSymbol(void *sym, const void *s, size_t n) { memmove(sym, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 #define hipErrorNotReady 600
