@@ -889,19 +889,19 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  * conversion or 24-bit-multiply instruction 4.4, rcp/sqrt 8.4) and by the in-order LDS queue second (a table read
  * queued behind atomics waits for all of them).
  *
- *  (1) Bank-private histogram copies.  A ds_add_u64 costs the LDS pipe 6.4 clk per wave when the lanes hit distinct
- *      banks and 11.9 clk with data-dependent addresses (64 lanes x 2 dwords over 64 banks, processed 16 lanes at
- *      a time).  With 16 copies laid out copy-minor -- word (bin, copy) at bin*16 + copy, copy = lane & 15 -- the 16 lanes
- *      of a pass always sit in 16 different bank pairs whatever their bins are: conflict free by construction
- *      (SQ_LDS_BANK_CONFLICT 1.3e10 -> 8.5e8).  16 x 768 x 8 B = 96 KB of LDS is what a CU has room for once, hence ONE
- *      workgroup of 16 waves per CU (4 per SIMD, 128 VGPRs each).
+ *  (1) Bank-private histogram copies of 32-bit fields.  A ds_add_u32 costs the LDS pipe 4.2 clk per wave when the lanes
+ *      hit distinct banks (ds_add_u64: 6.4; 9-12 with data-dependent addresses).  With 32 copies laid out copy-minor --
+ *      field (bin, copy) at dword bin*32 + copy, copy = lane & 31 -- the lanes of a pass always sit in different banks
+ *      whatever their bins are: conflict free by construction.  32 x 768 x 4 B = 96 KB of LDS is what a CU has room for
+ *      once, hence ONE workgroup of 16 waves per CU (4 per SIMD, 128 VGPRs each).  (Rounds 2-3: 16 copies of 64-bit
+ *      fields, 15.6 ms; this layout: 14.3 ms, profiles/r04_describe_field32.txt.)
  *  (2) One VALU instruction per contribution.  A contribution (mag * bary_v) * (wx * wy * wz) is formed as
  *      fma(m_v, w_c, M) in f64 with M = 1.5 * 2^(52 - f): the product of two f32-derived doubles is exact, the single
- *      rounding of the fma lands on the fixed-point grid 2^-f, and the low 48 bits of the result's bit pattern ARE that
- *      fixed-point number (the exponent field and bit 51 are the same for every contribution and fall outside the low
- *      48 bits), so the raw 64-bit pattern goes straight into ds_add_u64 and the sums of the low 48 bits are exact
- *      integers: order free, bitwise reproducible, rounded to nearest.  f is chosen per keypoint so that a copy's bin
- *      cannot leave 47 bits: (window voxels / 16) * gradient bound * 2^f < 2^47.
+ *      rounding of the fma lands on the fixed-point grid 2^-f, and the low 32 bits of the result's bit pattern ARE that
+ *      fixed-point number modulo 2^32, so the low dword goes straight into ds_add_u32 and the fields are exact integer
+ *      sums modulo 2^32: order free, bitwise reproducible, rounded to nearest.  The grid (f and a factor in [1, 2) on the
+ *      magnitudes) is set per keypoint from its measured gradient mass, and the kernel proves after the window that no
+ *      field wrapped -- see dw_scale in the kernel body.
  *  (3) The window weight expf(-sq / 2 sigma^2) comes from a per-keypoint table indexed by the integer squared distance
  *      when that is exact (integer centre, equal power-of-two units: every octave of a unit-voxel volume); the table
  *      entries are produced by the same restated glibc expf on the same float argument, so nothing changes bit-wise.
@@ -914,10 +914,11 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  *  (5) A chunk's LDS reads (tables, the next chunk's look-up) are issued before its 96 atomics.
  */
 #ifndef DW_THREADS
-#define DW_THREADS 1024
-#define DW_NCOPY 16
-#define DW_TMAX 2048                      /* entries of the weight table (squared voxel distances 0 .. DW_TMAX-1) */
-#define DW_CMAP 16384                     /* chunks of a round that get a direct chunk -> row entry (the rest: binary search) */
+#define DW_THREADS 512
+#define DW_NCOPY 8                        /* 64-bit words per bin: 2 * DW_NCOPY 32-bit fields */
+#define DW_TMAX 1792                      /* entries of the weight table (squared voxel distances 0 .. DW_TMAX-1) */
+#define DW_CMAP 7168                      /* chunks of a round that get a direct chunk -> row entry (the rest: binary search) */
+#define DW_WG_PER_CU 2                    /* resident workgroups per CU (their LDS must fit side by side) */
 #endif
 #define DW_NFIELD (2 * DW_NCOPY)           /* 32-bit histogram fields per bin: one per lane of a half wave */
 #define DW_WAVES (DW_THREADS / 64)
@@ -925,7 +926,7 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
 #define DW_NOUT ((S3D_DESC_NUMEL + DW_THREADS - 1) / DW_THREADS)   /* histogram bins a thread finalises */
 
 struct DwShared {
-    unsigned long long hist[DW_HIST_WORDS];
+    unsigned long long hist[DW_HIST_WORDS];   /* 2 * DW_HIST_WORDS 32-bit fields: field (bin, copy) at dword bin * DW_NFIELD + copy */
     unsigned long long etab[32];
     double part[DW_WAVES];
     float mesh[S3D_MESH_FLOATS];
@@ -1066,8 +1067,10 @@ __device__ __forceinline__ int dw_opaque(int x)
  * s3d_k_describe_redo_stats call that asked for a reset) */
 __device__ unsigned long long g_dw_stat[2];
 
+#define DW_WAVES_PER_EU (DW_WG_PER_CU * DW_THREADS / 256)          /* the CU's resident waves over its four SIMDs */
+#define DW_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DW_WAVES_PER_EU, DW_WAVES_PER_EU)))   /* 4: 128 registers per lane */
 template <bool COUNT_ONLY>
-__global__ void __launch_bounds__(DW_THREADS)
+__global__ void __launch_bounds__(DW_THREADS) DW_OCCUPANCY
 k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint32_t num, const float *__restrict__ d_mesh,
               float *__restrict__ out, size_t out_stride, uint32_t *__restrict__ stats, uint32_t *__restrict__ work)
 {
@@ -1135,6 +1138,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     g.r20 = key.R[2]; g.r21 = key.R[5]; g.r22 = key.R[8];
     const double inv_sig2 = 1.0 / (double)(key.sigma * key.sigma);
     const float iux = 1.0f / g.uxf, iuy = 1.0f / g.uyf, iuz = 1.0f / g.uzf;
+    const float hiux = 0.5f * iux, hiuy = 0.5f * iuy, hiuz = 0.5f * iuz;
     int xe, ye, ze;
     desc_bounds(key.cx, key.rad, g.uxf, nx, &g.xs, &xe);
     desc_bounds(key.cy, key.rad, g.uyf, ny, &g.ys, &ye);
@@ -1256,8 +1260,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         }
     }
 
-    for (int i = tz; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
-    if (tz < DW_NFIELD) sm.copy_units[tz] = 0ull;
+    {
+        const unsigned long long zero = (unsigned long long)(unsigned)dw_opaque(0);   /* (made here: a zero pair held from the kernel's start was spilled) */
+        for (int i = tz; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = zero;
+        if (tz < DW_NFIELD) sm.copy_units[tz] = zero;
+    }
     if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; sm.proof_over = 0; sm.proof_fine = 0; }
     __syncthreads();
     /* the next keypoint's record: loaded now (one word per lane of the first wave), parked in LDS further down */
@@ -1319,8 +1326,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     float mass = 0.0f;                                        /* |w grad| of the voxels this lane has sent to its histogram copy */
     auto front = [&](bool valid, float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
         DwVox v;
-        gx = 0.5f * gx; gy = 0.5f * gy; gz = 0.5f * gz;
-        gx = gx * iux; gy = gy * iuy; gz = gz * iuz;
+        gx = gx * hiux; gy = gy * hiuy; gz = gz * hiuz;        /* (0.5 d) / u of the reference: halving is exact, so d * (0.5 / u) rounds the same */
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
 #if !defined(DW_NO_FMA)
@@ -1590,9 +1596,10 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         __syncthreads();                                      /* every thread has read the bounds and the flags */
         set_scale(1.02 * tk);
         mass = 0.0f;
-        for (int i = tm; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = 0ull;
-        if (tm < DW_NFIELD) sm.copy_units[tm] = 0ull;
-        if (tid == 0) { sm.proof_over = 0; sm.proof_fine = 0; }
+        const unsigned long long zero = (unsigned long long)(unsigned)dw_opaque(0);
+        for (int i = tm; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = zero;
+        if (tm < DW_NFIELD) sm.copy_units[tm] = zero;
+        if (tid == 0) { sm.proof_over = (unsigned)zero; sm.proof_fine = (unsigned)zero; }
         __syncthreads();
         continue;
     }
@@ -1638,6 +1645,7 @@ static int dw_prepare(unsigned *grid)
         S3D_HIP(hipFuncSetAttribute((const void *)k_describe_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DwShared)));
         S3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
         if (n < 1) n = 256;
+        n *= DW_WG_PER_CU;
         if (dev < 0 || dev >= 64) { *grid = (unsigned)n; return S3D_OK; }
         ncu[dev] = n;
         done[dev] = 1;
