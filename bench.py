@@ -721,9 +721,10 @@ def main():
             "G_lds_atomic_lane_ops_per_s": round(24.0 * wv / t_describe / 1e9, 1),
             "lds_data_path_floor_ms": round(24.0 * (wv / 64.0) * 4.2 / 256.0 / 2.4e9 * 1e3, 2),
             "windows_described_since_start": int(described.value), "windows_described_twice": int(redone.value),
-            "bound": "VALU issue (about 245 instructions per window voxel, 45 of them f64) and the LDS pipe (24 conflict-free "
-                     "ds_add_u32 per voxel into 32 bank-private copies, 4.2 clk per wave and CU: lds_data_path_floor_ms) overlap "
-                     "imperfectly; not HBM, not MFMA -- DESIGN.md section 4, profiles/r04_describe_field32.txt"}
+            "bound": "VALU issue (about 245 instructions per window voxel, 45 of them f64: 10.7 ms at 512^3); the LDS pipe (24 "
+                     "conflict-free ds_add_u32 per voxel into 16 bank-private copies of 32-bit fields, 4.2 clk per wave and CU: "
+                     "lds_data_path_floor_ms) and the per-keypoint fixed work run under it (two 512-thread workgroups per CU); not "
+                     "HBM, not MFMA -- DESIGN.md section 4, profiles/r04_describe_field32.txt"}
     if rank == 0 and not args.no_match:
         # BASELINE configs[0] flavour, outside the timed region: the kpSift3D program on a 128^3 NIfTI-1 volume
         # (.nii.gz in, keypoint and descriptor CSVs out) -- process start, HIP initialisation, zlib and CSV
