@@ -29,8 +29,10 @@
 #include <mutex>
 
 #define TAB_MAX_HW 9
+#ifndef TAB_MW
 #define TAB_MW 4                          /* waves of a marching workgroup (they share a ring) */
-#define TAB_MAX_UHW 26                    /* ring of 2*uhw+2+2*TAB_MW <= 62 rows (62 KB of LDS), x segment of 64+2*uhw+3 <= 128 floats */
+#endif
+#define TAB_MAX_UHW ((62 - 2 - 2 * TAB_MW) / 2)   /* ring of 2*uhw+2+2*TAB_MW <= 62 rows (62 KB of LDS), x segment of 64+2*uhw+3 <= 128 floats: 26 */
 
 /* ---- the table -------------------------------------------------------------------------------------------------
  * march layout (p-major, TS = 4*NT + 1 words per position, all wave uniform -> scalar loads):
