@@ -870,11 +870,11 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
     return !(*vbx < 0 || *vby < 0 || *vbz < 0 || *vbx >= 4.0f || *vby >= 4.0f || *vbz >= 4.0f);
 }
 
-/* ==== the descriptor kernel: one 1024-thread workgroup per keypoint ========================================================
+/* ==== the descriptor kernel: one 512-thread workgroup per keypoint, two resident per CU ======================================
  *
  * extract_descrip (sift.c:1834-1928).  The window (sphere of radius rad intersected with the rotated 4x4x4 cell cube,
  * sift.c:1869-1884) is convex, so along every x-row of the bounding box the accepted voxels form ONE interval.  Rounds
- * of 1024 rows:
+ * of DW_THREADS rows:
  *   A1  one thread per row: the interval from the closed form (sphere chord, three slab constraints), then trimmed /
  *       extended by the reference's own float test at its two ends -- the accepted set is exactly the reference's
  *       (tests: count + coordinate checksum per keypoint), at ~4 voxel tests per row instead of 57-91;
@@ -890,11 +890,14 @@ __device__ __forceinline__ bool desc_window(const DescGeom &g, int x, int y, int
  * queued behind atomics waits for all of them).
  *
  *  (1) Bank-private histogram copies of 32-bit fields.  A ds_add_u32 costs the LDS pipe 4.2 clk per wave when the lanes
- *      hit distinct banks (ds_add_u64: 6.4; 9-12 with data-dependent addresses).  With 32 copies laid out copy-minor --
- *      field (bin, copy) at dword bin*32 + copy, copy = lane & 31 -- the lanes of a pass always sit in different banks
- *      whatever their bins are: conflict free by construction.  32 x 768 x 4 B = 96 KB of LDS is what a CU has room for
- *      once, hence ONE workgroup of 16 waves per CU (4 per SIMD, 128 VGPRs each).  (Rounds 2-3: 16 copies of 64-bit
- *      fields, 15.6 ms; this layout: 14.3 ms, profiles/r04_describe_field32.txt.)
+ *      hit distinct banks (ds_add_u64: 6.4; 9-12 with data-dependent addresses).  With 2 * DW_NCOPY = 16 copies laid out
+ *      copy-minor -- field (bin, copy) at dword bin*16 + copy, copy = lane & 15 -- the sixteen lanes of a quarter wave always
+ *      sit in sixteen different banks whatever their bins are (the two quarters of a 32-lane pass can still meet: a third
+ *      of the LDS cycles by PMC, and the LDS is not what bounds the kernel).  16 x 768 x 4 B = 48 KB + 31 KB of tables per
+ *      workgroup: TWO 512-thread workgroups per CU (16 waves, 128 VGPRs each), so that one keypoint's row intervals, scans,
+ *      barriers, table fills and normalisation run under the other's window.  (Rounds 2-3: one 1024-thread workgroup with
+ *      16 copies of 64-bit fields, 15.6 ms; 32 copies of 32-bit fields: 14.3; this layout: 12.5 -- profiles/
+ *      r04_describe_field32.txt.)
  *  (2) One VALU instruction per contribution.  A contribution (mag * bary_v) * (wx * wy * wz) is formed as
  *      fma(m_v, w_c, M) in f64 with M = 1.5 * 2^(52 - f): the product of two f32-derived doubles is exact, the single
  *      rounding of the fma lands on the fixed-point grid 2^-f, and the low 32 bits of the result's bit pattern ARE that
