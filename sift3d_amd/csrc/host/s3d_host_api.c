@@ -102,6 +102,8 @@ typedef struct {
     /* one process, N GPUs (s3d_host_slab.c): when set, detect / describe run on Z-slabs and d_level stays empty */
     struct s3d_mgpu *mgpu;
     int mgpu_env_checked, pyramid_on_slabs;
+    int host_pyramid;       /* -1 unset (the environment decides once), 0 none, 1 GSS, 2 GSS + DoG: copy the levels into the host
+                             * Pyramids at the end of SIFT3D_detect_keypoints (sift3d_amd_set_host_pyramid) */
     /* descriptor download beside the descriptor kernel: a copy stream and one event per batch */
     s3d_stream copy_stream;
     void *batch_ev[S3D_DESC_BATCHES];
@@ -130,6 +132,7 @@ static int ctx_new(void)
             g_ctx[i] = (s3d_ctx *)calloc(1, sizeof(s3d_ctx));
             if (g_ctx[i]) {
                 g_ctx[i]->in_use = 1;
+                g_ctx[i]->host_pyramid = -1;
                 h = i + 1;
             }
             break;
@@ -725,6 +728,26 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
     return SIFT3D_SUCCESS;
 }
 
+/* 0 / 1 / 2: see s3d_ctx.host_pyramid; unset -> SIFT3D_HOST_PYRAMID of the environment, read once per struct */
+static int host_pyramid_mode(s3d_ctx *c)
+{
+    if (c->host_pyramid < 0) {
+        const char *e = getenv("SIFT3D_HOST_PYRAMID");
+        const int v = e ? atoi(e) : 0;
+        c->host_pyramid = v < 0 ? 0 : v > 2 ? 2 : v;
+    }
+    return c->host_pyramid;
+}
+
+int sift3d_amd_set_host_pyramid(SIFT3D *const sift3d, int mode)
+{
+    if (mode < 0 || mode > 2) API_FAIL("sift3d_amd_set_host_pyramid: mode must be 0, 1 or 2");
+    if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+        API_FAIL("sift3d_amd: out of device contexts");
+    sift_ctx(sift3d)->host_pyramid = mode;
+    return SIFT3D_SUCCESS;
+}
+
 /* Number of GPUs this struct's detect / describe run on: sift3d_amd_set_num_gpus(), else the environment
  * (SIFT3D_NGPU, SIFT3D_SLAB_LOOPBACK), read once per struct.  Creates the device context on first use. */
 static int mgpu_for(SIFT3D *const sift3d)
@@ -791,7 +814,12 @@ int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoin
     free(dense);
     if (rc) return SIFT3D_FAILURE;
     if (build_gpyr_dev(sift3d, sift_ctx(sift3d), 1)) return SIFT3D_FAILURE;
-    return detect_dev(sift3d, sift_ctx(sift3d), kp);
+    if (detect_dev(sift3d, sift_ctx(sift3d), kp)) return SIFT3D_FAILURE;
+    {   /* a caller that reads sift3d->gpyr / dog voxels as it would after the reference's call (sift.c:989-1071) */
+        const int mode = host_pyramid_mode(sift_ctx(sift3d));
+        if (mode > 0 && sift3d_amd_download_pyramid(sift3d, mode > 1)) return SIFT3D_FAILURE;
+    }
+    return SIFT3D_SUCCESS;
 }
 
 int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, int nx, int ny, int nz, double ux,
@@ -800,7 +828,12 @@ int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, in
     if (d_vol == NULL || nx < 1 || ny < 1 || nz < 1) API_FAIL("sift3d_amd_detect_keypoints_dev: bad arguments");
     if (set_im_device(sift3d, NULL, d_vol, nx, ny, nz, ux, uy, uz)) return SIFT3D_FAILURE;
     if (build_gpyr_dev(sift3d, sift_ctx(sift3d), 1)) return SIFT3D_FAILURE;
-    return detect_dev(sift3d, sift_ctx(sift3d), kp);
+    if (detect_dev(sift3d, sift_ctx(sift3d), kp)) return SIFT3D_FAILURE;
+    {   /* a caller that reads sift3d->gpyr / dog voxels as it would after the reference's call (sift.c:989-1071) */
+        const int mode = host_pyramid_mode(sift_ctx(sift3d));
+        if (mode > 0 && sift3d_amd_download_pyramid(sift3d, mode > 1)) return SIFT3D_FAILURE;
+    }
+    return SIFT3D_SUCCESS;
 }
 
 /* Host-only planning: size the pyramids and build the filter bank for an nx x ny x nz volume exactly as

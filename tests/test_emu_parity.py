@@ -56,6 +56,47 @@ def test_detect_describe_aniso(emu, oracle):
     assert parity.check_detect_describe(emu, oracle, (36, 32, 28), (1, 0.8, 2), 60, seed=3) > 0
 
 
+@pytest.mark.parametrize("how", ["api", "env"])
+def test_host_pyramid_after_detect(emu, oracle, how, monkeypatch):
+    """sift3d_amd_set_host_pyramid / SIFT3D_HOST_PYRAMID: the host Pyramids hold the voxels after SIFT3D_detect_keypoints, as
+    they do after the reference's call (sift.c:989-1071) -- every GSS and DoG level bit-identical to the oracle's; without
+    the option the level data pointers stay NULL."""
+    from sift3d_amd import synth
+    import numpy as np
+    vol = synth.blobs(28, 26, 24, 40, 5)
+    units = (1.0, 1.0, 1.5)
+    oracle.detect(vol, units)
+    for mode in (0, 2):
+        s = abi.SIFT3D()
+        assert emu.sift.init_SIFT3D(C.byref(s)) == 0
+        if how == "api":
+            emu.sift.sift3d_amd_set_host_pyramid.argtypes = [C.POINTER(abi.SIFT3D), C.c_int]
+            assert emu.sift.sift3d_amd_set_host_pyramid(C.byref(s), mode) == 0
+            assert emu.sift.sift3d_amd_set_host_pyramid(C.byref(s), 3) != 0
+        else:
+            monkeypatch.setenv("SIFT3D_HOST_PYRAMID", str(mode))
+        im = emu.image_from_numpy(vol, units)
+        kp = abi.Keypoint_store()
+        emu.sift.init_Keypoint_store(C.byref(kp))
+        assert emu.sift.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+        for o in range(s.gpyr.num_octaves):
+            for k in range(s.gpyr.num_levels):
+                lv = s.gpyr.levels[o * s.gpyr.num_levels + k]
+                if mode == 0:
+                    assert not lv.data
+                else:
+                    assert parity.nbitdiff(emu.image_to_numpy(lv), oracle.level("gss", o, k - 1)[0]) == 0, ("gss", o, k - 1)
+            for k in range(s.dog.num_levels):
+                lv = s.dog.levels[o * s.dog.num_levels + k]
+                if mode == 0:
+                    assert not lv.data
+                else:
+                    assert parity.nbitdiff(emu.image_to_numpy(lv), oracle.level("dog", o, k - 1)[0]) == 0, ("dog", o, k - 1)
+        emu.sift.cleanup_Keypoint_store(C.byref(kp))
+        emu.free_image(im)
+        emu.sift.cleanup_SIFT3D(C.byref(s))
+
+
 @pytest.mark.parametrize("dims", [(14, 13, 12), (44, 12, 11)])   # rows shorter than / longer than two filter half widths (interior outputs)
 def test_dense(emu, oracle, dims):
     parity.check_dense(emu, oracle, dims, (1, 1, 2))
