@@ -181,7 +181,7 @@ orient_one(const s3d_pyramid_desc &pyr, const uint32_t *__restrict__ d_idx, cons
     if (cand >= num) return;
     if (PHASE == 2 && d_keep[cand] != 2u) return;
     if (PHASE == 4 && d_keep[cand] != 3u) return;          /* PHASE 3 served this one from its level's table */
-    if (PHASE == 4 || PHASE == 2) s3d_wave_lds_sync();     /* the previous candidate of this wave is done with the LDS tables */
+    if (PHASE == 4) s3d_wave_lds_sync();                   /* the previous candidate of this wave is done with the LDS tables */
     double *scr = d_scr + (size_t)slot * ORI_SCR;
     const unsigned tag = PHASE == 0 ? (((cand / (unsigned)pyr.num_levels) << 8) | (cand % (unsigned)pyr.num_levels))
                                     : (d_tag ? d_tag[cand] : 0u);        /* no tags: every candidate lives in level 0 */
@@ -552,9 +552,9 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
               double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R, uint32_t *__restrict__ d_keep,
               double *__restrict__ d_conf, s3d_ori_tab *__restrict__ tabs)
 {
-    if (PHASE == 4 || PHASE == 2) {                        /* few candidates have work here: a fixed grid of waves looks through them */
+    if (PHASE == 4) {
         for (unsigned c = blockIdx.x; c < nchunk; c += gridDim.x)
-            orient_one<PHASE>(pyr, d_idx, d_tag, d_center, cand0 + c, c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, d_conf, tabs);
+            orient_one<4>(pyr, d_idx, d_tag, d_center, cand0 + c, c, num, d_sigma, corner_thresh, d_scr, d_R, d_keep, d_conf, tabs);
     } else {
         orient_one<PHASE>(pyr, d_idx, d_tag, d_center, cand0 + blockIdx.x, blockIdx.x, num, d_sigma, corner_thresh, d_scr, d_R,
                           d_keep, d_conf, tabs);
@@ -735,10 +735,10 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
         hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
                            d_R, d_keep, d_conf);
         S3D_CHECK_LAUNCH();
-        /* pass 2 has work for about one candidate in ten: a fixed grid (a workgroup per candidate that returns at once for
-         * the other nine cost 0.15-0.23 ms per 512^3 detect) */
-        hipLaunchKernelGGL((k_orient_wave<2>), dim3(n < 8192u ? n : 8192u), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag,
-                           d_center, c0, n, num, d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
+        /* (pass 2 has work for about one candidate in ten; a fixed grid of 8192 waves looking through the candidates instead of a
+         * workgroup per candidate was measured at 250 against 150 us per 512^3 detect: the few heavy candidates pile up) */
+        hipLaunchKernelGGL((k_orient_wave<2>), dim3(n), dim3(64), 0, (hipStream_t)st, *pyr, d_idx, d_tag, d_center, c0, n, num,
+                           d_sigma, corner_thresh, scr, d_R, d_keep, d_conf, (s3d_ori_tab *)nullptr);
         S3D_CHECK_LAUNCH();
     }
     return S3D_OK;
