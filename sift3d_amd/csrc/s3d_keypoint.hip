@@ -1071,6 +1071,16 @@ __device__ __forceinline__ int dw_opaque(int x)
 /* how often the grid had to be redone: [0] windows described, [1] windows described twice (per device, since the last
  * s3d_k_describe_redo_stats call that asked for a reset) */
 __device__ unsigned long long g_dw_stat[2];
+#if defined(S3D_TESTING)
+/* test aid: the factor the sampled gradient mass is multiplied with before the grid is set from it (1: none) -- far below 1
+ * makes the proof fail, far above 1 makes the grid coarse: both must end in the redo and in the same descriptors */
+__device__ float g_dw_est_factor = 1.0f;
+extern "C" int s3d_k_set_describe_est_factor(float f)
+{
+    S3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_est_factor), &f, sizeof(f)));
+    return S3D_OK;
+}
+#endif
 
 #define DW_WAVES_PER_EU (DW_WG_PER_CU * DW_THREADS / 256)          /* the CU's resident waves over its four SIMDs */
 #define DW_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DW_WAVES_PER_EU, DW_WAVES_PER_EU)))   /* 4: 128 registers per lane */
@@ -1314,6 +1324,9 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         float tsum = 0.0f;
 #pragma unroll
         for (int w = 0; w < DW_WAVES; w++) tsum = tsum + sm.est_part[w];
+#if defined(S3D_TESTING)
+        tsum = tsum * g_dw_est_factor;
+#endif
         set_scale(1.15 * (double)tsum * (double)nrows / (double)(nsamp > 0 ? nsamp : 1) / (double)DW_NFIELD);
     }
 

@@ -878,3 +878,39 @@ def check_orient_tables(lib, dims, units, sigmas, ncand, seed=0, expect_tables=T
         L.s3d_k_set_orient_mode(-1)
         for p_ in d_lv + d_R + d_keep + d_scr + [d_idx, d_tag, d_sig, d_tab]:
             dev.free(p_)
+
+
+def check_describe_redo(lib, oracle, dims, units, nblobs, seed, factor):
+    """The descriptor kernel's redo path (s3d_keypoint.hip, dw_scale): with the sampled gradient mass spoiled by `factor`
+    (testing build only) every window's proof fails (factor << 1: the grid is too fine, fields could wrap) or finds the grid
+    coarse (factor >> 1); every window must then be described a second time with the grid of its measured mass, and the
+    descriptors must be the oracle's within the same 1e-4 as ever.  Returns (keypoints, windows redone)."""
+    L = lib.sift
+    L.s3d_k_set_describe_est_factor.argtypes = [C.c_float]
+    L.s3d_k_describe_redo_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    want_xyzos, want_sd, want_R = oracle.detect(vol, units)
+    s, im, kp = run_detect(lib, vol, units)
+    xyzos, sd, R = lib.keypoints_to_numpy(kp)
+    assert np.array_equal(xyzos, want_xyzos) and len(xyzos) > 0
+    a, b = C.c_ulonglong(), C.c_ulonglong()
+    try:
+        assert L.s3d_k_set_describe_est_factor(factor) == 0
+        assert L.s3d_k_describe_redo_stats(C.byref(a), C.byref(b), 1) == 0
+        d = abi.SIFT3D_Descriptor_store()
+        L.init_SIFT3D_Descriptor_store(C.byref(d))
+        assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+        bins, xyzs = lib.descriptors_to_numpy(d)
+        assert L.s3d_k_describe_redo_stats(C.byref(a), C.byref(b), 1) == 0
+    finally:
+        L.s3d_k_set_describe_est_factor(1.0)
+    wb, wx = oracle.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
+    ok = rel_close(bins, wb, rtol=1e-4, atol=1e-7)
+    assert ok.all(), f"{(~ok).sum()} descriptor floats beyond 1e-4 relative after the redo"
+    assert a.value == len(xyzos), (a.value, len(xyzos))
+    L.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+    L.cleanup_Keypoint_store(C.byref(kp))
+    lib.free_image(im)
+    L.cleanup_SIFT3D(C.byref(s))
+    return len(xyzos), int(b.value)

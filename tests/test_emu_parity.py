@@ -56,6 +56,14 @@ def test_detect_describe_aniso(emu, oracle):
     assert parity.check_detect_describe(emu, oracle, (36, 32, 28), (1, 0.8, 2), 60, seed=3) > 0
 
 
+@pytest.mark.parametrize("factor", [1e-3, 1e3])
+def test_describe_redo_path(emu, oracle, factor):
+    """The descriptor kernel proves after each window that its 32-bit histogram fields cannot have wrapped and redoes the
+    window otherwise (bench runs: 0-24 of 374 484 windows): forced here for every keypoint, both ways."""
+    k, redone = parity.check_describe_redo(emu, oracle, (40, 36, 32), (1, 1, 1), 120, 4, factor)
+    assert k > 0 and redone == k, (k, redone)
+
+
 @pytest.mark.parametrize("how", ["api", "env"])
 def test_host_pyramid_after_detect(emu, oracle, how, monkeypatch):
     """sift3d_amd_set_host_pyramid / SIFT3D_HOST_PYRAMID: the host Pyramids hold the voxels after SIFT3D_detect_keypoints, as

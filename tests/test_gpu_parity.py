@@ -609,6 +609,15 @@ def test_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits):
     parity.check_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits)
 
 
+@pytest.mark.parametrize("factor", [1e-3, 1e3])
+@pytest.mark.parametrize("dims,units", [((96, 88, 80), (1, 1, 1)), ((80, 72, 48), (0.7, 0.7, 1.5))])
+def test_describe_redo_path(libt, oracle, dims, units, factor):
+    """The descriptor kernel's proof-and-redo path, forced for every keypoint (the sampled gradient mass spoiled a
+    thousandfold either way, testing build): every window is described twice and the descriptors stay the oracle's."""
+    k, redone = parity.check_describe_redo(libt, oracle, dims, units, 900, 5, factor)
+    assert k > 20 and redone == k, (k, redone)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dims,units,sigmas,expect", [
     ((96, 88, 80), (1, 1, 1), (2.0159, 2.5398, 3.2), True),
