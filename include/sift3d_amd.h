@@ -420,7 +420,8 @@ int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog);
  * reference's call (sift.c:989-1071 leaves both pyramids on the host): mode 1 copies the Gaussian levels into the host
  * Pyramid at the end of every SIFT3D_detect_keypoints on `sift3d`, mode 2 the DoG levels as well, 0 (default) neither.
  * Without a call the environment variable SIFT3D_HOST_PYRAMID (0 / 1 / 2) decides -- the knob of an LD_PRELOAD deployment.
- * Costs the PCIe transfer of the pyramid (512^3: 3.7 GB, ~0.15 s); not available in the multi-GPU mode. */
+ * Costs the PCIe transfer of the pyramid (512^3: 3.7 GB, ~0.15 s).  In the multi-GPU mode every rank copies the planes it
+ * owns (sift3d_amd_download_pyramid likewise). */
 int sift3d_amd_set_host_pyramid(SIFT3D *const sift3d, int mode);
 /* Host-only: size the pyramid metadata and the Gaussian bank of `sift3d` for an nx x ny x nz volume as
  * SIFT3D_detect_keypoints would, without device work (used by the multi-GPU Z-slab driver). */

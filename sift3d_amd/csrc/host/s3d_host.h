@@ -32,6 +32,7 @@ int s3d_mgpu_configure(struct s3d_mgpu **m, int ngpu, int flags);
 int s3d_mgpu_detect(struct s3d_mgpu **m, const SIFT3D *sift3d, const float *host_dense, int nx, int ny, int nz,
                     double ux, double uy, double uz, Keypoint_store *kp);
 int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descriptor *out);
+int s3d_mgpu_download_pyramid(struct s3d_mgpu *m, SIFT3D *host, int want_dog);
 int s3d_mgpu_info(const struct s3d_mgpu *m, int r, void *info);
 void s3d_mgpu_free(struct s3d_mgpu *m);
 

@@ -807,6 +807,10 @@ int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoin
         free(dense);
         if (rc) return SIFT3D_FAILURE;
         c->have_pyramid = c->pyramid_on_slabs = 1;
+        {
+            const int mode = host_pyramid_mode(c);
+            if (mode > 0 && sift3d_amd_download_pyramid(sift3d, mode > 1)) return SIFT3D_FAILURE;
+        }
         return SIFT3D_SUCCESS;
     }
     rc = set_im_device(sift3d, src, NULL, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz);
@@ -1608,7 +1612,14 @@ int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog)
     s3d_ctx *c = sift_ctx(sift3d);
     Pyramid *g = &sift3d->gpyr, *d = &sift3d->dog;
     if (!SIFT3D_have_gpyr(sift3d)) API_FAIL("sift3d_amd_download_pyramid: no device pyramid");
-    if (c->pyramid_on_slabs) API_FAIL("sift3d_amd_download_pyramid: the pyramid is spread over several GPUs");
+    if (c->pyramid_on_slabs) {                             /* spread over several GPUs: every rank copies the planes it owns */
+        for (int i = 0; i < g->num_octaves * g->num_levels; i++)
+            if (im_resize(g->levels + i)) return SIFT3D_FAILURE;
+        if (want_dog)
+            for (int i = 0; i < d->num_octaves * d->num_levels; i++)
+                if (im_resize(d->levels + i)) return SIFT3D_FAILURE;
+        return s3d_mgpu_download_pyramid(c->mgpu, sift3d, want_dog);
+    }
     for (int i = 0; i < g->num_octaves * g->num_levels; i++) {
         Image *lv = g->levels + i;
         if (im_resize(lv)) return SIFT3D_FAILURE;

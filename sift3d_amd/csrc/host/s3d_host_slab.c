@@ -700,6 +700,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
 }
 
 static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp);
+static int slab_download(sift3d_amd_slab *sl, SIFT3D *host, int want_dog);
 
 /* A rank that fails here has peers that are waiting for it, or soon will be: it aborts its transport on the way out, so
  * that every rank returns SIFT3D_FAILURE instead of hanging (the loop-back group is poisoned as a whole; with RCCL the
@@ -1247,7 +1248,9 @@ int s3d_mgpu_configure(struct s3d_mgpu **pm, int ngpu, int flags)
 
 typedef struct {
     struct s3d_mgpu *m;
-    int r, op, rc;                    /* op 0: create, 1: detect, 2: describe */
+    int r, op, rc;                    /* op 0: create, 1: detect, 2: describe, 3: pyramid to the host */
+    SIFT3D *host_sift;                /* op 3: the caller's struct (host pyramids sized) */
+    int want_dog;
     const SIFT3D *params;
     const float *host;                /* whole host volume (detect) */
     const Keypoint_store *kp;         /* global list (describe) */
@@ -1278,6 +1281,9 @@ static void *mgpu_thread(void *arg)
         j->rc = sift3d_amd_slab_detect(m->sl[r], j->host + (size_t)inf.z0 * m->nx * m->ny, 0, &m->kp[r]);
         break;
     }
+    case 3:
+        j->rc = slab_download(m->sl[r], j->host_sift, j->want_dog);
+        break;
     default:
         j->rc = describe_sel(m->sl[r], j->kp, j->sel, j->nsel, j->out);
     }
@@ -1383,6 +1389,54 @@ int s3d_mgpu_detect(struct s3d_mgpu **pm, const SIFT3D *p, const float *host_den
         }
     }
     return SIFT3D_SUCCESS;
+}
+
+/* ---- the pyramid back on the host (sift3d_amd_download_pyramid / sift3d_amd_set_host_pyramid in the N-GPU mode) ------
+ * Every rank copies the planes it OWNS of each level of the sharded octaves into the caller's host Pyramid (already
+ * sized: the destination regions of the ranks are disjoint), rank 0 the replicated octaves; DoG level k of an octave is
+ * GSS k - GSS k+1 formed on the device over the same planes (s3d_k_subtract: the pyramid's own kernel). */
+static int slab_download(sift3d_amd_slab *sl, SIFT3D *host, int want_dog)
+{
+    const int G = sl->t.world, rank = sl->t.rank;
+    float *d_tmp = NULL;
+    size_t tmp_elems = 0;
+    int rc = SIFT3D_FAILURE;
+    if (host->gpyr.num_octaves != sl->no || host->gpyr.num_levels != sl->nl)
+        SLAB_FAIL("sift3d_amd slab: the host pyramid does not have the slab's shape");
+    for (int o = 0; o < sl->no; o++) {
+        const size_t pe = (size_t)sl->dims[o][0] * sl->dims[o][1];
+        const int sharded = G > 1 && o <= sl->o_shard;
+        const long z0 = sharded ? sl->part[o][0] : 0, z1 = sharded ? sl->part[o][1] : sl->dims[o][2];
+        const size_t n = (size_t)(z1 - z0) * pe;
+        if ((!sharded && rank != 0) || z1 <= z0) continue;
+        for (int k = 0; k < sl->nl; k++) {
+            Image *hl = host->gpyr.levels + o * sl->nl + k;
+            if (hl->data == NULL || hl->nx != sl->dims[o][0] || hl->ny != sl->dims[o][1] || hl->nz != sl->dims[o][2])
+                SLAB_FAIL("sift3d_amd slab: host level (%d, %d) is not sized for the download", o, k);
+            if (s3d_rt_d2h(hl->data + (size_t)z0 * pe, lev_ptr(&sl->lev[o * sl->nl + k], z0), n * sizeof(float), sl->cs)) goto out;
+        }
+        if (!want_dog) continue;
+        if (n > tmp_elems) {
+            dfree(&d_tmp);
+            tmp_elems = 0;
+            if (s3d_rt_malloc((void **)&d_tmp, n * sizeof(float))) goto out;
+            tmp_elems = n;
+        }
+        for (int k = 0; k < host->dog.num_levels; k++) {
+            Image *hl = host->dog.levels + o * host->dog.num_levels + k;
+            if (hl->data == NULL || hl->nx != sl->dims[o][0] || hl->ny != sl->dims[o][1] || hl->nz != sl->dims[o][2])
+                SLAB_FAIL("sift3d_amd slab: host DoG level (%d, %d) is not sized for the download", o, k);
+            if (s3d_k_subtract(lev_ptr(&sl->lev[o * sl->nl + k], z0), lev_ptr(&sl->lev[o * sl->nl + k + 1], z0), d_tmp, n, sl->cs) ||
+                s3d_rt_d2h(hl->data + (size_t)z0 * pe, d_tmp, n * sizeof(float), sl->cs) || s3d_rt_sync(sl->cs))
+                goto out;
+        }
+    }
+    if (s3d_rt_sync(sl->cs)) goto out;
+    rc = SIFT3D_SUCCESS;
+out:
+    if (rc) snprintf(g_slab_err, sizeof(g_slab_err), "sift3d_amd slab: pyramid download: %s", s3d_rt_last_error());
+    dfree(&d_tmp);
+    return rc;
 }
 
 /* ---- who describes which keypoint --------------------------------------------------------------------------------
@@ -1528,6 +1582,25 @@ int s3d_mgpu_describe(struct s3d_mgpu *m, const Keypoint_store *kp, SIFT3D_Descr
     }
     free(owner); free(sel); free(fill);
     return rc;
+}
+
+/* The pyramid of the last s3d_mgpu_detect into the host Pyramids of `host` (levels sized by the caller). */
+int s3d_mgpu_download_pyramid(struct s3d_mgpu *m, SIFT3D *host, int want_dog)
+{
+    mgpu_job jobs[256];
+    int cur = 0, rc;
+    if (!m || !m->built) SLAB_FAIL("sift3d_amd: no multi-GPU pyramid to download");
+    DEV(s3d_rt_get_device(&cur));
+    memset(jobs, 0, sizeof(mgpu_job) * (size_t)m->ngpu);
+    for (int r = 0; r < m->ngpu; r++) { jobs[r].m = m; jobs[r].r = r; jobs[r].op = 3; jobs[r].host_sift = host; jobs[r].want_dog = want_dog; }
+    rc = mgpu_run(m, jobs);
+    s3d_rt_set_device(cur);
+    if (rc) {
+        S3D_MSG("sift3d_amd: multi-GPU pyramid download failed: %s\n", g_slab_err);
+        mgpu_teardown(m);
+        return SIFT3D_FAILURE;
+    }
+    return SIFT3D_SUCCESS;
 }
 
 int s3d_mgpu_info(const struct s3d_mgpu *m, int r, void *info)

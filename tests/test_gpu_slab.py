@@ -196,6 +196,38 @@ def test_failed_rank_does_not_hang_on_the_device(hip_testing):
     hip.free_image(im)
 
 
+def test_host_pyramid_from_the_ranks_on_the_device(hip):
+    """sift3d_amd_set_host_pyramid(2) with four loop-back ranks sharing this GPU: the host Pyramids after
+    SIFT3D_detect_keypoints equal, bit for bit, what the single-GPU path downloads for the same volume (every GSS and DoG
+    level: the ranks' owned planes of the sharded octaves stitched together, rank 0's copy of the replicated ones)."""
+    from tests.util import nbitdiff
+    L = S.bind(hip.sift)
+    L.sift3d_amd_set_host_pyramid.argtypes = [C.POINTER(abi.SIFT3D), C.c_int]
+    vol = synth.blobs(96, 80, 256, 1800, 9)
+    levels = []
+    for ranks in (1, 4):
+        s = S.make_params(L)
+        if ranks > 1:
+            assert L.sift3d_amd_set_num_gpus(C.byref(s), ranks, S.SLAB_LOOPBACK) == 0
+        assert L.sift3d_amd_set_host_pyramid(C.byref(s), 2) == 0
+        im = hip.image_from_numpy(vol, (1.0, 1.0, 1.5))
+        kp = abi.Keypoint_store()
+        L.init_Keypoint_store(C.byref(kp))
+        assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0 and kp.slab.num > 10
+        got = []
+        for pyr in (s.gpyr, s.dog):
+            for i in range(pyr.num_octaves * pyr.num_levels):
+                assert pyr.levels[i].data, (ranks, i)
+                got.append(hip.image_to_numpy(pyr.levels[i]).copy())
+        levels.append(got)
+        L.cleanup_Keypoint_store(C.byref(kp))
+        hip.free_image(im)
+        L.cleanup_SIFT3D(C.byref(s))
+    assert len(levels[0]) == len(levels[1]) > 10
+    for i, (a, b) in enumerate(zip(*levels)):
+        assert a.shape == b.shape and nbitdiff(a, b) == 0, i
+
+
 def test_describe_load_balance_on_the_device(hip):
     """Structure crowded into the top quarter of the volume, four loop-back ranks: with balancing the owner's neighbour
     takes the windows its halo planes hold and the replicated octaves spread out; stores bit-identical to the single-GPU

@@ -216,6 +216,50 @@ def test_window_outside_the_ranks_planes_fails_loudly(emu):
     L.cleanup_SIFT3D(C.byref(s))
 
 
+@pytest.mark.parametrize("ranks,dims,units", [(2, (32, 32, 64), (1.0, 1.0, 1.0)), (3, (28, 24, 96), (1.0, 1.0, 1.5))])
+def test_host_pyramid_from_the_ranks(emu, oracle, ranks, dims, units):
+    """sift3d_amd_set_host_pyramid(2) in the N-GPU mode: after SIFT3D_detect_keypoints the host Pyramids hold every GSS and
+    DoG level, stitched from the planes each rank owns (sharded octaves) and rank 0's copy (replicated ones), bit for bit the
+    oracle's -- what the reference leaves on the host (sift.c:989-1071); sift3d_amd_download_pyramid does the same on request."""
+    from tests.util import nbitdiff
+    L = emu.sift
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, 150, 21)
+    oracle.set_params(sigma_n=PARAMS["sigma_n"], sigma0=PARAMS["sigma0"])
+    try:
+        oracle.detect(vol, units)
+        s = abi.SIFT3D()
+        assert L.init_SIFT3D(C.byref(s)) == 0
+        for k, v in PARAMS.items():
+            assert getattr(L, f"set_{k}_SIFT3D")(C.byref(s), v) == 0
+        assert L.sift3d_amd_set_num_gpus(C.byref(s), ranks, slabmod.SLAB_LOOPBACK) == 0
+        L.sift3d_amd_set_host_pyramid.argtypes = [C.POINTER(abi.SIFT3D), C.c_int]
+        assert L.sift3d_amd_set_host_pyramid(C.byref(s), 2) == 0
+        im = emu.image_from_numpy(vol, units)
+        kp = abi.Keypoint_store()
+        L.init_Keypoint_store(C.byref(kp))
+        assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0
+
+        def check():
+            for o in range(s.gpyr.num_octaves):
+                for k in range(s.gpyr.num_levels):
+                    lv = s.gpyr.levels[o * s.gpyr.num_levels + k]
+                    assert nbitdiff(emu.image_to_numpy(lv), oracle.level("gss", o, k - 1)[0]) == 0, ("gss", o, k - 1)
+                for k in range(s.dog.num_levels):
+                    lv = s.dog.levels[o * s.dog.num_levels + k]
+                    assert nbitdiff(emu.image_to_numpy(lv), oracle.level("dog", o, k - 1)[0]) == 0, ("dog", o, k - 1)
+        check()
+        # on request as well, into the same host images
+        L.sift3d_amd_download_pyramid.argtypes = [C.POINTER(abi.SIFT3D), C.c_int]
+        assert L.sift3d_amd_download_pyramid(C.byref(s), 1) == 0
+        check()
+        emu.free_image(im)
+        L.cleanup_Keypoint_store(C.byref(kp))
+        L.cleanup_SIFT3D(C.byref(s))
+    finally:
+        oracle.set_params()
+
+
 def test_gather_edge_cases(emu):
     """sift3d_amd_slab_gather: a descriptor store that does not match the keypoint list is refused (it used to be read
     past its end); a rank set without keypoints empties BOTH global stores."""
