@@ -509,29 +509,54 @@ __device__ __forceinline__ float4 blend4(float4 a, float4 b, float f)
 
 /* ---- Z pass ------------------------------------------------------------------------------------- */
 /* E-plane c of the z axis for this lane's float4 column */
-template <int HW>
+/* four floats of a plane: 16-byte aligned where rows are (nx % 4 == 0), dword aligned otherwise (RAGGED) */
+template <bool RAGGED>
+__device__ __forceinline__ float4 ld_quad(const float *p)
+{
+    if (RAGGED) {
+        const s3d_f4u v = *reinterpret_cast<const s3d_f4u *>(p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <bool RAGGED>
+__device__ __forceinline__ void st_quad(float *p, const float4 &a)
+{
+    if (RAGGED) {
+        s3d_f4u v;
+        v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w;
+        *reinterpret_cast<s3d_f4u *>(p) = v;
+    } else {
+        *reinterpret_cast<float4 *>(p) = a;
+    }
+}
+
+template <int HW, bool RAGGED = false>
 __device__ __forceinline__ float4 z_ext(const float *__restrict__ col, size_t zs, int c, int nz, const EdgeFrac &ef)
 {
     if (c < 0) c = -c;
-    if (c <= nz - 2) return *reinterpret_cast<const float4 *>(col + (size_t)c * zs);
+    if (c <= nz - 2) return ld_quad<RAGGED>(col + (size_t)c * zs);
     const int j = c - (nz - 1);
-    const float4 a = *reinterpret_cast<const float4 *>(col + (size_t)(nz - 2 - j) * zs);
-    const float4 b = *reinterpret_cast<const float4 *>(col + (size_t)(nz - 1 - j) * zs);
+    const float4 a = ld_quad<RAGGED>(col + (size_t)(nz - 2 - j) * zs);
+    const float4 b = ld_quad<RAGGED>(col + (size_t)(nz - 1 - j) * zs);
     return blend4(a, b, ef.f[j]);
 }
 
-template <int HW, bool SPLIT>
+/* RAGGED: nx4 is nx itself and a plane is a flat run of nx * ny floats that need not be a multiple of four: dword-aligned
+ * quads, the last one clamped onto the end of the plane (it recomputes up to three outputs of its neighbour: same values). */
+template <int HW, bool SPLIT, bool RAGGED = false>
 __global__ void __launch_bounds__(256)
 k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int ny, int nz, int zbeg, int zend,
           int chunk, S3dTaps taps, EdgeFrac ef)
 {
     constexpr int W = 2 * HW + 1;
-    const size_t ncol = (size_t)nx4 * ny;
+    const size_t zs = RAGGED ? (size_t)nx4 * ny : (size_t)nx4 * ny * 4;   /* floats per z plane */
+    const size_t ncol = RAGGED ? (zs + 3) / 4 : (size_t)nx4 * ny;
     const size_t colid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (colid >= ncol) return;
-    const size_t zs = ncol * 4;                       /* floats per z plane */
-    const float *col = src + colid * 4;
-    float *out = dst + colid * 4;
+    const size_t coff = RAGGED && colid * 4 + 4 > zs ? zs - 4 : colid * 4;
+    const float *col = src + coff;
+    float *out = dst + coff;
     /* output planes [zbeg, zend) of a volume addressed by global z (the whole volume, or a Z-slab) */
     const int p0 = zbeg + blockIdx.y * chunk;
     const int p1 = (p0 + chunk < zend) ? p0 + chunk : zend;
@@ -541,15 +566,15 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
      * range) so the steady state is straight-line code */
     float4 ring[W];
     const int c0 = p0 - HW;
-    float4 n0 = z_ext<HW>(col, zs, c0, nz, ef);
-    float4 n1 = z_ext<HW>(col, zs, c0 + (1 < T ? 1 : 0), nz, ef);
+    float4 n0 = z_ext<HW, RAGGED>(col, zs, c0, nz, ef);
+    float4 n1 = z_ext<HW, RAGGED>(col, zs, c0 + (1 < T ? 1 : 0), nz, ef);
     auto slow_step = [&](int t, int u) {
         ring[u] = n0;
         n0 = n1;
-        if (t + 2 < T) n1 = z_ext<HW>(col, zs, c0 + t + 2, nz, ef);
+        if (t + 2 < T) n1 = z_ext<HW, RAGGED>(col, zs, c0 + t + 2, nz, ef);
         if (t >= 2 * HW) {
             const float4 acc = ring_dot<HW>(ring, u, taps);
-            *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * zs) = acc;
+            st_quad<RAGGED>(out + (size_t)(p0 + t - 2 * HW) * zs, acc);
         }
     };
     int Tfast = T - 2;
@@ -567,9 +592,9 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
             if (c < 0) c = -c;
             ring[u] = n0;
             n0 = n1;
-            n1 = *reinterpret_cast<const float4 *>(col + (size_t)c * zs);
+            n1 = ld_quad<RAGGED>(col + (size_t)c * zs);
             const float4 acc = ring_dot<HW>(ring, u, taps);
-            *reinterpret_cast<float4 *>(out + (size_t)(p0 + t - 2 * HW) * zs) = acc;
+            st_quad<RAGGED>(out + (size_t)(p0 + t - 2 * HW) * zs, acc);
         }
     }
     for (; tb < T; tb += W) {
@@ -792,7 +817,12 @@ k_bary_x_mc(const float *__restrict__ sm, float *__restrict__ dst, int nx, int n
 /* DIV: every source voxel is divided by `div` as it is loaded, i.e. the filter runs on im_scale's output (imutil.c:1977:
  * samp / max, the same IEEE division) without that image ever being written -- the first filter of the pyramid reads the
  * caller's volume directly. */
-template <int HW, bool DIV>
+/* RAGGED: nx % 4 != 0.  Rows are only dword aligned (s3d_f4u loads and stores), the row's last quad is PARTIAL: its lane
+ * loads the four floats that end the row (clamped: nothing past the row is read, the caller's input volume carries no
+ * slack) -- so the body slots of that quad hold the wrong columns, and up to two more edge lanes put the right ones
+ * there (columns xp .. nx-2; nx-1 and beyond are the high-edge blends that overwrite those slots anyway) -- and stores
+ * only its nx % 4 real outputs. */
+template <int HW, bool DIV, bool RAGGED = false>
 __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk,
                                               const S3dTaps &taps, const EdgeFrac &efx, const EdgeFrac &efy, const float div)
 {
@@ -829,6 +859,9 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
         else if (lane <= 3 * HW) {
             c = nx - 1 + (lane - 2 * HW);
             if (c >= x0 && c < x0 + XY_STRIP) { slot = OFF + (c - x0); have = 1; }
+        } else if (RAGGED && lane <= 3 * HW + 2) {      /* the real columns of the partial quad (see above) */
+            c = (nx & ~3) + (lane - 3 * HW - 1);
+            if (c <= nx - 2 && c >= x0 && c < x0 + XY_STRIP) { slot = OFF + (c - x0); have = 1; }
         }
         if (have) {
             if (c < 0) c = -c;
@@ -844,7 +877,8 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
      * allocator had spilled exactly such a pair to scratch and reloaded it inside the row loop */
     if (!isblend) fj = -1.0f;
     const bool live = xq < nx;                        /* nx % 4 == 0: a lane is all-in or all-out */
-    const int xq_ld = live ? xq : nx - 4;             /* clamped, aligned, always readable */
+    const bool whole = !RAGGED || xq + 4 <= nx;       /* RAGGED: one live lane of the row's last strip holds a partial quad */
+    const int xq_ld = RAGGED ? (live && whole ? xq : nx - 4) : (live ? xq : nx - 4);   /* clamped, always readable (aligned unless RAGGED) */
 
     /* Raw loads of one source row, issued three rows ahead.  They are UNCONDITIONAL on purpose: a load
      * under a divergent `if` makes the compiler wait for it at the join (its destination registers
@@ -853,7 +887,8 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
     auto load_row = [&](int y) -> Raw {
         Raw r;
         const float *row = sp + (size_t)y * nx;
-        r.b = *reinterpret_cast<const float4 *>(row + xq_ld);
+        if (RAGGED) r.b = ld_quad<true>(row + xq_ld);
+        else r.b = *reinterpret_cast<const float4 *>(row + xq_ld);
         r.a0 = row[colA];
         r.a1 = row[colB];
         if (DIV) {
@@ -895,6 +930,17 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
         }
         return acc;
     };
+    /* this lane's outputs of one row */
+    auto store_out = [&](float *o, const float4 &acc) {
+        if (whole) {
+            st_quad<true>(o, acc);
+        } else {                                          /* RAGGED: the row's last 1..3 columns */
+            const int nval = nx - xq;
+            o[0] = acc.x;
+            if (nval > 1) o[1] = acc.y;
+            if (nval > 2) o[2] = acc.z;
+        }
+    };
     /* source row behind E_y[c]:  mirrored / plain -> that row; c = ny-1+j -> the LOWER of its two rows */
     auto first_row = [&](int c) -> int {
         if (c < 0) c = -c;
@@ -930,7 +976,8 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
         ring[u] = e;
         if (t >= 2 * HW) {
             const float4 acc = ring_dot<HW>(ring, u, taps);
-            if (live) *reinterpret_cast<float4 *>(dp + (size_t)(p0 + t - 2 * HW) * nx + xq) = acc;
+            if (RAGGED) { if (live) store_out(dp + (size_t)(p0 + t - 2 * HW) * nx + xq, acc); }
+            else if (live) *reinterpret_cast<float4 *>(dp + (size_t)(p0 + t - 2 * HW) * nx + xq) = acc;
         }
     };
 
@@ -953,7 +1000,8 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
             q[DEPTH - 1] = load_row(first_row(c0 + t + DEPTH));
             ring[u] = xpass(cur);
             const float4 acc = ring_dot<HW>(ring, u, taps);
-            if (live) *reinterpret_cast<float4 *>(dp + (size_t)(p0 + t - 2 * HW) * nx + xq) = acc;
+            if (RAGGED) { if (live) store_out(dp + (size_t)(p0 + t - 2 * HW) * nx + xq, acc); }
+            else if (live) *reinterpret_cast<float4 *>(dp + (size_t)(p0 + t - 2 * HW) * nx + xq) = acc;
         }
     }
     for (; tb < T; tb += W) {                             /* tail groups */
@@ -966,21 +1014,21 @@ __device__ __forceinline__ void gauss_xy_body(const float *__restrict__ src, flo
 /* >= 3 waves per SIMD caps the ring kernels at 168 VGPRs: enough up to HW = 8 (width 17, the widest filter of the default
  * bank) without a private segment; wider filters take 2 waves per SIMD rather than spill inside the march */
 #define GAUSS_XY_WAVES(HW) ((HW) >= 9 ? 2 : 3)
-template <int HW>
+template <int HW, bool RAGGED = false>
 __global__ void __launch_bounds__(64, GAUSS_XY_WAVES(HW))
 k_gauss_xy(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
            EdgeFrac efx, EdgeFrac efy)
 {
-    gauss_xy_body<HW, false>(src, dst, nx, ny, chunk, taps, efx, efy, 1.0f);
+    gauss_xy_body<HW, false, RAGGED>(src, dst, nx, ny, chunk, taps, efx, efy, 1.0f);
 }
 
-template <int HW>
+template <int HW, bool RAGGED = false>
 __global__ void __launch_bounds__(64, GAUSS_XY_WAVES(HW))
 k_gauss_xy_div(const float *__restrict__ src, float *__restrict__ dst, int nx, int ny, int chunk, S3dTaps taps,
                EdgeFrac efx, EdgeFrac efy, const float *__restrict__ d_div)
 {
     const float m = *d_div;
-    gauss_xy_body<HW, true>(src, dst, nx, ny, chunk, taps, efx, efy, m == 0.0f ? 1.0f : m);   /* k_scale_div leaves an all-zero image alone */
+    gauss_xy_body<HW, true, RAGGED>(src, dst, nx, ny, chunk, taps, efx, efy, m == 0.0f ? 1.0f : m);   /* k_scale_div leaves an all-zero image alone */
 }
 
 /* f_j exactly as the reference's boundary pass evaluates it for uf == 1 (imutil.c:2378-2380) */
@@ -1003,7 +1051,7 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
     const int hw = width / 2;
     if (nc != 1 || uf[0] != 1.0f || uf[1] != 1.0f || uf[2] != 1.0f) return 0;
     if (hw < 1 || hw > S3D_FAST_MAX_HW) return 0;
-    if (nx % 4 != 0) return 0;
+    if (nx < 8) return 0;                              /* (nx % 4 != 0: the RAGGED instantiations) */
     if (nx - 1 <= hw || ny - 1 <= hw || nz - 1 <= hw) return 0;
     if (nx > (1 << 22) || ny > (1 << 22) || nz > (1 << 22)) return 0;
     return 1;
@@ -1056,15 +1104,24 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
     const size_t plane = (size_t)nx * ny;
     if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
     if (g_ev[0]) S3D_HIP(hipEventRecord(g_ev[0], st));
-    if (d_div)
+    const bool ragged = nx % 4 != 0;
+    const dim3 gxy(s3d_div_up(nx, XY_STRIP), ncy, zb - za);
+    if (d_div && ragged)
+        hipLaunchKernelGGL((k_gauss_xy_div<HW, true>), gxy, dim3(64), 0, st, d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey, d_div);
+    else if (d_div)
         hipLaunchKernelGGL((k_gauss_xy_div<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st,
                            d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey, d_div);
+    else if (ragged)
+        hipLaunchKernelGGL((k_gauss_xy<HW, true>), gxy, dim3(64), 0, st, d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey);
     else
         hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st,
                            d_src + za * plane, d_tmp + za * plane, nx, ny, cy, t, ex, ey);
     S3D_CHECK_LAUNCH();
     if (g_ev[1]) S3D_HIP(hipEventRecord(g_ev[1], st));
-    if (!(g_gauss_mode & 1))
+    if (ragged)
+        hipLaunchKernelGGL((k_gauss_z<HW, false, true>), dim3(s3d_div_up(s3d_div_up(plane, 4), 256), ncz), dim3(256), 0, st,
+                           d_tmp, d_dst, nx, ny, nz, z0, z1, cz, t, ez);
+    else if (!(g_gauss_mode & 1))
         hipLaunchKernelGGL((k_gauss_z<HW, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
                            d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez);
     else
@@ -1085,8 +1142,12 @@ static int launch_fast_xy(const float *d_src, float *d_dst, int nx, int ny, int 
     const unsigned ncy = s3d_div_up(ny, cy);
     const size_t plane = (size_t)nx * ny;
     if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
-    hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st, d_src + za * plane,
-                       d_dst + za * plane, nx, ny, cy, t, ex, ey);
+    if (nx % 4 != 0)
+        hipLaunchKernelGGL((k_gauss_xy<HW, true>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st, d_src + za * plane,
+                           d_dst + za * plane, nx, ny, cy, t, ex, ey);
+    else
+        hipLaunchKernelGGL((k_gauss_xy<HW>), dim3(s3d_div_up(nx, XY_STRIP), ncy, zb - za), dim3(64), 0, st, d_src + za * plane,
+                           d_dst + za * plane, nx, ny, cy, t, ex, ey);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }

@@ -564,7 +564,8 @@ def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False, units=(1, 1
         if mode == 0 and vol.size <= 64 ** 3:
             bad = np.array([1.0, 1.0, 0.5], np.float32)
             assert L.s3d_k_sep_fir_div_eligible(nx, ny, nz, bad.ctypes.data, 5) == 0
-            assert L.s3d_k_sep_fir_div_eligible(nx + 1, ny, nz, uf.ctypes.data, 5) == 0
+            assert L.s3d_k_sep_fir_div_eligible(nx + 1, ny, nz, uf.ctypes.data, 5) == 1      # ragged rows: the RAGGED kernels
+            assert L.s3d_k_sep_fir_div_eligible(7, ny, nz, uf.ctypes.data, 5) == 0           # rows too short for them
             assert L.s3d_k_sep_fir_div(d_src, d_b, d_t, nx, ny, nz, 0, nz, bad.ctypes.data, taps.ctypes.data, taps.size,
                                        d_max, None) != 0
     finally:
@@ -687,7 +688,9 @@ def check_sep_fir_tab_vs_plain(lib, dims, units, sigmas):
                 dev.sep_fir(d_src, d_a, d_t, nx, ny, nz, 1, uf, taps)
                 out.append(dev.download(d_a, vol.shape))
                 ran = L.s3d_k_gauss_tab_launches() - n0
-                assert (ran >= 1) == (mode == 0), f"mode {mode}: {ran} table-driven passes"
+                # unit spacing on all three axes is the fused kernels' (their RAGGED instantiations when nx % 4 != 0)
+                want_tab = mode == 0 and not all(float(u) == 1.0 for u in units)
+                assert (ran >= 1) == want_tab, f"mode {mode}: {ran} table-driven passes"
             nd = nbitdiff(out[0], out[1])
             assert nd == 0, f"dims {dims} units {units} sigma {sigma}: {nd} of {out[0].size} elements differ"
     finally:

@@ -24,7 +24,13 @@ def emu():
 
 
 @pytest.mark.parametrize("dims,units,nc,sigma,unit", [
-    ((21, 19, 17), (1, 1, 1), 1, 0.973294, 1.0),       # generic path (nx % 4 != 0)
+    ((21, 19, 17), (1, 1, 1), 1, 0.973294, 1.0),       # ragged rows (nx % 4 == 1): the RAGGED instantiations of the fused kernels
+    ((22, 12, 11), (1, 1, 1), 1, 2.45255, 1.0),        # nx % 4 == 2, width 17
+    ((23, 11, 12), (1, 1, 1), 1, 1.54501, 1.0),        # nx % 4 == 3
+    ((261, 10, 9), (1, 1, 1), 1, 1.22627, 1.0),        # two strips, the partial quad at the start of the second (nx % 4 == 1)
+    ((258, 11, 10), (1, 1, 1), 1, 2.45255, 1.0),       # ... nx % 4 == 2, the high-edge blends reach back into the first strip's halo
+    ((255, 9, 9), (1, 1, 1), 1, 0.973294, 1.0),        # one strip, its last lane partial (nx % 4 == 3)
+    ((9, 21, 10), (1, 1, 1), 1, 0.973294, 1.0),        # the shortest rows the fused kernels take
     ((24, 19, 17), (1, 1, 1), 1, 1.22627, 1.0),        # fused fast path
     ((20, 18, 16), (2, 2, 2), 1, 2.45255, 1.0),        # octave-1 spacing (half-voxel taps)
     ((19, 23, 18), (1, 0.7, 2), 1, 1.54501, 1.0),      # anisotropic (non-dyadic: coordinate drift)
@@ -215,6 +221,7 @@ def test_window_weight_expf_matches_host_libm(emu):
 
 
 @pytest.mark.parametrize("dims,units", [((32, 32, 64), (1, 1, 1.5)), ((32, 28, 48), (1, 1, 1)), ((24, 24, 40), (2, 2, 2)),
+                                        ((30, 27, 44), (1, 1, 1)), ((29, 26, 40), (1, 1, 1.5)),     # ragged rows: the RAGGED fused kernels on plane ranges
                                         ((21, 19, 40), (1, 0.7, 1.3))])
 def test_sep_fir_slab_ranges(emu, oracle, dims, units):
     """Plane ranges of s3d_k_sep_fir_slab (the Z-slab form) equal the whole-volume pass bit for bit; widths 7 and 13
@@ -233,7 +240,7 @@ S3 = (0.7, 0.973294, 1.94659)                                         # widths 5
     ((23, 19, 17), (2, 2, 2), S3, [(3, 11)]),                              # odd dims, taps half a voxel apart, halo up to 4
     ((21, 18, 26), (1, 1, 1.5), S3, [(0, 10), (10, 26)]),                  # non-dyadic spacing along z: the drifting coordinate
     ((9, 7, 6), (2, 4, 2), S3[:2], []),                                    # smaller than one tile
-    ((17, 22, 19), (1, 1, 1), S3, [(5, 12)]),                              # unit spacing (nx % 4 != 0: not the streaming path's)
+    ((7, 22, 19), (1, 1, 1), S3[:1], [(5, 12)]),                           # unit spacing, rows too short for the streaming path (nx < 8)
 ])
 def test_sep_fir_tile3(emu, oracle, dims, units, sigmas, splits):
     """The one-launch tile kernel for small volumes: bit-identical to the oracle and to the three passes."""
@@ -257,6 +264,7 @@ def test_sep_fir_tab(emu, oracle, dims, units, sigmas, splits, chunk):
 
 
 @pytest.mark.parametrize("dims,zero,units,mode", [((32, 28, 24), False, (1, 1, 1), 0), ((24, 24, 20), True, (1, 1, 1), 0),
+                                                  ((30, 27, 24), False, (1, 1, 1), 0), ((269, 9, 10), False, (1, 1, 1), 0),   # ragged rows, one and two strips
                                                   ((31, 27, 24), False, (1, 1, 1), 8), ((70, 20, 22), False, (0.7, 0.7, 1.5), 8),
                                                   ((25, 24, 20), True, (1, 0.8, 2), 8)])
 def test_sep_fir_div(emu, oracle, dims, zero, units, mode):

@@ -601,7 +601,7 @@ S3 = (0.7, 0.973294, 1.94659)                                         # widths 5
     ((21, 18, 26), (1, 1, 1.5), S3, [(0, 10), (10, 26)]),
     ((33, 47, 29), (1, 0.7, 1.3), S3, [(4, 17)]),
     ((9, 7, 6), (2, 4, 2), S3[:2], []),
-    ((17, 22, 19), (1, 1, 1), S3, [(5, 12)]),
+    ((7, 22, 19), (1, 1, 1), S3[:1], [(5, 12)]),            # (nx < 8: rows too short for the streaming path, ragged or not)
 ])
 def test_sep_fir_tile3(lib, oracle, dims, units, sigmas, splits):
     """The one-launch tile kernel for small volumes (k_gauss3_tile): bit-identical to the oracle and to the three passes,
