@@ -34,6 +34,9 @@
  *    Together 16 B/voxel of HBM traffic against 24 B/voxel algorithmic.
  *    Rings are statically indexed by unrolling the march (2hw+1)x.  The y (z) range is cut in
  *    chunks for occupancy; each chunk re-reads 2hw warm-up rows (planes).
+ *    Rows need not be a multiple of four floats long: the RAGGED instantiations of the three kernels take
+ *    dword-aligned quads (the comment at gauss_xy_body says how the row's partial quad is handled); the
+ *    aligned instantiations are untouched by them.
  */
 #include "s3d_common.h"
 #include "s3d_math.h"
