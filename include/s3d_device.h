@@ -58,8 +58,19 @@ int s3d_rt_host_free(void *p);
 const char *s3d_rt_last_error(void);
 
 /* ---- image ops ---------------------------------------------------------------------------------- */
-/* *d_max = max |v[i]|     (im_max_abs, imutil/imutil.c:1959-1973).  d_max is overwritten. */
+/* *d_max = max |v[i]|     (im_max_abs, imutil/imutil.c:1959-1973).  d_max is overwritten.  Order-free reduction over the
+ * bit patterns of |v|: exact for finite values and infinities; if any v[i] is a NaN the result is a NaN ("sticky") -- the
+ * reference's sequential scan then gives something else, see s3d_k_seqmax. */
 int s3d_k_absmax(const float *d_v, size_t n, float *d_max, s3d_stream stream);
+/* The reference's maximum whatever the input holds: max |a[i]| (d_b == NULL) or max |a[i] - b[i]| as the SEQUENTIAL scan
+ * max = (max > samp ? max : samp) computes it (imutil/imutil.c:1959-1973, sift3d/sift.c:1161-1166, immacros.h:36): a NaN
+ * replaces the running maximum and the next sample replaces the NaN, so the result is the maximum of the samples behind the
+ * last NaN in index order (0 if none follow), and that NaN itself if it is the last sample.  Without a NaN: s3d_k_absmax /
+ * s3d_k_dogmax plus three launches that return at once.  d_rec16: 16 bytes of device scratch (8-byte aligned) owned by the
+ * call until it has run.  s3d_k_seqmax_parts leaves there { sticky max bits, max bits behind the last NaN, index + 1 of the
+ * last NaN as 64 bits (0: none) } for callers that combine several index ranges (the Z-slab ranks). */
+int s3d_k_seqmax(const float *d_a, const float *d_b, size_t n, float *d_max, void *d_rec16, s3d_stream stream);
+int s3d_k_seqmax_parts(const float *d_a, const float *d_b, size_t n, void *d_rec16, s3d_stream stream);
 /* v[i] = v[i] / *d_max unless *d_max == 0   (im_scale, imutil/imutil.c:1977-1991; true division) */
 int s3d_k_scale_div(float *d_v, size_t n, const float *d_max, s3d_stream stream);
 /* dst(x,y,z) = src(2x,2y,2z), dst dims = floor(n/2)   (im_downsample_2x, imutil/imutil.c:1742-1768) */
@@ -104,8 +115,11 @@ void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z);
 /* record HIP events (from s3d_rt_event_create) before k_gauss_xy, between, and after k_gauss_z of the
  * next fused applications; NULLs switch it off.  For bench.py's per-kernel timing. */
 void s3d_k_gauss_set_events(void *before_xy, void *between, void *after_z);
-/* profiling knob, see s3d_gauss.hip */
+/* profiling knobs, see s3d_gauss.hip -- and mode 64, "verbatim", which is not one: every axis pass on the per-element
+ * kernel that evaluates both samples of every tap as the reference does (0 * NaN is NaN).  The host pipelines select it
+ * for volumes that hold non-finite voxels and restore what s3d_k_gauss_get_mode returned before. */
 void s3d_k_gauss_set_mode(int mode);
+int s3d_k_gauss_get_mode(void);
 /* Volumes of up to max_voxels output voxels run the three passes of an application in one launch (k_gauss3_tile: the
  * coarse octaves of a pyramid, bound by launch and L2 latency); 0 = never, < 0 = the default (64^3, or S3D_TILE3_MAX).
  * Per calling thread.  s3d_k_gauss_tile3_launches: how many such launches the calling thread has made (tests). */
@@ -122,7 +136,7 @@ int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp, int nx, i
                        s3d_stream stream);
 
 /* ---- DoG + extrema  (build_dog sift3d/sift.c:1052-1071, detect_extrema sift.c:1074-1212) -------- */
-/* *d_max = max |a - b|  : per-level `dogmax` (sift.c:1161-1166) without materialising the DoG. */
+/* *d_max = max |a - b|  : per-level `dogmax` (sift.c:1161-1166) without materialising the DoG (sticky like s3d_k_absmax). */
 int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float *d_max, s3d_stream stream);
 /* d_max3[k] = max |d_levels4[k] - d_levels4[k+1]|, k = 0..2, in one pass (16-byte aligned levels; the host array
  * of four device pointers is read at call time). */
@@ -189,11 +203,14 @@ typedef struct {
  * variant, sift.c:1534-1604; d_sigma is then per candidate).
  * Outputs: d_R[9*i] row-major rotation, d_keep[i] = 1 iff not rejected and conf >= corner_thresh,
  * d_conf[i] (optional) = corner score, 0 when rejected.  Three launches per chunk: window sums (a wave per
- * candidate), decisions (a thread per candidate), the ordered sum for the few the bound left undecided. */
+ * candidate), decisions (a thread per candidate), the ordered sum for the few the bound left undecided.
+ * d_fail (optional): one word the call sets to 1 (and never clears) when some candidate's window holds a NaN gradient --
+ * the reference's eigen_Mat_rm fails on the NaN structure tensor (LAPACK dsyevd, info > 0) and with it the whole
+ * SIFT3D_detect_keypoints / SIFT3D_assign_orientations call (sift.c:1430-1431, 1293-1296); such a candidate is not kept. */
 int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                  const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
                  float *d_R, uint32_t *d_keep, double *d_conf,
-                 void *d_scratch /* s3d_k_orient_scratch_bytes(num) bytes */, s3d_stream stream);
+                 void *d_scratch /* s3d_k_orient_scratch_bytes(num) bytes */, uint32_t *d_fail, s3d_stream stream);
 /* The same with the levels' window tables: d_tabs = s3d_k_orient_tab_bytes(pyr) bytes of device memory the call fills
  * (one launch, a wave per level) and the window sums then replay -- the window of a candidate with an integer centre
  * away from the faces of the volume is a property of its level, whatever the units are (which
@@ -213,7 +230,8 @@ size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr);
 int s3d_k_orient_wants_tab(const s3d_pyramid_desc *pyr);
 int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                      const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                     float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream stream);
+                     float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, uint32_t *d_fail,
+                     s3d_stream stream);
 /* Test / profiling knob of the calling thread: how s3d_k_orient_tab uses the tables -- 0 not at all, 1 one kernel that
  * replays or enumerates per candidate, 2 a table-walk kernel plus the general kernel for the candidates it flags; anything
  * else restores the default (S3D_ORI_MODE, else 0: measured at 512^3, the tables do not pay -- profiles/r03_orient_experiments.txt). */

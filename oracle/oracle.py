@@ -48,6 +48,10 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+class ReferenceFails(RuntimeError):
+    """The reference's own call returns SIFT3D_FAILURE on this input (and the product must as well)."""
+
+
 class Oracle:
     """The plain-C restatement."""
 
@@ -123,6 +127,8 @@ class Oracle:
         nz, ny, nx = v.shape
         u = np.asarray(units, np.float64)
         k = self.L.orc_detect(self.ctx, _p(v, _f32p), nx, ny, nz, _p(u, _f64p))
+        if k == -2:
+            raise ReferenceFails("a NaN gradient in a candidate's orientation window: SIFT3D_detect_keypoints fails")
         if k < 0:
             raise RuntimeError("orc_detect failed")
         xyzos = np.zeros((k, 5), np.int32)

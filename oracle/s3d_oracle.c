@@ -433,7 +433,11 @@ static int alloc_pyr(orc_ctx *c, int nx, int ny, int nz, const double units[3])
     return ORC_OK;
 }
 
-/* assign_eig_ori, sift.c:1354-1514.  Returns 0 ok, 1 reject. */
+/* assign_eig_ori, sift.c:1354-1514.  Returns 0 ok, 1 reject, 2 failure: a NaN gradient in the window makes
+ * the window gradient NaN (not rejected by ori_grad_thresh: the comparison is false) and the structure tensor NaN, on which
+ * LAPACK's dsyevd does not converge (info > 0): eigen_Mat_rm and assign_eig_ori return SIFT3D_FAILURE, and with them
+ * SIFT3D_detect_keypoints (sift.c:1430-1431, 1293-1296; imutil.c:3052-3058).  Observed on oracle/_ref, not assumed:
+ * tests/test_oracle_vs_ref.py::test_nonfinite. */
 static int eig_ori(const level_t *im, const float vc[3], double sigma, float R[9], double *conf)
 {
     const double rad = sigma * 3.0;                    /* ori_rad_fctr */
@@ -479,6 +483,7 @@ static int eig_ori(const level_t *im, const float vc[3], double sigma, float R[9
             }
     A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
     if (gwx * gwx + gwy * gwy + gwz * gwz < (float)1E-10) return 1;   /* ori_grad_thresh */
+    if (A[0][0] + A[1][1] + A[2][2] != A[0][0] + A[1][1] + A[2][2]) return 2;   /* a NaN term: dsyevd fails */
     orc_eig3(A, L, Q);
     for (int i = 0; i < 2; i++)
         if (fabs(L[i] / L[i + 1]) > 0.90) return 1;                   /* max_eig_ratio */
@@ -622,6 +627,7 @@ long orc_detect(orc_ctx *c, const float *vol, int nx, int ny, int nz, const doub
         float *R = (float *)malloc(sizeof(float) * 9 * (nc ? nc : 1));
         int32_t *keep = (int32_t *)malloc(sizeof(int32_t) * (nc ? nc : 1));
         size_t k = 0;
+        int failed = 0;
         if (!R || !keep) return -1;
         #pragma omp parallel for schedule(dynamic, 16)
         for (size_t i = 0; i < nc; i++) {
@@ -632,6 +638,14 @@ long orc_detect(orc_ctx *c, const float *vol, int nx, int ny, int nz, const doub
             double conf;
             const int rej = eig_ori(lev, vc, 1.5 * sd, R + 9 * i, &conf);    /* ori_sig_fctr */
             keep[i] = !(rej || conf < c->corner_thresh);
+            if (rej == 2) {
+                #pragma omp atomic write
+                failed = 1;
+            }
+        }
+        if (failed) {                      /* assign_orientations returns the error after the loop (sift.c:1293-1299) */
+            free(R); free(keep);
+            return -2;
         }
         for (size_t i = 0; i < nc; i++) k += keep[i];
         c->nkp = k;

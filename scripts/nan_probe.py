@@ -77,16 +77,35 @@ def same(a, b):
     return True
 
 
+def run_oracle(O, vol, units):
+    try:
+        xyzos, sd, R = O.detect(vol, units)
+    except orc.ReferenceFails:
+        return ("detect failed",)
+    bins = None
+    if len(xyzos):
+        bins, _ = O.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
+    return xyzos, sd, R, bins
+
+
 def main():
     ref = orc.load_ref()
     emu = emu_lib()
+    O = orc.Oracle()
     for dims, units in (((32, 32, 32), (1, 1, 1)), ((40, 36, 28), (1, 0.8, 2)), ((72, 68, 66), (1, 1, 1))):
         for name, vol in cases(dims, 1):
             r = run(ref, vol, units)
             e = run(emu, vol, units)
+            q = run_oracle(O, vol, units)
+            okq = same(r, q) or (isinstance(r[0], str) and isinstance(q[0], str))
+            if okq and not isinstance(r[0], str) and len(r[0]) and isinstance(r[3], np.ndarray):
+                okq = np.array_equal(np.isnan(r[3]), np.isnan(q[3])) and np.allclose(np.nan_to_num(r[3]), np.nan_to_num(q[3]), rtol=1e-4, atol=1e-7)
+            if isinstance(r[0], str) and isinstance(e[0], str):
+                print(f"{dims} {units} {name}: ref and emu both FAIL the call; oracle {'agrees' if okq else 'DIFFERS'}", flush=True)
+                continue
             kr = len(r[0]) if not isinstance(r[0], str) else r[0]
             ke = len(e[0]) if not isinstance(e[0], str) else e[0]
-            msg = f"{dims} {units} {name}: ref {kr} emu {ke}"
+            msg = f"{dims} {units} {name}: [oracle {'ok' if okq else 'DIFFERS'}] ref {kr} emu {ke}"
             if same(r, e):
                 msg += " keypoints equal"
                 if kr:

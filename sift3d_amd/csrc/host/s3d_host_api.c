@@ -77,8 +77,10 @@ typedef struct {
     unsigned long long *d_bits;             /* S3D_FUSED_KP_MAX bitmaps of bits_words words */
     size_t bits_words;
     uint32_t *d_scratch;
-    float *d_red;           /* small reduction slots */
-    uint32_t *d_count;      /* [0] candidates, [1] keypoints, [4] work counter of the descriptor kernel */
+    float *d_red;           /* small reduction slots: 64 words, see RED_* */
+    uint32_t *d_count;      /* = d_red + RED_COUNT: [0] candidates, [1] keypoints, [2] orientation failed (a NaN window),
+                             * [4] work counter of the descriptor kernel */
+    int verbatim;           /* the pass in flight runs on the literal kernels (a volume with non-finite voxels) */
     uint32_t cand_cap;
     uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
     uint32_t *d_kscratch;   /* block counters of s3d_k_compact_keys: cand_cap/256 + 2 (grows with cand_cap) */
@@ -116,6 +118,14 @@ typedef struct {
     void *h_stage[3];
     size_t h_stage_bytes[3];
 } s3d_ctx;
+
+/* words of c->d_red.  The input's maximum sits directly in front of the counters, so that the copy that fetches the
+ * candidate count brings it along: its bit pattern tells whether the volume held a NaN or an infinity. */
+#define RED_DOGMAX 1        /* 3 words: the DoG maxima of the octave in flight */
+#define RED_REC 40          /* 4 words, 8-byte aligned: the record of s3d_k_seqmax */
+#define RED_INMAX 55        /* max |input voxel| */
+#define RED_COUNT 56        /* 8 words: c->d_count */
+#define S3D_REDO_VERBATIM 2 /* detect_dev: the input held a non-finite voxel, run the pass again on the literal kernels */
 
 #define S3D_MAX_CTX 256
 static s3d_ctx *g_ctx[S3D_MAX_CTX];
@@ -174,7 +184,7 @@ static void ctx_free_pyramid(s3d_ctx *c)
 static void ctx_free_all(s3d_ctx *c)
 {
     ctx_free_pyramid(c);
-    dfree(&c->d_red); dfree(&c->d_count); dfree(&c->d_mesh);
+    dfree(&c->d_red); c->d_count = NULL; dfree(&c->d_mesh);
     dfree(&c->d_keys); dfree(&c->d_desc);
     c->desc_cap = 0;
     for (int i = 0; i < 4; i++) { dfree(&c->d_aux[i]); c->aux_elems[i] = 0; }
@@ -240,7 +250,7 @@ static int ctx_stage(s3d_ctx *c, int slot, size_t bytes, void **out)
 static int ctx_base(s3d_ctx *c)
 {
     if (!c->d_red) DEV(s3d_rt_malloc((void **)&c->d_red, 64 * sizeof(float)));
-    if (!c->d_count) DEV(s3d_rt_malloc((void **)&c->d_count, 8 * sizeof(uint32_t)));
+    c->d_count = (uint32_t *)(c->d_red + RED_COUNT);
     if (!c->d_mesh) {
         float mesh[S3D_MESH_FLOATS];
         s3d_mesh_table(mesh);
@@ -541,8 +551,25 @@ static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const fl
     } else {
         c->in_src = d_vol;
     }
-    DEV(s3d_k_absmax(c->in_src, n, c->d_red, c->stream));
+    if (c->verbatim) DEV(s3d_k_seqmax(c->in_src, NULL, n, c->d_red + RED_INMAX, c->d_red + RED_REC, c->stream));
+    else DEV(s3d_k_absmax(c->in_src, n, c->d_red + RED_INMAX, c->stream));
     return SIFT3D_SUCCESS;
+}
+
+/* One Gaussian application of the pyramid.  A pass over a volume with non-finite voxels (c->verbatim) takes the
+ * per-element kernel for every axis: it evaluates both samples of every tap as the reference does (0 * NaN is NaN,
+ * s3d_gauss.hip g_verbatim), where the streaming kernels read one. */
+static int pyr_fir(s3d_ctx *c, const float *src, float *dst, int nx, int ny, int nz, const float uf[3], const Sep_FIR_filter *f)
+{
+    int rc;
+    if (!c->verbatim) return s3d_k_sep_fir(src, dst, c->d_tmp, nx, ny, nz, 1, uf, f->kernel, f->width, c->stream);
+    {
+        const int mode = s3d_k_gauss_get_mode();
+        s3d_k_gauss_set_mode(64);
+        rc = s3d_k_sep_fir_path(src, dst, c->d_tmp, nx, ny, nz, 1, uf, f->kernel, f->width, 1, c->stream);
+        s3d_k_gauss_set_mode(mode);
+    }
+    return rc;
 }
 
 /* detect_extrema (sift.c:1074-1212) for one octave: DoG maxima, extrema bitmaps, ordered compaction into the candidate
@@ -557,25 +584,26 @@ static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es
     float *const *lp = &c->d_level[o * L];
     const size_t nwords = (n + 63) / 64;
     int fused = 1;                                       /* all keypoint levels in one pass over the GSS levels */
-    if (nkp <= S3D_FUSED_KP_MAX) {
+    if (nkp <= S3D_FUSED_KP_MAX && !c->verbatim) {
         unsigned long long *bits[S3D_FUSED_KP_MAX];
         for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
         /* three keypoint levels: the DoG maxima come out of the extrema pass itself (running lower bound,
          * then the exact thresholds on the survivors) instead of a pass of their own over four levels */
         fused = s3d_k_extrema_fused_runmax((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz,
-                                           sift3d->peak_thresh, c->d_red + 1, bits, es);
+                                           sift3d->peak_thresh, c->d_red + RED_DOGMAX, bits, es);
         if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
         if (fused == 0)
             DEV(s3d_k_extrema_refilter((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
-                                       c->d_red + 1, bits, es));
+                                       c->d_red + RED_DOGMAX, bits, es));
         if (fused == 0)                                 /* the nkp bitmaps in one count / scan / emit */
             DEV(s3d_k_compact_bits_multi(bits[0], nwords, nkp, c->bits_words, 0u, c->d_cand_idx, c->d_cand_tag,
                                          ((uint32_t)o << 8) | 1u, c->cand_cap, c->d_count, c->d_scratch, es));
     }
     for (int ks = 1; fused != 0 && ks <= nkp; ks++) {   /* DoG level ks <-> s = ks-1 ; uses GSS ks-1..ks+2 */
-        DEV(s3d_k_dogmax(lp[ks], lp[ks + 1], n, c->d_red + 1, es));
+        /* the level's DoG maximum as the reference's sequential scan leaves it (a NaN in the level: s3d_k_seqmax) */
+        DEV(s3d_k_seqmax(lp[ks], lp[ks + 1], n, c->d_red + RED_DOGMAX, c->d_red + RED_REC, es));
         DEV(s3d_k_extrema(lp[ks - 1], lp[ks], lp[ks + 1], lp[ks + 2], lv->nx, lv->ny, lv->nz, sift3d->peak_thresh,
-                          c->d_red + 1, c->d_bits, es));
+                          c->d_red + RED_DOGMAX, c->d_bits, es));
         DEV(s3d_k_compact_bits(c->d_bits, nwords, c->d_cand_idx, c->d_cand_tag, ((uint32_t)o << 8) | (uint32_t)ks,
                                c->cand_cap, c->d_count, c->d_scratch, es));
     }
@@ -613,15 +641,14 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
     }
     unit_factors(units, 1.0, uf);
     if (c->in_src == NULL) API_FAIL("sift3d_amd: no input volume");
-    if (s3d_k_sep_fir_div_eligible(l0->nx, l0->ny, l0->nz, uf, gss->first_gauss.f.width)) {
+    if (!c->verbatim && s3d_k_sep_fir_div_eligible(l0->nx, l0->ny, l0->nz, uf, gss->first_gauss.f.width)) {
         DEV(s3d_k_sep_fir_div(c->in_src, c->d_level[0], c->d_tmp, l0->nx, l0->ny, l0->nz, 0, l0->nz, uf,
-                              gss->first_gauss.f.kernel, gss->first_gauss.f.width, c->d_red, c->stream));
+                              gss->first_gauss.f.kernel, gss->first_gauss.f.width, c->d_red + RED_INMAX, c->stream));
     } else {
         const size_t n = (size_t)l0->nx * l0->ny * l0->nz;
         if (c->in_src != c->d_im) DEV(s3d_rt_d2d(c->d_im, c->in_src, n * sizeof(float), c->stream));
-        DEV(s3d_k_scale_div(c->d_im, n, c->d_red, c->stream));
-        DEV(s3d_k_sep_fir(c->d_im, c->d_level[0], c->d_tmp, l0->nx, l0->ny, l0->nz, 1, uf, gss->first_gauss.f.kernel,
-                          gss->first_gauss.f.width, c->stream));
+        DEV(s3d_k_scale_div(c->d_im, n, c->d_red + RED_INMAX, c->stream));
+        DEV(pyr_fir(c, c->d_im, c->d_level[0], l0->nx, l0->ny, l0->nz, uf, &gss->first_gauss.f));
     }
     c->in_src = NULL;                                     /* the caller's volume is not ours beyond this call */
     for (int o = 0; o < g->num_octaves; o++) {
@@ -632,8 +659,7 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
             /* level s = k-1+first_level+... uses gauss_octave[s] with s counted from 0 (quirk C-11):
              * filter index k-1 maps level k-1 -> k */
             const Sep_FIR_filter *f = &gss->gauss_octave[k - 1].f;
-            DEV(s3d_k_sep_fir(c->d_level[o * L + k - 1], c->d_level[o * L + k], c->d_tmp, lv->nx, lv->ny, lv->nz, 1,
-                              uf, f->kernel, f->width, c->stream));
+            DEV(pyr_fir(c, c->d_level[o * L + k - 1], c->d_level[o * L + k], lv->nx, lv->ny, lv->nz, uf, f));
         }
         if (es) {
             if (!c->oct_ev[o]) DEV(s3d_rt_event_create(&c->oct_ev[o]));
@@ -658,7 +684,8 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
     const Pyramid *g = &sift3d->gpyr;
     const int L = g->num_levels;
     s3d_pyramid_desc pd;
-    uint32_t counts[2] = {0, 0};
+    uint32_t counts[3] = {0, 0, 0};
+    uint32_t inmax_count[2] = {0, 0};
     uint32_t cap = candidate_capacity(c);
     for (int attempt = 0; attempt < 2; attempt++) {
         s3d_stream es = c->stream;
@@ -671,8 +698,13 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
                 if (extrema_octave(sift3d, c, o, es)) return SIFT3D_FAILURE;
         }
         c->extrema_enqueued = 0;
-        DEV(s3d_rt_d2h(counts, c->d_count, sizeof(uint32_t), es));
+        DEV(s3d_rt_d2h(inmax_count, c->d_red + RED_INMAX, 2 * sizeof(uint32_t), es));    /* RED_COUNT = RED_INMAX + 1 */
         DEV(s3d_rt_sync(es));
+        counts[0] = inmax_count[1];
+        /* An infinity or a NaN among the input voxels (the order-free maximum is sticky, s3d_k_absmax): the reference's
+         * answer then depends on WHERE they are -- its maxima are sequential scans, its filters multiply them by zero
+         * weights -- which the streaming kernels do not reproduce.  The caller runs the pass again on the literal ones. */
+        if (!c->verbatim && (inmax_count[0] & 0x7fffffffu) >= 0x7f800000u) return S3D_REDO_VERBATIM;
         if (counts[0] <= c->cand_cap) break;
         cap = counts[0] + 1024;                           /* candidate list overflowed: grow and redo */
         if (attempt == 1) API_FAIL("sift3d_amd: candidate buffer overflow");
@@ -695,11 +727,17 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
             c->oritab_bytes = s3d_k_orient_tab_bytes(&pd);
         }
         DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
-                             c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_wants_tab(&pd) ? c->d_oritab : NULL, c->stream));
+                             c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_wants_tab(&pd) ? c->d_oritab : NULL,
+                             c->d_count + 2, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
                                c->d_Rk, c->d_count + 1, c->d_kscratch, c->stream));
-        DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, sizeof(uint32_t), c->stream));
+        DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, 2 * sizeof(uint32_t), c->stream));
         DEV(s3d_rt_sync(c->stream));
+        if (counts[2]) {
+            /* a candidate's window holds a NaN gradient: the reference's eigen_Mat_rm fails there and the call with it */
+            API_FAIL("sift3d_amd: a NaN voxel inside a keypoint candidate's orientation window (the reference's "
+                     "SIFT3D_detect_keypoints fails here: eigen_Mat_rm, sift.c:1430)");
+        }
     }
     {
         const uint32_t K = counts[1];
@@ -781,6 +819,9 @@ int sift3d_amd_get_slab_info(const SIFT3D *const sift3d, int r, sift3d_amd_slab_
     return c ? s3d_mgpu_info(c->mgpu, r, info) : SIFT3D_FAILURE;
 }
 
+static int detect_single(SIFT3D *const sift3d, const float *host_dense, const float *d_vol, int nx, int ny, int nz,
+                         double ux, double uy, double uz, Keypoint_store *const kp);
+
 int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoint_store *const kp) /* sift.c:1609 */
 {
     float *dense = NULL;
@@ -813,12 +854,37 @@ int SIFT3D_detect_keypoints(SIFT3D *const sift3d, const Image *const im, Keypoin
         }
         return SIFT3D_SUCCESS;
     }
-    rc = set_im_device(sift3d, src, NULL, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz);
-    if (rc == SIFT3D_SUCCESS && dense) rc = s3d_rt_sync(sift_ctx(sift3d)->stream) ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
+    rc = detect_single(sift3d, src, NULL, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz, kp);
     free(dense);
-    if (rc) return SIFT3D_FAILURE;
-    if (build_gpyr_dev(sift3d, sift_ctx(sift3d), 1)) return SIFT3D_FAILURE;
-    if (detect_dev(sift3d, sift_ctx(sift3d), kp)) return SIFT3D_FAILURE;
+    return rc;
+}
+
+/* set_im_SIFT3D + build_gpyr + detect_extrema + assign_orientations on one GPU, from a dense host volume or a device
+ * volume.  The first pass runs on the streaming kernels and learns from the input's maximum -- fetched with the candidate
+ * count, no extra synchronisation -- whether every voxel was finite; if not, the pass is repeated on the literal kernels
+ * (c->verbatim), which reproduce what the reference does with NaNs and infinities (s3d_k_seqmax, s3d_gauss.hip g_verbatim). */
+static int detect_single(SIFT3D *const sift3d, const float *host_dense, const float *d_vol, int nx, int ny, int nz,
+                         double ux, double uy, double uz, Keypoint_store *const kp)
+{
+    int rc = SIFT3D_FAILURE;
+    for (int verbatim = 0; verbatim < 2; verbatim++) {
+        s3d_ctx *c;
+        if (!sift3d->kernels.downsample_2 && !(sift3d->kernels.downsample_2 = ctx_new()))
+            API_FAIL("sift3d_amd: out of device contexts");
+        c = sift_ctx(sift3d);
+        c->verbatim = verbatim;
+        rc = set_im_device(sift3d, host_dense, d_vol, nx, ny, nz, ux, uy, uz);
+        if (rc == SIFT3D_SUCCESS) rc = build_gpyr_dev(sift3d, c, 1);
+        if (rc == SIFT3D_SUCCESS) rc = detect_dev(sift3d, c, kp);
+        c->verbatim = 0;
+        if (rc != S3D_REDO_VERBATIM) break;
+    }
+    /* (the upload of host_dense has completed: detect_dev synchronised the stream, and so does every failure path's
+     * caller before it frees the buffer -- the stream is synchronised here for those) */
+    if (rc != SIFT3D_SUCCESS) {
+        (void)s3d_rt_sync(sift_ctx(sift3d)->stream);
+        return SIFT3D_FAILURE;
+    }
     {   /* a caller that reads sift3d->gpyr / dog voxels as it would after the reference's call (sift.c:989-1071) */
         const int mode = host_pyramid_mode(sift_ctx(sift3d));
         if (mode > 0 && sift3d_amd_download_pyramid(sift3d, mode > 1)) return SIFT3D_FAILURE;
@@ -830,14 +896,7 @@ int sift3d_amd_detect_keypoints_dev(SIFT3D *const sift3d, const float *d_vol, in
                                     double uy, double uz, Keypoint_store *const kp)
 {
     if (d_vol == NULL || nx < 1 || ny < 1 || nz < 1) API_FAIL("sift3d_amd_detect_keypoints_dev: bad arguments");
-    if (set_im_device(sift3d, NULL, d_vol, nx, ny, nz, ux, uy, uz)) return SIFT3D_FAILURE;
-    if (build_gpyr_dev(sift3d, sift_ctx(sift3d), 1)) return SIFT3D_FAILURE;
-    if (detect_dev(sift3d, sift_ctx(sift3d), kp)) return SIFT3D_FAILURE;
-    {   /* a caller that reads sift3d->gpyr / dog voxels as it would after the reference's call (sift.c:989-1071) */
-        const int mode = host_pyramid_mode(sift_ctx(sift3d));
-        if (mode > 0 && sift3d_amd_download_pyramid(sift3d, mode > 1)) return SIFT3D_FAILURE;
-    }
-    return SIFT3D_SUCCESS;
+    return detect_single(sift3d, NULL, d_vol, nx, ny, nz, ux, uy, uz, kp);
 }
 
 /* Host-only planning: size the pyramids and build the filter bank for an nx x ny x nz volume exactly as
@@ -1243,7 +1302,7 @@ static int max_abs_dev(const Image *im, int scale, float *out)
         s3d_ctx *c = &g_shared;
         if (ctx_base(c) == 0 && ctx_aux(c, 0, n) == 0 &&
             s3d_rt_h2d(c->d_aux[0], dense, n * sizeof(float), c->stream) == 0 &&
-            s3d_k_absmax(c->d_aux[0], n, c->d_red, c->stream) == 0 &&
+            s3d_k_seqmax(c->d_aux[0], NULL, n, c->d_red, c->d_red + RED_REC, c->stream) == 0 &&
             (!scale || s3d_k_scale_div(c->d_aux[0], n, c->d_red, c->stream) == 0) &&
             s3d_rt_d2h(out, c->d_red, sizeof(float), c->stream) == 0 &&
             (!scale || s3d_rt_d2h(dense, c->d_aux[0], n * sizeof(float), c->stream) == 0) &&
@@ -1472,7 +1531,7 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
     if (s3d_rt_h2d(d_centers, centers, num * 3 * sizeof(float), c->stream) ||
         s3d_rt_h2d(d_sig, sig, num * sizeof(double), c->stream) ||
         s3d_rt_h2d(d_tags, tags, num * sizeof(uint32_t), c->stream) ||
-        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, d_oscr, c->stream) ||
+        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, d_oscr, NULL, c->stream) ||
         s3d_rt_d2h(R, d_R, num * 9 * sizeof(float), c->stream) ||
         s3d_rt_d2h(keep, d_keep, num * sizeof(uint32_t), c->stream) ||
         s3d_rt_d2h(*conf, d_conf, num * sizeof(double), c->stream) || s3d_rt_sync(c->stream)) {
@@ -1538,7 +1597,7 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
             s3d_rt_malloc(&d_oscr, s3d_k_orient_scratch_bytes((uint32_t)n)) == 0 &&
             s3d_rt_h2d(d_sig, &ori_sigma, sizeof(double), c->stream) == 0 &&
             s3d_k_orient(&pd, NULL, NULL, NULL, (uint32_t)n, d_sig, sift3d->corner_thresh, d_R, d_keep, NULL,
-                         d_oscr, c->stream) == 0 &&
+                         d_oscr, NULL, c->stream) == 0 &&
             s3d_k_dense_rot_hist(c->d_aux[1], nx, ny, nz, unitsf, sigma_win, d_R, d_keep, c->d_mesh, d_out,
                                  c->stream) == 0 &&
             s3d_k_dense_post(d_out, d_in, n, c->stream) == 0 && s3d_rt_sync(c->stream) == 0)

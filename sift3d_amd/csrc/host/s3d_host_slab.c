@@ -117,6 +117,7 @@ struct sift3d_amd_slab {
     uint32_t *d_scratch, *d_kscratch, *d_count;
     float *d_red;
     int first_div;                      /* this detect folds im_scale into the first filter (s3d_k_sep_fir_div) */
+    int verbatim;                       /* the pass in flight runs on the literal kernels (a volume with non-finite voxels) */
     uint32_t cap;
     uint32_t *d_cand_idx, *d_cand_tag, *d_keep;
     float *d_R, *d_Rk;
@@ -129,7 +130,7 @@ struct sift3d_amd_slab {
     double *d_sigma;
     double h_sigma[S3D_MAX_OCTAVES * S3D_MAX_LEVELS];
     float h_flag;
-    uint32_t h_counts[2];
+    uint32_t h_counts[3];               /* candidates | keypoints, an orientation window with a NaN gradient */
     s3d_pyramid_desc pd;
     size_t desc_cap;
     void *h_keys;                       /* pinned staging of the descriptor keys, kept between calls */
@@ -228,7 +229,9 @@ static int filter_reach(const sift3d_amd_slab *sl, const Sep_FIR_filter *f, int 
     const int hw = f->width / 2;
     float uf[3];
     octave_uf(sl, o, uf);
-    if (uf[0] == 1.0f && uf[1] == 1.0f && uf[2] == 1.0f) return hw;     /* fused unit-spacing path: exact */
+    /* fused unit-spacing path: exact.  (The literal kernel of a verbatim pass reads the plane behind the last tap as
+     * well, with weight 0 -- 0 * NaN is NaN, s3d_gauss.hip g_verbatim -- like the other spacings' generic passes.) */
+    if (uf[0] == 1.0f && uf[1] == 1.0f && uf[2] == 1.0f && !sl->verbatim) return hw;
     return (int)ceilf((float)hw * uf[2]) + 1;                           /* + 1: the reference's drifting tap coordinate */
 }
 
@@ -379,7 +382,7 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
     }
     if (dmalloc(sl, &sl->d_bits, S3D_FUSED_KP_MAX * sl->bits_words * sizeof(unsigned long long), 1) ||
         dmalloc(sl, &sl->d_scratch, 3 * (sl->bits_words / 1024 + 16) * sizeof(uint32_t), 1) ||
-        dmalloc(sl, &sl->d_red, 16 * sizeof(float), 1) || dmalloc(sl, &sl->d_count, 8 * sizeof(uint32_t), 1) ||
+        dmalloc(sl, &sl->d_red, 32 * sizeof(float), 1) || dmalloc(sl, &sl->d_count, 8 * sizeof(uint32_t), 1) ||
         dmalloc(sl, &sl->d_sigma, sizeof(double) * S3D_MAX_OCTAVES * S3D_MAX_LEVELS, 0))
         return SIFT3D_FAILURE;
     if (sl->dry) return dmalloc(sl, &sl->d_mesh, sizeof(float) * S3D_MESH_FLOATS, 0);
@@ -621,6 +624,47 @@ static int build_pyramid(sift3d_amd_slab *sl)
     return finish_halos(sl);
 }
 
+#define SLAB_RED_REC 12             /* 4 words of sl->d_red (8-byte aligned): the record of s3d_k_seqmax_parts */
+#define SLAB_RED_LOCALMAX 9         /* this rank's own input maximum, kept beside the all-reduced one */
+#define SLAB_REDO_VERBATIM 2        /* find_candidates: some rank's slab holds a non-finite voxel */
+#define SLAB_NAN_WINDOW 3           /* slab_detect_pass: the reference fails on this volume, and so does every rank -- together */
+
+/* max |a| or max |a - b| over a volume spread over the ranks in z order, as the reference's SEQUENTIAL scan leaves it when
+ * NaNs are present (s3d_k_seqmax: the maximum of the samples behind the last NaN; that NaN if nothing follows it).  Every
+ * rank scans its n_local samples (s3d_k_seqmax_parts), the records travel through allgather_host -- bytes, no arithmetic
+ * in the transport -- and every rank folds them in rank order.  Only verbatim passes come here: cost does not matter. */
+static int slab_seqmax(sift3d_amd_slab *sl, const float *d_a, const float *d_b, size_t n_local, float *d_out)
+{
+    const int G = sl->t.world;
+    uint32_t mine[6], *all, run = 0u;
+    int run_nan = 0;
+    DEV(s3d_k_seqmax_parts(d_a, d_b, n_local, sl->d_red + SLAB_RED_REC, sl->cs));
+    DEV(s3d_rt_d2h(mine, sl->d_red + SLAB_RED_REC, 4 * sizeof(uint32_t), sl->cs));
+    if (slab_sync(sl)) return SIFT3D_FAILURE;
+    mine[4] = (uint32_t)((unsigned long long)n_local & 0xffffffffu);
+    mine[5] = (uint32_t)((unsigned long long)n_local >> 32);
+    if ((all = (uint32_t *)malloc((size_t)G * sizeof(mine))) == NULL) SLAB_FAIL("sift3d_amd slab: out of host memory");
+    if (G == 1) memcpy(all, mine, sizeof(mine));
+    else if (sl->t.allgather_host(sl->t.self, mine, all, sizeof(mine))) { free(all); SLAB_FAIL("sift3d_amd slab: transport: allgather_host failed"); }
+    for (int q = 0; q < G; q++) {
+        const uint32_t *r = all + 6 * q;
+        const unsigned long long last = ((unsigned long long)r[3] << 32) | r[2], nq = ((unsigned long long)r[5] << 32) | r[4];
+        if (nq == 0) continue;
+        if (r[0] > 0x7f800000u) {                            /* a NaN in rank q's samples: what came before is forgotten */
+            run_nan = last == nq;
+            run = r[1];
+        } else {                                             /* (a running NaN is replaced by the rank's first sample) */
+            run = run_nan ? r[0] : (run > r[0] ? run : r[0]);
+            run_nan = 0;
+        }
+    }
+    free(all);
+    if (run_nan) run = 0x7fc00000u;
+    DEV(s3d_rt_h2d(d_out, &run, sizeof(run), sl->cs));
+    if (slab_sync(sl)) return SIFT3D_FAILURE;              /* `run` is a stack word */
+    return SIFT3D_SUCCESS;
+}
+
 /* detect_extrema over my planes of every octave; the candidate list in the reference's scan order */
 static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
 {
@@ -643,7 +687,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
             const s3d_lev *L = &sl->lev[o * nl];
             if (zb <= za) continue;          /* only in a replicated octave with fewer planes than ranks: no collectives there */
             const size_t nwords = ((size_t)(zb - za) * pe + 63) / 64;
-            const int fused = nkp == 3 && nxo >= 4;         /* all keypoint levels in one pass (s3d_k_extrema_fused) */
+            const int fused = nkp == 3 && nxo >= 4 && !sl->verbatim;   /* all keypoint levels in one pass (s3d_k_extrema_fused) */
             if (fused) {
                 const float *l6[6];
                 unsigned long long *bits[3];
@@ -652,25 +696,38 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
                 if (shard_o || G == 1) {
                     /* survivors under a running lower bound of the DoG maxima, the exact maxima of my planes as a
                      * by-product; the maxima over all ranks (sift.c:1161-1169), then the exact thresholds on the survivors */
-                    if (s3d_k_extrema_fused_runmax(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
-                        SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                    const int fr = s3d_k_extrema_fused_runmax(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs);
+                    if (fr < 0) SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                    if (fr > 0) goto per_level;             /* not eligible (a level of >= 2^31 voxels): nothing was launched */
                     if (shard_o) COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 3, sl->cs));   /* the three maxima at once */
                     DEV(s3d_k_extrema_refilter(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs));
+                } else if ((size_t)nzo * pe >= 0x7FFFFF00ull || pe * (size_t)(zb - za) < 4) {
+                    goto per_level;                         /* s3d_k_extrema_fused would decline (same rule, s3d_extrema.hip) */
                 } else {
                     /* replicated octave: every rank holds the whole level (the maxima are over all of it, no collective --
                      * ranks without planes are not here) and tests its own planes */
                     const float *l4[4];
                     for (int k = 0; k < 4; k++) l4[k] = lev_view(&L[k + 1]);
                     DEV(s3d_k_dogmax3(l4, (size_t)nzo * pe, sl->d_red + 1, sl->cs));
-                    if (s3d_k_extrema_fused(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs) != 0)
-                        SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                    const int fr = s3d_k_extrema_fused(l6, 3, nxo, nyo, nzo, za, zb, sl->plan.peak_thresh, sl->d_red + 1, bits, sl->cs);
+                    if (fr < 0) SLAB_FAIL("sift3d_amd slab: extrema failed: %s", s3d_rt_last_error());
+                    if (fr > 0) goto per_level;
                 }
                 DEV(s3d_k_compact_bits_multi(bits[0], nwords, 3, sl->bits_words, (uint32_t)((size_t)za * pe), sl->d_cand_idx,
                                              sl->d_cand_tag, ((uint32_t)o << 8) | 1u, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
                 continue;
             }
+per_level:
             for (int ks = 1; ks <= nkp; ks++) {
-                if (shard_o) {      /* max |DoG| over my planes, then over the ranks (sift.c:1161-1169) */
+                if (sl->verbatim) { /* the sequential scan's result (a level with NaNs), over the ranks in z order */
+                    if (shard_o) {
+                        if (slab_seqmax(sl, lev_ptr(&L[ks], za), lev_ptr(&L[ks + 1], za), (size_t)(zb - za) * pe, sl->d_red + 1))
+                            return SIFT3D_FAILURE;
+                    } else {
+                        DEV(s3d_k_seqmax(lev_view(&L[ks]), lev_view(&L[ks + 1]), (size_t)nzo * pe, sl->d_red + 1,
+                                         sl->d_red + SLAB_RED_REC, sl->cs));
+                    }
+                } else if (shard_o) {      /* max |DoG| over my planes, then over the ranks (sift.c:1161-1169) */
                     DEV(s3d_k_dogmax(lev_ptr(&L[ks], za), lev_ptr(&L[ks + 1], za), (size_t)(zb - za) * pe, sl->d_red + 1, sl->cs));
                     COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red + 1, 1, sl->cs));
                 } else {            /* replicated octave: every rank sees the whole level */
@@ -682,10 +739,16 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
                                             ((uint32_t)o << 8) | (uint32_t)ks, sl->cap, sl->d_count, sl->d_scratch, sl->cs));
             }
         }
-        DEV(s3d_rt_d2h(sl->h_counts, sl->d_count, sizeof(uint32_t), sl->cs));
-        if (slab_sync(sl)) return SIFT3D_FAILURE;
-        /* the redo decision must be collective: a rank that looped alone would re-enter the all-reduces */
-        sl->h_flag = sl->h_counts[0] > sl->cap ? 1.0f : 0.0f;
+        {
+            uint32_t localmax = 0;
+            DEV(s3d_rt_d2h(sl->h_counts, sl->d_count, sizeof(uint32_t), sl->cs));
+            DEV(s3d_rt_d2h(&localmax, sl->d_red + SLAB_RED_LOCALMAX, sizeof(uint32_t), sl->cs));
+            if (slab_sync(sl)) return SIFT3D_FAILURE;
+            /* the redo decision must be collective: a rank that looped alone would re-enter the all-reduces.  2: my slab
+             * holds a NaN or an infinity (the order-free maximum is sticky, s3d_k_absmax) -- every rank then runs the
+             * pass again on the literal kernels (slab_detect). */
+            sl->h_flag = !sl->verbatim && (localmax & 0x7fffffffu) >= 0x7f800000u ? 2.0f : sl->h_counts[0] > sl->cap ? 1.0f : 0.0f;
+        }
         if (G > 1) {
             DEV(s3d_rt_h2d(sl->d_red + 8, &sl->h_flag, sizeof(float), sl->cs));
             COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red + 8, 1, sl->cs));
@@ -693,6 +756,7 @@ static int find_candidates(sift3d_amd_slab *sl, uint32_t *ncand)
             if (slab_sync(sl)) return SIFT3D_FAILURE;
         }
         if (sl->h_flag == 0.0f) break;
+        if (sl->h_flag >= 2.0f) return SLAB_REDO_VERBATIM;
         cap = sl->h_counts[0] + 1024 > sl->cap ? sl->h_counts[0] + 1024 : sl->cap + 1024;
     }
     *ncand = sl->h_counts[0];
@@ -710,6 +774,7 @@ int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device,
     const double t0 = now_ms();
     const int rc = slab_detect(sl, vol, on_device, kp);
     sl->detect_ms = now_ms() - t0;
+    if (rc == SLAB_NAN_WINDOW) return SIFT3D_FAILURE;      /* every rank is here: a result, not a broken rank */
     if (rc != SIFT3D_SUCCESS && sl->t.world > 1) {
         if (sl->t.abort) sl->t.abort(sl->t.self);
         sl->pending = 0;
@@ -718,7 +783,26 @@ int sift3d_amd_slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device,
     return rc;
 }
 
+static int slab_detect_pass(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp);
+
+/* The first pass runs on the streaming kernels; if some rank's slab turns out to hold a NaN or an infinity (a collective
+ * decision, find_candidates) every rank repeats it on the literal kernels, which reproduce what the reference does with
+ * such voxels (s3d_k_seqmax, s3d_gauss.hip g_verbatim) -- the gauss mode is a property of the calling thread = this rank. */
 static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp)
+{
+    int rc = slab_detect_pass(sl, vol, on_device, kp);
+    if (rc == SLAB_REDO_VERBATIM) {
+        const int mode = s3d_k_gauss_get_mode();
+        s3d_k_gauss_set_mode(64);
+        sl->verbatim = 1;
+        rc = slab_detect_pass(sl, vol, on_device, kp);
+        sl->verbatim = 0;
+        s3d_k_gauss_set_mode(mode);
+    }
+    return rc == SIFT3D_SUCCESS || rc == SLAB_NAN_WINDOW ? rc : SIFT3D_FAILURE;
+}
+
+static int slab_detect_pass(sift3d_amd_slab *sl, const float *vol, int on_device, Keypoint_store *kp)
 {
     const int z0 = sl->part[0][0], z1 = sl->part[0][1];
     const size_t n_local = (size_t)(z1 - z0) * sl->nx * sl->ny;
@@ -731,8 +815,13 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
     if (on_device) DEV(s3d_rt_d2d(own, vol, n_local * sizeof(float), sl->cs));
     else DEV(s3d_rt_h2d(own, vol, n_local * sizeof(float), sl->cs));
     /* im_scale with the global maximum (sift.c:903, imutil.c:1977-1991) */
-    DEV(s3d_k_absmax(own, n_local, sl->d_red, sl->cs));
-    if (sl->t.world > 1) COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red, 1, sl->cs));
+    if (sl->verbatim) {
+        if (slab_seqmax(sl, own, NULL, n_local, sl->d_red)) return SIFT3D_FAILURE;
+    } else {
+        DEV(s3d_k_absmax(own, n_local, sl->d_red, sl->cs));
+        DEV(s3d_rt_d2d(sl->d_red + SLAB_RED_LOCALMAX, sl->d_red, sizeof(float), sl->cs));   /* read in find_candidates */
+        if (sl->t.world > 1) COMM_TIMED(sl, sl->t.allreduce_max(sl->t.self, sl->d_red, 1, sl->cs));
+    }
     {   /* the division rides in the first filter's loads where the fused kernels take the configuration (the raw planes
          * then travel as halos: a neighbour's plane divided on load is its scaled plane) */
         float uf0[3];
@@ -741,12 +830,17 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
         if (!sl->first_div) DEV(s3d_k_scale_div(own, n_local, sl->d_red, sl->cs));
     }
     if (build_pyramid(sl)) return SIFT3D_FAILURE;
-    if (find_candidates(sl, &ncand)) return SIFT3D_FAILURE;
+    {
+        const int fc = find_candidates(sl, &ncand);
+        if (fc == SLAB_REDO_VERBATIM) return SLAB_REDO_VERBATIM;
+        if (fc) return SIFT3D_FAILURE;
+    }
     collect_comm_times(sl);                 /* find_candidates drained the stream: every pair is complete */
     sl->num_candidates = (long)ncand;
     sl->num_keypoints = 0;
     kp->nx = sl->nx; kp->ny = sl->ny; kp->nz = sl->nz;
-    if (ncand == 0) return resize_Keypoint_store(kp, 0);
+    sl->h_counts[1] = sl->h_counts[2] = 0;
+    if (ncand > 0) {
     {
         const size_t need = s3d_k_orient_scratch_bytes(ncand);
         if (need > sl->orient_bytes) {
@@ -763,11 +857,34 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
         sl->oritab_bytes = s3d_k_orient_tab_bytes(&sl->pd);
     }
     DEV(s3d_k_orient_tab(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, NULL, ncand, sl->d_sigma, sl->plan.corner_thresh, sl->d_R,
-                         sl->d_keep, NULL, sl->d_orient, s3d_k_orient_wants_tab(&sl->pd) ? sl->d_oritab : NULL, sl->cs));
+                         sl->d_keep, NULL, sl->d_orient, s3d_k_orient_wants_tab(&sl->pd) ? sl->d_oritab : NULL,
+                         sl->d_count + 2, sl->cs));
     DEV(s3d_k_compact_keys(&sl->pd, sl->d_cand_idx, sl->d_cand_tag, sl->d_R, sl->d_keep, ncand, sl->d_xyzos, sl->d_Rk,
                            sl->d_count + 1, sl->d_kscratch, sl->cs));
-    DEV(s3d_rt_d2h(sl->h_counts + 1, sl->d_count + 1, sizeof(uint32_t), sl->cs));
+    DEV(s3d_rt_d2h(sl->h_counts + 1, sl->d_count + 1, 2 * sizeof(uint32_t), sl->cs));
     DEV(s3d_rt_sync(sl->cs));
+    }
+    if (sl->verbatim) {
+        /* A NaN gradient in some candidate's orientation window: the reference's eigen_Mat_rm fails on it and
+         * SIFT3D_detect_keypoints with it (sift.c:1430-1431, 1293-1296) -- on whichever rank the candidate lives, so the
+         * ranks agree on it before any of them returns.  (Finite volumes have no NaN to find: first passes skip this.) */
+        uint32_t *flags = (uint32_t *)malloc((size_t)sl->t.world * sizeof(uint32_t));
+        uint32_t any = sl->h_counts[2];
+        if (!flags) SLAB_FAIL("sift3d_amd slab: out of host memory");
+        if (sl->t.world > 1) {
+            if (sl->t.allgather_host(sl->t.self, &sl->h_counts[2], flags, sizeof(uint32_t))) { free(flags); SLAB_FAIL("sift3d_amd slab: transport: allgather_host failed"); }
+            for (int q = 0; q < sl->t.world; q++) any |= flags[q];
+        }
+        free(flags);
+        if (any) {
+            /* not SLAB_FAIL's way out through the caller's abort: every rank leaves here, the transports stay usable */
+            snprintf(g_slab_err, sizeof(g_slab_err), "sift3d_amd: a NaN voxel inside a keypoint candidate's orientation window (the "
+                     "reference's SIFT3D_detect_keypoints fails here: eigen_Mat_rm, sift.c:1430)");
+            S3D_MSG("%s\n", g_slab_err);
+            (void)resize_Keypoint_store(kp, 0);
+            return SLAB_NAN_WINDOW;
+        }
+    }
     K = sl->h_counts[1];
     sl->num_keypoints = (long)K;
     if (resize_Keypoint_store(kp, K)) return SIFT3D_FAILURE;

@@ -372,6 +372,11 @@ static thread_local int g_no_dyadic = 0;      /* profiling / test knob of the ca
 static thread_local int g_tab_over_dyadic = 0; /* A/B knob: the table-driven march also where the dyadic y / z kernels apply */
 static thread_local int g_force_tab = 0;      /* test knob: the table-driven passes (s3d_gauss_tab.hip) whatever the size of the volume */
 static thread_local int g_no_tab = 0;         /* profiling knob: never the table-driven passes */
+/* Only k_conv_axis, whatever the configuration: every tap evaluates (1 - frac) * src[lo] + frac * src[lo + 1] as
+ * convolve_sep_gen does (imutil.c:2316-2330), also where frac is 0 -- which the streaming, table-driven and dyadic kernels
+ * use to skip the second sample.  For finite voxels that is the same number; 0 * NaN is NaN, so a NaN voxel spreads one
+ * position further than the taps reach.  The host's pipelines switch this on for volumes with non-finite voxels. */
+static thread_local int g_verbatim = 0;
 
 /* s3d_gauss_tab.hip: 0 done, 1 not eligible, -1 error */
 extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
@@ -1052,6 +1057,7 @@ static int edge_fracs(int n, int hw, EdgeFrac *ef)
 static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int width)
 {
     const int hw = width / 2;
+    if (g_verbatim) return 0;
     if (nc != 1 || uf[0] != 1.0f || uf[1] != 1.0f || uf[2] != 1.0f) return 0;
     if (hw < 1 || hw > S3D_FAST_MAX_HW) return 0;
     if (nx < 8) return 0;                              /* (nx % 4 != 0: the RAGGED instantiations) */
@@ -1066,9 +1072,16 @@ static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /
  * bit 1 = no specialisation of the generic axis pass at all (k_conv_axis only); bit 2 = unused (was: the per-wave LDS-ring z
  * kernel of round 3, superseded by the table-driven march); bit 3 = the table-driven passes (s3d_gauss_tab.hip) also on
  * small volumes (tests); bit 4 = never the table-driven passes (A/B runs); bit 5 = the table-driven march also where the
- * dyadic y / z kernels apply (A/B runs) */
+ * dyadic y / z kernels apply (A/B runs); bit 6 = verbatim (see g_verbatim: the per-element kernel only, fused forms included) */
+extern "C" int s3d_k_gauss_get_mode(void)
+{
+    return g_verbatim ? 64 : (g_gauss_mode & 1) | (g_no_dyadic << 1) | (g_force_tab << 3) | (g_no_tab << 4) | (g_tab_over_dyadic << 5);
+}
+
 extern "C" void s3d_k_gauss_set_mode(int mode)
 {
+    g_verbatim = (mode >> 6) & 1;
+    if (g_verbatim) mode = 2;
     g_gauss_mode = mode & 1;
     g_no_dyadic = (mode >> 1) & 1;
     g_tab_over_dyadic = (mode >> 5) & 1;
@@ -1202,6 +1215,7 @@ static int fast_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx,
 static int fast_mc_eligible(int nx, int ny, int nz, int nc, const float uf[3], int width)
 {
     const int hw = width / 2;
+    if (g_verbatim) return 0;
     if (nc < 4 || (nc & 3) || uf[0] != 1.0f || uf[1] != 1.0f || uf[2] != 1.0f) return 0;
     if (hw < 1 || hw > S3D_FAST_MAX_HW) return 0;
     if (nx - 1 <= hw || ny - 1 <= hw || nz - 1 <= hw) return 0;

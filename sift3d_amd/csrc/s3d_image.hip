@@ -5,48 +5,52 @@
 #define RED_BLOCK 256
 #define RED_MAX_BLOCKS 4096
 
-/* wave64 max via xor-shuffles, then one LDS slot per wave */
-__device__ __forceinline__ float block_max(float v)
+/* wave64 max via xor-shuffles, then one LDS slot per wave.  The maxima are taken over the BIT PATTERNS of |v|: for
+ * finite values and infinities that is the float order, and every NaN pattern lies above all of them, so a NaN anywhere in
+ * the input survives the reduction whatever the order of the comparisons ("sticky").  The reference's scan is not
+ * order free when a NaN is present (s3d_k_seqmax below); a sticky result is how the callers find out that they need it. */
+__device__ __forceinline__ unsigned block_max(unsigned v)
 {
-    __shared__ float part[RED_BLOCK / 64];
+    __shared__ unsigned part[RED_BLOCK / 64];
     for (int m = 32; m >= 1; m >>= 1) {
-        const float o = __shfl_xor(v, m);
+        const unsigned o = (unsigned)__shfl_xor((int)v, m);
         v = v > o ? v : o;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) part[wave] = v;
     __syncthreads();
-    float r = part[0];
+    unsigned r = part[0];
     for (int w = 1; w < RED_BLOCK / 64; w++) r = r > part[w] ? r : part[w];
     return r;
 }
 
+__device__ __forceinline__ unsigned absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+
 /* max|v| : non-negative floats order like their bit patterns, so atomicMax on uint is exact.
- * mode 0: |a[i]| ; mode 1: |a[i] - b[i]|   (im_max_abs imutil.c:1959 ; dogmax sift.c:1161-1166) */
+ * mode 0: |a[i]| ; mode 1: |a[i] - b[i]|   (im_max_abs imutil.c:1959 ; dogmax sift.c:1161-1166). */
 template <int MODE>
 __global__ void __launch_bounds__(RED_BLOCK) k_absmax(const float *__restrict__ a, const float *__restrict__ b,
                                                      size_t n, unsigned *out)
 {
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * RED_BLOCK;
-    float m = 0.0f;
+    unsigned m = 0u;
     for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n4; i += stride) {
         float4 v = reinterpret_cast<const float4 *>(a)[i];
         if (MODE == 1) {
             const float4 w = reinterpret_cast<const float4 *>(b)[i];
             v.x = v.x - w.x; v.y = v.y - w.y; v.z = v.z - w.z; v.w = v.w - w.w;
         }
-        const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z), aw = fabsf(v.w);
-        m = m > ax ? m : ax; m = m > ay ? m : ay; m = m > az ? m : az; m = m > aw ? m : aw;
+        m = umax(umax(umax(m, absbits(v.x)), umax(absbits(v.y), absbits(v.z))), absbits(v.w));
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n; i += stride) {
         float v = a[i];
         if (MODE == 1) v = v - b[i];
-        const float av = fabsf(v);
-        m = m > av ? m : av;
+        m = umax(m, absbits(v));
     }
     m = block_max(m);
-    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(m));
+    if (threadIdx.x == 0) atomicMax(out, m);
 }
 
 static int launch_absmax(const float *a, const float *b, size_t n, float *d_max, hipStream_t st)
@@ -73,15 +77,117 @@ extern "C" int s3d_k_dogmax(const float *d_a, const float *d_b, size_t n, float 
     return launch_absmax(d_a, d_b, n, d_max, (hipStream_t)st);
 }
 
+/* ---- the reference's maximum when a NaN is present -------------------------------------------------------------------
+ * im_max_abs (imutil.c:1959-1973) and the per-level dogmax (sift.c:1161-1166) are sequential scans in (z, y, x) order with
+ * max = SIFT3D_MAX(max, samp) = (max > samp ? max : samp) (immacros.h:36): a NaN sample REPLACES the running maximum (the
+ * comparison is false) and the next sample replaces the NaN (false again).  The result is therefore
+ *     the maximum of the samples BEHIND the last NaN in scan order (0 if there are none), NaN if the last sample is NaN,
+ * not "NaN if any NaN" and not "the maximum of the finite samples": with peak_thresh * dogmax as the extrema threshold the
+ * three give different keypoints.  Three small kernels on a record rec[4] = { sticky maximum over all samples, maximum over
+ * the samples behind the last NaN, index + 1 of the last NaN (64 bits, 0 = none) }; they return at once when the sticky
+ * maximum is not a NaN, and a Z-slab rank combines the records of all ranks (s3d_host_slab.c). */
+template <int MODE>
+__global__ void __launch_bounds__(RED_BLOCK) k_seqmax_last(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                          const unsigned *__restrict__ rec, unsigned long long *last)
+{
+    if (rec[0] <= 0x7f800000u) return;
+    const size_t stride = (size_t)gridDim.x * RED_BLOCK;
+    unsigned long long l = 0ull;
+    for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n; i += stride) {
+        float v = a[i];
+        if (MODE == 1) v = v - b[i];
+        if (v != v) l = (unsigned long long)i + 1ull;          /* i ascends: the thread's last one stays */
+    }
+    __shared__ unsigned long long part[RED_BLOCK];
+    part[threadIdx.x] = l;
+    __syncthreads();
+    for (int s = RED_BLOCK / 2; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s && part[threadIdx.x + s] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && part[0]) atomicMax(last, part[0]);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(RED_BLOCK) k_seqmax_after(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                           unsigned *__restrict__ rec)
+{
+    if (rec[0] <= 0x7f800000u) return;
+    const size_t i0 = (size_t)(((unsigned long long)rec[3] << 32) | rec[2]);     /* behind the last NaN: no NaN in [i0, n) */
+    const size_t stride = (size_t)gridDim.x * RED_BLOCK;
+    unsigned m = 0u;
+    for (size_t i = i0 + (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n; i += stride) {
+        float v = a[i];
+        if (MODE == 1) v = v - b[i];
+        m = umax(m, absbits(v));
+    }
+    m = block_max(m);
+    if (threadIdx.x == 0) atomicMax(rec + 1, m);
+}
+
+/* *out = the reference's result from the record of the WHOLE scan (n samples) */
+template <int MODE>
+__global__ void k_seqmax_final(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                               const unsigned *__restrict__ rec, unsigned *out)
+{
+    const size_t last = (size_t)(((unsigned long long)rec[3] << 32) | rec[2]);
+    unsigned r = rec[0];
+    if (rec[0] > 0x7f800000u) {
+        r = rec[1];
+        if (last == n) {                                         /* the scan ends on the NaN: |that sample| */
+            float v = a[n - 1];
+            if (MODE == 1) v = v - b[n - 1];
+            r = absbits(v);
+        }
+    }
+    *out = r;
+}
+
+extern "C" int s3d_k_seqmax_parts(const float *d_a, const float *d_b, size_t n, void *d_rec16, s3d_stream stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *rec = (unsigned *)d_rec16;
+    if (rec == nullptr || ((uintptr_t)rec & 7)) S3D_FAIL("s3d_k_seqmax: the record must be 16 bytes, 8-byte aligned");
+    S3D_HIP(hipMemsetAsync(rec, 0, 16, st));
+    if (n == 0) return S3D_OK;
+    unsigned blocks = s3d_div_up(n / 4 + 1, RED_BLOCK);
+    if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
+    if (d_b) {
+        hipLaunchKernelGGL(k_absmax<1>, dim3(blocks), dim3(RED_BLOCK), 0, st, d_a, d_b, n, rec);
+        hipLaunchKernelGGL(k_seqmax_last<1>, dim3(blocks), dim3(RED_BLOCK), 0, st, d_a, d_b, n, rec, (unsigned long long *)(rec + 2));
+        hipLaunchKernelGGL(k_seqmax_after<1>, dim3(blocks), dim3(RED_BLOCK), 0, st, d_a, d_b, n, rec);
+    } else {
+        hipLaunchKernelGGL(k_absmax<0>, dim3(blocks), dim3(RED_BLOCK), 0, st, d_a, d_b, n, rec);
+        hipLaunchKernelGGL(k_seqmax_last<0>, dim3(blocks), dim3(RED_BLOCK), 0, st, d_a, d_b, n, rec, (unsigned long long *)(rec + 2));
+        hipLaunchKernelGGL(k_seqmax_after<0>, dim3(blocks), dim3(RED_BLOCK), 0, st, d_a, d_b, n, rec);
+    }
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+extern "C" int s3d_k_seqmax(const float *d_a, const float *d_b, size_t n, float *d_max, void *d_rec16, s3d_stream stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (s3d_k_seqmax_parts(d_a, d_b, n, d_rec16, stream)) return S3D_ERR;
+    if (n == 0) {
+        S3D_HIP(hipMemsetAsync(d_max, 0, sizeof(float), st));
+        return S3D_OK;
+    }
+    if (d_b) hipLaunchKernelGGL(k_seqmax_final<1>, dim3(1), dim3(1), 0, st, d_a, d_b, n, (const unsigned *)d_rec16, (unsigned *)d_max);
+    else hipLaunchKernelGGL(k_seqmax_final<0>, dim3(1), dim3(1), 0, st, d_a, d_b, n, (const unsigned *)d_rec16, (unsigned *)d_max);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
 /* The three dogmax values of an octave with num_kp_levels = 3 in ONE pass over the four GSS levels involved
- * (six level reads as three k_absmax<1> launches): out[k] = max |l[k] - l[k+1]|, k = 0..2. */
+ * (six level reads as three k_absmax<1> launches): out[k] = max |l[k] - l[k+1]|, k = 0..2 (sticky, see block_max). */
 struct DogMax3Args { const float *l[4]; };
 __global__ void __launch_bounds__(RED_BLOCK) k_dogmax3(DogMax3Args a, size_t n, unsigned *out)
 {
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * RED_BLOCK;
-    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
-    auto upd = [](float m, float x, float y) { const float d = fabsf(x - y); return m > d ? m : d; };
+    unsigned m0 = 0u, m1 = 0u, m2 = 0u;
+    auto upd = [](unsigned m, float x, float y) { return umax(m, absbits(x - y)); };
 #pragma unroll 2
     for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n4; i += stride) {
         const float4 p = reinterpret_cast<const float4 *>(a.l[0])[i], q = reinterpret_cast<const float4 *>(a.l[1])[i];
@@ -99,9 +205,9 @@ __global__ void __launch_bounds__(RED_BLOCK) k_dogmax3(DogMax3Args a, size_t n, 
     __syncthreads();
     m2 = block_max(m2);
     if (threadIdx.x == 0) {
-        atomicMax(out, __float_as_uint(m0));
-        atomicMax(out + 1, __float_as_uint(m1));
-        atomicMax(out + 2, __float_as_uint(m2));
+        atomicMax(out, m0);
+        atomicMax(out + 1, m1);
+        atomicMax(out + 2, m2);
     }
 }
 

@@ -563,7 +563,7 @@ k_orient_wave(s3d_pyramid_desc pyr, const uint32_t *__restrict__ d_idx, const ui
 
 __global__ void __launch_bounds__(64)
 k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thresh, double *__restrict__ d_scr, float *__restrict__ d_R,
-                uint32_t *__restrict__ d_keep, double *__restrict__ d_conf)
+                uint32_t *__restrict__ d_keep, double *__restrict__ d_conf, uint32_t *__restrict__ d_fail)
 {
     const unsigned local = blockIdx.x * 64u + threadIdx.x;
     const unsigned cand = cand0 + local;
@@ -578,6 +578,22 @@ k_orient_decide(uint32_t cand0, uint32_t nchunk, uint32_t num, double corner_thr
     int keep = 0;
     double conf = 0.0;
     const float grad_thr = (float)1E-10;                   /* ori_grad_thresh, sift.c:49,1426 */
+
+    /* A NaN gradient in the window (a NaN voxel next to one of its voxels): the reference's window gradient is then NaN
+     * too, so the ori_grad_thresh test does not reject (sift.c:1426, the comparison is false), eigen_Mat_rm hands the NaN
+     * tensor to LAPACK's dsyevd, that does not converge (info > 0), assign_eig_ori returns SIFT3D_FAILURE and
+     * SIFT3D_detect_keypoints FAILS (sift.c:1430-1431, 1293-1296; imutil.c:3052-3058).  A component's diagonal sum is NaN
+     * exactly when one of its terms is: the terms are finite otherwise (level voxels are bounded by 1). */
+    {
+        const double chk = a00 + a11 + a22;
+        if (chk != chk) {
+            for (int i = 0; i < 9; i++) d_R[(size_t)cand * 9 + i] = 0.0f;
+            d_keep[cand] = 0u;
+            if (d_conf) d_conf[cand] = 0.0;
+            if (d_fail) *d_fail = 1u;
+            return;
+        }
+    }
 
     double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
     double L[3], Q[3][3];
@@ -691,7 +707,8 @@ extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
 
 extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                                 const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, s3d_stream st)
+                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, uint32_t *d_fail,
+                                s3d_stream st)
 {
     if (num == 0) return S3D_OK;
     if (!d_scratch) return S3D_ERR;
@@ -733,7 +750,7 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
         }
         S3D_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)st, c0, n, num, corner_thresh, scr,
-                           d_R, d_keep, d_conf);
+                           d_R, d_keep, d_conf, d_fail);
         S3D_CHECK_LAUNCH();
         /* (pass 2 has work for about one candidate in ten; a fixed grid of 8192 waves looking through the candidates instead of a
          * workgroup per candidate was measured at 250 against 150 us per 512^3 detect: the few heavy candidates pile up) */
@@ -746,10 +763,10 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
 
 extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
                             const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                            float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, s3d_stream st)
+                            float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, uint32_t *d_fail, s3d_stream st)
 {
     return s3d_k_orient_tab(pyr, d_idx, d_tag, d_center, num, d_sigma, corner_thresh, d_R, d_keep, d_conf, d_scratch,
-                            nullptr, st);
+                            nullptr, d_fail, st);
 }
 
 /* ---- stable compaction of the surviving candidates ----------------------------------------------- */
@@ -946,6 +963,7 @@ struct DwShared {
     unsigned long long copy_units[DW_NFIELD];   /* per histogram copy: an upper bound of what any of its fields can hold (the proof) */
     float est_part[DW_WAVES];
     unsigned proof_over, proof_fine;      /* a copy's bound exceeds the field / some copy's bound shows the grid is as fine as intended */
+    unsigned nan_seen;                    /* an accepted voxel of this keypoint's window has a NaN gradient */
     unsigned win_chk, win_vox;
     unsigned next[2];                     /* the keypoint this workgroup takes next (claimed one keypoint ahead) */
     uint32_t nkey[2][(sizeof(s3d_desc_key) + 3) / 4];   /* ... and its record, fetched while the current one is worked on */
@@ -1078,6 +1096,14 @@ __device__ float g_dw_est_factor = 1.0f;
 extern "C" int s3d_k_set_describe_est_factor(float f)
 {
     S3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_est_factor), &f, sizeof(f)));
+    return S3D_OK;
+}
+/* test aid: nonzero = only lanes 16..31 of every wave take chunks (four times as many each), so that the whole gradient
+ * mass of histogram copy k sits on ONE of its four lanes (k + 16) -- the proof must count it wherever it sits */
+__device__ int g_dw_lane_test = 0;
+extern "C" int s3d_k_set_describe_lane_test(int on)
+{
+    S3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_lane_test), &on, sizeof(on)));
     return S3D_OK;
 }
 #endif
@@ -1280,7 +1306,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         for (int i = tz; i < DW_HIST_WORDS; i += DW_THREADS) sm.hist[i] = zero;
         if (tz < DW_NFIELD) sm.copy_units[tz] = zero;
     }
-    if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; sm.proof_over = 0; sm.proof_fine = 0; }
+    if (tid == 0) { sm.win_chk = 0; sm.win_vox = 0; sm.proof_over = 0; sm.proof_fine = 0; sm.nan_seen = 0; }
     __syncthreads();
     /* the next keypoint's record: loaded now (one word per lane of the first wave), parked in LDS further down */
     constexpr int KEY_WORDS = (int)((sizeof(s3d_desc_key) + 3) / 4);
@@ -1515,7 +1541,15 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         }
         __syncthreads();
         const int total = sm.seg_off[DW_THREADS];
-        turns += DW_UNIFORM((unsigned)total / DW_THREADS + 1u);
+#if defined(S3D_TESTING)
+        const int lane_test = g_dw_lane_test;
+        const int cfirst = !lane_test ? tid : (lane & 48) == 16 ? (tid >> 6) * 16 + (lane & 15) : 0x7fffffff;
+        const int cstep = lane_test ? DW_THREADS / 4 : DW_THREADS;
+#else
+        const int cfirst = tid;
+        constexpr int cstep = DW_THREADS;
+#endif
+        turns += DW_UNIFORM((unsigned)total / (unsigned)cstep + 1u);
         /* ---- B: one chunk per thread and turn; the next chunk's look-up and loads are issued before this chunk's
          * atomics (they would otherwise queue behind them) ---- */
         if (COUNT_ONLY) {                                           /* test aid: count + checksum of the window set */
@@ -1525,8 +1559,8 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                     atomicAdd(&sm.win_chk, ((unsigned)(ch.x0 + j - g.xs) | (ch.fv & ~1023u)) * 2654435761u);
                 atomicAdd(&sm.win_vox, (unsigned)ch.nval);
             }
-        } else if (tid < total) {
-            int c = tid;
+        } else if (cfirst < total) {
+            int c = cfirst;
             DwChunk ch = lookup(c);
             DwLoads L = gather(ch);
             for (;;) {
@@ -1546,7 +1580,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                 v3 = front(ch.nval > 3, fmaxf(vbx + 3.0f * svx, 0.0f), fmaxf(vby + 3.0f * svy, 0.0f), fmaxf(vbz + 3.0f * svz, 0.0f),
                            L.w3, L.xb.w - L.xb.y, L.yp.w - L.ym.w, L.zp.w - L.zm.w);
                 if (!(v0.safe && v1.safe && v2.safe && v3.safe)) { resolve(v0); resolve(v1); resolve(v2); resolve(v3); }
-                c += DW_THREADS;
+                c += cstep;
                 const bool more = c < total;
                 if (more) { ch = lookup(c); L = gather(ch); }
                 back(v0); back(v1); back(v2); back(v3);
@@ -1559,18 +1593,25 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     }
     if (COUNT_ONLY) break;
     if (tid == 0 && attempt == 0) atomicAdd(&g_dw_stat[0], 1ull);
-    /* (3) the proof.  Copy k = lanes k and k + 32 of every wave; a contribution is rounded to the grid (<= 1/2 each, 24 per
-     * voxel, <= 4 turns voxels per lane), a lane's float sum is short by < 1e-5 of itself. */
+    /* (3) the proof.  Copy k is fed by the 64 / DW_NFIELD lanes k, k + DW_NFIELD, ... of every wave: their masses together
+     * bound what a field of the copy can hold; a contribution is rounded to the grid (<= 1/2 each, 24 per voxel, <= 4 turns
+     * voxels per lane), a lane's float sum is short by < 1e-5 of itself.  The same sums tell whether an accepted voxel had a
+     * NaN gradient (a lane's mass is a sum of |w grad|: NaN from then on). */
     {
         const int lp = dw_opaque(lane);
+        float mk = mass;
+#pragma unroll
+        for (int mm = DW_NFIELD; mm < 64; mm <<= 1) {
 #if defined(S3D_EMU)
-        const float m2 = mass + __shfl_xor(mass, 32);
+            mk = mk + __shfl_xor(mk, mm);
 #else
-        const float m2 = mass + __int_as_float(__builtin_amdgcn_ds_bpermute((lp ^ 32) << 2, __float_as_int(mass)));
+            mk = mk + __int_as_float(__builtin_amdgcn_ds_bpermute((lp ^ mm) << 2, __float_as_int(mk)));
 #endif
+        }
         if (lp < DW_NFIELD) {
-            double d = ldexp((double)m2, fbits) * 1.0001 + 96.0 * (double)turns;
+            double d = ldexp((double)mk, fbits) * 1.0001 + 48.0 * (double)turns * (double)(64 / DW_NFIELD);
             if (!(d < 1e18)) d = 1e18;
+            if (mk != mk) sm.nan_seen = 1u;
             atomicAdd(&sm.copy_units[lp], (unsigned long long)d);
         }
     }
@@ -1605,6 +1646,22 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     double norm = sqrt(dw_block_sum(ss, sm.part, tm)) + 2.220446049250313e-16; /* + DBL_EPSILON */
     /* (the barriers of the sum lie between the flags' writers and these reads) */
     const bool over = DW_UNIFORM(sm.proof_over) != 0u, fine = DW_UNIFORM(sm.proof_fine) != 0u;
+    if (DW_UNIFORM(sm.nan_seen) != 0u) {
+        /* A NaN gradient among the window's voxels.  The reference (sift.c:1646-1683, 1733-1760, 1896-1915): icos_hist_bin
+         * accepts face 0 for it (every comparison with a NaN is false) with NaN barycentric weights, the three vertex
+         * bins of up to eight cells become NaN, the first normalisation turns EVERY bin into NaN (norm is NaN), the
+         * truncation SIFT3D_MIN(NaN, trunc_thresh) = (NaN < t ? NaN : t) turns every bin into trunc_thresh, and the second
+         * normalisation scales that constant vector: the same 768 floats whatever else the window holds. */
+        double nn = 0.0;
+        for (int i = 0; i < S3D_DESC_NUMEL; i++) nn += (double)trunc * (double)trunc;
+        nn = sqrt(nn) + 2.220446049250313e-16;
+        const float ninv = (float)(1.0 / nn);
+#pragma unroll
+        for (int q = 0; q < DW_NOUT; q++)
+            if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tm + q * DW_THREADS] = trunc * ninv;
+        __syncthreads();                                      /* every thread has read the flag before the next keypoint clears it */
+        break;
+    }
     if (attempt < 2 && (over || !(fine || attempt > 0 || fbits >= 100))) {
         /* redo with the grid of the measured mass */
         if (tid == 0 && attempt == 0) atomicAdd(&g_dw_stat[1], 1ull);

@@ -53,6 +53,8 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 
 namespace emu {
 
+inline const char *&last_kernel() { static const char *k = "?"; return k; }
+
 struct Fiber {
     ucontext_t ctx;
     char *stack;
@@ -153,8 +155,8 @@ inline void run_block() {
             }
         }
         if (!progressed) {
-            fprintf(stderr, "hip_emu: deadlock (divergent barrier or wave op) in block (%u,%u,%u)\n",
-                    s.blockIdx.x, s.blockIdx.y, s.blockIdx.z);
+            fprintf(stderr, "hip_emu: deadlock (divergent barrier or wave op) in block (%u,%u,%u) of %s\n",
+                    s.blockIdx.x, s.blockIdx.y, s.blockIdx.z, last_kernel());
             abort();
         }
     }
@@ -285,6 +287,7 @@ static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 static inline unsigned atomicExch(unsigned *p, unsigned v) { unsigned o = *p; *p = v; return o; }
 
@@ -328,7 +331,7 @@ static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+    (emu::last_kernel() = #kern, emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); }))
 #define __expf(x) expf(x)
 static inline int __float2int_rn(float x) { return (int)nearbyintf(x); }
 /* wave-scope sync used by single-wave workgroups: a wave-collective rendezvous in the emulator */

@@ -837,14 +837,14 @@ def check_orient_tables(lib, dims, units, sigmas, ncand, seed=0, expect_tables=T
     d_scr = [dev.malloc(scr_bytes) for _ in range(2)]
     d_tab = dev.malloc(tab_bytes)
     L.s3d_k_orient_tab.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_double,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.s3d_k_set_orient_mode.argtypes = [C.c_int]
     try:
         L.s3d_k_set_orient_mode(mode)
         for i, tabs in enumerate((None, d_tab)):
             L.s3d_rt_memset(C.c_void_p(d_scr[i]), 0, scr_bytes, None)
             assert L.s3d_k_orient_tab(C.byref(pd), d_idx, d_tag, None, n, d_sig, 0.4, d_R[i], d_keep[i], None, d_scr[i],
-                                      tabs, None) == 0
+                                      tabs, None, None) == 0
         assert L.s3d_rt_sync(None) == 0
         R = [dev.download(p_, (n, 9)) for p_ in d_R]
         keep = [dev.download(p_, (n,), np.uint32) for p_ in d_keep]
@@ -883,8 +883,10 @@ def check_orient_tables(lib, dims, units, sigmas, ncand, seed=0, expect_tables=T
             dev.free(p_)
 
 
-def check_describe_redo(lib, oracle, dims, units, nblobs, seed, factor):
-    """The descriptor kernel's redo path (s3d_keypoint.hip, dw_scale): with the sampled gradient mass spoiled by `factor`
+def check_describe_redo(lib, oracle, dims, units, nblobs, seed, factor, lane_test=False):
+    """(lane_test: only lanes 16..31 of every wave take window chunks, so that each histogram copy's gradient mass sits on one of
+    the four lanes that feed it -- the proof has to count it there.)
+    The descriptor kernel's redo path (s3d_keypoint.hip, dw_scale): with the sampled gradient mass spoiled by `factor`
     (testing build only) every window's proof fails (factor << 1: the grid is too fine, fields could wrap) or finds the grid
     coarse (factor >> 1); every window must then be described a second time with the grid of its measured mass, and the
     descriptors must be the oracle's within the same 1e-4 as ever.  Returns (keypoints, windows redone)."""
@@ -900,6 +902,9 @@ def check_describe_redo(lib, oracle, dims, units, nblobs, seed, factor):
     a, b = C.c_ulonglong(), C.c_ulonglong()
     try:
         assert L.s3d_k_set_describe_est_factor(factor) == 0
+        if lane_test:
+            L.s3d_k_set_describe_lane_test.argtypes = [C.c_int]
+            assert L.s3d_k_set_describe_lane_test(1) == 0
         assert L.s3d_k_describe_redo_stats(C.byref(a), C.byref(b), 1) == 0
         d = abi.SIFT3D_Descriptor_store()
         L.init_SIFT3D_Descriptor_store(C.byref(d))
@@ -908,6 +913,8 @@ def check_describe_redo(lib, oracle, dims, units, nblobs, seed, factor):
         assert L.s3d_k_describe_redo_stats(C.byref(a), C.byref(b), 1) == 0
     finally:
         L.s3d_k_set_describe_est_factor(1.0)
+        if lane_test:
+            L.s3d_k_set_describe_lane_test(0)
     wb, wx = oracle.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
     ok = rel_close(bins, wb, rtol=1e-4, atol=1e-7)
     assert ok.all(), f"{(~ok).sum()} descriptor floats beyond 1e-4 relative after the redo"
@@ -917,3 +924,158 @@ def check_describe_redo(lib, oracle, dims, units, nblobs, seed, factor):
     lib.free_image(im)
     L.cleanup_SIFT3D(C.byref(s))
     return len(xyzos), int(b.value)
+
+
+# ---- non-finite voxels ------------------------------------------------------------------------------------------------
+# What the reference does with NaNs and infinities is specific (sequential maxima: imutil.c:1959-1973, sift.c:1161-1166;
+# 0 * NaN in the filters: imutil.c:2316-2330; a NaN structure tensor fails LAPACK and the call: sift.c:1430; a NaN gradient
+# in a descriptor window leaves the constant descriptor: sift.c:1896-1915) and is pinned by tests/golden/nonfinite.npz,
+# written from oracle/_ref by tests/golden/make_golden_nonfinite.py.
+SLAB_PARAMS = {"sigma_n": 0.8, "sigma0": 1.2}      # small windows: a 32-slice slab can be sharded (tests/test_slab_gloo.py)
+NONFINITE_BASES = {
+    "iso48": ((48, 44, 40), (1.0, 1.0, 1.0), 120, 2, None),
+    "aniso40": ((40, 36, 28), (1.0, 0.8, 2.0), 50, 1, None),
+    "iso72": ((72, 68, 66), (1.0, 1.0, 1.0), 400, 1, None),
+    "slab64": ((32, 32, 64), (1.0, 1.0, 1.0), 130, 1, SLAB_PARAMS),
+}
+NONFINITE_CASES = [
+    # (base, name, edits): an edit is (z-slice, y-slice, x-slice, value)
+    ("iso48", "nan_first", [((0, 1), (0, 1), (0, 1), np.nan)]),
+    ("iso48", "nan_interior", [((38, 39), (16, 17), (42, 43), np.nan)]),          # keypoints survive, some windows hold it
+    ("iso48", "nan_interior2", [((20, 21), (23, 24), (42, 43), np.nan)]),
+    ("iso48", "nan_last", [((39, 40), (43, 44), (47, 48), np.nan)]),
+    ("iso48", "nan_background_low", [((0, 8), (0, 44), (0, 48), np.nan)]),         # a masked background slab
+    ("iso48", "nan_background_high", [((32, 40), (0, 44), (0, 48), np.nan)]),
+    ("iso48", "nan_xband", [((0, 40), (0, 44), (0, 9), np.nan)]),
+    ("iso48", "pos_inf", [((5, 6), (6, 7), (7, 8), np.inf)]),
+    ("iso48", "neg_inf", [((20, 21), (22, 23), (24, 25), -np.inf)]),
+    ("iso48", "nan_and_inf", [((38, 39), (16, 17), (42, 43), np.nan), ((5, 6), (6, 7), (7, 8), np.inf)]),
+    ("aniso40", "nan_first", [((0, 1), (0, 1), (0, 1), np.nan)]),
+    ("aniso40", "nan_xband", [((0, 28), (0, 36), (0, 8), np.nan)]),
+    ("aniso40", "nan_last", [((27, 28), (35, 36), (39, 40), np.nan)]),
+    ("aniso40", "nan_background_high", [((21, 28), (0, 36), (0, 40), np.nan)]),
+    ("iso72", "nan_center", [((33, 34), (34, 35), (36, 37), np.nan)]),
+    ("iso72", "nan_last", [((65, 66), (67, 68), (71, 72), np.nan)]),
+    ("iso72", "nan_far_edge", [((40, 41), (65, 66), (69, 70), np.nan)]),           # 31 keypoints over three octaves survive
+    ("iso72", "nan_corner_high", [((64, 65), (65, 66), (69, 70), np.nan)]),
+    ("slab64", "nan_rank0", [((3, 4), (5, 6), (5, 6), np.nan)]),
+    ("slab64", "nan_rank1", [((60, 61), (20, 21), (20, 21), np.nan)]),
+    ("slab64", "nan_rank1_b", [((52, 53), (2, 3), (29, 30), np.nan)]),
+    ("slab64", "nan_rank1_c", [((62, 63), (2, 3), (29, 30), np.nan)]),
+    ("slab64", "nan_rank1_d", [((44, 45), (29, 30), (28, 29), np.nan)]),
+    ("slab64", "nan_rank0_b", [((24, 25), (3, 4), (3, 4), np.nan)]),
+    ("slab64", "nan_seam", [((31, 33), (10, 11), (10, 11), np.nan)]),
+    ("slab64", "nan_last", [((63, 64), (31, 32), (31, 32), np.nan)]),
+    ("slab64", "nan_background_low", [((0, 5), (0, 32), (0, 32), np.nan)]),
+    ("slab64", "nan_background_high", [((59, 64), (0, 32), (0, 32), np.nan)]),
+    ("slab64", "pos_inf", [((40, 41), (6, 7), (7, 8), np.inf)]),
+]
+
+
+def nonfinite_case(base, edits):
+    """(volume, units, params) of one entry of NONFINITE_CASES."""
+    (nx, ny, nz), units, nblobs, seed, params = NONFINITE_BASES[base]
+    vol = synth.blobs(nx, ny, nz, nblobs, seed)
+    for (zs, ys, xs, val) in edits:
+        vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
+    return vol, units, params
+
+
+def detect_describe_or_fail(lib, vol, units, params=None, ngpu=0):
+    """SIFT3D_detect_keypoints + SIFT3D_extract_descriptors through the C API; None when the detect call fails (as the
+    reference's does when a candidate's orientation window holds a NaN gradient), else (xyzos, sd, R, bins).
+    ngpu > 1: on that many loop-back Z-slab ranks (sift3d_amd_set_num_gpus)."""
+    L = lib.sift
+    s = abi.SIFT3D()
+    assert L.init_SIFT3D(C.byref(s)) == 0
+    if params:
+        for k, v in params.items():
+            assert getattr(L, f"set_{k}_SIFT3D")(C.byref(s), v) == 0
+    if ngpu > 1:
+        assert L.sift3d_amd_set_num_gpus(C.byref(s), ngpu, 1) == 0          # 1 = SIFT3D_AMD_SLAB_LOOPBACK
+    im = lib.image_from_numpy(vol, units)
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    out = None
+    try:
+        if L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0:
+            xyzos, sd, R = lib.keypoints_to_numpy(kp)
+            bins = np.zeros((0, 768), np.float32)
+            if len(xyzos):
+                d = abi.SIFT3D_Descriptor_store()
+                L.init_SIFT3D_Descriptor_store(C.byref(d))
+                assert L.SIFT3D_extract_descriptors(C.byref(s), C.byref(kp), C.byref(d)) == 0
+                bins, _ = lib.descriptors_to_numpy(d)
+                bins = bins.copy()
+                L.cleanup_SIFT3D_Descriptor_store(C.byref(d))
+            out = (xyzos.copy(), sd.copy(), R.copy(), bins)
+    finally:
+        L.cleanup_Keypoint_store(C.byref(kp))
+        lib.free_image(im)
+        L.cleanup_SIFT3D(C.byref(s))
+    return out
+
+
+def assert_same_nonfinite_result(got, want, what):
+    """`want` from the reference / oracle: both fail, or the same keypoints (bit-exact), R within 1e-5, descriptors
+    within 1e-4 relative with the constant NaN-window descriptors (all 768 bins equal) in the same rows and bit-equal."""
+    if want is None:
+        assert got is None, f"{what}: the reference's call fails on this volume, the product's returned {len(got[0])} keypoints"
+        return 0
+    assert got is not None, f"{what}: the product's call failed, the reference finds {len(want[0])} keypoints"
+    assert got[0].shape == want[0].shape and np.array_equal(got[0], want[0]), \
+        f"{what}: keypoints differ ({len(got[0])} vs {len(want[0])})"
+    assert np.array_equal(got[1], want[1]), what
+    if len(want[0]):
+        assert np.abs(got[2].reshape(-1, 9) - want[2].reshape(-1, 9)).max() <= 1e-5, what
+        gb, wb = got[3], want[3]
+        assert np.isfinite(wb).all() and np.isfinite(gb).all(), what
+        uw, ug = np.ptp(wb, axis=1) == 0, np.ptp(gb, axis=1) == 0
+        assert np.array_equal(uw, ug), f"{what}: NaN-window descriptors in different rows"
+        assert np.array_equal(gb[ug].view(np.uint32), wb[uw].view(np.uint32)), what
+        ok = rel_close(gb, wb, rtol=1e-4, atol=1e-7)
+        assert ok.all(), f"{what}: {(~ok).sum()} descriptor floats beyond 1e-4 relative"
+    return len(want[0])
+
+
+def nonfinite_golden():
+    """{(base, name): None (the reference's detect fails) or (xyzos, sd, R, bins)} of tests/golden/nonfinite.npz."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nonfinite.npz"))
+    out = {}
+    for base, name, _ in NONFINITE_CASES:
+        k = f"{base}/{name}/"
+        if int(g[k + "fail"]):
+            out[(base, name)] = None
+        else:
+            n = len(g[k + "xyzos"])
+            out[(base, name)] = (g[k + "xyzos"], g[k + "sd"], g[k + "R"].reshape(n, 3, 3), g[k + "desc"].reshape(n, 768))
+    return out, g
+
+
+def nonfinite_input_checked(g, base, name, edits):
+    """The case's volume, regenerated, after checking that it is the one the fixture was written for."""
+    import hashlib
+    vol, units, params = nonfinite_case(base, edits)
+    assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).digest() == g[f"{base}/{name}/sha256"].tobytes(), "generator drifted"
+    return vol, units, params
+
+
+def oracle_detect_describe_or_fail(oracle, vol, units, params=None):
+    """The restatement's answer in the shape of detect_describe_or_fail."""
+    from oracle import oracle as orc
+    if params:
+        oracle.set_params(peak=params.get("peak_thresh", 0.1), corner=params.get("corner_thresh", 0.4),
+                          num_kp_levels=params.get("num_kp_levels", 3), sigma_n=params.get("sigma_n", 1.15),
+                          sigma0=params.get("sigma0", 1.6))
+    try:
+        try:
+            xyzos, sd, R = oracle.detect(vol, units)
+        except orc.ReferenceFails:
+            return None
+        bins = np.zeros((0, 768), np.float32)
+        if len(xyzos):
+            bins, _ = oracle.describe(xyzos[:, :3].astype(np.float64), xyzos[:, 3:5], sd, R)
+        return xyzos, sd, R, bins
+    finally:
+        if params:
+            oracle.set_params()

@@ -70,6 +70,13 @@ def test_describe_redo_path(emu, oracle, factor):
     assert k > 0 and redone == k, (k, redone)
 
 
+def test_describe_proof_counts_every_lane_of_a_copy(emu, oracle):
+    """The whole gradient mass of every histogram copy on ONE of its four lanes (k + 16; the other lanes take no chunks) and
+    a grid a thousand times too fine: the proof has to notice and redo every window (see tests/test_gpu_parity.py)."""
+    k, redone = parity.check_describe_redo(emu, oracle, (40, 36, 32), (1, 1, 1), 120, 4, 1e-3, lane_test=True)
+    assert k > 0 and redone == k, (k, redone)
+
+
 @pytest.mark.parametrize("how", ["api", "env"])
 def test_host_pyramid_after_detect(emu, oracle, how, monkeypatch):
     """sift3d_amd_set_host_pyramid / SIFT3D_HOST_PYRAMID: the host Pyramids hold the voxels after SIFT3D_detect_keypoints, as
@@ -279,3 +286,66 @@ def test_extrema_runmax(emu, d):
     """DoG maxima as a by-product of the extrema pass (running lower bound + exact refilter) = the two-pass form = the
     per-level kernel; rows of any length (the four voxels of a thread straddle row ends, dword-aligned loads)."""
     parity.check_extrema_runmax(emu, d, [(0, d[2]), (0, d[2] // 2), (d[2] // 2 - 3, d[2])])
+
+
+def _nonfinite_subset(which):
+    return [pytest.param(b, n, e, id=f"{b}-{n}") for b, n, e in parity.NONFINITE_CASES if (b, n) in which]
+
+
+@pytest.mark.parametrize("base,name,edits", _nonfinite_subset({
+    ("iso48", "nan_first"), ("iso48", "nan_interior"), ("iso48", "nan_background_low"), ("iso48", "nan_and_inf"),
+    ("iso48", "pos_inf"), ("iso48", "nan_last"), ("aniso40", "nan_xband"), ("slab64", "nan_rank1_c")}))
+def test_nonfinite_voxels(emu, base, name, edits):
+    """NaN / infinite voxels through SIFT3D_detect_keypoints + SIFT3D_extract_descriptors: what the UNMODIFIED reference
+    answers (tests/golden/nonfinite.npz): the same failure, or the same keypoints, orientations and descriptors.  The first
+    pass over such a volume runs on the streaming kernels, notices the sticky maximum and is repeated on the literal ones
+    (s3d_host_api.c detect_single)."""
+    want, g = parity.nonfinite_golden()
+    vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+    got = parity.detect_describe_or_fail(emu, vol, units, params)
+    parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name}")
+
+
+def test_seqmax_kernels(emu):
+    """s3d_k_seqmax = the reference's sequential maximum (im_max_abs / dogmax: a NaN replaces the running maximum, the next
+    sample replaces the NaN), s3d_k_absmax = the order-free sticky one; |a| and |a - b| forms, NaN first / last / several /
+    none, infinities, an empty tail."""
+    import numpy as np
+    dev = parity.dev_of(emu)
+    L = dev.L
+    L.s3d_k_seqmax.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.s3d_k_absmax.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+
+    def seq(v):                                          # imutil.c:1959-1973 / sift.c:1161-1166, literally
+        m = np.float32(0.0)
+        for s in np.abs(v):
+            m = m if m > s else s
+        return m
+
+    n = 2051
+    base = rng.standard_normal(n).astype(np.float32)
+    other = rng.standard_normal(n).astype(np.float32)
+    cases = []
+    for nanpos in ([], [0], [n - 1], [7, 900], [900, n - 1], [n - 2], list(range(100, 2000))):
+        v = base.copy()
+        v[nanpos] = np.nan
+        cases.append(v)
+    v = base.copy(); v[5] = np.inf; cases.append(v)
+    v = base.copy(); v[5] = np.inf; v[1000] = np.nan; cases.append(v)
+    v = base.copy(); v[1500] = -np.inf; v[1000] = np.nan; cases.append(v)
+    d_a, d_b, d_m, d_rec = dev.malloc(4 * n), dev.upload(other), dev.malloc(4), dev.malloc(16)
+    try:
+        for v in cases:
+            L.s3d_rt_h2d(C.c_void_p(d_a), v.ctypes.data_as(C.c_void_p), 4 * n, None)
+            for b, vv in ((None, v), (d_b, v - other)):
+                assert L.s3d_k_seqmax(d_a, b, n, d_m, d_rec, None) == 0 and L.s3d_rt_sync(None) == 0
+                got = dev.download(d_m, (1,))[0]
+                want = seq(vv)
+                assert (np.isnan(got) and np.isnan(want)) or got == want, (got, want)
+            assert L.s3d_k_absmax(d_a, n, d_m, None) == 0 and L.s3d_rt_sync(None) == 0
+            got = dev.download(d_m, (1,))[0]
+            assert np.isnan(got) if np.isnan(v).any() else got == np.abs(v).max()
+    finally:
+        for p_ in (d_a, d_b, d_m, d_rec):
+            dev.free(p_)

@@ -444,19 +444,14 @@ def test_window_weight_expf_matches_host_libm(lib):
     assert nchecked >= 20000 and ndiff_cr > 0      # glibc's expf is not correctly rounded in ~6e-4 of cases
 
 
-def test_benchmark_size_vs_reference_golden(lib):
-    """BASELINE configs[1] end to end against the UNMODIFIED reference's output on the same 512^3 volume
-    (tests/golden/full512.npz, written by tests/golden/make_golden_512.py from oracle/_ref): all 31 207 keypoints and
-    their order bit-exact, R within 1e-5, every 32nd descriptor within 1e-4 relative, sixteen fixed +-1 projections
-    of EVERY descriptor within the bound the 1e-4 band implies (|sum s_i e_i| <= 1e-4 * ||d||_1 + 768e-7), and every one of
-    the 42 GSS and 35 DoG levels equal to the reference's by SHA-256."""
+def _check_full_size_golden(lib, g, vol, units, report):
+    """One full-size fixture in the layout of make_golden_512.py / make_golden_full.py against the product: keypoints and
+    their order bit-exact, R within 1e-5, every `every`-th descriptor within 1e-4 relative, sixteen fixed +-1 projections
+    of EVERY descriptor within the bound the 1e-4 band implies (|sum s_i e_i| <= 1e-4 * ||d||_1 + 768e-7), and every
+    GSS and DoG level equal to the reference's by SHA-256."""
     import hashlib
-    gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full512.npz")
-    g = np.load(gpath)
-    n = int(g["n"])
-    vol = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
     assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).digest() == g["sha256"].tobytes(), "generator drifted"
-    s, im, kp = parity.run_detect(lib, vol, (1, 1, 1))
+    s, im, kp = parity.run_detect(lib, vol, units)
     xyzos, sd, R = lib.keypoints_to_numpy(kp)
     assert np.array_equal(xyzos, g["xyzos"].astype(xyzos.dtype)), f"keypoints differ: {len(xyzos)} vs {len(g['xyzos'])}"
     assert np.array_equal(sd, g["sd"])
@@ -478,8 +473,8 @@ def test_benchmark_size_vs_reference_golden(lib):
     bound = 1e-4 * np.abs(bins.astype(np.float64)).sum(1, keepdims=True) + 768e-7
     worst = (np.abs(proj - g["proj"]) / bound).max()
     assert worst <= 1.0, f"descriptor projection off by {worst:.2f} x the 1e-4 band"
-    # every GSS and DoG level of the 512^3 pyramids, by SHA-256 against the reference's
-    assert "gss_sha" in g.files, "tests/golden/full512.npz predates the level hashes: re-run make_golden_512.py"
+    # every GSS and DoG level of the pyramids, by SHA-256 against the reference's
+    assert "gss_sha" in g.files, "the fixture predates the level hashes: re-run its generator"
     assert lib.sift.sift3d_amd_download_pyramid(C.byref(s), 1) == 0
     for name, pyr in (("gss_sha", s.gpyr), ("dog_sha", s.dog)):
         want_sha = g[name]
@@ -493,11 +488,39 @@ def test_benchmark_size_vs_reference_golden(lib):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump({"K": int(len(xyzos)), "sampled_descriptors": int(len(got)), "max_rel_dev_bins_over_1e-3": float(rel.max()),
-               "worst_projection_over_band": float(worst)}, open(os.path.join(out, "golden_512.json"), "w"))
+               "worst_projection_over_band": float(worst), "levels_sha_equal": int(len(g["gss_sha"]) + len(g["dog_sha"]))},
+              open(os.path.join(out, report), "w"))
     lib.sift.cleanup_SIFT3D_Descriptor_store(C.byref(d))
     lib.sift.cleanup_Keypoint_store(C.byref(kp))
     lib.free_image(im)
     lib.sift.cleanup_SIFT3D(C.byref(s))
+    return len(xyzos)
+
+
+def test_benchmark_size_vs_reference_golden(lib):
+    """BASELINE configs[1] end to end against the UNMODIFIED reference's output on the same 512^3 volume
+    (tests/golden/full512.npz, written by tests/golden/make_golden_512.py from oracle/_ref): all 31 207 keypoints and
+    their order bit-exact, R within 1e-5, every 32nd descriptor within 1e-4 relative, sixteen fixed +-1 projections
+    of EVERY descriptor within the bound the 1e-4 band implies (|sum s_i e_i| <= 1e-4 * ||d||_1 + 768e-7), and every one of
+    the 42 GSS and 35 DoG levels equal to the reference's by SHA-256."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full512.npz"))
+    n = int(g["n"])
+    vol = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
+    assert _check_full_size_golden(lib, g, vol, (1, 1, 1), "golden_512.json") == 31207
+
+
+@pytest.mark.parametrize("name", ["aniso07", "odd511"])
+def test_any_spacing_full_size_vs_reference_golden(lib, name):
+    """The any-spacing (table-driven) and ragged-row paths at full size against the UNMODIFIED reference
+    (tests/golden/full_aniso07.npz: 512 x 512 x 300 voxels of 0.7 x 0.7 x 1.5 -- tap spacings 1.43 / 1.43 / 0.67 voxels at
+    octave 0; full_odd511.npz: 511 x 509 x 303 unit voxels -- no row a multiple of 4 in any octave; written by
+    tests/golden/make_golden_full.py from oracle/_ref): keypoints bit-exact, every GSS / DoG level by SHA-256,
+    descriptors inside the 1e-4 band.  These are the shapes bench.py reports as extras."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"full_{name}.npz"))
+    nx, ny, nz = (int(v) for v in g["dims"])
+    units = tuple(float(u) for u in g["units"])
+    vol = synth.blobs(nx, ny, nz, synth.default_nblobs(nx, ny, nz), 0)
+    assert _check_full_size_golden(lib, g, vol, units, f"golden_{name}.json") > 10000
 
 
 @pytest.mark.parametrize("fixture", ["pair512.npz", "pair512_affine.npz"])
@@ -618,6 +641,16 @@ def test_describe_redo_path(libt, oracle, dims, units, factor):
     assert k > 20 and redone == k, (k, redone)
 
 
+def test_describe_proof_counts_every_lane_of_a_copy(libt, oracle):
+    """Histogram copy k of the descriptor kernel is fed by lanes k, k + 16, k + 32 and k + 48 of every wave.  With the
+    whole gradient mass of each copy on its lane k + 16 only (testing build: the other lanes take no chunks) and the grid
+    set a thousand times too fine, the proof must still see that the 32-bit fields can wrap and redo every window --
+    a proof that added up lanes k and k + 32 only would see no mass at all, keep the wrapped histograms and return wrong
+    descriptors."""
+    k, redone = parity.check_describe_redo(libt, oracle, (96, 88, 80), (1, 1, 1), 900, 5, 1e-3, lane_test=True)
+    assert k > 20 and redone == k, (k, redone)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dims,units,sigmas,expect", [
     ((96, 88, 80), (1, 1, 1), (2.0159, 2.5398, 3.2), True),
@@ -682,3 +715,84 @@ def test_detect_full_size_any_spacing(lib, dims, units):
     kernels the same keypoints come out (coordinates, level, orientation bits)."""
     k = parity.check_detect_modes_agree(lib, dims, units, modes=(0, 2))
     assert k > 1000
+
+
+# ---- non-finite voxels -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("base,name,edits", [pytest.param(b, n, e, id=f"{b}-{n}") for b, n, e in parity.NONFINITE_CASES])
+def test_nonfinite_voxels_vs_reference_golden(lib, base, name, edits):
+    """Volumes with NaN / infinite voxels against the UNMODIFIED reference's answers (tests/golden/nonfinite.npz, written
+    by make_golden_nonfinite.py from oracle/_ref): SIFT3D_detect_keypoints fails where the reference's does (a NaN gradient
+    in a candidate's orientation window: LAPACK dsyevd, sift.c:1430), else keypoints bit-identical, R within 1e-5,
+    descriptors within 1e-4 with the constant NaN-window descriptors in the same rows, bit-equal.  NaN at the first / an
+    interior / the last voxel, NaN slabs (a masked background), +-inf, both, unit and anisotropic voxels."""
+    want, g = parity.nonfinite_golden()
+    vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+    got = parity.detect_describe_or_fail(lib, vol, units, params)
+    parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name}")
+
+
+@pytest.mark.parametrize("dims,units,edits", [
+    ((160, 150, 140), (1, 1, 1), [((100, 101), (146, 147), (155, 156), np.nan)]),          # streaming first pass (> 64^3), a far-edge NaN
+    ((160, 150, 140), (1, 1, 1), [((0, 140), (0, 150), (0, 12), np.nan)]),                 # a masked band
+    ((150, 140, 90), (0.7, 0.7, 1.5), [((60, 61), (135, 136), (146, 147), np.nan)]),       # table-driven first pass
+    ((131, 129, 127), (1, 1, 1), [((126, 127), (128, 129), (130, 131), np.nan)]),          # ragged rows, the last voxel
+    ((131, 129, 127), (1, 1, 1), [((90, 91), (125, 126), (127, 128), np.inf), ((100, 101), (3, 4), (127, 128), np.nan)]),
+])
+def test_nonfinite_voxels_live_oracle(lib, oracle, dims, units, edits):
+    """The same at sizes where the FIRST pass takes the streaming / table-driven / ragged kernels (whose answer on such a
+    volume is discarded) before the literal ones: against the oracle restatement, live (itself pinned to the reference on
+    non-finite input by tests/test_oracle_golden.py::test_nonfinite)."""
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, synth.default_nblobs(nx, ny, nz), 3)
+    for (zs, ys, xs, val) in edits:
+        vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
+    want = parity.oracle_detect_describe_or_fail(oracle, vol, units)
+    got = parity.detect_describe_or_fail(lib, vol, units)
+    parity.assert_same_nonfinite_result(got, want, f"{dims} {units}")
+
+
+def test_seqmax_kernels(lib):
+    """s3d_k_seqmax (the reference's sequential maximum under NaNs) and the sticky s3d_k_absmax on a volume that takes
+    every workgroup of the reductions: NaN nowhere / first / last / scattered / a block of them, infinities."""
+    dev = parity.dev_of(lib)
+    L = dev.L
+    L.s3d_k_seqmax.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.s3d_k_absmax.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    n = 3 * 1024 * 1024 + 77
+
+    def seq(v):                                          # = the scan of imutil.c:1959-1973: the maximum behind the last NaN
+        a = np.abs(v)
+        nan = np.nonzero(np.isnan(a))[0]
+        if len(nan) == 0:
+            return a.max()
+        if nan[-1] == len(a) - 1:
+            return np.float32(np.nan)
+        return max(np.float32(0), a[nan[-1] + 1:].max())
+
+    base = rng.standard_normal(n).astype(np.float32)
+    other = rng.standard_normal(n).astype(np.float32)
+    cases = []
+    for nanpos in ([], [0], [n - 1], [7, 2_000_000], [2_000_000, n - 1], [n - 2], list(range(100, 3_000_000, 997))):
+        v = base.copy()
+        v[nanpos] = np.nan
+        cases.append(v)
+    v = base.copy(); v[1_000_000:1_500_000] = np.nan; cases.append(v)
+    v = base.copy(); v[5] = np.inf; cases.append(v)
+    v = base.copy(); v[5] = np.inf; v[1000] = np.nan; cases.append(v)
+    v = base.copy(); v[2_500_000] = -np.inf; v[1000] = np.nan; cases.append(v)
+    d_a, d_b, d_m, d_rec = dev.malloc(4 * n), dev.upload(other), dev.malloc(4), dev.malloc(16)
+    try:
+        for v in cases:
+            L.s3d_rt_h2d(C.c_void_p(d_a), v.ctypes.data_as(C.c_void_p), 4 * n, None)
+            for b, vv in ((None, v), (d_b, v - other)):
+                assert L.s3d_k_seqmax(d_a, b, n, d_m, d_rec, None) == 0 and L.s3d_rt_sync(None) == 0
+                got = dev.download(d_m, (1,))[0]
+                want = seq(vv)
+                assert (np.isnan(got) and np.isnan(want)) or got == want, (got, want)
+            assert L.s3d_k_absmax(d_a, n, d_m, None) == 0 and L.s3d_rt_sync(None) == 0
+            got = dev.download(d_m, (1,))[0]
+            assert np.isnan(got) if np.isnan(v).any() else got == np.abs(v).max()
+    finally:
+        for p_ in (d_a, d_b, d_m, d_rec):
+            dev.free(p_)

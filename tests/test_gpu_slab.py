@@ -384,3 +384,15 @@ def test_config3_1024_cubed(hip):
     assert got_kp == want_kp and got_desc == want_desc
     assert np.array_equal(draw8[:, 3072:], draw[:, 3072:])                      # descriptor coordinates and scales
     L.cleanup_SIFT3D(C.byref(s8))
+
+
+@pytest.mark.parametrize("base,name,edits", [pytest.param(b, n, e, id=f"{b}-{n}") for b, n, e in parity.NONFINITE_CASES if b == "slab64"])
+def test_nonfinite_voxels_on_loopback_ranks(hip, base, name, edits):
+    """NaN / infinite voxels on two Z-slab ranks of the device (behind the plain entry points) against the UNMODIFIED
+    reference's answers (tests/golden/nonfinite.npz): the collective decision to repeat the pass on the literal kernels,
+    the sequential maxima folded over the ranks in z order, the common failure where a candidate's orientation window
+    holds a NaN."""
+    want, g = parity.nonfinite_golden()
+    vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+    got = parity.detect_describe_or_fail(hip, vol, units, params, ngpu=2)
+    parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name} on 2 ranks")

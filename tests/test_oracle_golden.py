@@ -3,6 +3,7 @@ unmodified reference build (tests/golden/make_golden.py).  Bit-exact everywhere.
 import os
 
 import numpy as np
+import pytest
 
 from sift3d_amd import synth
 from tests.conftest import GOLDEN
@@ -163,3 +164,22 @@ def test_pair512_fixture_is_self_consistent():
     assert m.min() >= -1 and m.max() < kb and (m >= 0).sum() == 17874
     hit = m[m >= 0]
     assert len(np.unique(hit)) == len(hit)
+
+
+def _nonfinite_params():
+    from tests import parity
+    return [pytest.param(b, n, e, id=f"{b}-{n}") for b, n, e in parity.NONFINITE_CASES]
+
+
+@pytest.mark.parametrize("base,name,edits", _nonfinite_params())
+def test_nonfinite(oracle, base, name, edits):
+    """Volumes with NaN / infinite voxels: the restatement against the UNMODIFIED reference's answers
+    (tests/golden/nonfinite.npz, make_golden_nonfinite.py) -- the call fails where the reference's does (a NaN gradient
+    in a candidate's orientation window), else the same keypoints, orientations and descriptors, the constant
+    NaN-window descriptors included.  What is pinned: the sequential maxima (a NaN resets them), 0 * NaN in the filters,
+    the LAPACK failure, the descriptor of a window with a NaN gradient."""
+    from tests import parity
+    want, g = parity.nonfinite_golden()
+    vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+    got = parity.oracle_detect_describe_or_fail(oracle, vol, units, params)
+    parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name}")

@@ -102,3 +102,25 @@ def test_nn_match_unnormalised_live(oracle, reference, scale, poison):
     rc, want, _ = parity.nn_match_api(reference, d1, d2, 0.8)
     assert rc == 0
     assert np.array_equal(oracle.nn_match(d1, d2, 0.8), want)
+
+
+def _nonfinite_ids():
+    from tests import parity
+    return [f"{b}-{n}" for b, n, _ in parity.NONFINITE_CASES]
+
+
+def test_nonfinite_golden_is_the_live_reference(reference):
+    """tests/golden/nonfinite.npz is what oracle/_ref answers today, case for case (failures included) -- the fixture
+    travels to the GPU box, the reference does not."""
+    from tests import parity
+    want, g = parity.nonfinite_golden()
+    for base, name, edits in parity.NONFINITE_CASES:
+        if base == "iso72" and name != "nan_far_edge":
+            continue                                     # (the largest volumes: one is enough for this check)
+        vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+        got = parity.detect_describe_or_fail(reference, vol, units, params)
+        w = want[(base, name)]
+        assert (got is None) == (w is None), (base, name)
+        if w is not None:
+            assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and nbitdiff(got[2], w[2]) == 0
+            assert nbitdiff(got[3], w[3]) == 0

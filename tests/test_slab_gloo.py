@@ -224,3 +224,39 @@ def test_more_gpus_than_devices_is_refused(emu):
     assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im), C.byref(kp)) == 0 and kp.slab.num > 0
     emu.free_image(im)
     L.cleanup_SIFT3D(C.byref(s))
+
+
+@pytest.mark.parametrize("ngpu,base,name,edits", [pytest.param(2, b, n, e, id=f"{b}-{n}")
+                                                  for b, n, e in parity.NONFINITE_CASES if b == "slab64"])
+def test_nonfinite_voxels_on_loopback_ranks(emu, ngpu, base, name, edits):
+    """NaN / infinite voxels on Z-slab ranks (behind the plain entry points): the reference's answer
+    (tests/golden/nonfinite.npz).  The ranks agree that a slab holds such a voxel, repeat the pass on the literal kernels,
+    fold their sequential maxima in z order (slab_seqmax: the maximum behind the LAST NaN of the whole scan, wherever
+    it lies) and fail together where a candidate's orientation window holds a NaN -- without breaking the transports:
+    the same struct then serves a finite volume."""
+    want, g = parity.nonfinite_golden()
+    vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+    got = parity.detect_describe_or_fail(emu, vol, units, params, ngpu=ngpu)
+    parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name} on {ngpu} ranks")
+
+
+def test_finite_volume_after_a_failed_nonfinite_one(emu):
+    """A detect that fails the reference's way (NaN in an orientation window) leaves the rank threads and their
+    transports usable: the next volume on the same struct gives the single-process result."""
+    L = emu.sift
+    want, g = parity.nonfinite_golden()
+    e = dict(((b, n), ed) for b, n, ed in parity.NONFINITE_CASES)[("slab64", "nan_rank0")]
+    bad, units, params = parity.nonfinite_input_checked(g, "slab64", "nan_rank0", e)
+    assert want[("slab64", "nan_rank0")] is None
+    good = synth.blobs(32, 32, 64, 130, 1)
+    want_x, want_sd, want_R, want_b, want_c = single_process(emu, good, units, params)
+    s = slabmod.make_params(L, params)
+    assert L.sift3d_amd_set_num_gpus(C.byref(s), 2, slabmod.SLAB_LOOPBACK) == 0
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    im_bad, im_good = emu.image_from_numpy(bad, units), emu.image_from_numpy(good, units)
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im_bad), C.byref(kp)) != 0
+    assert L.SIFT3D_detect_keypoints(C.byref(s), C.byref(im_good), C.byref(kp)) == 0
+    x, sd, R = emu.keypoints_to_numpy(kp)
+    assert len(want_x) > 5 and np.array_equal(x, want_x) and np.array_equal(R, want_R)
+    L.cleanup_SIFT3D(C.byref(s))
