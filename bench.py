@@ -499,20 +499,24 @@ def add_roofline(result, dev, n):
     ach = GAUSS_XY_BYTES_PER_VOXEL * nv / (worst["xy_ms"] * 1e-3) / 1e9
     # HBM bytes per launch of that kernel from PMC passes (scripts/pmc_hbm.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
     # FETCH_SIZE doubled per the gfx950 correction).  A rocprofv3 counter pass cannot run inside this process, so the figure
-    # is read from profiles/pmc_gauss.json -- and used ONLY if that file was measured on this very kernel source (SHA-256 of
-    # csrc/s3d_gauss.hip) at 512^3; otherwise traffic is null.  traffic_source says which run and commit measured it.
+    # is read from profiles/pmc_gauss.json -- and used ONLY if that file was measured on these very kernels: the SHA-256 over
+    # the MACHINE CODE of the k_gauss_xy / k_gauss_z functions inside the library this process has loaded
+    # (sift3d_amd/codeobj.py; a comment edit or a change elsewhere in the file does not move it) at 512^3; otherwise traffic is
+    # null.  traffic_source says which run and commit measured it.
     traffic, traffic_source = None, None
     try:
-        import hashlib
+        from sift3d_amd import codeobj
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_gauss.json")))
-        sha = hashlib.sha256(open(os.path.join(ROOT, "sift3d_amd", "csrc", "s3d_gauss.hip"), "rb").read()).hexdigest()
-        if int(nv) == int(pmc["voxels"]) and pmc.get("gauss_source_sha256") == sha:
+        isa = codeobj.kernel_isa_sha256(os.path.join(ROOT, "sift3d_amd", "lib", "libsift3d_amd.so"), codeobj.GAUSS_KERNELS)
+        if int(nv) == int(pmc["voxels"]) and isa and pmc.get("gauss_kernels_isa_sha256") == isa:
             traffic = pmc["kernels"][f"k_gauss_xy<{worst['width'] // 2}>"]["hbm_bytes_per_launch"]
-            traffic_source = f"profiles/pmc_gauss.json: run {pmc.get('run')}, commit {pmc.get('commit')}, same s3d_gauss.hip"
+            traffic_source = (f"profiles/pmc_gauss.json: run {pmc.get('run')}, commit {pmc.get('commit')}, the same machine code "
+                              f"of k_gauss_xy / k_gauss_z (sha256 {isa[:16]}...)")
         else:
-            traffic_source = "profiles/pmc_gauss.json was measured on a different s3d_gauss.hip: not used"
-    except Exception:
-        traffic = None
+            traffic_source = (f"profiles/pmc_gauss.json was measured on other machine code of the fused Gaussian kernels "
+                              f"({str(pmc.get('gauss_kernels_isa_sha256'))[:16]}... vs loaded {isa[:16]}...): not used")
+    except Exception as e:                                # noqa: BLE001
+        traffic, traffic_source = None, f"profiles/pmc_gauss.json unusable: {e}"
     # What the kernel physically does, next to the algorithmic figure: the PMC bytes of one launch over the same
     # HIP-event time.  `frac` credits the fusion (two algorithmic passes for one read and one write of the volume);
     # `physical_frac` is the DRAM-side rate against the same 8 TB/s -- the guide's float4-copy ceiling is 6.29 TB/s.

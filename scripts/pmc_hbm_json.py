@@ -51,6 +51,9 @@ def short(name):
 
 
 sha = hashlib.sha256(open(os.path.join(ROOT, "sift3d_amd", "csrc", "s3d_gauss.hip"), "rb").read()).hexdigest()
+sys.path.insert(0, ROOT)
+from sift3d_amd import codeobj          # noqa: E402
+isa = codeobj.kernel_isa_sha256(os.path.join(ROOT, "sift3d_amd", "lib", "libsift3d_amd.so"), codeobj.GAUSS_KERNELS)
 # ---- (1) the fused Gaussians ----
 f, w = per_kernel("gauss_only", "FETCH_SIZE"), per_kernel("gauss_only", "WRITE_SIZE")
 nvox = 512 ** 3
@@ -66,7 +69,7 @@ for k in sorted(f):
 doc = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of scripts/gauss_only.py: 512^3 "
                "f32, 3 launches per kernel, 1x MI355X.  Counter unit KB.  FETCH_SIZE doubled (gfx950 reports half the bytes of wide "
                "coalesced streaming reads, MI355X_MICROARCH.md section HBM); WRITE_SIZE taken as is.",
-       "run": tag, "commit": commit, "gauss_source_sha256": sha, "voxels": nvox, "kernels": kern}
+       "run": tag, "commit": commit, "gauss_source_sha256": sha, "gauss_kernels_isa_sha256": isa, "voxels": nvox, "kernels": kern}
 json.dump(doc, open(os.path.join(OUT, f"{tag}_pmc_gauss.json"), "w"), indent=1)
 with open(os.path.join(OUT, f"{tag}_pmc_gauss.md"), "w") as o:
     o.write(f"# {tag} -- HBM traffic of the fused Gaussian kernels from PMC counters (commit {commit})\n\n{doc['note']}\n\n")
