@@ -60,6 +60,13 @@ __device__ __forceinline__ void s3d_block_lds_sync()
 }
 #endif
 
+/* nothing is scheduled across this point (the emulator build has no scheduler to tell) */
+#if defined(S3D_EMU)
+#define S3D_SCHED_BARRIER() ((void)0)
+#else
+#define S3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 /* a wave-uniform value the compiler cannot see to be uniform (derived from threadIdx): to a scalar register, so that what
  * is indexed with it is loaded through the scalar cache */
 #ifndef S3D_UNIFORM
