@@ -281,7 +281,33 @@ def dry_plan(L, dims, world, params=None):
     finally:
         L.cleanup_SIFT3D(C.byref(s))
     plane = dims[0] * dims[1] * 4
+    # Link traffic of one detect and what it has to hide under.  A rank sends `plan_send_lo/hi_bytes` to its two Z-neighbours
+    # and receives as much; the two directions of an xGMI link run concurrently, the two neighbours sit on different links,
+    # so a rank's exposed transfer time is max(lo, hi) / link rate -- at the 153 GB/s of MI355X_MICROARCH.md and at a
+    # pessimistic 60 GB/s -- plus the seed all-gather of the first replicated octave.  The compute beside it: the single-GPU
+    # detect of the same volume (profiles/r04_run5_bench_single_1024.json: 48.7 ms at 1024^3, 46 ps per voxel; 6.5 ms at
+    # 512^3) divided by the ranks, i.e. what the halos have to overlap with for linear scaling.  Overlap is by
+    # construction partial: a level's Gaussian needs only the next filter's reach (8 planes) at once, the window halo of
+    # the keypoint levels (26 / 32 / 39 planes at the default parameters) travels on a second stream and communicator and
+    # is needed only by orientation + description.
+    ps_per_voxel = 46.0
+    detect_ms_single = ps_per_voxel * 1e-12 * dims[0] * dims[1] * dims[2] * 1e3
+    links = []
+    for i in out:
+        worst = max(i.plan_send_lo_bytes, i.plan_send_hi_bytes)
+        links.append({"rank": int(i.rank), "send_lo_MB": round(i.plan_send_lo_bytes / 1e6, 1), "send_hi_MB": round(i.plan_send_hi_bytes / 1e6, 1),
+                      "halo_bytes_per_link": int(worst), "seed_gather_MB": round(i.plan_seed_gather_bytes / 1e6, 1),
+                      "link_ms_at_153GBs": round((worst + i.plan_seed_gather_bytes / max(1, world - 1)) / 153e9 * 1e3, 2),
+                      "link_ms_at_60GBs": round((worst + i.plan_seed_gather_bytes / max(1, world - 1)) / 60e9 * 1e3, 2)})
     return {"volume": list(dims), "ranks": world,
+            "halo_planes_per_level_octave0": [int(v) for v in out[0].plan_halo_planes[:int(out[0].num_levels)]],
+            "per_rank_links": links,
+            "halo_MB_per_detect_all_ranks": round(sum(i.plan_send_lo_bytes + i.plan_send_hi_bytes for i in out) / 1e6, 1),
+            "time_model": {"single_gpu_detect_ms": round(detect_ms_single, 2), "ideal_detect_ms_per_rank": round(detect_ms_single / world, 2),
+                           "worst_link_ms_at_153GBs": max(l["link_ms_at_153GBs"] for l in links),
+                           "worst_link_ms_at_60GBs": max(l["link_ms_at_60GBs"] for l in links),
+                           "note": "near-linear needs the link time hidden under ideal_detect_ms_per_rank; describe (2x detect, "
+                                   "no traffic) dilutes what stays exposed"},
             "slices_per_rank": [int(i.z1 - i.z0) for i in out], "z_bounds": [int(out[0].z0)] + [int(i.z1) for i in out],
             "sharded_octaves": int(out[0].o_shard) + 1, "octaves": int(out[0].num_octaves), "halo_planes": int(out[0].halo),
             # planes a rank holds per sharded octave-0 level: its slices plus the halo on each interior side
@@ -585,6 +611,10 @@ def main():
         log(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a number for a different GPU count")
         raise SystemExit(2)
     dist = None
+    if world > 1 or args.gpus > 1:
+        # RCCL's own warnings on stderr: a first contact with a fabric that fails must be diagnosable from the tail of the
+        # run's output (the library adds ncclGetLastError to its error texts: csrc/s3d_rccl.hip nccl_failed)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
     if world > 1 or os.environ.get("S3D_BENCH_FORCE_SLAB"):     # FORCE_SLAB: the N > 1 code path with a world of one (1-GPU boxes)
         import torch
         import torch.distributed as dist

@@ -390,6 +390,9 @@ int im_restride(const Image *const src, const size_t *const strides, Image *cons
 int draw_grid(Image *grid, int nx, int ny, int nz, int spacing, int line_width);                 /* imutil.c:973 */
 int trace_Mat_rm(Mat_rm *mat, void *trace);                                                      /* imutil.c:3301 */
 int print_Mat_rm(const Mat_rm *const mat);                                                       /* imutil.c:803 */
+void sprint_type_Mat_rm(const Mat_rm *const mat, char *const str);                               /* imutil.c:678 */
+char *im_get_parent_dir(const char *path);                                                       /* imutil.c:1322; free() the result */
+void err_exit(const char *str);                                                                  /* imutil.c:4112; does not return */
 /* Defaults the reference exports as data (its regSift3D prints them: cli/regSift3D.c:83-84) */
 extern const double SIFT3D_nn_thresh_default;                            /* reg.h:20, reg.c:24 */
 extern const double SIFT3D_err_thresh_default;                           /* imutil.h:33, imutil.c:102 */

@@ -97,6 +97,12 @@ typedef struct {
      * orientation step -- 0 when they overlapped the pyramid kernels completely. */
     double comm_ms, halo_wait_ms;
     long num_described;       /* keypoints this rank described in the last describe (after load balancing) */
+    /* the plan's link traffic per detect: bytes this rank sends to its lower / upper neighbour (it receives as much from
+     * each), its receive volume of the seed all-gather of the first replicated octave, and the halo planes of the levels
+     * of a sharded octave (0 beyond num_levels): filter reach for the plain levels, the window reach of its own keypoints
+     * for levels 1 .. num_kp_levels */
+    double plan_send_lo_bytes, plan_send_hi_bytes, plan_seed_gather_bytes;
+    int plan_halo_planes[8];
 } sift3d_amd_slab_info;
 
 /* Plan and allocate rank t->rank of a t->world-way job on an nx x ny x nz volume with the parameters of

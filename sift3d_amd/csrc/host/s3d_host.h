@@ -28,6 +28,7 @@ int s3d_check_desc_windows(const s3d_desc_key *keys, size_t num, const s3d_pyram
 /* ---- one process, N GPUs behind the reference entry points (s3d_host_slab.c) --------------------------- */
 struct s3d_mgpu;
 int s3d_mgpu_wanted(const struct s3d_mgpu *m);            /* > 1: the multi-GPU path is switched on */
+int s3d_mgpu_built(const struct s3d_mgpu *m);             /* the rank threads and their slabs exist (a failed job tears them down) */
 int s3d_mgpu_configure(struct s3d_mgpu **m, int ngpu, int flags);
 int s3d_mgpu_detect(struct s3d_mgpu **m, const SIFT3D *sift3d, const float *host_dense, int nx, int ny, int nz,
                     double ux, double uy, double uz, Keypoint_store *kp);

@@ -211,24 +211,22 @@ static void ctx_release(int handle)
     c = g_ctx[handle - 1];
     g_ctx[handle - 1] = NULL;
     for (int i = 0; i < S3D_MAX_CTX; i++) live += g_ctx[i] != NULL;
-    /* The matcher's scratch (score matrix and operand copies, up to ~9 GiB at 31 k x 31 k) and the tap tables of the
-     * table-driven filter passes are kept per device between calls.  They belong to no SIFT3D struct, so they go when
-     * the last one does -- decided and done under the registry lock, so that a context created meanwhile cannot have what
-     * it has just allocated taken away: a process that is done with its structs gets the memory back, one that works in a
-     * loop keeps a struct alive anyway. */
-    if (c && live == 0) {                               /* the last one: its streams drained first, then the shared pools */
-        s3d_mgpu_free(c->mgpu);
-        ctx_free_all(c);
-        free(c);
-        c = NULL;
-        s3d_k_nn_release_scratch();
-        s3d_k_tap_tables_release();
-    }
     pthread_mutex_unlock(&g_ctx_lock);
+    /* Only the decision is taken under the registry lock; the teardown -- stream syncs, hipFree, thread joins -- runs
+     * outside it, so that other threads' structs are not held up behind a device teardown. */
     if (c) {
         s3d_mgpu_free(c->mgpu);
         ctx_free_all(c);
         free(c);
+    }
+    /* The matcher's scratch (score matrix and operand copies, up to ~9 GiB at 31 k x 31 k) and the tap tables of the
+     * table-driven filter passes are kept per device between calls.  They belong to no SIFT3D struct, so they go when the
+     * last one does: a process that is done with its structs gets the memory back, one that works in a loop keeps a struct
+     * alive anyway.  Both pools lock themselves: a struct created in the meantime at worst re-creates what it asks for next
+     * (a table a thread is about to launch with is pinned and stays, s3d_gauss_tab.hip). */
+    if (live == 0) {
+        s3d_k_nn_release_scratch();
+        s3d_k_tap_tables_release();
     }
 }
 
@@ -1157,7 +1155,13 @@ int SIFT3D_extract_descriptors(SIFT3D *const sift3d, const Keypoint_store *const
     first = sift3d->gpyr.levels;
     desc->nx = first->nx; desc->ny = first->ny; desc->nz = first->nz;
     if (s3d_resize_descriptor_store(desc, (long)kp->slab.num)) return SIFT3D_FAILURE;
-    if (sift_ctx(sift3d)->pyramid_on_slabs) return s3d_mgpu_describe(sift_ctx(sift3d)->mgpu, kp, desc->buf);
+    if (sift_ctx(sift3d)->pyramid_on_slabs) {
+        if (s3d_mgpu_describe(sift_ctx(sift3d)->mgpu, kp, desc->buf)) {
+            if (!s3d_mgpu_built(sift_ctx(sift3d)->mgpu)) sift_ctx(sift3d)->have_pyramid = sift_ctx(sift3d)->pyramid_on_slabs = 0;
+            return SIFT3D_FAILURE;
+        }
+        return SIFT3D_SUCCESS;
+    }
     if (describe_from_gpyr(sift3d, kp, desc->buf, 1)) return SIFT3D_FAILURE;
     fill_desc_coords(kp, desc->buf);
     return SIFT3D_SUCCESS;
@@ -1677,7 +1681,13 @@ int sift3d_amd_download_pyramid(SIFT3D *const sift3d, int want_dog)
         if (want_dog)
             for (int i = 0; i < d->num_octaves * d->num_levels; i++)
                 if (im_resize(d->levels + i)) return SIFT3D_FAILURE;
-        return s3d_mgpu_download_pyramid(c->mgpu, sift3d, want_dog);
+        if (s3d_mgpu_download_pyramid(c->mgpu, sift3d, want_dog)) {
+            /* the rank threads and their slabs are gone (s3d_mgpu_download_pyramid tears a failed job down): say "no pyramid"
+             * to the next describe instead of sending it to slabs that no longer exist */
+            c->have_pyramid = c->pyramid_on_slabs = 0;
+            return SIFT3D_FAILURE;
+        }
+        return SIFT3D_SUCCESS;
     }
     for (int i = 0; i < g->num_octaves * g->num_levels; i++) {
         Image *lv = g->levels + i;

@@ -459,3 +459,33 @@ int print_Mat_rm(const Mat_rm *const mat)
     }
     return SIFT3D_SUCCESS;
 }
+
+/* ---- three one-liners that complete libimutil's non-OpenCL / non-DICOM / non-TPS export list ---------------------------- */
+/* imutil.c:678-693: the element type's C name into a caller's buffer (the strings are the contract) */
+void sprint_type_Mat_rm(const Mat_rm *const mat, char *const str)
+{
+    static const char *const names[] = {"double", "float", "int"};
+    const char *n = "<sprint_type_Mat_rm: unknown type>";
+    if (mat->type == SIFT3D_DOUBLE) n = names[0];
+    else if (mat->type == SIFT3D_FLOAT) n = names[1];
+    else if (mat->type == SIFT3D_INT) n = names[2];
+    strcpy(str, n);
+}
+
+/* imutil.c:1322-1337: a malloc'ed copy of `path` cut at its last file separator, where the
+ * path has one past its first character (the separator itself is cut off); a bare file name (or "/name") comes back whole,
+ * as upstream */
+char *im_get_parent_dir(const char *path)
+{
+    char *dir = strndup(path, FILENAME_MAX);
+    const char *sep = strrchr(path, '/');
+    if (dir != NULL && sep != NULL && sep > path) dir[sep - path] = '\0';
+    return dir;
+}
+
+/* imutil.c:4111-4116 */
+void err_exit(const char *str)
+{
+    S3D_MSG("Error! Exiting at %s \n", str);
+    exit(1);
+}

@@ -428,6 +428,9 @@ int sift3d_amd_slab_create(sift3d_amd_slab **out, const SIFT3D *params, const si
     return SIFT3D_SUCCESS;
 }
 
+static void planned_halo_bytes(const sift3d_amd_slab *sl, double *to_lo, double *to_hi, double *gather);
+static int halo_of_level(const sift3d_amd_slab *sl, int o, int k);
+
 /* The plan of rank `rank` of a `world`-way job without touching a device: partition, halo, sharded octaves and the bytes
  * sift3d_amd_slab_create would allocate (the candidate and descriptor lists a detect sizes later are not in it).  Fails,
  * with the message of the real call, where that would refuse the decomposition. */
@@ -460,6 +463,8 @@ int sift3d_amd_slab_get_info(const sift3d_amd_slab *sl, sift3d_amd_slab_info *in
     info->detect_ms = sl->detect_ms; info->describe_ms = sl->describe_ms;
     info->comm_ms = sl->comm_ms; info->halo_wait_ms = sl->halo_wait_ms;
     info->num_described = sl->num_described;
+    planned_halo_bytes(sl, &info->plan_send_lo_bytes, &info->plan_send_hi_bytes, &info->plan_seed_gather_bytes);
+    for (int k = 0; k < 8; k++) info->plan_halo_planes[k] = k < sl->nl && sl->o_shard >= 0 ? halo_of_level(sl, 0, k) : 0;
     return SIFT3D_SUCCESS;
 }
 
@@ -522,6 +527,18 @@ static int finish_halos(sift3d_amd_slab *sl)
     return SIFT3D_SUCCESS;
 }
 
+/* Planes beyond its centre plane that a keypoint of GSS level k (k = 1 .. nkp <-> s = 0 .. nkp-1) reads, in octave voxels
+ * -- the same number in every octave: the descriptor window's radius is 2 * 7.0711 * sd physical units (sift.c:1846-1847)
+ * with sd = sigma0 2^((k - 1) / nkp) times the octave's voxel size, plus the gradient stencil and the rounding of the
+ * bounds (+ 3); the orientation window (4.5 sd) lies inside it.  Default parameters: 26 / 32 / 39 planes for k = 1 / 2 / 3
+ * (rounds 2-4 shipped the largest, 39 = sl->H, for all three: 17 % more halo bytes). */
+static int window_reach(const sift3d_amd_slab *sl, int k)
+{
+    const double sd = sl->plan.gpyr.sigma0 * pow(2.0, (double)(k - 1) / sl->nkp);
+    const int w = (int)ceil(2.0 * 7.071067812 * sd / sl->units[2]) + 3;
+    return w < sl->H ? w : sl->H;
+}
+
 /* halo planes level k of a sharded octave needs from each neighbour once it is complete */
 static int halo_of_level(const sift3d_amd_slab *sl, int o, int k)
 {
@@ -530,8 +547,29 @@ static int halo_of_level(const sift3d_amd_slab *sl, int o, int k)
         const int rch = filter_reach(sl, &sl->plan.gss.gauss_octave[k].f, o);
         if (rch > h) h = rch;                               /* the next Gaussian's reach */
     }
-    if (k >= 1 && k <= sl->nkp && sl->H > h) h = sl->H;      /* levels s = 0..nkp-1: orientation + descriptor windows */
+    if (k >= 1 && k <= sl->nkp) {                            /* levels s = 0..nkp-1: orientation + descriptor windows */
+        const int w = window_reach(sl, k);
+        if (w > h) h = w;
+    }
     return h;
+}
+
+/* What a detect of this plan moves over the links: bytes this rank SENDS to its lower / upper neighbour (it receives the
+ * same amounts), and its share of the seed all-gather of the first replicated octave.  Mirrors build_pyramid's exchanges. */
+static void planned_halo_bytes(const sift3d_amd_slab *sl, double *to_lo, double *to_hi, double *gather)
+{
+    const int G = sl->t.world;
+    double planes_b = 0.0;
+    *to_lo = *to_hi = *gather = 0.0;
+    if (G == 1) return;
+    planes_b += (double)filter_reach(sl, &sl->plan.gss.first_gauss.f, 0) * sl->nx * sl->ny * sizeof(float);
+    for (int o = 0; o <= sl->o_shard && o < sl->no; o++) {
+        const double pb = (double)sl->dims[o][0] * sl->dims[o][1] * sizeof(float);
+        for (int k = 0; k < sl->nl; k++) planes_b += (double)halo_of_level(sl, o, k) * pb;
+    }
+    if (sl->t.rank > 0) *to_lo = planes_b;
+    if (sl->t.rank < G - 1) *to_hi = planes_b;
+    if (sl->o_shard + 1 < sl->no) *gather = (double)(G - 1) * sl->seed_elems * sizeof(float);
 }
 
 /* d_div != NULL: the source is divided by *d_div as it is loaded (im_scale folded into the first filter; the caller has
@@ -1324,6 +1362,7 @@ struct s3d_mgpu {
 extern int sift3d_amd_rccl_create_all(int world, const int *devices, sift3d_amd_transport *t) __attribute__((weak));
 
 int s3d_mgpu_wanted(const struct s3d_mgpu *m) { return m ? m->ngpu : 0; }
+int s3d_mgpu_built(const struct s3d_mgpu *m) { return m ? m->built : 0; }
 
 static void mgpu_teardown(struct s3d_mgpu *m)
 {
@@ -1520,6 +1559,16 @@ static int slab_download(sift3d_amd_slab *sl, SIFT3D *host, int want_dog)
     int rc = SIFT3D_FAILURE;
     if (host->gpyr.num_octaves != sl->no || host->gpyr.num_levels != sl->nl)
         SLAB_FAIL("sift3d_amd slab: the host pyramid does not have the slab's shape");
+    /* every host level is checked before anything is allocated or copied: the failure paths below are device errors only */
+    for (int o = 0; o < sl->no; o++) {
+        const int ndog = want_dog ? host->dog.num_levels : 0;
+        for (int k = 0; k < sl->nl + ndog; k++) {
+            const Image *hl = k < sl->nl ? host->gpyr.levels + o * sl->nl + k : host->dog.levels + o * host->dog.num_levels + (k - sl->nl);
+            if (hl->data == NULL || hl->nx != sl->dims[o][0] || hl->ny != sl->dims[o][1] || hl->nz != sl->dims[o][2])
+                SLAB_FAIL("sift3d_amd slab: host %s level (%d, %d) is not sized for the download", k < sl->nl ? "GSS" : "DoG", o,
+                          k < sl->nl ? k : k - sl->nl);
+        }
+    }
     for (int o = 0; o < sl->no; o++) {
         const size_t pe = (size_t)sl->dims[o][0] * sl->dims[o][1];
         const int sharded = G > 1 && o <= sl->o_shard;
@@ -1528,8 +1577,6 @@ static int slab_download(sift3d_amd_slab *sl, SIFT3D *host, int want_dog)
         if ((!sharded && rank != 0) || z1 <= z0) continue;
         for (int k = 0; k < sl->nl; k++) {
             Image *hl = host->gpyr.levels + o * sl->nl + k;
-            if (hl->data == NULL || hl->nx != sl->dims[o][0] || hl->ny != sl->dims[o][1] || hl->nz != sl->dims[o][2])
-                SLAB_FAIL("sift3d_amd slab: host level (%d, %d) is not sized for the download", o, k);
             if (s3d_rt_d2h(hl->data + (size_t)z0 * pe, lev_ptr(&sl->lev[o * sl->nl + k], z0), n * sizeof(float), sl->cs)) goto out;
         }
         if (!want_dog) continue;
@@ -1541,8 +1588,6 @@ static int slab_download(sift3d_amd_slab *sl, SIFT3D *host, int want_dog)
         }
         for (int k = 0; k < host->dog.num_levels; k++) {
             Image *hl = host->dog.levels + o * host->dog.num_levels + k;
-            if (hl->data == NULL || hl->nx != sl->dims[o][0] || hl->ny != sl->dims[o][1] || hl->nz != sl->dims[o][2])
-                SLAB_FAIL("sift3d_amd slab: host DoG level (%d, %d) is not sized for the download", o, k);
             if (s3d_k_subtract(lev_ptr(&sl->lev[o * sl->nl + k], z0), lev_ptr(&sl->lev[o * sl->nl + k + 1], z0), d_tmp, n, sl->cs) ||
                 s3d_rt_d2h(hl->data + (size_t)z0 * pe, d_tmp, n * sizeof(float), sl->cs) || s3d_rt_sync(sl->cs))
                 goto out;

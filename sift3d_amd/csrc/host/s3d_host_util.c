@@ -194,40 +194,40 @@ void init_GSS_filters(GSS_filters *const gss)
     gss->first_gauss.f.kernel = NULL;
 }
 
-void cleanup_GSS_filters(GSS_filters *const gss) /* imutil.c:3806-3828 */
+/* Drops whatever bank `gss` holds and leaves it empty (reusable, unlike upstream's: imutil.c:3806-3828) */
+void cleanup_GSS_filters(GSS_filters *const gss)
 {
-    if (gss->num_filters < 1) return;
-    cleanup_Gauss_filter(&gss->first_gauss);
-    for (int i = 0; i < gss->num_filters; i++) cleanup_Gauss_filter(gss->gauss_octave + i);
-    free(gss->gauss_octave);
-    gss->gauss_octave = NULL;
-    gss->num_filters = -1;
+    const int held = gss->num_filters;
+    Gauss_filter *const bank = gss->gauss_octave;
+    if (held >= 1) {
+        cleanup_Gauss_filter(&gss->first_gauss);
+        for (Gauss_filter *g = bank; g != bank + held; g++) cleanup_Gauss_filter(g);
+        free(bank);
+    }
+    init_GSS_filters(gss);
 }
 
-/* Filter bank from the OCTAVE-0 scales of pyr, reused by every octave (imutil.c:3752-3802) */
+/* The filter bank of a pyramid (imutil.c:3752-3802).  The scales form ONE chain -- sigma_n (the input's nominal blur), then
+ * the level scales of the first octave in order -- and filter j takes link j of the chain to link j + 1: link 0 is
+ * first_gauss (input -> first level), links 1 .. num_levels - 1 are gauss_octave[0 ..], which every octave reuses because
+ * the level scales repeat relative to the octave's voxel size. */
 int make_gss(GSS_filters *const gss, const Pyramid *const pyr)
 {
-    const int num_filters = pyr->num_levels - 1;
-    const int first_level = pyr->first_level;
-    const int last_level = pyr->first_level + pyr->num_levels - 1;
-    const Image *next;
-    if (num_filters < 1) {
+    const int links = pyr->num_levels;                       /* chain of num_levels + 1 scales */
+    double from = pyr->sigma_n;
+    if (links < 2) {
         S3D_MSG("make_gss: pyr has only %d levels, must have at least 2", pyr->num_levels);
         return SIFT3D_FAILURE;
     }
     cleanup_GSS_filters(gss);
-    init_GSS_filters(gss);
-    gss->num_filters = num_filters;
-    gss->first_level = first_level;
-    if ((gss->gauss_octave = (Gauss_filter *)calloc((size_t)num_filters, sizeof(Gauss_filter))) == NULL)
-        return SIFT3D_FAILURE;
-    next = SIFT3D_PYR_IM_GET(pyr, pyr->first_octave, first_level);
-    if (init_Gauss_incremental_filter(&gss->first_gauss, pyr->sigma_n, next->s, 3)) return SIFT3D_FAILURE;
-    for (int s = first_level; s < last_level; s++) {
-        const Image *cur = SIFT3D_PYR_IM_GET(pyr, pyr->first_octave, s);
-        next = SIFT3D_PYR_IM_GET(pyr, pyr->first_octave, s + 1);
-        if (init_Gauss_incremental_filter(gss->gauss_octave + (s - first_level), cur->s, next->s, 3))
-            return SIFT3D_FAILURE;
+    if ((gss->gauss_octave = (Gauss_filter *)calloc((size_t)(links - 1), sizeof(Gauss_filter))) == NULL) return SIFT3D_FAILURE;
+    gss->num_filters = links - 1;
+    gss->first_level = pyr->first_level;
+    for (int j = 0; j < links; j++) {
+        const double to = SIFT3D_PYR_IM_GET(pyr, pyr->first_octave, pyr->first_level + j)->s;
+        Gauss_filter *const dst = j == 0 ? &gss->first_gauss : gss->gauss_octave + (j - 1);
+        if (init_Gauss_incremental_filter(dst, from, to, 3)) return SIFT3D_FAILURE;
+        from = to;
     }
     return SIFT3D_SUCCESS;
 }

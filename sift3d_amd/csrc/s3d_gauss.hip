@@ -404,7 +404,13 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
     const int hw = width / 2;
     const int uhw = (int)ceilf((float)hw * uf);
     /* the reference indexes out of bounds here; refuse instead */
-    if (uhw >= dims[axis] - 1) S3D_FAIL("image too small for this filter along the axis");
+    if (uhw >= dims[axis] - 1) {
+        char m[300];
+        snprintf(m, sizeof(m), "image too small for this filter along axis %d: %d voxels, but the %d taps at %g voxels apart reach "
+                 "%d voxels to either side and the pass needs n >= ceil(hw * spacing) + 2 = %d (the reference reads outside "
+                 "the row here, imutil.c:2355-2393)", axis, dims[axis], width, (double)uf, uhw, uhw + 2);
+        S3D_FAIL(m);
+    }
     if (d_src == d_dst) S3D_FAIL("in-place axis pass is not supported");
     if (d_div) {                                          /* only the table-driven x pass divides on load */
         const int r = nc == 1 && axis == 0 ? s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, 0, z0, z1, taps, width, uf, uhw, d_div, st) : 1;

@@ -92,15 +92,34 @@ struct TapTab {
     int dev, n, hw, uhw, W;
     unsigned uf_bits;
     int *d_m, *d_xlo, *d_xfr;                              /* nullptr: unusable (flag set or allocation failed) */
+    int pins;                                              /* callers between tap_table() and their launch (under g_tab_lock) */
+    unsigned long long last_use;
 };
 
 #define TAB_CACHE 256
 static TapTab g_tab[TAB_CACHE];
 static int g_ntab = 0;
+static unsigned long long g_tab_clock = 0;
 static std::mutex g_tab_lock;
 
-/* The table of (n, hw, uf) on the current device; built (and waited for) the first time it is asked for, so that any
- * stream may use it afterwards.  nullptr: not available -- the caller takes another kernel. */
+/* the slot's device memory goes back: hipFree waits for the device, i.e. for every kernel that reads the table */
+static void tap_free_locked(TapTab *t)
+{
+    if (t->d_m == nullptr) return;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(t->dev) == hipSuccess) hipFree(t->d_m - 4);
+    if (have) hipSetDevice(cur);
+    t->d_m = t->d_xlo = t->d_xfr = nullptr;
+}
+
+/* The table of (n, hw, uf) on the current device, PINNED: built (and waited for) the first time it is asked for, so that any
+ * stream may use it afterwards; the caller launches and then calls tap_unpin (TapPin below does).  nullptr: not available
+ * -- the caller takes another kernel.  The cache holds TAB_CACHE tables; a long-lived process that walks through more
+ * distinct (extent, filter, spacing) triples than that -- scans of ever different slice counts -- evicts the least recently
+ * used unpinned one (rounds 3-4 stopped building tables at that point, and every later shape silently took the slow
+ * kernels).  A pinned table is never freed, neither by eviction nor by s3d_k_tap_tables_release: a thread that works
+ * through the flat device API while another drops the process's last SIFT3D struct keeps what it is about to launch with. */
 static const TapTab *tap_table(int n, int hw, float uf, int uhw)
 {
     int dev = 0;
@@ -109,12 +128,25 @@ static const TapTab *tap_table(int n, int hw, float uf, int uhw)
     memcpy(&ub, &uf, 4);
     std::lock_guard<std::mutex> guard(g_tab_lock);
     for (int i = 0; i < g_ntab; i++)
-        if (g_tab[i].dev == dev && g_tab[i].n == n && g_tab[i].hw == hw && g_tab[i].uf_bits == ub)
-            return g_tab[i].d_m ? &g_tab[i] : nullptr;
-    if (g_ntab == TAB_CACHE) return nullptr;               /* more distinct passes than any pyramid has: no new tables */
+        if (g_tab[i].dev == dev && g_tab[i].n == n && g_tab[i].hw == hw && g_tab[i].uf_bits == ub) {
+            if (g_tab[i].d_m == nullptr) return nullptr;
+            g_tab[i].pins++;
+            g_tab[i].last_use = ++g_tab_clock;
+            return &g_tab[i];
+        }
+    int slot = g_ntab;
+    if (g_ntab == TAB_CACHE) {                             /* full: the least recently used table nobody is about to use */
+        slot = -1;
+        for (int i = 0; i < g_ntab; i++)
+            if (g_tab[i].pins == 0 && (slot < 0 || g_tab[i].last_use < g_tab[slot].last_use)) slot = i;
+        if (slot < 0) return nullptr;
+        tap_free_locked(&g_tab[slot]);
+    }
     TapTab t;
     t.dev = dev; t.n = n; t.hw = hw; t.uhw = uhw; t.W = 2 * uhw + 2 + 2 * TAB_MW; t.uf_bits = ub;
     t.d_m = t.d_xlo = t.d_xfr = nullptr;
+    t.pins = 0;
+    t.last_use = ++g_tab_clock;
     const int NT = 2 * hw + 1;
     const size_t words = (size_t)n * NT, mwords = (size_t)n * (4 * NT + 1);
     int *blk = nullptr;
@@ -138,21 +170,54 @@ static const TapTab *tap_table(int n, int hw, float uf, int uhw)
             hipFree(blk);
         }
     }
-    g_tab[g_ntab] = t;
-    return g_tab[g_ntab++].d_m ? &g_tab[g_ntab - 1] : nullptr;
+    g_tab[slot] = t;
+    if (slot == g_ntab) g_ntab++;
+    if (g_tab[slot].d_m == nullptr) return nullptr;
+    g_tab[slot].pins = 1;
+    return &g_tab[slot];
 }
 
-/* device memory held by the tables of every device goes back (called with the last context of the process) */
+static void tap_unpin(const TapTab *t)
+{
+    if (t == nullptr) return;
+    std::lock_guard<std::mutex> guard(g_tab_lock);
+    TapTab *m = const_cast<TapTab *>(t);
+    if (m->pins > 0) m->pins--;
+}
+
+struct TapPin {                                            /* unpins when the launching function returns */
+    const TapTab *t;
+    explicit TapPin(const TapTab *p) : t(p) {}
+    ~TapPin() { tap_unpin(t); }
+    TapPin(const TapPin &) = delete;
+    TapPin &operator=(const TapPin &) = delete;
+};
+
+/* device memory held by the tables of every device goes back (called with the last context of the process); a table some
+ * thread is about to launch with stays, its slot too */
 extern "C" void s3d_k_tap_tables_release(void)
 {
     std::lock_guard<std::mutex> guard(g_tab_lock);
-    int cur = 0;
-    const bool have = hipGetDevice(&cur) == hipSuccess;
-    for (int i = 0; i < g_ntab; i++)
-        if (g_tab[i].d_m && hipSetDevice(g_tab[i].dev) == hipSuccess) hipFree(g_tab[i].d_m - 4);
-    if (have) hipSetDevice(cur);
-    g_ntab = 0;
+    for (int i = 0; i < g_ntab; i++) {                     /* (slots never move: a pinned caller holds a pointer into the array) */
+        if (g_tab[i].pins > 0) continue;
+        tap_free_locked(&g_tab[i]);
+        g_tab[i].dev = -1;                                 /* matches no device: the slot is the first to be reused */
+        g_tab[i].last_use = 0;
+    }
+    while (g_ntab > 0 && g_tab[g_ntab - 1].dev == -1) g_ntab--;
 }
+
+#if defined(S3D_TESTING)
+/* test aid: tables in the cache / how many of them hold device memory */
+extern "C" void s3d_k_tap_tables_stats(int *slots, int *live)
+{
+    std::lock_guard<std::mutex> guard(g_tab_lock);
+    int l = 0;
+    for (int i = 0; i < g_ntab; i++) l += g_tab[i].d_m != nullptr;
+    if (slots) *slots = g_ntab;
+    if (live) *live = l;
+}
+#endif
 
 /* ---- marching pass (y or z) ---------------------------------------------------------------------------------------
  * A workgroup is MW waves on the SAME 64 float4 columns; output rows are dealt to them round-robin (group g = rows
@@ -453,7 +518,9 @@ static int tab_eligible(int nx, int ny, int nz, int axis, int z0, int z1, int hw
 extern "C" int s3d_k_conv_x_tab_available(int nx, int ny, int nz, int width, float uf, int uhw)
 {
     if (!(width & 1) || !tab_eligible(nx, ny, nz, 0, 0, nz, width / 2, uhw)) return 0;
-    return tap_table(nx, width / 2, uf, uhw) != nullptr;
+    const TapTab *t = tap_table(nx, width / 2, uf, uhw);
+    tap_unpin(t);
+    return t != nullptr;
 }
 
 /* d_div != NULL (axis 0 only): the source is divided by *d_div as it is loaded */
@@ -465,6 +532,7 @@ extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int
     if (!tab_eligible(nx, ny, nz, axis, z0, z1, hw, uhw) || (d_div && axis != 0)) return 1;
     const TapTab *t = tap_table(dims[axis], hw, uf, uhw);
     if (!t) return 1;
+    TapPin pin(t);                                         /* until the launch below has been enqueued */
     S3dTaps tp;
     memset(&tp, 0, sizeof(tp));
     memcpy(tp.t, taps, sizeof(float) * width);

@@ -37,6 +37,7 @@ struct Api {
     decltype(&ncclGroupStart) GroupStart;
     decltype(&ncclGroupEnd) GroupEnd;
     decltype(&ncclGetErrorString) GetErrorString;
+    const char *(*GetLastError)(ncclComm_t);     /* optional (RCCL >= 2.13): the library's own account of its last failure */
 };
 Api g_api;
 pthread_mutex_t g_api_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -63,6 +64,7 @@ int load_api()
             S3D_SYM(CommCount) S3D_SYM(GetVersion) S3D_SYM(AllReduce)
             S3D_SYM(AllGather) S3D_SYM(Send) S3D_SYM(Recv) S3D_SYM(GroupStart) S3D_SYM(GroupEnd) S3D_SYM(GetErrorString)
 #undef S3D_SYM
+            g_api.GetLastError = (const char *(*)(ncclComm_t))dlsym(h, "ncclGetLastError");
             if (rc == S3D_OK) g_api.h = h;
             else dlclose(h);
         }
@@ -71,13 +73,23 @@ int load_api()
     return rc;
 }
 
+/* A failed RCCL call leaves "<call>: <ncclGetErrorString> -- <ncclGetLastError>" as the device layer's error text (and on
+ * stderr): the second part is RCCL's own description of what went wrong (a refused peer, a transport it could not set up),
+ * which is what a first contact with a new fabric needs; NCCL_DEBUG=WARN in the environment adds RCCL's warnings. */
+static int nccl_failed(const char *call, ncclResult_t r)
+{
+    char m[400];
+    const char *last = g_api.GetLastError ? g_api.GetLastError(nullptr) : nullptr;
+    snprintf(m, sizeof(m), "%s%s%s", g_api.GetErrorString(r), last && last[0] ? " -- " : "", last && last[0] ? last : "");
+    s3d_rt_set_error(call, m);
+    fprintf(stderr, "sift3d_amd rccl: %s: %s\n", call, m);
+    return S3D_ERR;
+}
+
 #define S3D_NCCL(call)                                                     \
     do {                                                                   \
         ncclResult_t r_ = (call);                                          \
-        if (r_ != ncclSuccess) {                                           \
-            s3d_rt_set_error(#call, g_api.GetErrorString(r_));             \
-            return S3D_ERR;                                                \
-        }                                                                  \
+        if (r_ != ncclSuccess) return nccl_failed(#call, r_);              \
     } while (0)
 
 /* Staging for the host-side all-gathers (keypoint records, descriptor records, the second unique id): allocated ONCE

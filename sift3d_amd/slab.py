@@ -45,7 +45,24 @@ class SlabInfo(C.Structure):               # sift3d_amd_slab_info
                 ("halo", C.c_int), ("num_octaves", C.c_int), ("num_levels", C.c_int), ("num_candidates", C.c_long),
                 ("num_keypoints", C.c_long), ("halo_bytes", C.c_double), ("device_bytes", C.c_double), ("detect_ms", C.c_double),
                 ("describe_ms", C.c_double), ("comm_ms", C.c_double), ("halo_wait_ms", C.c_double),
-                ("num_described", C.c_long)]
+                ("num_described", C.c_long), ("plan_send_lo_bytes", C.c_double), ("plan_send_hi_bytes", C.c_double),
+                ("plan_seed_gather_bytes", C.c_double), ("plan_halo_planes", C.c_int * 8)]
+
+
+def _last_errors(L) -> str:
+    """What the C driver and the device layer (incl. RCCL: "<call>: <ncclGetErrorString> -- <ncclGetLastError>") last said on
+    the calling thread -- a first-contact problem with a fabric has to be readable from a failed run's stderr."""
+    out = []
+    for fn in ("sift3d_amd_slab_last_error", "s3d_rt_last_error"):
+        try:
+            f = getattr(L, fn)
+            f.restype = C.c_char_p
+            m = f()
+            if m:
+                out.append(m.decode("utf-8", "replace"))
+        except Exception:                                   # noqa: BLE001
+            pass
+    return " | ".join(out) if out else "(no message)"
 
 
 def bind(L: C.CDLL) -> C.CDLL:
@@ -289,7 +306,7 @@ class Slab:
         """vol: device address (on_device) or a float32 numpy array of this rank's base slices [z0, z1)."""
         ptr = vol if on_device else np.ascontiguousarray(vol, np.float32).ctypes.data
         if self.L.sift3d_amd_slab_detect(self.h, ptr, 1 if on_device else 0, C.byref(self.kp)) != 0:
-            raise RuntimeError("sift3d_amd_slab_detect failed")
+            raise RuntimeError("sift3d_amd_slab_detect failed: " + _last_errors(self.L))
         return int(self.kp.slab.num)
 
     def describe(self, to_host: bool = True) -> int:
@@ -297,7 +314,7 @@ class Slab:
         rc = self.L.sift3d_amd_slab_describe(self.h, C.byref(self.kp), C.byref(self.desc) if to_host else None,
                                              C.byref(self.d_desc))
         if rc != 0:
-            raise RuntimeError("sift3d_amd_slab_describe failed")
+            raise RuntimeError("sift3d_amd_slab_describe failed: " + _last_errors(self.L))
         return self.d_desc.value or 0
 
     def gather(self, with_desc: bool = True):

@@ -135,14 +135,16 @@ def test_denseSift3D_emulated(progs, oracle, tmp_path, emu_env):
 
 
 @pytest.mark.gpu
-def test_denseSift3D_end_to_end(progs, oracle, tmp_path):
-    _dense_end_to_end(progs, oracle, tmp_path, (22, 20, 18), None)
+@pytest.mark.parametrize("dims,units", [((22, 20, 18), (1.0, 1.0, 2.0)),
+                                        ((80, 72, 66), (0.8, 0.8, 1.5)),      # anisotropic slices: the generic 12-channel passes
+                                        ((96, 64, 64), (1.0, 1.0, 1.0))])     # unit voxels: the fused front end (k_bary_x_wave) + marches
+def test_denseSift3D_end_to_end(progs, oracle, tmp_path, dims, units):
+    _dense_end_to_end(progs, oracle, tmp_path, dims, None, units)
 
 
-def _dense_end_to_end(progs, oracle, tmp_path, dims, env):
+def _dense_end_to_end(progs, oracle, tmp_path, dims, env, units=(1.0, 1.0, 2.0)):
     nx, ny, nz = dims
-    units = (1.0, 1.0, 2.0)
-    vol = synth.blobs(nx, ny, nz, 30, 5) * 37.0 + 3.0
+    vol = synth.blobs(nx, ny, nz, max(30, nx * ny * nz // 2000), 5) * 37.0 + 3.0
     src = str(tmp_path / "vol.nii")
     open(src, "wb").write(nifti1_bytes(np.ascontiguousarray(vol.transpose(2, 1, 0)), units))
     r = run(progs["denseSift3D"], src, str(tmp_path / "d" / "bin%.nii.gz"), env=env)

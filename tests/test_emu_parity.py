@@ -357,3 +357,27 @@ def test_seqmax_kernels(emu):
     finally:
         for p_ in (d_a, d_b, d_m, d_rec):
             dev.free(p_)
+
+
+def test_tap_table_cache_evicts(emu, oracle):
+    """The table cache of the table-driven Gaussian passes holds 256 tables.  A process that walks through more distinct
+    (extent, filter, spacing) triples than that keeps getting tables -- the least recently used one goes -- instead of being
+    refused from then on (rounds 3-4: every later shape silently took the slow kernels); a filter over an extent whose table
+    was evicted in between still equals the oracle."""
+    L = emu.sift
+    L.s3d_k_conv_x_tab_available.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.s3d_k_tap_tables_stats.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    L.s3d_k_gauss_set_mode(8)
+    try:
+        assert parity.check_sep_fir_tab(emu, oracle, (23, 19, 17), (1, 0.7, 1.3), (0.973294,)) == 3     # three tables of its own
+        for nx in range(30, 330):                                                # 300 more: the cache wraps
+            assert L.s3d_k_conv_x_tab_available(nx, 9, 9, 5, 1.25, 3) == 1, nx
+        slots, live = C.c_int(), C.c_int()
+        L.s3d_k_tap_tables_stats(C.byref(slots), C.byref(live))
+        assert slots.value == 256 and live.value == 256
+        assert L.s3d_k_conv_x_tab_available(30, 9, 9, 5, 1.25, 3) == 1           # evicted long ago: rebuilt
+        assert parity.check_sep_fir_tab(emu, oracle, (23, 19, 17), (1, 0.7, 1.3), (0.973294,)) == 3
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+        L.s3d_k_tap_tables_release()

@@ -393,3 +393,39 @@ def test_im_permute_restride_upsample_grid_like_the_reference(lib, reference):
             assert np.isfinite(a).all()
         else:
             assert np.array_equal(mine[k][0], ref[k][0]) and mine[k][1:] == ref[k][1:], k
+
+
+def test_small_string_helpers(lib, reference):
+    """sprint_type_Mat_rm, im_get_parent_dir and err_exit (imutil.c:678, 1322, 4112): the last libimutil exports outside
+    OpenCL / DICOM / TPS -- same strings as the reference, err_exit ends the process with status 1."""
+    import subprocess
+    import sys
+    for u in (lib.sift, reference.imutil):
+        u.sprint_type_Mat_rm.argtypes = [P(abi.Mat_rm), C.c_char_p]
+        u.sprint_type_Mat_rm.restype = None
+        u.im_get_parent_dir.argtypes = [C.c_char_p]
+        u.im_get_parent_dir.restype = C.c_void_p
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    def parent(u, path):
+        p_ = u.im_get_parent_dir(path.encode())
+        s_ = C.string_at(p_).decode()
+        libc.free(p_)
+        return s_
+
+    for typ in (0, 1, 2, 7):
+        got = []
+        for u in (lib.sift, reference.imutil):
+            m = abi.Mat_rm()
+            m.type = typ
+            buf = C.create_string_buffer(64)
+            u.sprint_type_Mat_rm(C.byref(m), buf)
+            got.append(buf.value)
+        assert got[0] == got[1], typ
+    for path in ("a/b/c.nii.gz", "/abs/file.csv", "file.nii", "/file", "dir/", "a//b", "", "x/y/"):
+        assert parent(lib.sift, path) == parent(reference.imutil, path), path
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.err_exit.argtypes = [ctypes.c_char_p]; "
+            "L.err_exit(b'the test'); print('survived')")
+    r = subprocess.run([sys.executable, "-c", code, sift3d_amd.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 1 and "survived" not in r.stdout and "Error! Exiting at the test" in r.stderr

@@ -118,6 +118,16 @@ def test_bench_dry_run_plans_without_a_device():
         assert wk["volume"] == [512, 512, 512 * N] and wk["slices_per_rank"] == [512] * N
         assert st["halo_planes"] == 39 and min(st["slices_per_rank"]) >= st["halo_planes"]
         assert 1 <= st["sharded_octaves"] <= st["octaves"] == 8 and st["fits_288_GB"] and max(st["HBM_GiB_per_rank"]) < 64
+        # per-level halo thickness: a filter's reach for the plain levels, the level's OWN window reach for the keypoint levels
+        assert st["halo_planes_per_level_octave0"] == [3, 26, 32, 39, 8, 1]
+        links = st["per_rank_links"]
+        assert len(links) == N and links[0]["send_lo_MB"] == 0.0 and links[-1]["send_hi_MB"] == 0.0
+        assert all(l["halo_bytes_per_link"] > 0 and 0 < l["link_ms_at_153GBs"] < l["link_ms_at_60GBs"] for l in links)
+        plane = 1024 * 1024 * 4
+        per_side_octave0 = (3 + 3 + 26 + 32 + 39 + 8 + 1) * plane       # first filter's reach + the six levels
+        assert links[0]["halo_bytes_per_link"] >= per_side_octave0
+        tm = st["time_model"]
+        assert abs(tm["ideal_detect_ms_per_rank"] * N - tm["single_gpu_detect_ms"]) < 0.05 * N and tm["worst_link_ms_at_60GBs"] > tm["worst_link_ms_at_153GBs"] > 0
     assert rec["plans"]["8"]["strong"]["sharded_octaves"] == 2                     # slabs of 128, 64 slices; octaves >= 2 replicated
     assert "thinner than the descriptor halo" in rec["refusal_example"]["refused"]
     # a job that cannot be decomposed: refused in the plan, not at run time
