@@ -1415,6 +1415,17 @@ int im_downsample_2x(const Image *const src, Image *const dst) /* imutil.c:1742 
     return rc;
 }
 
+/* 1 / 0: some voxel of the device volume is a NaN or an infinity (the sticky maximum's bit pattern), -1 on a device error.
+ * One reduction and a 4-byte copy: the raw-image and dense entry points are not the hot path, they ask before they start. */
+static int volume_nonfinite(s3d_ctx *c, const float *d_v, size_t n)
+{
+    uint32_t bits = 0;
+    if (s3d_k_absmax(d_v, n, c->d_red + 3, c->stream) || s3d_rt_d2h(&bits, c->d_red + 3, sizeof(bits), c->stream) ||
+        s3d_rt_sync(c->stream))
+        return -1;
+    return (bits & 0x7fffffffu) >= 0x7f800000u;
+}
+
 /* ---- raw-image variants (sift.c:1978-2006, 2131-2195, 1534-1604) --------------------------------------- */
 /* smooth_scale_raw_input on the device: d_out = im_scale(G_{sigma_n -> sigma0}(d_in)) */
 static int smooth_scale_raw_dev(const SIFT3D *sift3d, s3d_ctx *c, const float *d_in, float *d_out, float *d_tmp,
@@ -1427,8 +1438,22 @@ static int smooth_scale_raw_dev(const SIFT3D *sift3d, s3d_ctx *c, const float *d
     if (init_Gauss_incremental_filter(&gauss, sift3d->gpyr.sigma_n, sift3d->gpyr.sigma0, IM_NDIMS))
         return SIFT3D_FAILURE;
     unit_factors(units, 1.0, uf);
-    rc = s3d_k_sep_fir(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, c->stream) ||
-         s3d_k_absmax(d_out, n, c->d_red + 2, c->stream) || s3d_k_scale_div(d_out, n, c->d_red + 2, c->stream);
+    {
+        /* a volume with non-finite voxels: the literal filter kernel and the sequential maximum (see detect_single) */
+        const int nf = volume_nonfinite(c, d_in, n);
+        if (nf < 0) { cleanup_Gauss_filter(&gauss); API_FAIL("sift3d_amd: raw smoothing failed: %s", s3d_rt_last_error()); }
+        if (nf) {
+            const int mode = s3d_k_gauss_get_mode();
+            s3d_k_gauss_set_mode(64);
+            rc = s3d_k_sep_fir_path(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, 1, c->stream) ||
+                 s3d_k_seqmax(d_out, NULL, n, c->d_red + 2, c->d_red + RED_REC, c->stream) ||
+                 s3d_k_scale_div(d_out, n, c->d_red + 2, c->stream);
+            s3d_k_gauss_set_mode(mode);
+        } else {
+            rc = s3d_k_sep_fir(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, c->stream) ||
+                 s3d_k_absmax(d_out, n, c->d_red + 2, c->stream) || s3d_k_scale_div(d_out, n, c->d_red + 2, c->stream);
+        }
+    }
     cleanup_Gauss_filter(&gauss);
     if (rc) API_FAIL("sift3d_amd: raw smoothing failed: %s", s3d_rt_last_error());
     return SIFT3D_SUCCESS;
@@ -1508,6 +1533,7 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
     double *d_sig = NULL, *d_conf = NULL;
     uint32_t *d_keep = NULL, *d_tags = NULL;
     void *d_oscr = NULL;
+    uint32_t ori_failed = 0;
     int rc = SIFT3D_FAILURE;
     if (s3d_verify_keys(kp, im->nx, im->ny, im->nz)) return SIFT3D_FAILURE;
     if (!s->kernels.downsample_2 && !(s->kernels.downsample_2 = ctx_new())) API_FAIL("sift3d_amd: out of device contexts");
@@ -1535,11 +1561,17 @@ int SIFT3D_assign_orientations(const SIFT3D *const sift3d, const Image *const im
     if (s3d_rt_h2d(d_centers, centers, num * 3 * sizeof(float), c->stream) ||
         s3d_rt_h2d(d_sig, sig, num * sizeof(double), c->stream) ||
         s3d_rt_h2d(d_tags, tags, num * sizeof(uint32_t), c->stream) ||
-        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, d_oscr, NULL, c->stream) ||
+        s3d_rt_memset(c->d_count + 2, 0, sizeof(uint32_t), c->stream) ||
+        s3d_k_orient(&pd, NULL, d_tags, d_centers, (uint32_t)num, d_sig, -1.0, d_R, d_keep, d_conf, d_oscr, c->d_count + 2, c->stream) ||
+        s3d_rt_d2h(&ori_failed, c->d_count + 2, sizeof(uint32_t), c->stream) ||
         s3d_rt_d2h(R, d_R, num * 9 * sizeof(float), c->stream) ||
         s3d_rt_d2h(keep, d_keep, num * sizeof(uint32_t), c->stream) ||
         s3d_rt_d2h(*conf, d_conf, num * sizeof(double), c->stream) || s3d_rt_sync(c->stream)) {
         S3D_MSG("SIFT3D_assign_orientations: device error: %s \n", s3d_rt_last_error());
+        goto done;
+    }
+    if (ori_failed) {      /* a NaN gradient in some keypoint's window: the reference's eigen_Mat_rm fails there (sift.c:1580-1598) */
+        S3D_MSG("SIFT3D_assign_orientations: a NaN voxel inside a keypoint's orientation window (eigen_Mat_rm fails in the reference) \n");
         goto done;
     }
     for (size_t i = 0; i < num; i++) {
@@ -1586,6 +1618,7 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
         uint32_t *d_keep = NULL;
         double *d_sig = NULL;
         void *d_oscr = NULL;
+        uint32_t ori_failed = 0;
         rc = SIFT3D_FAILURE;
         if (n >= 0x7FFFFFFFull) API_FAIL("sift3d_amd: volume too large for dense_rotate");
         if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n)) return SIFT3D_FAILURE;
@@ -1600,14 +1633,18 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
             s3d_rt_malloc((void **)&d_sig, sizeof(double)) == 0 &&
             s3d_rt_malloc(&d_oscr, s3d_k_orient_scratch_bytes((uint32_t)n)) == 0 &&
             s3d_rt_h2d(d_sig, &ori_sigma, sizeof(double), c->stream) == 0 &&
+            s3d_rt_memset(c->d_count + 2, 0, sizeof(uint32_t), c->stream) == 0 &&
             s3d_k_orient(&pd, NULL, NULL, NULL, (uint32_t)n, d_sig, sift3d->corner_thresh, d_R, d_keep, NULL,
-                         d_oscr, NULL, c->stream) == 0 &&
+                         d_oscr, c->d_count + 2, c->stream) == 0 &&
             s3d_k_dense_rot_hist(c->d_aux[1], nx, ny, nz, unitsf, sigma_win, d_R, d_keep, c->d_mesh, d_out,
                                  c->stream) == 0 &&
-            s3d_k_dense_post(d_out, d_in, n, c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
-            rc = SIFT3D_SUCCESS;
+            s3d_k_dense_post(d_out, d_in, n, c->stream) == 0 &&
+            s3d_rt_d2h(&ori_failed, c->d_count + 2, sizeof(uint32_t), c->stream) == 0 && s3d_rt_sync(c->stream) == 0)
+            rc = ori_failed ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
         else
             S3D_MSG("sift3d_amd: dense_rotate failed: %s\n", s3d_rt_last_error());
+        if (ori_failed)    /* sift.c:2553-2567: an orientation error at any voxel ends the call */
+            S3D_MSG("sift3d_amd: dense_rotate: a NaN voxel inside an orientation window (eigen_Mat_rm fails in the reference)\n");
         s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_sig); s3d_rt_free(d_oscr);
         return rc;
     }
@@ -1617,14 +1654,22 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
     if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units)) return SIFT3D_FAILURE;
     if (init_Gauss_filter(&gauss, sigma_win, 3)) return SIFT3D_FAILURE;
     unit_factors(out_units, 1.0, uf);                      /* quirk C-17: the OUTPUT image's entry units */
-    /* unit tap spacing: barycentric image + blur fused (the image never leaves LDS); otherwise the two steps */
-    rc = s3d_k_dense_bary_blur(c->d_aux[1], d_out, c->d_aux[2], nx, ny, nz, unitsf, uf, c->d_mesh, gauss.f.kernel,
-                               gauss.f.width, c->stream);
-    if (rc == 1)
-        rc = s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream) ||
-             s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream) ||
-             s3d_k_sep_fir(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,
-                           c->stream);
+    {
+        /* non-finite voxels (they survive the smoothing as NaNs): the two separate steps with the literal filter kernel */
+        const int nf = volume_nonfinite(c, c->d_aux[1], n);
+        const int mode = s3d_k_gauss_get_mode();
+        if (nf < 0) { cleanup_Gauss_filter(&gauss); API_FAIL("sift3d_amd: dense blur failed: %s", s3d_rt_last_error()); }
+        if (nf) s3d_k_gauss_set_mode(64);
+        /* unit tap spacing: barycentric image + blur fused (the image never leaves LDS); otherwise the two steps */
+        rc = nf ? 1 : s3d_k_dense_bary_blur(c->d_aux[1], d_out, c->d_aux[2], nx, ny, nz, unitsf, uf, c->d_mesh, gauss.f.kernel,
+                                            gauss.f.width, c->stream);
+        if (rc == 1)
+            rc = s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream) ||
+                 s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream) ||
+                 s3d_k_sep_fir_path(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,
+                                    nf ? 1 : 0, c->stream);
+        if (nf) s3d_k_gauss_set_mode(mode);
+    }
     cleanup_Gauss_filter(&gauss);
     if (rc) API_FAIL("sift3d_amd: dense blur failed: %s", s3d_rt_last_error());
     DEV(s3d_k_dense_post(d_out, d_in, n, c->stream));

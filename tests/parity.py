@@ -1079,3 +1079,44 @@ def oracle_detect_describe_or_fail(oracle, vol, units, params=None):
     finally:
         if params:
             oracle.set_params()
+
+
+DENSE_NONFINITE_CASES = [
+    ((26, 24, 22), (1.0, 1.0, 1.0), [((10, 11), (11, 12), (12, 13), np.nan)]),
+    ((26, 24, 22), (1.0, 1.0, 1.0), [((0, 1), (0, 1), (0, 1), np.nan), ((21, 22), (23, 24), (25, 26), np.nan)]),
+    ((26, 24, 22), (1.0, 1.0, 1.0), [((5, 6), (6, 7), (7, 8), np.inf)]),
+    ((24, 22, 20), (1.0, 0.8, 2.0), [((0, 5), (0, 22), (0, 24), np.nan)]),               # a masked slab
+    ((24, 22, 20), (1.0, 0.8, 2.0), [((9, 10), (10, 11), (11, 12), -np.inf), ((15, 16), (3, 4), (20, 21), np.nan)]),
+]
+
+
+def dense_or_fail(lib, vol, units, rotate=0):
+    """SIFT3D_extract_dense_descriptors; None when the call fails."""
+    s = abi.SIFT3D()
+    assert lib.sift.init_SIFT3D(C.byref(s)) == 0
+    s.dense_rotate = rotate
+    im = lib.image_from_numpy(vol, units)
+    out = abi.Image()
+    lib.imutil.init_im(C.byref(out))
+    rc = lib.sift.SIFT3D_extract_dense_descriptors(C.byref(s), C.byref(im), C.byref(out))
+    got = lib.image_to_numpy(out).copy() if rc == 0 else None
+    lib.free_image(im)
+    lib.free_image(out)
+    lib.sift.cleanup_SIFT3D(C.byref(s))
+    return got
+
+
+def check_dense_nonfinite(lib, want_fn, dims, units, edits):
+    """Dense descriptors of a volume with NaN / infinite voxels: dense_rotate = 0 -- NaNs in the same output elements,
+    every other element bit-identical to want_fn(vol, units) (the oracle's or the reference's); dense_rotate = 1 -- the
+    call fails where the reference's does (an orientation window with a NaN gradient)."""
+    vol = dense_input(dims, 5)
+    for (zs, ys, xs, val) in edits:
+        vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
+    got = dense_or_fail(lib, vol, units, 0)
+    want = want_fn(vol, units)
+    assert got is not None and want is not None
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"NaNs in different elements ({int(np.isnan(got).sum())} vs {int(np.isnan(want).sum())})"
+    fin = ~np.isnan(want)
+    assert np.array_equal(got[fin].view(np.uint32), want[fin].view(np.uint32)), "finite elements differ"
+    return int(np.isnan(want).sum())

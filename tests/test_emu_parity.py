@@ -381,3 +381,15 @@ def test_tap_table_cache_evicts(emu, oracle):
     finally:
         L.s3d_k_gauss_set_mode(0)
         L.s3d_k_tap_tables_release()
+
+
+@pytest.mark.parametrize("dims,units,edits", parity.DENSE_NONFINITE_CASES[:3])
+def test_dense_nonfinite(emu, oracle, dims, units, edits):
+    """SIFT3D_extract_dense_descriptors on volumes with NaN / infinite voxels: as the reference (the oracle is pinned to it
+    live in tests/test_oracle_vs_ref.py): same NaN elements, the rest bit-identical; dense_rotate = 1 fails as upstream."""
+    parity.check_dense_nonfinite(emu, lambda v, u: oracle.dense(v, u), dims, units, edits)
+    if edits is parity.DENSE_NONFINITE_CASES[0][2]:          # (an orientation per voxel is slow under the emulator: once)
+        vol = parity.dense_input(dims, 5)
+        for (zs, ys, xs, val) in edits:
+            vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
+        assert parity.dense_or_fail(emu, vol, units, 1) is None

@@ -796,3 +796,18 @@ def test_seqmax_kernels(lib):
     finally:
         for p_ in (d_a, d_b, d_m, d_rec):
             dev.free(p_)
+
+
+@pytest.mark.parametrize("dims,units,edits", parity.DENSE_NONFINITE_CASES + [
+    ((96, 80, 72), (1.0, 1.0, 1.0), [((40, 41), (41, 42), (50, 51), np.nan)]),            # past 64^3: the fused front end is what a finite volume takes
+    ((80, 72, 66), (0.8, 0.8, 1.5), [((0, 9), (0, 72), (0, 80), np.nan)])])
+def test_dense_nonfinite(lib, oracle, dims, units, edits):
+    """SIFT3D_extract_dense_descriptors on volumes with NaN / infinite voxels against the oracle (pinned to the reference on
+    such input by tests/test_oracle_vs_ref.py::test_dense_nonfinite_live): NaNs in the same output elements, every other
+    element bit-identical; dense_rotate = 1 fails as the reference does (a NaN inside an orientation window)."""
+    parity.check_dense_nonfinite(lib, lambda v, u: oracle.dense(v, u), dims, units, edits)
+    if dims[0] * dims[1] * dims[2] < 30000:
+        vol = parity.dense_input(dims, 5)
+        for (zs, ys, xs, val) in edits:
+            vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
+        assert parity.dense_or_fail(lib, vol, units, 1) is None

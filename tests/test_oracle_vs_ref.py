@@ -124,3 +124,16 @@ def test_nonfinite_golden_is_the_live_reference(reference):
         if w is not None:
             assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and nbitdiff(got[2], w[2]) == 0
             assert nbitdiff(got[3], w[3]) == 0
+
+
+def test_dense_nonfinite_live(oracle, reference):
+    """Dense descriptors (dense_rotate = 0) of volumes with NaN / infinite voxels: the restatement against the live
+    reference -- NaNs in the same output elements, the rest bit-identical; with dense_rotate = 1 the reference's call
+    fails on each of them (an orientation window with a NaN gradient: eigen_Mat_rm)."""
+    from tests import parity
+    for dims, units, edits in parity.DENSE_NONFINITE_CASES:
+        parity.check_dense_nonfinite(reference, lambda v, u: oracle.dense(v, u), dims, units, edits)
+        vol = parity.dense_input(dims, 5)
+        for (zs, ys, xs, val) in edits:
+            vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
+        assert parity.dense_or_fail(reference, vol, units, 1) is None
