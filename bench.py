@@ -535,7 +535,9 @@ def add_roofline(result, dev, n):
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_gauss.json")))
         isa = codeobj.kernel_isa_sha256(os.path.join(ROOT, "sift3d_amd", "lib", "libsift3d_amd.so"), codeobj.GAUSS_KERNELS)
         if int(nv) == int(pmc["voxels"]) and isa and pmc.get("gauss_kernels_isa_sha256") == isa:
-            traffic = pmc["kernels"][f"k_gauss_xy<{worst['width'] // 2}>"]["hbm_bytes_per_launch"]
+            hw_ = worst['width'] // 2                       # the aligned instantiation: "k_gauss_xy<8>" or "k_gauss_xy<8, false>"
+            key = [k for k in pmc["kernels"] if k.replace(" ", "") in (f"k_gauss_xy<{hw_}>", f"k_gauss_xy<{hw_},false>")][0]
+            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
             traffic_source = (f"profiles/pmc_gauss.json: run {pmc.get('run')}, commit {pmc.get('commit')}, the same machine code "
                               f"of k_gauss_xy / k_gauss_z (sha256 {isa[:16]}...)")
         else:

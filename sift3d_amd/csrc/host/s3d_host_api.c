@@ -112,6 +112,11 @@ typedef struct {
     /* extrema beside the Gaussians of the following octaves: a second stream, one event per finished octave */
     s3d_stream ext_stream;
     void *oct_ev[S3D_MAX_OCTAVES];
+    /* octave o + 1 beside the last levels of octave o: a stream and a scratch volume per octave >= 1, and an event per
+     * octave that says "the level the next octave is decimated from is complete" (build_gpyr_dev) */
+    s3d_stream oct_stream[S3D_MAX_OCTAVES];
+    void *dec_ev[S3D_MAX_OCTAVES];
+    float *d_tmp_oct[S3D_MAX_OCTAVES];
     int extrema_enqueued;   /* build_gpyr_dev put the extrema pass on ext_stream; detect_dev collects it */
     /* pinned host staging that lives with the context (a fresh malloc of a few MB per call is an mmap plus a page fault
      * per 4 KB): [0] descriptor keys up, [1] keypoint coordinates down, [2] keypoint rotations down */
@@ -171,6 +176,7 @@ static void dfree(void *pp)
 static void ctx_free_pyramid(s3d_ctx *c)
 {
     dfree(&c->d_im); dfree(&c->d_tmp);
+    for (int i = 0; i < S3D_MAX_OCTAVES; i++) dfree(&c->d_tmp_oct[i]);
     for (int i = 0; i < S3D_MAX_OCTAVES * S3D_MAX_LEVELS; i++) dfree(&c->d_level[i]);
     dfree(&c->d_bits); dfree(&c->d_scratch);
     dfree(&c->d_cand_idx); dfree(&c->d_cand_tag); dfree(&c->d_keep); dfree(&c->d_kscratch);
@@ -194,6 +200,10 @@ static void ctx_free_all(s3d_ctx *c)
     for (int i = 0; i < S3D_MAX_OCTAVES; i++)
         if (c->oct_ev[i]) { s3d_rt_event_destroy(c->oct_ev[i]); c->oct_ev[i] = NULL; }
     if (c->ext_stream) { s3d_rt_stream_destroy(c->ext_stream); c->ext_stream = NULL; }
+    for (int i = 0; i < S3D_MAX_OCTAVES; i++) {
+        if (c->dec_ev[i]) { s3d_rt_event_destroy(c->dec_ev[i]); c->dec_ev[i] = NULL; }
+        if (c->oct_stream[i]) { s3d_rt_stream_destroy(c->oct_stream[i]); c->oct_stream[i] = NULL; }
+    }
     c->extrema_enqueued = 0;
     for (int i = 0; i < 3; i++) {
         if (c->h_stage[i]) s3d_rt_host_free(c->h_stage[i]);
@@ -447,6 +457,7 @@ static int ctx_ensure_pyramid(SIFT3D *const sift3d, s3d_ctx *c)
         c->level_elems[o] = (size_t)lv->nx * lv->ny * lv->nz;
         for (int k = 0; k < g->num_levels; k++)
             DEV(s3d_rt_malloc((void **)&c->d_level[o * g->num_levels + k], c->level_elems[o] * sizeof(float)));
+        if (o >= 1) DEV(s3d_rt_malloc((void **)&c->d_tmp_oct[o], c->level_elems[o] * sizeof(float)));
     }
     maxwords = (n0 + 63) / 64;
     c->bits_words = maxwords;
@@ -557,14 +568,15 @@ static int set_im_device(SIFT3D *const sift3d, const float *host_dense, const fl
 /* One Gaussian application of the pyramid.  A pass over a volume with non-finite voxels (c->verbatim) takes the
  * per-element kernel for every axis: it evaluates both samples of every tap as the reference does (0 * NaN is NaN,
  * s3d_gauss.hip g_verbatim), where the streaming kernels read one. */
-static int pyr_fir(s3d_ctx *c, const float *src, float *dst, int nx, int ny, int nz, const float uf[3], const Sep_FIR_filter *f)
+static int pyr_fir(s3d_ctx *c, s3d_stream st, float *tmp, const float *src, float *dst, int nx, int ny, int nz,
+                   const float uf[3], const Sep_FIR_filter *f)
 {
     int rc;
-    if (!c->verbatim) return s3d_k_sep_fir(src, dst, c->d_tmp, nx, ny, nz, 1, uf, f->kernel, f->width, c->stream);
+    if (!c->verbatim) return s3d_k_sep_fir(src, dst, tmp, nx, ny, nz, 1, uf, f->kernel, f->width, st);
     {
         const int mode = s3d_k_gauss_get_mode();
         s3d_k_gauss_set_mode(64);
-        rc = s3d_k_sep_fir_path(src, dst, c->d_tmp, nx, ny, nz, 1, uf, f->kernel, f->width, 1, c->stream);
+        rc = s3d_k_sep_fir_path(src, dst, tmp, nx, ny, nz, 1, uf, f->kernel, f->width, 1, st);
         s3d_k_gauss_set_mode(mode);
     }
     return rc;
@@ -646,30 +658,53 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
         const size_t n = (size_t)l0->nx * l0->ny * l0->nz;
         if (c->in_src != c->d_im) DEV(s3d_rt_d2d(c->d_im, c->in_src, n * sizeof(float), c->stream));
         DEV(s3d_k_scale_div(c->d_im, n, c->d_red + RED_INMAX, c->stream));
-        DEV(pyr_fir(c, c->d_im, c->d_level[0], l0->nx, l0->ny, l0->nz, uf, &gss->first_gauss.f));
+        DEV(pyr_fir(c, c->stream, c->d_tmp, c->d_im, c->d_level[0], l0->nx, l0->ny, l0->nz, uf, &gss->first_gauss.f));
     }
     c->in_src = NULL;                                     /* the caller's volume is not ours beyond this call */
-    for (int o = 0; o < g->num_octaves; o++) {
-        const Image *lv = g->levels + o * L;
-        double lu[3] = {lv->ux, lv->uy, lv->uz};
-        unit_factors(lu, 1.0, uf);
-        for (int k = 1; k < L; k++) {
-            /* level s = k-1+first_level+... uses gauss_octave[s] with s counted from 0 (quirk C-11):
-             * filter index k-1 maps level k-1 -> k */
-            const Sep_FIR_filter *f = &gss->gauss_octave[k - 1].f;
-            DEV(pyr_fir(c, c->d_level[o * L + k - 1], c->d_level[o * L + k], lv->nx, lv->ny, lv->nz, uf, f));
+    /* Octave o + 1 is decimated from level ds of octave o (sift.c:1036-1045) and needs nothing else from it: its chain of
+     * Gaussians -- for the coarse octaves ~50 dependent launches of 5-50 us that leave the GPU idle, 0.8 ms of a 512^3 detect
+     * -- starts on a stream of its own as soon as that level exists and runs beside the remaining levels of octave o (and
+     * the extrema pass), which are bandwidth bound and lose little to the small kernels squeezed in between. */
+    {
+        static int no_fork = -1;                          /* diagnostics: S3D_NO_OCTAVE_STREAMS=1, read once */
+        const int ds = L - 3 > 0 ? L - 3 : 0;             /* downsample level index: max(s_end-2, first) */
+        if (no_fork < 0) no_fork = S3D_DIAG_ENV("S3D_NO_OCTAVE_STREAMS") != NULL;
+        for (int o = 0; o < g->num_octaves; o++) {
+            const Image *lv = g->levels + o * L;
+            const int forked = o >= 1 && !no_fork;
+            const s3d_stream so = forked ? c->oct_stream[o] : c->stream;
+            float *const tmp = forked ? c->d_tmp_oct[o] : c->d_tmp;
+            double lu[3] = {lv->ux, lv->uy, lv->uz};
+            unit_factors(lu, 1.0, uf);
+            for (int k = 0; k < L; k++) {
+                if (k >= 1) {
+                    /* level s = k-1+first_level+... uses gauss_octave[s] with s counted from 0 (quirk C-11):
+                     * filter index k-1 maps level k-1 -> k */
+                    DEV(pyr_fir(c, so, tmp, c->d_level[o * L + k - 1], c->d_level[o * L + k], lv->nx, lv->ny, lv->nz, uf,
+                                &gss->gauss_octave[k - 1].f));
+                }
+                if (k == ds && o != g->num_octaves - 1 && !no_fork) {      /* seed the next octave, on its stream */
+                    if (!c->oct_stream[o + 1]) DEV(s3d_rt_stream_create_nonblocking(&c->oct_stream[o + 1]));
+                    if (!c->dec_ev[o]) DEV(s3d_rt_event_create(&c->dec_ev[o]));
+                    DEV(s3d_rt_event_record(c->dec_ev[o], so));
+                    DEV(s3d_rt_stream_wait_event(c->oct_stream[o + 1], c->dec_ev[o]));
+                    DEV(s3d_k_decimate2(c->d_level[o * L + ds], lv->nx, lv->ny, lv->nz, c->d_level[(o + 1) * L],
+                                        c->oct_stream[o + 1]));
+                }
+            }
+            if (no_fork && o != g->num_octaves - 1)
+                DEV(s3d_k_decimate2(c->d_level[o * L + ds], lv->nx, lv->ny, lv->nz, c->d_level[(o + 1) * L], c->stream));
+            if (es || forked) {
+                if (!c->oct_ev[o]) DEV(s3d_rt_event_create(&c->oct_ev[o]));
+                DEV(s3d_rt_event_record(c->oct_ev[o], so));
+            }
+            if (es) {
+                DEV(s3d_rt_stream_wait_event(es, c->oct_ev[o]));
+                if (extrema_octave(sift3d, c, o, es)) return SIFT3D_FAILURE;
+            }
         }
-        if (es) {
-            if (!c->oct_ev[o]) DEV(s3d_rt_event_create(&c->oct_ev[o]));
-            DEV(s3d_rt_event_record(c->oct_ev[o], c->stream));
-            DEV(s3d_rt_stream_wait_event(es, c->oct_ev[o]));
-            if (extrema_octave(sift3d, c, o, es)) return SIFT3D_FAILURE;
-        }
-        if (o != g->num_octaves - 1) {
-            int ds = L - 1 - 2;                           /* downsample level index: max(s_end-2, first) */
-            if (ds < 0) ds = 0;
-            DEV(s3d_k_decimate2(c->d_level[o * L + ds], lv->nx, lv->ny, lv->nz, c->d_level[(o + 1) * L], c->stream));
-        }
+        /* whatever follows on the caller's stream sees the whole pyramid */
+        for (int o = 1; o < g->num_octaves && !no_fork; o++) DEV(s3d_rt_stream_wait_event(c->stream, c->oct_ev[o]));
     }
     c->have_pyramid = 1;
     c->extrema_enqueued = es != NULL;
