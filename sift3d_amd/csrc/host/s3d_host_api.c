@@ -684,6 +684,8 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
                                 &gss->gauss_octave[k - 1].f));
                 }
                 if (k == ds && o != g->num_octaves - 1 && !no_fork) {      /* seed the next octave, on its stream */
+                    /* (an ordinary stream: at the device's highest stream priority the chain's kernels were dispatched with
+                     * 100-200 us between them and the detect took 7.2 instead of 6.6 ms -- profiles/r05_octave_streams_ab.txt) */
                     if (!c->oct_stream[o + 1]) DEV(s3d_rt_stream_create_nonblocking(&c->oct_stream[o + 1]));
                     if (!c->dec_ev[o]) DEV(s3d_rt_event_create(&c->dec_ev[o]));
                     DEV(s3d_rt_event_record(c->dec_ev[o], so));

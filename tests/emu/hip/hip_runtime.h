@@ -310,6 +310,8 @@ static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 
 /* explicitly created side streams get a non-null handle (everything runs at enqueue time in the emulator, so the handle is never
  * looked at): host code that takes a second stream as "overlap is on" then runs its overlapped form here too */
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { static char h; *s = &h; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { static char h; *s = &h; return 0; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 /* S3D_EMU_DEVICES: how many "GPUs" the emulator reports (the in-process N-GPU mode wants one per rank) */
