@@ -54,7 +54,8 @@ def _run(cmd):
 # Sources with diagnostic switches / test hooks behind -DS3D_TESTING (csrc/host/s3d_host.h): compiled a second time for
 # lib/libsift3d_amd_testing.so, which differs from the product library in these objects only.  The product library has
 # neither sift3d_amd_slab_test_inject nor the S3D_* environment switches.
-TESTING_SOURCES = ["s3d_gauss.hip", "s3d_keypoint.hip", "host/s3d_host_api.c", "host/s3d_host_match.c", "host/s3d_host_slab.c"]
+TESTING_SOURCES = ["s3d_gauss.hip", "s3d_gauss_tab.hip", "s3d_extrema.hip", "s3d_keypoint.hip", "host/s3d_host_api.c", "host/s3d_host_match.c",
+                   "host/s3d_host_slab.c"]
 
 
 def build(verbose: bool = False) -> str:

@@ -315,11 +315,21 @@ k_extrema_refilter(ExtArgs<NKP> a, unsigned idx0, size_t nwords, double peak, co
 /* Keypoint levels s = 0 .. nkp-1 of one octave at once.  d_levels: nkp+3 GSS levels starting at L(s-1) of
  * the first keypoint level; d_dogmax: nkp maxima (max|DoG| of each keypoint level); d_bits: nkp bitmaps.
  * Returns 1 without doing anything when not eligible (nx < 4, nkp not instantiated). */
+#if defined(S3D_TESTING)
+/* test aid (emulator build): the fused kernel declines every configuration, as it does for levels of >= 2^31 voxels -- the
+ * callers' per-level fall-backs are otherwise out of a test's reach */
+static volatile int g_ext_decline = 0;                  /* process-wide: the loop-back ranks are other threads */
+extern "C" void s3d_k_extrema_test_decline(int on) { g_ext_decline = on; }
+#endif
+
 static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
                                 double peak_thresh, const float *d_dogmax, unsigned *d_runmax,
                                 unsigned long long *const *d_bits, s3d_stream st)
 {
     const size_t n = (size_t)nx * ny * nz, plane = (size_t)nx * ny;
+#if defined(S3D_TESTING)
+    if (g_ext_decline) return 1;
+#endif
     if (nkp != 3 || nx < 4) return 1;
     if (nx < 1 || ny < 1 || nz < 1 || n >= 0xFFFFFF00ull) S3D_FAIL("level too large for 32-bit voxel indices");
     if (z0 < 0 || z1 > nz || z0 >= z1) S3D_FAIL("bad slab");

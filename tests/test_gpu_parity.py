@@ -811,3 +811,26 @@ def test_dense_nonfinite(lib, oracle, dims, units, edits):
         for (zs, ys, xs, val) in edits:
             vol[zs[0]:zs[1], ys[0]:ys[1], xs[0]:xs[1]] = val
         assert parity.dense_or_fail(lib, vol, units, 1) is None
+
+
+def test_tap_table_cache_evicts(libt, oracle):
+    """More distinct (extent, filter, spacing) triples than the 256 tables the cache holds: the least recently used table
+    goes, later shapes keep getting the table-driven kernels (testing build: the cache's statistics), and a filter whose
+    table was evicted in between still equals the oracle."""
+    L = libt.sift
+    L.s3d_k_conv_x_tab_available.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.s3d_k_tap_tables_stats.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.s3d_k_gauss_set_mode.argtypes = [C.c_int]
+    L.s3d_k_tap_tables_release()
+    L.s3d_k_gauss_set_mode(8)
+    try:
+        assert parity.check_sep_fir_tab(libt, oracle, (70, 23, 18), (0.7, 0.7, 1.5), (0.973294,)) == 3
+        for nx in range(30, 330):
+            assert L.s3d_k_conv_x_tab_available(nx, 9, 9, 5, 1.25, 3) == 1, nx
+        slots, live = C.c_int(), C.c_int()
+        L.s3d_k_tap_tables_stats(C.byref(slots), C.byref(live))
+        assert slots.value == 256 and live.value == 256
+        assert parity.check_sep_fir_tab(libt, oracle, (70, 23, 18), (0.7, 0.7, 1.5), (0.973294,)) == 3
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+        L.s3d_k_tap_tables_release()

@@ -396,3 +396,21 @@ def test_nonfinite_voxels_on_loopback_ranks(hip, base, name, edits):
     vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
     got = parity.detect_describe_or_fail(hip, vol, units, params, ngpu=2)
     parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name} on 2 ranks")
+
+
+def test_fused_extrema_declined_falls_back_per_level(hip_testing):
+    """The fused extrema kernel declining a level (testing build's switch; in production: levels of >= 2^31 voxels): the
+    single-GPU path and two loop-back ranks take the per-level kernels and collectives, same keypoints."""
+    L = hip_testing.sift
+    L.s3d_k_extrema_test_decline.argtypes = [C.c_int]
+    vol = synth.blobs(96, 96, 192, 2500, 4)
+    want = parity.detect_describe_or_fail(hip_testing, vol, (1.0, 1.0, 1.0))
+    L.s3d_k_extrema_test_decline(1)
+    try:
+        one = parity.detect_describe_or_fail(hip_testing, vol, (1.0, 1.0, 1.0))
+        two = parity.detect_describe_or_fail(hip_testing, vol, (1.0, 1.0, 1.0), ngpu=2)
+    finally:
+        L.s3d_k_extrema_test_decline(0)
+    assert len(want[0]) > 100
+    for got in (one, two):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])

@@ -260,3 +260,25 @@ def test_finite_volume_after_a_failed_nonfinite_one(emu):
     x, sd, R = emu.keypoints_to_numpy(kp)
     assert len(want_x) > 5 and np.array_equal(x, want_x) and np.array_equal(R, want_R)
     L.cleanup_SIFT3D(C.byref(s))
+
+
+def test_fused_extrema_declined_falls_back_per_level(emu):
+    """Where the fused extrema kernel declines a level (>= 2^31 voxels in production; forced here by the emulator build's
+    test switch) the single-GPU path and the Z-slab ranks take the per-level kernels -- with their own sequence of
+    collectives (one maximum per level instead of three at once) -- and the result is unchanged.  Round 4's slab driver
+    treated the decline as a failure and aborted the transports."""
+    L = emu.sift
+    L.s3d_k_extrema_test_decline.argtypes = [C.c_int]
+    dims, units, nblobs, seed = (24, 24, 128), (1.0, 1.0, 1.0), 260, 8          # two sharded octaves + replicated ones
+    vol = synth.blobs(*dims, nblobs, seed)
+    want = single_process(emu, vol, units)
+    L.s3d_k_extrema_test_decline(1)
+    try:
+        got1 = single_process(emu, vol, units)
+        out = run_loopback(emu.sift, 2, dims, units, nblobs, seed)
+    finally:
+        L.s3d_k_extrema_test_decline(0)
+    for a, b in zip(got1, want):
+        assert np.array_equal(a, b)
+    for (kp, (bins, xyzs), _, inf) in out:
+        assert np.array_equal(kp[0], want[0]) and np.array_equal(kp[2], want[2]) and np.array_equal(bins, want[3])
