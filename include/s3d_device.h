@@ -91,6 +91,10 @@ int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny, int nz, in
  * (octave 0 of a unit-voxel volume: the roofline configuration), the generic pass otherwise. */
 int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,
                   const float uf[3], const float *taps, int width, s3d_stream stream);
+/* The same for one channel, plus s3d_k_absmax of the result into *d_max (the z pass keeps the maximum: no pass of its own).
+ * Returns 1 without doing anything where the fused unit-spacing kernels do not apply; the caller then runs the two steps. */
+int s3d_k_sep_fir_max(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, const float uf[3],
+                      const float *taps, int width, float *d_max, s3d_stream stream);
 /* Z-slab form: the pointers are VIEWS addressed by global z -- element (x,y,z)
  * at view[(z*ny + y)*nx + x] -- of which only the caller's planes plus halos are backed by memory.
  * Produces dst planes [z0, z1) from src planes [z0-h, z1+h) clamped to [0, nz), h = ceil(hw*uf[2]) + 1 (the
@@ -307,7 +311,9 @@ int s3d_k_dense_bary(const float *d_smooth, int nx, int ny, int nz, const float 
  * configuration is not eligible (run the two separate calls instead), 0 on success, -1 on error. */
 int s3d_k_dense_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, int nx, int ny, int nz,
                           const float unitsf[3], const float uf[3], const float *d_mesh, const float *taps,
-                          int width, s3d_stream stream);
+                          int width, const float *d_post_in, s3d_stream stream);
+/* profiling runs: the marching passes of the above in `nchunks` chunks (0: the built-in choice); per calling thread */
+void s3d_k_dense_set_chunks(int nchunks);
 /* dense_rotate = 1 (sift.c:2521-2588, 2295-2343): per-voxel sphere histogram of gradients rotated by the
  * voxel's own orientation.  d_R / d_keep: output of s3d_k_orient run with one candidate per voxel
  * (d_idx = d_tag = d_center = NULL); rejected voxels use the identity.  sigma = sigma0*7.0711/4. */

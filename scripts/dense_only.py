@@ -20,6 +20,9 @@ d_out = dev.malloc(vol.nbytes * 12)
 s = abi.SIFT3D()
 assert lib.sift.init_SIFT3D(C.byref(s)) == 0
 ou = (C.c_double * 3)(1.0, 1.0, 1.0)
+if int(os.environ.get("DENSE_CHUNKS", "0")) > 0:       # the marching passes in that many chunks (A/B runs)
+    lib.sift.s3d_k_dense_set_chunks.argtypes = [C.c_int]
+    lib.sift.s3d_k_dense_set_chunks(int(os.environ["DENSE_CHUNKS"]))
 for i in range(4):
     dev.sync()
     t0 = time.perf_counter()

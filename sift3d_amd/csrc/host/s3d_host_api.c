@@ -127,6 +127,8 @@ typedef struct {
 /* words of c->d_red.  The input's maximum sits directly in front of the counters, so that the copy that fetches the
  * candidate count brings it along: its bit pattern tells whether the volume held a NaN or an infinity. */
 #define RED_DOGMAX 1        /* 3 words: the DoG maxima of the octave in flight */
+#define RED_RAWMAX 5        /* raw-image / dense entry points: max |smoothed voxel| (im_scale's divisor) */
+#define RED_PROBE 6         /* volume_nonfinite's sticky maximum */
 #define RED_REC 40          /* 4 words, 8-byte aligned: the record of s3d_k_seqmax */
 #define RED_INMAX 55        /* max |input voxel| */
 #define RED_COUNT 56        /* 8 words: c->d_count */
@@ -1457,39 +1459,53 @@ int im_downsample_2x(const Image *const src, Image *const dst) /* imutil.c:1742 
 static int volume_nonfinite(s3d_ctx *c, const float *d_v, size_t n)
 {
     uint32_t bits = 0;
-    if (s3d_k_absmax(d_v, n, c->d_red + 3, c->stream) || s3d_rt_d2h(&bits, c->d_red + 3, sizeof(bits), c->stream) ||
+    if (s3d_k_absmax(d_v, n, c->d_red + RED_PROBE, c->stream) || s3d_rt_d2h(&bits, c->d_red + RED_PROBE, sizeof(bits), c->stream) ||
         s3d_rt_sync(c->stream))
         return -1;
     return (bits & 0x7fffffffu) >= 0x7f800000u;
 }
 
 /* ---- raw-image variants (sift.c:1978-2006, 2131-2195, 1534-1604) --------------------------------------- */
-/* smooth_scale_raw_input on the device: d_out = im_scale(G_{sigma_n -> sigma0}(d_in)) */
+/* smooth_scale_raw_input on the device: d_out = im_scale(G_{sigma_n -> sigma0}(d_in)).
+ * A volume with non-finite voxels needs the literal filter kernel and the sequential maximum (see detect_single).  Whether it
+ * has any is read off the maximum this function computes anyway: a NaN or an infinity in the input reaches the smoothed
+ * volume (the taps are positive), and the sticky maximum keeps it.
+ *   RAW_CHECK      fast kernels, one look at the maximum (a 4-byte copy and a stream sync), the literal kernels if need be;
+ *   RAW_LITERAL    the literal kernels;
+ *   RAW_OPTIMISTIC fast kernels and no look: the caller reads c->d_red[RED_RAWMAX] once its own pipeline has drained and comes
+ *                  back with RAW_LITERAL if that is not finite (the streaming kernels are memory-safe on any bit pattern). */
+enum { RAW_CHECK = 0, RAW_LITERAL = 1, RAW_OPTIMISTIC = 2 };
+static int raw_max_nonfinite(uint32_t bits) { return (bits & 0x7fffffffu) >= 0x7f800000u; }
+
 static int smooth_scale_raw_dev(const SIFT3D *sift3d, s3d_ctx *c, const float *d_in, float *d_out, float *d_tmp,
-                                int nx, int ny, int nz, const double units[3])
+                                int nx, int ny, int nz, const double units[3], int how)
 {
     Gauss_filter gauss;
     float uf[3];
     const size_t n = (size_t)nx * ny * nz;
-    int rc;
+    float *const d_max = c->d_red + RED_RAWMAX;
+    int rc = 0;
     if (init_Gauss_incremental_filter(&gauss, sift3d->gpyr.sigma_n, sift3d->gpyr.sigma0, IM_NDIMS))
         return SIFT3D_FAILURE;
     unit_factors(units, 1.0, uf);
-    {
-        /* a volume with non-finite voxels: the literal filter kernel and the sequential maximum (see detect_single) */
-        const int nf = volume_nonfinite(c, d_in, n);
-        if (nf < 0) { cleanup_Gauss_filter(&gauss); API_FAIL("sift3d_amd: raw smoothing failed: %s", s3d_rt_last_error()); }
-        if (nf) {
-            const int mode = s3d_k_gauss_get_mode();
-            s3d_k_gauss_set_mode(64);
-            rc = s3d_k_sep_fir_path(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, 1, c->stream) ||
-                 s3d_k_seqmax(d_out, NULL, n, c->d_red + 2, c->d_red + RED_REC, c->stream) ||
-                 s3d_k_scale_div(d_out, n, c->d_red + 2, c->stream);
-            s3d_k_gauss_set_mode(mode);
-        } else {
+    if (how != RAW_LITERAL) {
+        rc = s3d_k_sep_fir_max(d_in, d_out, d_tmp, nx, ny, nz, uf, gauss.f.kernel, gauss.f.width, d_max, c->stream);
+        if (rc == 1)
             rc = s3d_k_sep_fir(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, c->stream) ||
-                 s3d_k_absmax(d_out, n, c->d_red + 2, c->stream) || s3d_k_scale_div(d_out, n, c->d_red + 2, c->stream);
+                 s3d_k_absmax(d_out, n, d_max, c->stream);
+        if (!rc && how == RAW_CHECK) {
+            uint32_t bits = 0;
+            rc = s3d_rt_d2h(&bits, d_max, sizeof(bits), c->stream) || s3d_rt_sync(c->stream);
+            if (!rc && raw_max_nonfinite(bits)) how = RAW_LITERAL;
         }
+        if (!rc && how != RAW_LITERAL) rc = s3d_k_scale_div(d_out, n, d_max, c->stream);
+    }
+    if (!rc && how == RAW_LITERAL) {
+        const int mode = s3d_k_gauss_get_mode();
+        s3d_k_gauss_set_mode(64);
+        rc = s3d_k_sep_fir_path(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, 1, c->stream) ||
+             s3d_k_seqmax(d_out, NULL, n, d_max, c->d_red + RED_REC, c->stream) || s3d_k_scale_div(d_out, n, d_max, c->stream);
+        s3d_k_gauss_set_mode(mode);
     }
     cleanup_Gauss_filter(&gauss);
     if (rc) API_FAIL("sift3d_amd: raw smoothing failed: %s", s3d_rt_last_error());
@@ -1513,7 +1529,7 @@ static int raw_prepare(const SIFT3D *sift3d, s3d_ctx *c, const Image *im, s3d_py
         API_FAIL("sift3d_amd: upload failed: %s", s3d_rt_last_error());
     }
     free(dense);
-    if (smooth_scale_raw_dev(sift3d, c, c->d_aux[0], c->d_aux[1], c->d_aux[2], im->nx, im->ny, im->nz, units))
+    if (smooth_scale_raw_dev(sift3d, c, c->d_aux[0], c->d_aux[1], c->d_aux[2], im->nx, im->ny, im->nz, units, RAW_CHECK))
         return SIFT3D_FAILURE;
     memset(pd, 0, sizeof(*pd));
     pd->num_octaves = 1; pd->num_levels = 1; pd->first_level = 0;
@@ -1659,7 +1675,7 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
         rc = SIFT3D_FAILURE;
         if (n >= 0x7FFFFFFFull) API_FAIL("sift3d_amd: volume too large for dense_rotate");
         if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n)) return SIFT3D_FAILURE;
-        if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units)) return SIFT3D_FAILURE;
+        if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units, RAW_CHECK)) return SIFT3D_FAILURE;
         memset(&pd, 0, sizeof(pd));
         pd.num_octaves = 1; pd.num_levels = 1; pd.first_level = 0;
         pd.dims[0][0] = nx; pd.dims[0][1] = ny; pd.dims[0][2] = nz;
@@ -1685,31 +1701,42 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
         s3d_rt_free(d_R); s3d_rt_free(d_keep); s3d_rt_free(d_sig); s3d_rt_free(d_oscr);
         return rc;
     }
-    /* aux 1: smoothed input, aux 2: scratch (12 channels), aux 3: 12-channel barycentric image */
-    if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n * HIST_NUMEL) || ctx_aux(c, 3, n * HIST_NUMEL))
-        return SIFT3D_FAILURE;
-    if (smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units)) return SIFT3D_FAILURE;
+    /* aux 1: smoothed input, aux 2: scratch (12 channels); aux 3 (the 12-channel barycentric image) only for the separate steps */
+    if (ctx_base(c) || ctx_aux(c, 1, n) || ctx_aux(c, 2, n * HIST_NUMEL)) return SIFT3D_FAILURE;
     if (init_Gauss_filter(&gauss, sigma_win, 3)) return SIFT3D_FAILURE;
     unit_factors(out_units, 1.0, uf);                      /* quirk C-17: the OUTPUT image's entry units */
-    {
-        /* non-finite voxels (they survive the smoothing as NaNs): the two separate steps with the literal filter kernel */
-        const int nf = volume_nonfinite(c, c->d_aux[1], n);
-        const int mode = s3d_k_gauss_get_mode();
-        if (nf < 0) { cleanup_Gauss_filter(&gauss); API_FAIL("sift3d_amd: dense blur failed: %s", s3d_rt_last_error()); }
-        if (nf) s3d_k_gauss_set_mode(64);
-        /* unit tap spacing: barycentric image + blur fused (the image never leaves LDS); otherwise the two steps */
-        rc = nf ? 1 : s3d_k_dense_bary_blur(c->d_aux[1], d_out, c->d_aux[2], nx, ny, nz, unitsf, uf, c->d_mesh, gauss.f.kernel,
-                                            gauss.f.width, c->stream);
-        if (rc == 1)
-            rc = s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream) ||
+    /* Unit tap spacing: smoothing, barycentric image + x pass, y pass, z pass + postproc_Hist -- six launches and no host
+     * round trip in between; whether the volume held a non-finite voxel is read off the smoothed maximum afterwards, and such
+     * a volume is done again below (the streaming kernels skip the zero-fraction sample the literal filter multiplies in,
+     * which matters exactly when that sample is a NaN or an infinity). */
+    rc = smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units, RAW_OPTIMISTIC);
+    if (rc == 0) {
+        uint32_t bits = 0;
+        rc = s3d_k_dense_bary_blur(c->d_aux[1], d_out, c->d_aux[2], nx, ny, nz, unitsf, uf, c->d_mesh, gauss.f.kernel,
+                                   gauss.f.width, d_in, c->stream);
+        if (rc >= 0 && (s3d_rt_d2h(&bits, c->d_red + RED_RAWMAX, sizeof(bits), c->stream) || s3d_rt_sync(c->stream))) rc = -1;
+        if (rc == 0 && !raw_max_nonfinite(bits)) {
+            cleanup_Gauss_filter(&gauss);
+            return SIFT3D_SUCCESS;
+        }
+        if (rc >= 0) {
+            /* not eligible for the fused form (rc == 1) and / or non-finite voxels: the separate steps, on the literal filter
+             * kernel where the volume asks for it */
+            const int nf = raw_max_nonfinite(bits);
+            const int mode = s3d_k_gauss_get_mode();
+            rc = ctx_aux(c, 3, n * HIST_NUMEL) ||
+                 (nf && smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units, RAW_LITERAL));
+            if (nf) s3d_k_gauss_set_mode(64);
+            rc = rc || s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream) ||
                  s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream) ||
                  s3d_k_sep_fir_path(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,
-                                    nf ? 1 : 0, c->stream);
-        if (nf) s3d_k_gauss_set_mode(mode);
+                                    nf ? 1 : 0, c->stream) ||
+                 s3d_k_dense_post(d_out, d_in, n, c->stream);
+            if (nf) s3d_k_gauss_set_mode(mode);
+        }
     }
     cleanup_Gauss_filter(&gauss);
     if (rc) API_FAIL("sift3d_amd: dense blur failed: %s", s3d_rt_last_error());
-    DEV(s3d_k_dense_post(d_out, d_in, n, c->stream));
     return SIFT3D_SUCCESS;
 }
 

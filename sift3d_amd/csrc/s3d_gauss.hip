@@ -40,6 +40,7 @@
  */
 #include "s3d_common.h"
 #include "s3d_math.h"
+#include "s3d_ring.h"
 
 /* ------------------------------------------------------------------------------------------------
  * 1. generic per-element pass
@@ -383,14 +384,6 @@ extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int
                                    const float *taps, int width, float uf, int uhw, const float *d_div, s3d_stream stream);
 extern "C" int s3d_k_conv_x_tab_available(int nx, int ny, int nz, int width, float uf, int uhw);
 
-static int check_taps(const float *taps, int width, S3dTaps *out)
-{
-    if (width < 1 || width > S3D_MAX_TAPS || !(width & 1)) S3D_FAIL("filter width must be odd and <= S3D_MAX_TAPS");
-    memset(out, 0, sizeof(*out));
-    memcpy(out->t, taps, sizeof(float) * width);
-    return S3D_OK;
-}
-
 /* one axis pass over the planes [z0, z1) of a volume addressed by global z (z0 = 0, z1 = nz: all) */
 static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int nz, int nc, int axis, int z0, int z1,
                            const float *taps, int width, float uf, s3d_stream st, const float *d_div = nullptr)
@@ -485,89 +478,27 @@ extern "C" int s3d_k_conv_axis(const float *d_src, float *d_dst, int nx, int ny,
 /* ------------------------------------------------------------------------------------------------
  * 2. streaming fast path (uf == 1, nc == 1)
  * ---------------------------------------------------------------------------------------------- */
-#define S3D_FAST_MAX_HW 9
 #define XY_STRIP 256              /* columns per wave: 64 lanes x float4 */
-
-struct EdgeFrac {                 /* f_j of the high-side mirror, j = 0..hw */
-    float f[S3D_FAST_MAX_HW + 1];
-};
-
-/* acc (+)= taps over a statically indexed ring whose newest entry sits in slot U */
-template <int HW>
-__device__ __forceinline__ float4 ring_dot(const float4 (&ring)[2 * HW + 1], const int U, const S3dTaps &taps)
-{
-    constexpr int W = 2 * HW + 1;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-        const float4 s = ring[(U - k + 2 * W) % W];
-        const float t = taps.t[k];
-        acc.x = acc.x + t * s.x;
-        acc.y = acc.y + t * s.y;
-        acc.z = acc.z + t * s.z;
-        acc.w = acc.w + t * s.w;
-    }
-    return acc;
-}
-
-__device__ __forceinline__ float4 blend4(float4 a, float4 b, float f)
-{
-    const float om = 1.0f - f;
-    float4 r;
-    r.x = om * a.x + f * b.x;
-    r.y = om * a.y + f * b.y;
-    r.z = om * a.z + f * b.z;
-    r.w = om * a.w + f * b.w;
-    return r;
-}
 
 /* ---- Z pass ------------------------------------------------------------------------------------- */
 /* E-plane c of the z axis for this lane's float4 column */
-/* four floats of a plane: 16-byte aligned where rows are (nx % 4 == 0), dword aligned otherwise (RAGGED) */
-template <bool RAGGED>
-__device__ __forceinline__ float4 ld_quad(const float *p)
-{
-    if (RAGGED) {
-        const s3d_f4u v = *reinterpret_cast<const s3d_f4u *>(p);
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    return *reinterpret_cast<const float4 *>(p);
-}
-template <bool RAGGED>
-__device__ __forceinline__ void st_quad(float *p, const float4 &a)
-{
-    if (RAGGED) {
-        s3d_f4u v;
-        v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w;
-        *reinterpret_cast<s3d_f4u *>(p) = v;
-    } else {
-        *reinterpret_cast<float4 *>(p) = a;
-    }
-}
-
-template <int HW, bool RAGGED = false>
-__device__ __forceinline__ float4 z_ext(const float *__restrict__ col, size_t zs, int c, int nz, const EdgeFrac &ef)
-{
-    if (c < 0) c = -c;
-    if (c <= nz - 2) return ld_quad<RAGGED>(col + (size_t)c * zs);
-    const int j = c - (nz - 1);
-    const float4 a = ld_quad<RAGGED>(col + (size_t)(nz - 2 - j) * zs);
-    const float4 b = ld_quad<RAGGED>(col + (size_t)(nz - 1 - j) * zs);
-    return blend4(a, b, ef.f[j]);
-}
-
 /* RAGGED: nx4 is nx itself and a plane is a flat run of nx * ny floats that need not be a multiple of four: dword-aligned
  * quads, the last one clamped onto the end of the plane (it recomputes up to three outputs of its neighbour: same values). */
-template <int HW, bool SPLIT, bool RAGGED = false>
+/* MAXOUT: the sticky maximum of |output| (the bit patterns' maximum, as k_absmax takes it) into *maxout -- im_scale's
+ * divisor without a pass of its own (smooth_scale_raw_input, sift.c:1978-2006): one atomic per wave. */
+template <int HW, bool SPLIT, bool RAGGED = false, bool MAXOUT = false>
 __global__ void __launch_bounds__(256)
 k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int ny, int nz, int zbeg, int zend,
-          int chunk, S3dTaps taps, EdgeFrac ef)
+          int chunk, S3dTaps taps, EdgeFrac ef, unsigned *__restrict__ maxout = nullptr)
 {
     constexpr int W = 2 * HW + 1;
     const size_t zs = RAGGED ? (size_t)nx4 * ny : (size_t)nx4 * ny * 4;   /* floats per z plane */
     const size_t ncol = RAGGED ? (zs + 3) / 4 : (size_t)nx4 * ny;
-    const size_t colid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (colid >= ncol) return;
+    size_t colid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (colid >= ncol) {
+        if (!MAXOUT) return;
+        colid = ncol - 1;                            /* the wave reduces its maximum: spare lanes redo the last column (same bytes) */
+    }
     const size_t coff = RAGGED && colid * 4 + 4 > zs ? zs - 4 : colid * 4;
     const float *col = src + coff;
     float *out = dst + coff;
@@ -579,6 +510,7 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
     /* two planes in flight per lane; steps t < Tfast are guard free (real plane, output due, prefetch in
      * range) so the steady state is straight-line code */
     float4 ring[W];
+    unsigned vmax = 0u;
     const int c0 = p0 - HW;
     float4 n0 = z_ext<HW, RAGGED>(col, zs, c0, nz, ef);
     float4 n1 = z_ext<HW, RAGGED>(col, zs, c0 + (1 < T ? 1 : 0), nz, ef);
@@ -589,6 +521,12 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
         if (t >= 2 * HW) {
             const float4 acc = ring_dot<HW>(ring, u, taps);
             st_quad<RAGGED>(out + (size_t)(p0 + t - 2 * HW) * zs, acc);
+            if (MAXOUT) {
+                const unsigned a = __float_as_uint(acc.x) & 0x7fffffffu, b = __float_as_uint(acc.y) & 0x7fffffffu,
+                               c = __float_as_uint(acc.z) & 0x7fffffffu, d = __float_as_uint(acc.w) & 0x7fffffffu;
+                const unsigned ab = a > b ? a : b, cd = c > d ? c : d, m4 = ab > cd ? ab : cd;
+                vmax = vmax > m4 ? vmax : m4;
+            }
         }
     };
     int Tfast = T - 2;
@@ -615,6 +553,13 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
 #pragma unroll
         for (int u = 0; u < W; u++)
             if (tb + u < T) slow_step(tb + u, u);
+    }
+    if (MAXOUT) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)vmax, m);
+            vmax = vmax > o ? vmax : o;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(maxout, vmax);
     }
 }
 
@@ -700,225 +645,6 @@ k_conv_x_mc(const float *__restrict__ src, float *__restrict__ dst, int nx, int 
         }
     }
     *reinterpret_cast<float4 *>(dst + r * (size_t)nx * nc + q) = acc;
-}
-
-/* Dense-descriptor front end fused with the x pass of its 12-channel blur.  The barycentric image
- * (sift.c:2412-2441: three weights per voxel into the channels of the hit face's vertices, zero elsewhere
- * and on the volume's border) is never written to HBM: the EXTENDED row E of a tile -- E[c] = voxel -c (c < 0), voxel c
- * (c <= nx-2), (1-f_j) voxel[nx-2-j] + f_j voxel[nx-1-j] (c = nx-1+j; imutil.c:2378-2380) -- goes into LDS, twelve channels
- * per position, and every output is the plain sum of taps over it: no boundary case is left in the convolution.  Same
- * arithmetic, same order as k_dense_bary followed by k_conv_x_mc: bit-identical; saves 2 x 48 B/voxel.
- *
- * Round 5 form: a WAVE per row tile, no workgroup barrier (rounds 3-4: a workgroup per tile, one thread per output float4,
- * 619 / 516-560 us at 256^3).  A lane owns BW_P = 4 CONSECUTIVE voxels of the row: their windows overlap, so the 4 + 2 HW
- * slots they need are read once per channel quad (5.5 LDS reads per output float4 instead of 19) while the four accumulator
- * quads take the terms in the reference's order -- output x receives tap k = 0 .. 2 HW from the source positions x + HW - k,
- * and walking the source positions downwards serves the four outputs at four consecutive k.  The three channel quads are
- * done one after the other (16 accumulators live, not 48).  A wave owns a whole tile of 256 voxels: stage 1 (face search of
- * the tile's extended row; the three weights are WRITTEN to their channels over a zeroed slot instead of selected per
- * channel: 187 instead of ~380 instructions per position), the convolution and the store of a row are one wave's private
- * sequence over its private LDS region -- wave-scope ordering only.  LDS layout: one array per channel quad, slot i at
- * float4 index i + (i >> 2): lane l reads slots 4 l + m, i.e. index 5 l + m + (m >> 2) -- an odd stride, conflict free.
- * The 4 output float4 of a lane and quad are 192 bytes apart in the row: they replace the lane's first four slots of the
- * quad's array (every lane has read its window by then) and the row leaves in store order, every global store instruction
- * writing 1 KB contiguous.
- * Measured (256^3, profiles/r05_dense_experiments.txt): 460 us (min 406).  A third of the LDS reads and 35 % fewer VALU
- * instructions than the round-4 kernel bought 10 %; prefetch depth 1 / 2 / 3, the face searches of a row interleaved or one
- * at a time, 2 / 3 / 4 waves per workgroup and 4 / 8 / 16 rows per wave all land within 3 % of each other -- see the
- * profile notes for what that leaves. */
-#define BW_TILE 256
-#define BW_P 4
-#ifndef BW_WAVES
-#define BW_WAVES 4                     /* waves per workgroup: 16.5 KB of LDS each */
-#endif
-#ifndef BW_ROWS
-#define BW_ROWS 4                      /* rows a wave marches over */
-#endif
-#ifndef BW_EU
-#define BW_EU 3                        /* waves per SIMD the register allocation is held to */
-#endif
-template <int HW>
-__global__ void __launch_bounds__(64 * BW_WAVES) __attribute__((amdgpu_waves_per_eu(BW_EU)))
-k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int ny, int nz, float iux, float iuy,
-              float iuz, const float *__restrict__ d_mesh, S3dTaps taps, EdgeFrac ef)
-{
-    constexpr int NST = BW_TILE + 2 * HW;                      /* slots of the extended row of a tile */
-    constexpr int NSTP = NST + (NST >> 2) + 1;                 /* ... padded */
-    constexpr int NR1 = (NST + 63) / 64;                       /* stage-1 rounds of a wave */
-    constexpr int NOUT4 = BW_TILE * 3;                         /* float4 of a tile's output row */
-    constexpr int BUF = 3 * NSTP;
-    constexpr int NM = BW_P + 2 * HW;                          /* source slots a lane walks */
-    static_assert(BW_TILE == 64 * BW_P, "a lane owns BW_P voxels of the wave's tile");
-    __shared__ float mesh[S3D_MESH_FLOATS];
-    __shared__ __attribute__((aligned(16))) float4 bufs[BW_WAVES][BUF];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float4 *const buf = bufs[wv];
-    for (int i = tid; i < S3D_MESH_FLOATS; i += 64 * BW_WAVES) mesh[i] = d_mesh[i];
-    __syncthreads();                                           /* the only workgroup barrier */
-    const int x0 = blockIdx.x * BW_TILE, z = blockIdx.z;
-    const int y0 = (blockIdx.y * BW_WAVES + wv) * BW_ROWS;
-    if (y0 >= ny) return;
-    const int y1 = y0 + BW_ROWS < ny ? y0 + BW_ROWS : ny;
-    const size_t plane = (size_t)nx * ny;
-    const bool zin = z >= 1 && z <= nz - 2;
-    const int zl = z < 1 ? 1 : (z > nz - 2 ? nz - 2 : z);
-    auto clampx = [&](int x) { return x < 1 ? 1 : (x > nx - 2 ? nx - 2 : x); };
-    struct Grad { float xm, xp, ym, yp, zm, zp; };
-    auto load = [&](int y, int xl) -> Grad {
-        const int yl = y < 1 ? 1 : (y > ny - 2 ? ny - 2 : y);
-        const float *p = sm + ((size_t)zl * plane + (size_t)yl * nx + xl);
-        Grad g;
-        g.xm = p[-1]; g.xp = p[1]; g.ym = p[-nx]; g.yp = p[nx]; g.zm = p[-(ptrdiff_t)plane]; g.zp = p[plane];
-        return g;
-    };
-    /* the twelve channels of voxel xv into h (zero outside the interior and where the gradient is flat) */
-    auto voxel = [&](const Grad &q, int xv, int y, float *h) {
-#pragma unroll
-        for (int k = 0; k < S3D_NVERT; k++) h[k] = 0.0f;
-        if (zin && xv >= 1 && xv <= nx - 2 && y >= 1 && y <= ny - 2) {
-            V3 g;
-            g.x = 0.5f * (q.xp - q.xm);
-            g.y = 0.5f * (q.yp - q.ym);
-            g.z = 0.5f * (q.zp - q.zm);
-            g.x = g.x * iux; g.y = g.y * iuy; g.z = g.z * iuz;
-            V3 bary;
-            const int face = s3d_icos_bin_fast(mesh, g, &bary);
-            if (face >= 0) {
-                const int v0 = __float_as_int(S3D_MESH_AT(mesh, face, 13)), v1 = __float_as_int(S3D_MESH_AT(mesh, face, 14)),
-                          v2 = __float_as_int(S3D_MESH_AT(mesh, face, 15));
-#pragma unroll
-                for (int k = 0; k < S3D_NVERT; k++) h[k] = k == v0 ? bary.x : (k == v1 ? bary.y : (k == v2 ? bary.z : 0.0f));
-            }
-        }
-    };
-    /* this lane's stage-1 positions: slot i = 64 r + lane <-> E coordinate x0 - HW + i */
-    int xa[NR1];                                               /* voxel of the slot; -1: a blend (or unused) */
-    int xal[NR1];
-#pragma unroll
-    for (int r = 0; r < NR1; r++) {
-        const int i = 64 * r + lane;
-        int c = x0 - HW + i;
-        if (c < 0) c = -c;
-        xa[r] = (i < NST && c <= nx - 2) ? c : -1;
-        xal[r] = clampx(c);
-    }
-    /* blends E[nx - 1 + j], j = 0 .. HW (imutil.c:2378-2380), where they fall into this tile: lane j of the wave, after the
-     * rounds above -- only the row's last tile (or last two) has any */
-    const int jslot = (nx - 1 + lane) - (x0 - HW);             /* slot of blend j = lane */
-    const bool jb = lane <= HW && jslot >= 0 && jslot < NST;
-    const int xba = clampx(nx - 2 - lane), xbb = clampx(nx - 1 - lane);
-    const bool any_blend = __ballot(jb) != 0ull;
-    Grad G[NR1];
-#pragma unroll
-    for (int r = 0; r < NR1; r++) G[r] = load(y0, xal[r]);
-    const int nvox = nx - x0 < BW_TILE ? nx - x0 : BW_TILE;
-    for (int y = y0; y < y1; y++) {
-        /* ---- stage 1: the extended row of the tile into the three quad arrays ---- */
-#pragma unroll
-        for (int r = 0; r < NR1; r++) {
-            const int i = 64 * r + lane;
-            if (xa[r] >= 0) {
-                /* twelve zeros, then the three weights at their vertices' channels (LDS writes of a lane land in program
-                 * order): the dense form -- k == v0 ? b.x : k == v1 ? ... for twelve k -- was 72 of a position's ~380
-                 * instructions */
-                const int ph = i + (i >> 2);
-                const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                buf[ph] = z4; buf[NSTP + ph] = z4; buf[2 * NSTP + ph] = z4;
-                const Grad &q = G[r];
-                const int xv = xa[r];
-                if (zin && xv >= 1 && xv <= nx - 2 && y >= 1 && y <= ny - 2) {
-                    V3 g;
-                    g.x = 0.5f * (q.xp - q.xm);
-                    g.y = 0.5f * (q.yp - q.ym);
-                    g.z = 0.5f * (q.zp - q.zm);
-                    g.x = g.x * iux; g.y = g.y * iuy; g.z = g.z * iuz;
-                    V3 bary;
-                    const int face = s3d_icos_bin_fast(mesh, g, &bary);
-                    if (face >= 0) {
-                        float *const fb = reinterpret_cast<float *>(buf);
-                        const int v0 = __float_as_int(S3D_MESH_AT(mesh, face, 13)), v1 = __float_as_int(S3D_MESH_AT(mesh, face, 14)),
-                                  v2 = __float_as_int(S3D_MESH_AT(mesh, face, 15));
-                        fb[((v0 >> 2) * NSTP + ph) * 4 + (v0 & 3)] = bary.x;
-                        fb[((v1 >> 2) * NSTP + ph) * 4 + (v1 & 3)] = bary.y;
-                        fb[((v2 >> 2) * NSTP + ph) * 4 + (v2 & 3)] = bary.z;
-                    }
-                }
-            }
-#if !defined(BW_S1_FREE)
-            S3D_SCHED_BARRIER();                               /* one face search at a time: interleaved they cost 60 registers each */
-#endif
-        }
-        if (any_blend) {
-            const Grad qa = load(y, xba), qb = load(y, xbb);
-            if (jb) {
-                float h[S3D_NVERT], g[S3D_NVERT];
-                voxel(qa, nx - 2 - lane, y, h);
-                voxel(qb, nx - 1 - lane, y, g);
-                const float f = ef.f[lane], om = 1.0f - f;
-#pragma unroll
-                for (int k = 0; k < S3D_NVERT; k++) h[k] = om * h[k] + f * g[k];
-                const int ph = jslot + (jslot >> 2);
-                buf[ph] = make_float4(h[0], h[1], h[2], h[3]);
-                buf[NSTP + ph] = make_float4(h[4], h[5], h[6], h[7]);
-                buf[2 * NSTP + ph] = make_float4(h[8], h[9], h[10], h[11]);
-            }
-        }
-        /* the next row's gradients: in flight through the convolution */
-        if (y + 1 < y1) {
-#pragma unroll
-            for (int r = 0; r < NR1; r++) G[r] = load(y + 1, xal[r]);
-        }
-        s3d_wave_lds_sync();
-        /* ---- stage 2: 4 voxels x 12 channels per lane; source slot m = BW_P - 1 + 2 HW ... 0, tap k = p + 2 HW - m ---- */
-        /* one channel quad at a time: 16 accumulators (and the reads of one quad array) live instead of 48 */
-#pragma unroll 1
-        for (int q = 0; q < 3; q++) {
-            float4 acc[BW_P];
-#pragma unroll
-            for (int p = 0; p < BW_P; p++) acc[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const float4 *const e0 = buf + q * NSTP + 5 * lane;
-            /* one source slot ahead: the read of slot m - 1 is issued, then the (up to) 32 multiply-adds of slot m run.  The
-             * scheduling barriers keep the compiler from hoisting all 4 + 2 HW reads to the top. */
-#ifndef BW_PD
-#define BW_PD 1                        /* source slots read ahead of the one being worked on */
-#endif
-            float4 ring[BW_PD + 1];
-#pragma unroll
-            for (int d = 0; d <= BW_PD; d++) ring[d] = e0[(NM - 1 - d) + ((NM - 1 - d) >> 2)];
-#pragma unroll
-            for (int m = NM - 1; m >= 0; m--) {
-                const float4 s0 = ring[0];
-#pragma unroll
-                for (int d = 0; d < BW_PD; d++) ring[d] = ring[d + 1];
-                if (m - 1 - BW_PD >= 0) ring[BW_PD] = e0[(m - 1 - BW_PD) + ((m - 1 - BW_PD) >> 2)];
-                S3D_SCHED_BARRIER();
-#pragma unroll
-                for (int p = 0; p < BW_P; p++) {
-                    const int k = p + 2 * HW - m;
-                    if (k < 0 || k > 2 * HW) continue;
-                    const float t = taps.t[k];
-                    acc[p].x = acc[p].x + t * s0.x; acc[p].y = acc[p].y + t * s0.y;
-                    acc[p].z = acc[p].z + t * s0.z; acc[p].w = acc[p].w + t * s0.w;
-                }
-                S3D_SCHED_BARRIER();
-            }
-            /* every lane has read its window of this quad's array (LDS operations of a wave execute in order): the lane's four
-             * output float4 take the place of its first four slots -- voxel v of quad q at index v + (v >> 2) */
-            s3d_wave_lds_sync();
-#pragma unroll
-            for (int p = 0; p < BW_P; p++) buf[q * NSTP + 5 * lane + p] = acc[p];
-        }
-        s3d_wave_lds_sync();
-        float4 *const drow = reinterpret_cast<float4 *>(dst + ((size_t)z * plane + (size_t)y * nx + x0) * S3D_NVERT);
-#pragma unroll
-        for (int t = 0; t < NOUT4 / 64; t++) {
-            const int f = 64 * t + lane;
-            const int vx = f / 3;
-            const float4 v = buf[(f - 3 * vx) * NSTP + vx + (vx >> 2)];
-            if (f < 3 * nvox) drow[f] = v;
-        }
-        s3d_wave_lds_sync();                                   /* ... before the next row's stage 1 overwrites it */
-    }
 }
 
 /* ---- fused X+Y pass ----------------------------------------------------------------------------- */
@@ -1139,21 +865,6 @@ k_gauss_xy_div(const float *__restrict__ src, float *__restrict__ dst, int nx, i
     gauss_xy_body<HW, true, RAGGED>(src, dst, nx, ny, chunk, taps, efx, efy, m == 0.0f ? 1.0f : m);   /* k_scale_div leaves an all-zero image alone */
 }
 
-/* f_j exactly as the reference's boundary pass evaluates it for uf == 1 (imutil.c:2378-2380) */
-static int edge_fracs(int n, int hw, EdgeFrac *ef)
-{
-    const int dim_end = n - 1;
-    for (int j = 0; j <= hw; j++) {
-        const float c = (float)(dim_end + j);
-        const float m = 2.0f * (float)dim_end - c - 0.1f;
-        const int lo = (int)m;
-        if (lo != n - 2 - j || lo < 0) return -1;
-        ef->f[j] = m - (float)lo;
-    }
-    for (int j = hw + 1; j <= S3D_FAST_MAX_HW; j++) ef->f[j] = 0.0f;
-    return 0;
-}
-
 static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int width)
 {
     const int hw = width / 2;
@@ -1167,6 +878,21 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
 }
 
 static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk().  Per calling thread. */
+static thread_local int g_chunk_user = 0;      /* s3d_k_gauss_set_chunks was called: the targets are taken literally */
+
+/* Steps per chunk of a marching pass over n steps: equal chunks of about `target` steps (512 -> 3 x 171).  A volume that
+ * would put fewer than ~2 waves on every SIMD that way -- 256^3: 512 waves for the 1024 SIMDs, each waiting out the latency
+ * of every row it loads (k_gauss_xy<4> 62 us, k_gauss_z<4> 46 us for 67 MB) -- is cut into more, shorter chunks, as long as
+ * the 2 hw warm-up steps of a chunk stay below half of it. */
+static int march_chunk(int n, int target, size_t waves_per_chunk, int hw)
+{
+    int nch = (int)s3d_div_up(n, target);
+    if (!g_chunk_user) {
+        const int shortest = 4 * hw > 16 ? 4 * hw : 16;
+        while (waves_per_chunk * (size_t)nch < 2048 && n / (2 * nch) >= shortest) nch *= 2;
+    }
+    return (n + nch - 1) / nch;
+}
 
 /* profiling / test knob: bit 0 = Z kernel WITH a guard-free steady-state loop (more VGPRs; measured slower);
  * bit 1 = no specialisation of the generic axis pass at all (k_conv_axis only); bit 2 = unused (was: the per-wave LDS-ring z
@@ -1194,6 +920,7 @@ extern "C" void s3d_k_gauss_set_chunks(int chunk_xy, int chunk_z)
 {
     if (chunk_xy >= 8) g_chunk_xy = chunk_xy;
     if (chunk_z >= 8) g_chunk_z = chunk_z;
+    g_chunk_user = 1;
 }
 
 /* optional HIP events around the two fused kernels (bench.py times the dominant kernel with them) */
@@ -1207,15 +934,15 @@ extern "C" void s3d_k_gauss_set_events(void *before_xy, void *between, void *aft
  * Z-slab needs valid source planes [z0-HW, z1+HW) (clamped to the volume), i.e. the neighbours' halos. */
 template <int HW>
 static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
-                       const S3dTaps &t, hipStream_t st, const float *d_div = nullptr)
+                       const S3dTaps &t, hipStream_t st, const float *d_div = nullptr, float *d_maxout = nullptr)
 {
     EdgeFrac ex, ey, ez;
     if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
     const int za = z0 - HW > 0 ? z0 - HW : 0, zb = z1 + HW < nz ? z1 + HW : nz;
     const int nzo = z1 - z0;
     /* split the marching axis into equal chunks of about the target length (512 -> 3 x 171) */
-    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
-    const int cz = (nzo + (int)s3d_div_up(nzo, g_chunk_z) - 1) / (int)s3d_div_up(nzo, g_chunk_z);
+    const int cy = march_chunk(ny, g_chunk_xy, (size_t)s3d_div_up(nx, XY_STRIP) * (zb - za), HW);
+    const int cz = march_chunk(nzo, g_chunk_z, (size_t)s3d_div_up(s3d_div_up((size_t)nx * ny, 4), 256) * 4, HW);
     const unsigned ncy = s3d_div_up(ny, cy), ncz = s3d_div_up(nzo, cz);
     const size_t plane = (size_t)nx * ny;
     if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
@@ -1236,13 +963,16 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
     if (g_ev[1]) S3D_HIP(hipEventRecord(g_ev[1], st));
     if (ragged)
         hipLaunchKernelGGL((k_gauss_z<HW, false, true>), dim3(s3d_div_up(s3d_div_up(plane, 4), 256), ncz), dim3(256), 0, st,
-                           d_tmp, d_dst, nx, ny, nz, z0, z1, cz, t, ez);
+                           d_tmp, d_dst, nx, ny, nz, z0, z1, cz, t, ez, (unsigned *)nullptr);
+    else if (d_maxout)
+        hipLaunchKernelGGL((k_gauss_z<HW, false, false, true>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
+                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez, reinterpret_cast<unsigned *>(d_maxout));
     else if (!(g_gauss_mode & 1))
         hipLaunchKernelGGL((k_gauss_z<HW, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
-                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez);
+                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez, (unsigned *)nullptr);
     else
         hipLaunchKernelGGL((k_gauss_z<HW, true>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
-                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez);
+                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez, (unsigned *)nullptr);
     S3D_CHECK_LAUNCH();
     if (g_ev[2]) S3D_HIP(hipEventRecord(g_ev[2], st));
     return S3D_OK;
@@ -1254,7 +984,7 @@ static int launch_fast_xy(const float *d_src, float *d_dst, int nx, int ny, int 
 {
     EdgeFrac ex, ey;
     if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey)) S3D_FAIL("edge table");
-    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
+    const int cy = march_chunk(ny, g_chunk_xy, (size_t)s3d_div_up(nx, XY_STRIP) * (zb - za), HW);
     const unsigned ncy = s3d_div_up(ny, cy);
     const size_t plane = (size_t)nx * ny;
     if (ncy > 65535 || (unsigned)(zb - za) > 65535u) S3D_FAIL("volume too large for the fast-path grid");
@@ -1294,18 +1024,18 @@ static int fast_xy_eligible(int nx, int ny, int nz, int nc, const float uf[3], i
 }
 
 static int fast_dispatch(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int z0, int z1,
-                         int hw, const S3dTaps &t, hipStream_t st, const float *d_div = nullptr)
+                         int hw, const S3dTaps &t, hipStream_t st, const float *d_div = nullptr, float *d_maxout = nullptr)
 {
     switch (hw) {
-    case 1: return launch_fast<1>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 2: return launch_fast<2>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 3: return launch_fast<3>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 4: return launch_fast<4>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 5: return launch_fast<5>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 6: return launch_fast<6>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 7: return launch_fast<7>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 8: return launch_fast<8>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
-    case 9: return launch_fast<9>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div);
+    case 1: return launch_fast<1>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 2: return launch_fast<2>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 3: return launch_fast<3>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 4: return launch_fast<4>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 5: return launch_fast<5>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 6: return launch_fast<6>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 7: return launch_fast<7>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 8: return launch_fast<8>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
+    case 9: return launch_fast<9>(d_src, d_dst, d_tmp, nx, ny, nz, z0, z1, t, st, d_div, d_maxout);
     default: break;
     }
     S3D_FAIL("half width not instantiated");
@@ -1363,52 +1093,10 @@ static int fast_mc_dispatch(const float *d_src, float *d_dst, float *d_tmp, int 
     S3D_FAIL("half width not instantiated");
 }
 
-template <int HW>
-static int launch_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, int nx, int ny, int nz, const float unitsf[3],
-                            const float *d_mesh, const S3dTaps &t, hipStream_t st)
+/* for s3d_dense.hip: is the streaming multi-channel form (unit tap spacing on every axis) available for this volume? */
+extern "C" int s3d_k_fast_mc_eligible(int nx, int ny, int nz, int nc, const float uf[3], int width)
 {
-    EdgeFrac ex, ey, ez;
-    if (edge_fracs(nx, HW, &ex) || edge_fracs(ny, HW, &ey) || edge_fracs(nz, HW, &ez)) S3D_FAIL("edge table");
-    const size_t nxc = (size_t)nx * S3D_NVERT;
-    hipLaunchKernelGGL((k_bary_x_wave<HW>), dim3(s3d_div_up(nx, BW_TILE), s3d_div_up(ny, BW_WAVES * BW_ROWS), nz),
-                       dim3(64 * BW_WAVES), 0, st, d_smooth, d_dst, nx, ny, nz, 1.0f / unitsf[0], 1.0f / unitsf[1],
-                       1.0f / unitsf[2], d_mesh, t, ex);
-    S3D_CHECK_LAUNCH();
-    const int cy = (ny + (int)s3d_div_up(ny, g_chunk_xy) - 1) / (int)s3d_div_up(ny, g_chunk_xy);
-    const int cz = (nz + (int)s3d_div_up(nz, g_chunk_z) - 1) / (int)s3d_div_up(nz, g_chunk_z);
-    hipLaunchKernelGGL((k_march<HW>), dim3(s3d_div_up(nxc / 4, 256), s3d_div_up(ny, cy), nz), dim3(256), 0, st, d_dst,
-                       d_tmp, nxc / 4, nxc, ny, nxc * ny, cy, t, ey);
-    S3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_march<HW>), dim3(s3d_div_up(nxc / 4 * ny, 256), s3d_div_up(nz, cz), 1), dim3(256), 0, st,
-                       d_tmp, d_dst, nxc / 4 * ny, nxc * ny, nz, (size_t)0, cz, t, ez);
-    S3D_CHECK_LAUNCH();
-    return S3D_OK;
-}
-
-/* k_dense_bary + the 12-channel blur in one go for unit tap spacing (the x pass reads the barycentric image
- * from LDS).  Returns 1 -- and does nothing -- when the configuration is not eligible: the caller then runs
- * s3d_k_dense_bary and s3d_k_sep_fir. */
-extern "C" int s3d_k_dense_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, int nx, int ny, int nz,
-                                     const float unitsf[3], const float uf[3], const float *d_mesh, const float *taps,
-                                     int width, s3d_stream stream)
-{
-    hipStream_t st = (hipStream_t)stream;
-    S3dTaps t;
-    if (!fast_mc_eligible(nx, ny, nz, S3D_NVERT, uf, width) || ny > 65535) return 1;
-    if (check_taps(taps, width, &t)) return S3D_ERR;
-    switch (width / 2) {
-    case 1: return launch_bary_blur<1>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 2: return launch_bary_blur<2>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 3: return launch_bary_blur<3>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 4: return launch_bary_blur<4>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 5: return launch_bary_blur<5>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 6: return launch_bary_blur<6>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 7: return launch_bary_blur<7>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 8: return launch_bary_blur<8>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    case 9: return launch_bary_blur<9>(d_smooth, d_dst, d_tmp, nx, ny, nz, unitsf, d_mesh, t, st);
-    default: break;
-    }
-    return 1;
+    return fast_mc_eligible(nx, ny, nz, nc, uf, width);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1706,6 +1394,19 @@ extern "C" int s3d_k_sep_fir_path(const float *d_src, float *d_dst, float *d_tmp
     if (s3d_k_conv_axis(d_dst, d_tmp, nx, ny, nz, nc, 2, taps, width, uf[2], stream)) return S3D_ERR;
     S3D_HIP(hipMemcpyAsync(d_dst, d_tmp, sizeof(float) * (size_t)nx * ny * nz * nc, hipMemcpyDeviceToDevice, st));
     return S3D_OK;
+}
+
+/* s3d_k_sep_fir (single channel) + s3d_k_absmax of its output in one go: the z pass keeps the maximum.  Returns 1 -- and does
+ * nothing -- where the fused unit-spacing kernels do not apply (ragged rows included): the caller runs the two steps. */
+extern "C" int s3d_k_sep_fir_max(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, const float uf[3],
+                                 const float *taps, int width, float *d_max, s3d_stream stream)
+{
+    S3dTaps t;
+    if (width < 1 || width > S3D_MAX_TAPS || !(width & 1) || nx < 1 || ny < 1 || nz < 1) return 1;
+    if (!fast_eligible(nx, ny, nz, 1, uf, width) || (nx & 3) || d_tmp == d_src || d_tmp == d_dst) return 1;
+    if (check_taps(taps, width, &t)) return S3D_ERR;
+    S3D_HIP(hipMemsetAsync(d_max, 0, sizeof(float), (hipStream_t)stream));
+    return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, 0, nz, width / 2, t, (hipStream_t)stream, nullptr, d_max);
 }
 
 extern "C" int s3d_k_sep_fir(const float *d_src, float *d_dst, float *d_tmp, int nx, int ny, int nz, int nc,

@@ -4,6 +4,10 @@
 
 #define RED_BLOCK 256
 #define RED_MAX_BLOCKS 4096
+/* k_absmax: every block ends in one atomicMax on the same word, and those serialise at ~12 ns each -- 4096 blocks are 50 us of
+ * atomics behind a 256^3 volume that streams in 15.  Four blocks per CU, four independent float4 loads per thread and turn. */
+#define ABSMAX_MAX_BLOCKS 1024
+#define ABSMAX_UNROLL 4
 
 /* wave64 max via xor-shuffles, then one LDS slot per wave.  The maxima are taken over the BIT PATTERNS of |v|: for
  * finite values and infinities that is the float order, and every NaN pattern lies above all of them, so a NaN anywhere in
@@ -36,7 +40,24 @@ __global__ void __launch_bounds__(RED_BLOCK) k_absmax(const float *__restrict__ 
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * RED_BLOCK;
     unsigned m = 0u;
-    for (size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x; i < n4; i += stride) {
+    size_t i = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x;
+    for (; i + (ABSMAX_UNROLL - 1) * stride < n4; i += ABSMAX_UNROLL * stride) {
+        float4 v[ABSMAX_UNROLL], w[ABSMAX_UNROLL];
+#pragma unroll
+        for (int k = 0; k < ABSMAX_UNROLL; k++) v[k] = reinterpret_cast<const float4 *>(a)[i + k * stride];
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < ABSMAX_UNROLL; k++) w[k] = reinterpret_cast<const float4 *>(b)[i + k * stride];
+#pragma unroll
+            for (int k = 0; k < ABSMAX_UNROLL; k++) {
+                v[k].x = v[k].x - w[k].x; v[k].y = v[k].y - w[k].y; v[k].z = v[k].z - w[k].z; v[k].w = v[k].w - w[k].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ABSMAX_UNROLL; k++)
+            m = umax(umax(umax(m, absbits(v[k].x)), umax(absbits(v[k].y), absbits(v[k].z))), absbits(v[k].w));
+    }
+    for (; i < n4; i += stride) {
         float4 v = reinterpret_cast<const float4 *>(a)[i];
         if (MODE == 1) {
             const float4 w = reinterpret_cast<const float4 *>(b)[i];
@@ -57,8 +78,8 @@ static int launch_absmax(const float *a, const float *b, size_t n, float *d_max,
 {
     S3D_HIP(hipMemsetAsync(d_max, 0, sizeof(float), st));
     if (n == 0) return S3D_OK;
-    unsigned blocks = s3d_div_up(n / 4 + 1, RED_BLOCK);
-    if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
+    unsigned blocks = s3d_div_up(n / 4 + 1, RED_BLOCK * ABSMAX_UNROLL);
+    if (blocks > ABSMAX_MAX_BLOCKS) blocks = ABSMAX_MAX_BLOCKS;
     if (b)
         hipLaunchKernelGGL(k_absmax<1>, dim3(blocks), dim3(RED_BLOCK), 0, st, a, b, n, (unsigned *)d_max);
     else

@@ -12,7 +12,7 @@ mkdir -p "$OBJ"
 CXXFLAGS="-DS3D_TESTING -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -I$HERE -I$ROOT/include -I$CSRC -Wno-attributes -Wno-unknown-pragmas"
 for f in s3d_rt s3d_image s3d_gauss s3d_gauss_tab s3d_extrema s3d_keypoint s3d_dense s3d_match s3d_resample s3d_rccl; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$CSRC/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$OBJ/$f.o" ] \
-     || [ "$CSRC/s3d_math.h" -nt "$OBJ/$f.o" ] || [ "$CSRC/s3d_common.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/s3d_device.h" -nt "$OBJ/$f.o" ]; then
+     || [ "$CSRC/s3d_math.h" -nt "$OBJ/$f.o" ] || [ "$CSRC/s3d_common.h" -nt "$OBJ/$f.o" ] || [ "$CSRC/s3d_ring.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/s3d_device.h" -nt "$OBJ/$f.o" ]; then
     g++ $CXXFLAGS -x c++ -c "$CSRC/$f.hip" -o "$OBJ/$f.o"
   fi
 done

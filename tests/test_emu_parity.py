@@ -132,6 +132,20 @@ def test_dense_unit_voxels(emu, oracle, dims):
     parity.check_dense(emu, oracle, dims, (1, 1, 1))
 
 
+@pytest.mark.parametrize("dims,nchunks", [((24, 23, 25), 2), ((22, 12, 29), 3), ((44, 31, 13), 4),
+                                          ((16, 70, 52), 1), ((12, 100, 90), 2)])       # long enough for the steady-state blocks
+def test_dense_march_chunks(emu, oracle, dims, nchunks):
+    """The y pass and the z pass + postproc_Hist of the unit-spacing pipeline (k_dmarch) cut into several chunks along the
+    marching axis: chunk lengths that are not multiples of three, last chunks shorter than the rest, groups of three
+    steps whose last rows lie beyond the chunk (masked)."""
+    emu.sift.s3d_k_dense_set_chunks.argtypes = [C.c_int]
+    emu.sift.s3d_k_dense_set_chunks(nchunks)
+    try:
+        parity.check_dense(emu, oracle, dims, (1, 1, 1))
+    finally:
+        emu.sift.s3d_k_dense_set_chunks(0)
+
+
 def test_dense_rotate(emu, oracle):
     parity.check_dense_rotate(emu, oracle, (16, 14, 12), (1, 1, 2))
 
