@@ -228,7 +228,6 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
 {
     constexpr int NST = BW_TILE + 2 * HW;                      /* slots of the extended row of a tile */
     constexpr int NSTP = NST + (NST >> 2) + 1;                 /* ... padded */
-    constexpr int NR1 = (NST + 63) / 64;                       /* stage-1 rounds of a wave */
     constexpr int NOUT4 = BW_TILE * 3;                         /* float4 of a tile's output row */
     constexpr int BUF = 3 * NSTP;
     constexpr int NM = BW_P + 2 * HW;                          /* source slots a lane walks */
@@ -275,36 +274,61 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
             }
         }
     };
-    /* this lane's stage-1 positions: slot i = 64 r + lane <-> E coordinate x0 - HW + i */
-    int xa[NR1];                                               /* voxel of the slot; -1: a blend (or unused) */
-    int xal[NR1];
+    /* Stage-1 positions.  Slot i of the tile's extended row <-> E coordinate x0 - HW + i.  Only REAL voxels go through the
+     * face search: the tile's own 256 (rounds 0 .. 3: voxel x0 + 64 r + lane, slot HW + 64 r + lane) and, where the tile has
+     * neighbours in the row, the HW voxels before and the HW after it (one more round, lanes 0 .. 2 HW - 1).  The other slots
+     * are derived from those in LDS: mirrors E[-c] = voxel c (a copy) and the high-end blends E[nx - 1 + j] (imutil.c:2378-2380)
+     * -- 256-voxel rows: four rounds where the first cut of this kernel ran seven (five over the 274 slots, the mirrors
+     * searched again, and two more for the blends' two source voxels). */
+    constexpr int NRV = BW_TILE / 64;
+    const bool has_nb = x0 > 0 || x0 + BW_TILE <= nx - 2;      /* (wave uniform) */
+    int xa[NRV + 1];                                           /* voxel of the round; -1: none */
+    int si[NRV + 1];                                           /* ... its slot */
 #pragma unroll
-    for (int r = 0; r < NR1; r++) {
-        const int i = 64 * r + lane;
-        int c = x0 - HW + i;
-        if (c < 0) c = -c;
-        xa[r] = (i < NST && c <= nx - 2) ? c : -1;
-        xal[r] = clampx(c);
+    for (int r = 0; r < NRV; r++) {
+        const int xv = x0 + 64 * r + lane;
+        xa[r] = xv <= nx - 2 ? xv : -1;
+        si[r] = HW + 64 * r + lane;
     }
-    /* blends E[nx - 1 + j], j = 0 .. HW (imutil.c:2378-2380), where they fall into this tile: lane j of the wave, after the
-     * rounds above -- only the row's last tile (or last two) has any */
+    {
+        const bool left = lane < HW;
+        const int xv = left ? x0 - HW + lane : x0 + BW_TILE + lane - HW;
+        xa[NRV] = (left ? x0 > 0 : (lane < 2 * HW && xv <= nx - 2)) ? xv : -1;
+        si[NRV] = left ? lane : BW_TILE + lane;
+    }
+    /* derived slots.  Mirror (x0 == 0): lane j = 1 .. HW, slot HW - j <- slot HW + j.  Blend j = lane <= HW, where E[nx - 1 + j]
+     * falls into this tile: (1 - f_j) voxel[nx - 2 - j] + f_j voxel[nx - 1 - j]; voxel nx - 1 is a border voxel: zero. */
+    const bool jm = x0 == 0 && lane >= 1 && lane <= HW;
     const int jslot = (nx - 1 + lane) - (x0 - HW);             /* slot of blend j = lane */
     const bool jb = lane <= HW && jslot >= 0 && jslot < NST;
-    const int xba = clampx(nx - 2 - lane), xbb = clampx(nx - 1 - lane);
+    const int sa = (nx - 2 - lane) - (x0 - HW), sb = sa + 1;   /* slots of the blend's two voxels (sb: the zero voxel for j = 0) */
     const bool any_blend = __ballot(jb) != 0ull;
-    Grad G[NR1];
+    const bool far_blend = __ballot(jb && sa < 0) != 0ull;     /* a one-voxel last tile: a source lies before the tile's slots */
+    const int xba = clampx(nx - 2 - lane), xbb = clampx(nx - 1 - lane);
+    Grad G[NRV + 1];
 #pragma unroll
-    for (int r = 0; r < NR1; r++) G[r] = load(y0, xal[r]);
+    for (int r = 0; r <= NRV; r++) G[r] = load(y0, clampx(xa[r]));
     const int nvox = nx - x0 < BW_TILE ? nx - x0 : BW_TILE;
+    auto rd12 = [&](const int slot, float *h) {
+        const int ph = slot + (slot >> 2);
+        const float4 a = buf[ph], b = buf[NSTP + ph], c = buf[2 * NSTP + ph];
+        h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w;
+        h[8] = c.x; h[9] = c.y; h[10] = c.z; h[11] = c.w;
+    };
+    auto wr12 = [&](const int slot, const float *h) {
+        const int ph = slot + (slot >> 2);
+        buf[ph] = make_float4(h[0], h[1], h[2], h[3]);
+        buf[NSTP + ph] = make_float4(h[4], h[5], h[6], h[7]);
+        buf[2 * NSTP + ph] = make_float4(h[8], h[9], h[10], h[11]);
+    };
     for (int y = y0; y < y1; y++) {
         /* ---- stage 1: the extended row of the tile into the three quad arrays ---- */
-#pragma unroll
-        for (int r = 0; r < NR1; r++) {
-            const int i = 64 * r + lane;
+        auto round = [&](const int r) {
             if (xa[r] >= 0) {
                 /* twelve zeros, then the three weights at their vertices' channels (LDS writes of a lane land in program
                  * order): the dense form -- k == v0 ? b.x : k == v1 ? ... for twelve k -- was 72 of a position's ~380
                  * instructions */
+                const int i = si[r];
                 const int ph = i + (i >> 2);
                 const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 buf[ph] = z4; buf[NSTP + ph] = z4; buf[2 * NSTP + ph] = z4;
@@ -331,26 +355,38 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
 #if !defined(BW_S1_FREE)
             S3D_SCHED_BARRIER();                               /* one face search at a time: interleaved they cost 60 registers each */
 #endif
-        }
-        if (any_blend) {
-            const Grad qa = load(y, xba), qb = load(y, xbb);
+        };
+#pragma unroll
+        for (int r = 0; r < NRV; r++) round(r);
+        if (has_nb) round(NRV);
+        if (x0 == 0 || any_blend) {
+            s3d_wave_lds_sync();                               /* the searched slots are in place */
+            float h[S3D_NVERT], g[S3D_NVERT];
+            if (jm) {                                          /* (mirrors lie left of voxel 0, blends right of voxel nx - 2: no slot is both) */
+                rd12(HW + lane, h);
+                wr12(HW - lane, h);
+            }
             if (jb) {
-                float h[S3D_NVERT], g[S3D_NVERT];
-                voxel(qa, nx - 2 - lane, y, h);
-                voxel(qb, nx - 1 - lane, y, g);
+                if (far_blend) {                               /* (rows of 256 k + 1 voxels: the source is searched here) */
+                    const Grad qa = load(y, xba), qb = load(y, xbb);
+                    voxel(qa, nx - 2 - lane, y, h);
+                    voxel(qb, nx - 1 - lane, y, g);
+                } else {
+                    rd12(sa, h);
+#pragma unroll
+                    for (int k = 0; k < S3D_NVERT; k++) g[k] = 0.0f;
+                    if (lane > 0) rd12(sb, g);
+                }
                 const float f = ef.f[lane], om = 1.0f - f;
 #pragma unroll
                 for (int k = 0; k < S3D_NVERT; k++) h[k] = om * h[k] + f * g[k];
-                const int ph = jslot + (jslot >> 2);
-                buf[ph] = make_float4(h[0], h[1], h[2], h[3]);
-                buf[NSTP + ph] = make_float4(h[4], h[5], h[6], h[7]);
-                buf[2 * NSTP + ph] = make_float4(h[8], h[9], h[10], h[11]);
             }
+            if (jb) wr12(jslot, h);
         }
         /* the next row's gradients: in flight through the convolution */
         if (y + 1 < y1) {
 #pragma unroll
-            for (int r = 0; r < NR1; r++) G[r] = load(y + 1, xal[r]);
+            for (int r = 0; r <= NRV; r++) G[r] = load(y + 1, clampx(xa[r]));
         }
         s3d_wave_lds_sync();
         /* ---- stage 2: 4 voxels x 12 channels per lane; source slot m = BW_P - 1 + 2 HW ... 0, tap k = p + 2 HW - m ---- */
@@ -419,14 +455,18 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
  * 768 workgroups of 4 waves against 1024 resident at 4 waves per SIMD) -- the 176-step chunks of the Gaussian pyramid made
  * 1536 workgroups here, 1.5 rounds, the second one half empty, and re-read 2 HW warm-up steps per chunk.
  *
- * POST (z pass): postproc_Hist (sift.c:2267-2292) needs the 12 channels of a voxel, which sit in three neighbouring lanes.  A wave
- * therefore takes 63 columns = 21 whole voxels (lane 63 idles), parks the outputs of three consecutive steps in its private
- * LDS rows and after every third step lane l post-processes voxel l % 21 of step l / 21: 63 lanes busy, the f64 norms are
- * paid once per voxel, and the 48 bytes of a voxel leave from one lane -- k_dense_post's access pattern without its
- * 96 B/voxel round trip.  The caller's unscaled voxel (the final factor) is fetched one group ahead.  The number of steps is
- * padded to a multiple of three (the padding steps compute on stale ring slots and are masked at the store). */
-#define DM_WAVES 4
-#define DM_PAD 2                                   /* float4 of padding between a wave's three staging rows */
+ * POST (z pass): postproc_Hist (sift.c:2267-2292) needs the 12 channels of a voxel, which sit in three neighbouring lanes, and
+ * 64 is not a multiple of 3.  The workgroup is therefore THREE waves on 192 columns = 64 whole voxels: every thread parks the
+ * outputs of three consecutive steps in the workgroup's LDS rows, and after every third step thread (wave w, lane l)
+ * post-processes voxel l of step w -- all 192 threads busy, the f64 norms paid once per voxel, the 48 bytes of a voxel leaving
+ * from one lane (k_dense_post's access pattern without its 96 B/voxel round trip).  The staging rows are double buffered:
+ * one LDS-only barrier per group of three steps (the prefetched rows stay in flight).  The caller's unscaled voxel (the final
+ * factor) is fetched one group ahead.  The number of steps is padded to a multiple of three (the padding steps compute on
+ * stale ring slots and are masked at the store).  256^3: 1024 workgroups = 3072 waves, one round at 3 waves per SIMD; the
+ * first cut (a wave on 63 columns = 21 voxels, lane 63 idle, wave-private staging) needed 3121 waves: a second round for 49. */
+#define DM_WAVES 4                                 /* waves per workgroup: y pass */
+#define DM_PWAVES 3                                /* ... z pass + postproc_Hist */
+#define DM_PAD 2                                   /* float4 of padding between the staging rows */
 #ifndef DM_EU
 #define DM_EU 3                                    /* waves per SIMD the register allocation is held to */
 #endif
@@ -435,6 +475,13 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
 #endif
 #ifndef DM_DZ
 #define DM_DZ 5                                    /* ... z pass (at least; rounded up to make the ring a multiple of 3) */
+#endif
+
+/* a compiler-only fence: LDS contents read before it are read again after it */
+#if defined(S3D_EMU)
+#define S3D_LDS_REREAD() ((void)0)
+#else
+#define S3D_LDS_REREAD() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
 #endif
 
 template <int HW, int R>
@@ -459,22 +506,22 @@ __device__ __forceinline__ float4 ring_dot_r(const float4 (&ring)[R], const int 
 }
 
 template <int HW, int D, bool POST>
-__global__ void __launch_bounds__(64 * DM_WAVES) __attribute__((amdgpu_waves_per_eu(DM_EU)))
+__global__ void __launch_bounds__(64 * (POST ? DM_PWAVES : DM_WAVES)) __attribute__((amdgpu_waves_per_eu(DM_EU)))
 k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* float4 columns per batch */,
          size_t stride /* floats between consecutive steps */, int n /* steps */, size_t bstride /* floats per batch */,
          int chunk, S3dTaps taps, EdgeFrac ef, const float *__restrict__ in /* POST: the caller's volume */,
          unsigned pvox /* POST: voxels per step */)
 {
     constexpr int W = 2 * HW + 1, R = W + D;
-    constexpr int LPW = POST ? 63 : 64;                        /* columns of a wave */
+    constexpr int NW = POST ? DM_PWAVES : DM_WAVES, NT = 64 * NW;
     static_assert(!POST || R % 3 == 0, "the output's position in its group of three must be static");
-    __shared__ __attribute__((aligned(16))) float4 stage[POST ? DM_WAVES : 1][3][64 + DM_PAD];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t wcol0 = ((size_t)blockIdx.x * DM_WAVES + wv) * LPW;
-    if (wcol0 >= ncol) return;                                 /* (whole waves only) */
-    size_t colid = wcol0 + lane;
+    static_assert(DM_PWAVES == 3, "a step of the group per wave");
+    __shared__ __attribute__((aligned(16))) float4 stage[POST ? 2 : 1][POST ? 3 : 1][POST ? NT + DM_PAD : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t bcol0 = (size_t)blockIdx.x * NT;              /* the workgroup's first column */
+    size_t colid = bcol0 + tid;
     if (!POST && colid >= ncol) return;
-    if (colid >= ncol) colid = ncol - 1;                       /* POST: idle lanes march along a real column (they may own a voxel of the groups) */
+    if (colid >= ncol) colid = ncol - 1;                       /* POST: spare threads march along a real column (barriers; they may own a voxel of the groups) */
     /* addresses = a wave-uniform row (scalar registers) + the lane's 32-bit byte offset: the loads and stores take the
      * scalar-base form and no per-step pointer lives in vector registers */
     const unsigned loff = (unsigned)colid * 16u;
@@ -492,11 +539,10 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
     const int p1 = (p0 + chunk < n) ? p0 + chunk : n;
     const int nout = p1 - p0;                                  /* output steps s = 0 .. nout-1: row p0 + s */
     const int Sp = POST ? (nout + 2) / 3 * 3 : nout;           /* ... incl. the padding of the last group */
-    /* POST: this lane's voxel in the groups of three steps; lane 63 doubles lane 62 (same voxel, same bytes to the same
-     * address), so that the steady state needs no lane mask */
-    const int el = lane < 62 ? lane : 62;
-    const int er = el / 21, ei = el - 21 * er;                 /* step of the group, voxel of the wave */
-    const unsigned evox = (unsigned)(wcol0 / 3) + (unsigned)ei;
+    /* POST: this thread's voxel in the groups of three steps */
+    const int er = wv, ei = lane;                              /* step of the group, voxel of the workgroup */
+    const unsigned evox = (unsigned)(bcol0 / 3) + (unsigned)ei;
+    int ebuf = 0;                                              /* staging buffer of the group being parked */
     const bool evalid = POST && evox < pvox;
     const unsigned evc = evox < pvox ? evox : pvox - 1;
     float valn = 0.0f;
@@ -509,9 +555,10 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
      * output -- four at a time, so that the epilogue needs a dozen registers beside the ring instead of thirty (k_dense_post's
      * operations on every element, in its order). */
     auto epilogue = [&](const int pg, const bool masked) {
-        s3d_wave_lds_sync();
+        s3d_block_lds_sync();
         const int prow = pg + er;
-        const float4 *const sp = &stage[wv][er][3 * ei];
+        const float4 *const sp = &stage[ebuf][er][3 * ei];
+        ebuf ^= 1;                                             /* the next group is parked in the other buffer: no second barrier */
         const float val = valn;
         {                                                      /* the next group's factors */
             const int pr = prow + 3 < n ? prow + 3 : n - 1;
@@ -529,7 +576,7 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
             norm = __builtin_fma((double)v.z, (double)v.z, norm); norm = __builtin_fma((double)v.w, (double)v.w, norm);
         }
         const float inv1 = (float)(1.0 / (sqrt(norm) + 2.220446049250313e-16));
-        s3d_wave_lds_sync();                                   /* (the values are read again, not kept) */
+        S3D_LDS_REREAD();                                      /* (the values are read again, not kept) */
         norm = 0.0;
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -541,7 +588,7 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
             norm = __builtin_fma((double)v.z, (double)v.z, norm); norm = __builtin_fma((double)v.w, (double)v.w, norm);
         }
         const float inv2 = (float)(1.0 / (sqrt(norm) + 2.220446049250313e-16));
-        s3d_wave_lds_sync();
+        S3D_LDS_REREAD();
 #endif
         float4 *const o = reinterpret_cast<float4 *>(dst + ((size_t)prow * pvox + evox) * S3D_NVERT);
         const bool ok = !masked || (evalid && prow < p1);
@@ -557,7 +604,6 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
             v.x = v.x * val; v.y = v.y * val; v.z = v.z * val; v.w = v.w * val;
             if (ok) o[q] = v;
         }
-        s3d_wave_lds_sync();                                   /* ... before the next group is parked */
     };
     /* Output step s needs the extended rows p0 + s - HW .. p0 + s + HW; row index i (coordinate p0 - HW + i) lives in ring slot
      * (i - 2 HW) mod R, so that step s = R q + u finds its newest row in slot u and loads row i = s + 2 HW + D into slot
@@ -574,7 +620,7 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
      * every step, which ends the prefetching (k_march: 4.3 TB/s).  A load beyond the rows the chunk needs is clamped onto an
      * interior row and never used. */
     int sb = 0;
-    if (!POST || wcol0 + 63 <= ncol) {
+    if (!POST || bcol0 + NT <= ncol) {
         for (; sb + R <= nout && c0 + sb + R - 1 + 2 * HW + D <= n - 2 + D; sb += R) {
             /* (the D rows past the block are loaded clamped: they are only needed if another steady block follows, and then
              * they are interior) */
@@ -591,7 +637,7 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
                 if (!POST) {
                     *reinterpret_cast<float4 *>(dbase + (size_t)(p0 + s) * sbytes + loff) = acc;
                 } else {
-                    stage[wv][u % 3][lane] = acc;                         /* s % 3: R % 3 == 0 */
+                    stage[ebuf][u % 3][tid] = acc;                        /* s % 3: R % 3 == 0 */
                     if (u % 3 == 2) epilogue(p0 + s - 2, false);
                 }
             }
@@ -613,7 +659,7 @@ k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* 
                     if (!POST) {
                         *reinterpret_cast<float4 *>(dbase + (size_t)(p0 + s) * sbytes + loff) = acc;
                     } else {
-                        stage[wv][u % 3][lane] = acc;
+                        stage[ebuf][u % 3][tid] = acc;
                         if (u % 3 == 2) epilogue(p0 + s - 2, true);
                     }
                 }
@@ -627,10 +673,10 @@ static thread_local int g_dense_chunks = 0;        /* > 0: that many chunks (pro
 extern "C" void s3d_k_dense_set_chunks(int nchunks) { g_dense_chunks = nchunks; }
 static int dmarch_chunk(int n, size_t wgs, int hw, bool post)
 {
-    const size_t resident = 256 * DM_EU;            /* 256 CUs x DM_EU workgroups of 4 waves */
+    const size_t resident = 256 * (4 * DM_EU / (post ? DM_PWAVES : DM_WAVES));      /* workgroups the 256 CUs hold at DM_EU waves per SIMD */
     int nch;
     if (g_dense_chunks > 0) nch = g_dense_chunks;
-    else if (wgs >= resident) nch = (int)s3d_div_up(n, 176);      /* many rounds anyway: the pyramid's chunk length */
+    else if (wgs > resident) nch = (int)s3d_div_up(n, 176);       /* many rounds anyway: the pyramid's chunk length */
     else {
         nch = (int)(resident / wgs);               /* as many chunks as still fit one round ... */
         const int longest = n / (8 * hw > 32 ? 8 * hw : 32);      /* ... while the 2 hw warm-up steps stay below a quarter */
@@ -670,9 +716,9 @@ static int launch_bary_blur(const float *d_smooth, float *d_dst, float *d_tmp, i
     }
     const size_t ncolz = nxc / 4 * ny;                         /* z: d_tmp -> d_dst */
     if (d_post_in) {
-        const unsigned gx = s3d_div_up(ncolz, 63 * DM_WAVES);
+        const unsigned gx = s3d_div_up(ncolz, 64 * DM_PWAVES);
         const int cz = dmarch_chunk(nz, gx, HW, true);
-        hipLaunchKernelGGL((k_dmarch<HW, DmDepth<HW>::Z, true>), dim3(gx, s3d_div_up(nz, cz), 1), dim3(64 * DM_WAVES), 0, st,
+        hipLaunchKernelGGL((k_dmarch<HW, DmDepth<HW>::Z, true>), dim3(gx, s3d_div_up(nz, cz), 1), dim3(64 * DM_PWAVES), 0, st,
                            d_tmp, d_dst, ncolz, nxc * ny, nz, (size_t)0, cz, t, ez, d_post_in, (unsigned)((size_t)nx * ny));
     } else {
         const unsigned gx = s3d_div_up(ncolz, 64 * DM_WAVES);

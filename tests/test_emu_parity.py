@@ -124,11 +124,12 @@ def test_dense(emu, oracle, dims):
     parity.check_dense(emu, oracle, dims, (1, 1, 2))
 
 
-@pytest.mark.parametrize("dims", [(14, 13, 12), (44, 12, 11), (262, 11, 11), (301, 27, 11)])
+@pytest.mark.parametrize("dims", [(14, 13, 12), (44, 12, 11), (262, 11, 11), (301, 27, 11), (257, 12, 11), (523, 11, 12), (256, 11, 11)])
 def test_dense_unit_voxels(emu, oracle, dims):
     """Unit voxels: the barycentric image fused with the x pass of its blur (k_bary_x_wave: a wave per 256-voxel row tile,
     four voxels x twelve channels per lane) -- rows shorter than a tile, a second tile of 6 / 45 voxels whose extended row
-    holds the high-edge blends, more rows than a workgroup's waves march over."""
+    holds the high-edge blends, more rows than a workgroup's waves march over; a last tile of one voxel (the blends' sources lie
+    before its slots), three tiles (left and right neighbours searched), a row that is exactly one tile (no neighbours)."""
     parity.check_dense(emu, oracle, dims, (1, 1, 1))
 
 
