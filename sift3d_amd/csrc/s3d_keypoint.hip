@@ -1368,8 +1368,24 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
      * front: cell coordinates vb, window weight w, central differences (x2) -> face and the three vertex magnitudes. */
     struct DwVox { float m0, m1, m2, vbx, vby, vbz, gx, gy, gz; int face; bool safe; };
     float mass = 0.0f;                                        /* |w grad| of the voxels this lane has sent to its histogram copy */
+    /* DW_ABL (scripts/build_file_variants.py, timing only, results are wrong): 1 = the histogram atomics are not issued (what the
+     * VALU side costs alone), 2 = the front end stubbed to a few operations on the loaded values (what the LDS side costs alone),
+     * 3 = plain LDS stores instead of the atomics (the queue without the read-modify-write), 4 = 1 and 2 together (row intervals,
+     * scans, look-ups, gathers and the back end's arithmetic), 5 = the back end not run at all (everything up to it) */
+#if defined(DW_ABL)
+    unsigned abl_acc = 0u;
+#endif
     auto front = [&](bool valid, float vbx, float vby, float vbz, float w, float gx, float gy, float gz) {
         DwVox v;
+#if defined(DW_ABL) && (DW_ABL == 2 || DW_ABL == 4)
+        v.face = valid ? (int)(__float_as_uint(gx) & 15u) : -1;
+        v.safe = true;
+        v.m0 = w * fscale; v.m1 = gy; v.m2 = gz;
+        v.vbx = vbx; v.vby = vby; v.vbz = vbz;
+        v.gx = gx; v.gy = gy; v.gz = gz;
+        mass = mass + (valid ? w : 0.0f);
+        return v;
+#endif
         gx = gx * hiux; gy = gy * hiuy; gz = gz * hiuz;        /* (0.5 d) / u of the reference: halving is exact, so d * (0.5 / u) rounds the same */
         gx = gx * w; gy = gy * w; gz = gz * w;
         V3 gr;
@@ -1396,7 +1412,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const bool live = valid && !((double)gg < S3D_BARY_EPS_D);       /* icos_hist_bin's floor on |grad|^2, sift.c:1655 */
         const float mag = DW_SQRT(gg) * fscale;
         mass = mass + (valid ? mag : 0.0f);                      /* (resolve() may move it by an ulp: the proof allows 1e-4) */
+#if defined(DW_BACK_FLAT)
+        v.face = live && gg <= 3.4028234664e38f ? face : -1;    /* (a non-finite magnitude times a zero weight would not be zero) */
+#else
         v.face = live ? face : -1;
+#endif
         v.safe = (safe && !floor_unsure) || !(live || (valid && floor_unsure));
         v.m0 = mag * bary.x; v.m1 = mag * bary.y; v.m2 = mag * bary.z;
         v.vbx = vbx; v.vby = vby; v.vbz = vbz;
@@ -1424,6 +1444,43 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     };
     /* back: the trilinear spread over 8 cells x 3 vertices */
     auto back = [&](const DwVox &v) {
+#if defined(DW_ABL) && DW_ABL == 5
+        abl_acc += __float_as_uint(v.m0) + __float_as_uint(v.m1) + __float_as_uint(v.m2) + (unsigned)v.face + __float_as_uint(v.vbx + v.vby + v.vbz);
+        return;
+#endif
+#if defined(DW_BACK_FLAT)
+        /* straight-line form: a dead voxel (face < 0) sends zeros through face 0's bins, a cell beyond the 4 x 4 x 4 grid gets the
+         * weight 0 -- fma(m, 0, Mfix) has a zero low dword, and adding 0 changes no LDS word wherever the static cell offset
+         * points -- so all 24 atomics are issued by every lane and no exec mask changes inside the voxel */
+        const bool dead = v.face < 0;
+        const int fc = dead ? 0 : v.face;
+        int ibx = (int)v.vbx, iby = (int)v.vby, ibz = (int)v.vbz;
+        ibx = ibx > 3 ? 3 : ibx; iby = iby > 3 ? 3 : iby; ibz = ibz > 3 ? 3 : ibz;
+        const float fx = v.vbx - (float)ibx, fy = v.vby - (float)iby, fz = v.vbz - (float)ibz;
+        const double dvx = (double)fx, dvy = (double)fy, dvz = (double)fz;
+        const double m0 = dead ? 0.0 : (double)v.m0, m1 = dead ? 0.0 : (double)v.m1, m2 = dead ? 0.0 : (double)v.m2;
+        const unsigned cellb = (unsigned)(ibx + 4 * iby + 16 * ibz) * (unsigned)(S3D_NVERT * DW_NCOPY * 8) + copy8;
+        char *const p0 = hbase + cellb + (unsigned)sm.vofs[fc];
+        char *const p1 = hbase + cellb + (unsigned)sm.vofs[S3D_NFACES + fc];
+        char *const p2 = hbase + cellb + (unsigned)sm.vofs[2 * S3D_NFACES + fc];
+        const double wxs[2] = {1.0 - dvx, ibx < 3 ? dvx : 0.0}, wys[2] = {1.0 - dvy, iby < 3 ? dvy : 0.0},
+                     wzs[2] = {1.0 - dvz, ibz < 3 ? dvz : 0.0};
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+            for (int iy = 0; iy < 2; iy++) {
+                const double wxy = wxs[ix] * wys[iy];
+#pragma unroll
+                for (int iz = 0; iz < 2; iz++) {
+                    const double wc = wxy * wzs[iz];
+                    constexpr int DCB = S3D_NVERT * DW_NCOPY * 8;
+                    const int dc = (ix + 4 * iy + 16 * iz) * DCB;                          /* compile-time byte offset */
+                    atomicAdd(reinterpret_cast<unsigned *>(p0 + dc), (unsigned)__double_as_longlong(fma(m0, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned *>(p1 + dc), (unsigned)__double_as_longlong(fma(m1, wc, Mfix)));
+                    atomicAdd(reinterpret_cast<unsigned *>(p2 + dc), (unsigned)__double_as_longlong(fma(m2, wc, Mfix)));
+                }
+            }
+#else
         if (v.face < 0) return;
         /* base cell and offsets inside it; the clamps only matter for the last-bit slack of the stepped coordinates */
         int ibx = (int)v.vbx, iby = (int)v.vby, ibz = (int)v.vbz;
@@ -1446,11 +1503,22 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
                     const double wc = wxy * wzs[iz];
                     constexpr int DCB = S3D_NVERT * DW_NCOPY * 8;
                     const int dc = (ix + 4 * iy + 16 * iz) * DCB;                          /* compile-time byte offset */
+#if defined(DW_ABL) && (DW_ABL == 1 || DW_ABL == 4)
+                    abl_acc += (unsigned)__double_as_longlong(fma(m0, wc, Mfix)) + (unsigned)(size_t)(p0 + dc);
+                    abl_acc += (unsigned)__double_as_longlong(fma(m1, wc, Mfix)) + (unsigned)(size_t)(p1 + dc);
+                    abl_acc += (unsigned)__double_as_longlong(fma(m2, wc, Mfix)) + (unsigned)(size_t)(p2 + dc);
+#elif defined(DW_ABL) && DW_ABL == 3
+                    *reinterpret_cast<volatile unsigned *>(p0 + dc) = (unsigned)__double_as_longlong(fma(m0, wc, Mfix));
+                    *reinterpret_cast<volatile unsigned *>(p1 + dc) = (unsigned)__double_as_longlong(fma(m1, wc, Mfix));
+                    *reinterpret_cast<volatile unsigned *>(p2 + dc) = (unsigned)__double_as_longlong(fma(m2, wc, Mfix));
+#else
                     atomicAdd(reinterpret_cast<unsigned *>(p0 + dc), (unsigned)__double_as_longlong(fma(m0, wc, Mfix)));
                     atomicAdd(reinterpret_cast<unsigned *>(p1 + dc), (unsigned)__double_as_longlong(fma(m1, wc, Mfix)));
                     atomicAdd(reinterpret_cast<unsigned *>(p2 + dc), (unsigned)__double_as_longlong(fma(m2, wc, Mfix)));
+#endif
                 }
             }
+#endif
     };
     /* chunk c of the current round -> its first voxel and length */
     struct DwChunk { int x0, y, z, nval; unsigned fv; };
@@ -1592,6 +1660,9 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
          * round's row intervals instead of waiting. */
     }
     if (COUNT_ONLY) break;
+#if defined(DW_ABL)
+    if (abl_acc == 0x9e3779b9u) sm.win_chk = abl_acc;         /* (keeps the ablated arithmetic alive) */
+#endif
     if (tid == 0 && attempt == 0) atomicAdd(&g_dw_stat[0], 1ull);
     /* (3) the proof.  Copy k is fed by the 64 / DW_NFIELD lanes k, k + DW_NFIELD, ... of every wave: their masses together
      * bound what a field of the copy can hold; a contribution is rounded to the grid (<= 1/2 each, 24 per voxel, <= 4 turns
@@ -1645,7 +1716,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     const float trunc = (float)(double)(0.2f * 128.0f / S3D_DESC_NUMEL);   /* trunc_thresh, sift.c:55 */
     double norm = sqrt(dw_block_sum(ss, sm.part, tm)) + 2.220446049250313e-16; /* + DBL_EPSILON */
     /* (the barriers of the sum lie between the flags' writers and these reads) */
+#if defined(DW_ABL)
+    const bool over = false, fine = true;                     /* (the ablated sums prove nothing: every window once) */
+#else
     const bool over = DW_UNIFORM(sm.proof_over) != 0u, fine = DW_UNIFORM(sm.proof_fine) != 0u;
+#endif
     if (DW_UNIFORM(sm.nan_seen) != 0u) {
         /* A NaN gradient among the window's voxels.  The reference (sift.c:1646-1683, 1733-1760, 1896-1915): icos_hist_bin
          * accepts face 0 for it (every comparison with a NaN is false) with NaN barycentric weights, the three vertex
