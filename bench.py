@@ -152,10 +152,94 @@ def cpu_baseline(sample_n=160, timeout=600):
 METRIC = "Mvoxels/s detect+describe on 512^3 float32; 3D Gaussian achieved HBM GB/s vs roofline"
 
 
+class RankFailure(Exception):
+    """Some rank's job failed (its own error or a peer's); .errors = [(rank, text)]."""
+
+    def __init__(self, errors):
+        super().__init__("; ".join(f"rank {r}: {t}" for r, t in errors))
+        self.errors = errors
+
+
+PARITY_GOLDEN = os.path.join(ROOT, "tests", "golden", "bench_parity.json")
+PREFLIGHT_DIMS = (64, 64, 1024)                     # the geometry of tests/test_gpu_slab.py::test_loopback_ranks_equal_single_gpu[8-...]
+LIVE_CHECK_MAX_VOXELS = 1 << 25                     # volumes up to this size are also checked against a single-GPU run made on the spot
+
+
+def kp_digest(kp):
+    """(count, SHA-256) of a Keypoint_store: coordinates, scale, octave, level and the rotation of every keypoint, in list
+    order -- the bytes tests/test_gpu_slab.py::test_config3_1024_cubed hashes."""
+    import hashlib
+    import numpy as np
+    K = int(kp.slab.num)
+    if K == 0:
+        return 0, hashlib.sha256(b"").hexdigest()
+    raw = np.ctypeslib.as_array(C.cast(kp.buf, C.POINTER(C.c_uint8)), shape=(K, C.sizeof(abi.Keypoint)))
+    return K, hashlib.sha256(np.ascontiguousarray(raw[:, 72:112]).tobytes() + np.ascontiguousarray(raw[:, 0:36]).tobytes()).hexdigest()
+
+
+def single_gpu_digest(L, dev, dims, nblobs):
+    """kp_digest of the same volume detected whole on the calling thread's GPU (the product's single-GPU path)."""
+    from sift3d_amd import slab as S
+    nx, ny, nz = dims
+    d_vol = dev.upload(synth.blobs(nx, ny, nz, nblobs, seed=0))
+    s = S.make_params(L, bench_params())
+    kp = abi.Keypoint_store()
+    L.init_Keypoint_store(C.byref(kp))
+    try:
+        if L.sift3d_amd_detect_keypoints_dev(C.byref(s), C.c_void_p(d_vol), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_double(1.0),
+                                             C.c_double(1.0), C.c_double(1.0), C.byref(kp)) != 0:
+            raise RuntimeError("single-GPU detect of the parity check failed")
+        return kp_digest(kp)
+    finally:
+        L.cleanup_Keypoint_store(C.byref(kp))
+        L.cleanup_SIFT3D(C.byref(s))
+        dev.free(d_vol)
+
+
+def expected_parity(dims):
+    """The committed single-GPU result of this volume (default parameters, default blob count, seed 0), or None.  The file is
+    written by tests/golden/make_bench_parity.py on a GPU box; S3D_BENCH_PARITY_GOLDEN points the tests at another one."""
+    if bench_params() and not os.environ.get("S3D_BENCH_PARITY_GOLDEN"):
+        return None                                  # (the committed results are those of the default parameters)
+    try:
+        g = json.load(open(os.environ.get("S3D_BENCH_PARITY_GOLDEN", PARITY_GOLDEN)))
+    except (OSError, ValueError):
+        return None
+    return g.get("volumes", {}).get("x".join(str(d) for d in dims))
+
+
+def parity_block(L, dev, dims, per_rank):
+    """config.parity of an N > 1 line: what the ranks found against what ONE GPU finds in the same volume.  Every rank holds the
+    gathered list (sift3d_amd_slab_gather, reference order): they must agree with each other, with the committed single-GPU
+    result where there is one, and -- for volumes a single GPU detects in a moment -- with a single-GPU run made here."""
+    K, sha = per_rank[0]["kp_total"], per_rank[0]["kp_sha256"]
+    out = {"keypoints": K, "kp_sha256": sha, "expected": None, "kp_sha256_equals_single_gpu": None, "checked_against": []}
+    ok = all(r["kp_total"] == K and r["kp_sha256"] == sha for r in per_rank)
+    if not ok:
+        out["ranks_disagree"] = [[r["kp_total"], r["kp_sha256"][:16]] for r in per_rank]
+    exp = expected_parity(dims)
+    if exp is not None:
+        out["expected"] = int(exp["keypoints"])
+        same = K == int(exp["keypoints"]) and sha == exp["kp_sha256"]
+        out["kp_sha256_equals_single_gpu"] = bool(same)
+        out["checked_against"].append(f"tests/golden/bench_parity.json ({exp.get('source', 'single-GPU run of this library')})")
+        ok = ok and same
+    if float(dims[0]) * dims[1] * dims[2] <= LIVE_CHECK_MAX_VOXELS:
+        k1, sha1 = single_gpu_digest(L, dev, dims, per_rank[0]["nblobs"])
+        same = K == k1 and sha == sha1
+        out["expected"] = k1 if out["expected"] is None else out["expected"]
+        out["kp_sha256_equals_single_gpu"] = bool(same and out["kp_sha256_equals_single_gpu"] is not False)
+        out["checked_against"].append("a single-GPU detect of the same volume in this run (rank 0's GPU)")
+        ok = ok and same
+    out["ok"] = bool(ok)
+    return out
+
+
 def slab_job(L, dev, transport, dims, steps, warmup, sync_all, tag):
     """One rank's share of a Z-slab job on an nx x ny x nz volume through the C driver (include/sift3d_amd_slab.h):
-    synthesise + upload my slab, `warmup` untimed steps, one split step, `steps` timed steps.  sync_all(): barrier
-    over the ranks with this rank's stream drained.  Returns this rank's measurements."""
+    synthesise + upload my slab, `warmup` untimed steps, one split step, `steps` timed steps, then -- untimed -- the gathered
+    keypoint list's digest (kp_digest; collective).  sync_all(): barrier over the ranks with this rank's stream drained.
+    Returns this rank's measurements."""
     from sift3d_amd import slab as S
     nx, ny, nz = dims
     sl = S.Slab(L, transport, nx, ny, nz, params=bench_params())
@@ -172,29 +256,34 @@ def slab_job(L, dev, transport, dims, steps, warmup, sync_all, tag):
         sl.detect(d_vol, on_device=True)
         sl.describe(to_host=False)
 
-    for _ in range(warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    sl.detect(d_vol, on_device=True)
-    t_detect = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    sl.describe(to_host=False)
-    t_describe = time.perf_counter() - t0
-    split = sl.info()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    inf = sl.info()
-    out = {"elapsed": elapsed, "detect_ms": t_detect * 1e3, "describe_ms": t_describe * 1e3, "keypoints": int(inf.num_keypoints),
-           "candidates": int(inf.num_candidates), "halo_bytes": float(inf.halo_bytes), "o_shard": int(inf.o_shard),
-           "halo": int(inf.halo), "slices": int(inf.z1 - inf.z0), "device_GiB": inf.device_bytes / 2**30, "nblobs": nblobs,
-           "comm_ms": float(split.comm_ms), "halo_wait_ms": float(split.halo_wait_ms)}
-    dev.free(d_vol)
-    sl.close()
+    try:
+        for _ in range(warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        sl.detect(d_vol, on_device=True)
+        t_detect = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sl.describe(to_host=False)
+        t_describe = time.perf_counter() - t0
+        split = sl.info()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        inf = sl.info()
+        kp_all, _ = sl.gather(with_desc=False)              # untimed: the whole volume's list, reference order, on every rank
+        kp_total, kp_sha = kp_digest(kp_all)
+        L.cleanup_Keypoint_store(C.byref(kp_all))
+        out = {"elapsed": elapsed, "detect_ms": t_detect * 1e3, "describe_ms": t_describe * 1e3, "keypoints": int(inf.num_keypoints),
+               "candidates": int(inf.num_candidates), "halo_bytes": float(inf.halo_bytes), "o_shard": int(inf.o_shard),
+               "halo": int(inf.halo), "slices": int(inf.z1 - inf.z0), "device_GiB": inf.device_bytes / 2**30, "nblobs": nblobs,
+               "comm_ms": float(split.comm_ms), "halo_wait_ms": float(split.halo_wait_ms), "kp_total": kp_total, "kp_sha256": kp_sha}
+    finally:
+        dev.free(d_vol)
+        sl.close()
     return out
 
 
@@ -230,8 +319,14 @@ def bench_params():
     return {k: float(v) for k, v in (kv.split("=") for kv in e.split(","))}
 
 
-def slab_result(args, per_rank, extra, dims, world, tname, rccl):
+def slab_result(args, per_rank, extra, dims, world, tname, rccl, parity=None, preflight=None, fallback=None):
     elapsed, cfg = slab_summary(per_rank, dims, args.steps, world, tname)
+    if parity is not None:
+        cfg["parity"] = parity                   # keypoints of the N-rank run against one GPU's (parity_block)
+    if preflight is not None:
+        cfg["preflight"] = preflight             # the small job run over the same transport before the timed one
+    if fallback is not None:
+        cfg["transport_fallback"] = fallback     # the intended transport failed: why, and what this line was measured on
     nvox = float(dims[0]) * dims[1] * dims[2]
     pdesc = "default SIFT3D parameters" if not bench_params() else f"TEST parameters {bench_params()}"
     cfg["workload"] = (f"one {dims[0]}x{dims[1]}x{dims[2]} float32 blobs+noise volume ({per_rank[0]['nblobs']} blobs), unit voxels, "
@@ -343,11 +438,38 @@ def dry_run(args):
     print(json.dumps(out), flush=True)
 
 
+def arm_inject(L, stage):
+    """Test aid (TESTING / emulator builds of the library only): S3D_BENCH_TEST_INJECT="stage:rank:where" arms the driver's
+    one-shot failure hook (sift3d_amd_slab_test_inject) just before `stage` (preflight | timed)."""
+    e = os.environ.get("S3D_BENCH_TEST_INJECT")
+    if not e or not hasattr(L, "sift3d_amd_slab_test_inject"):
+        return
+    st, r, w = e.split(":")
+    if st == stage:
+        L.sift3d_amd_slab_test_inject.argtypes = [C.c_int, C.c_int]
+        L.sift3d_amd_slab_test_inject.restype = None
+        L.sift3d_amd_slab_test_inject(int(r), int(w))
+
+
+def preflight_dims(world):
+    """The pre-flight volume: PREFLIGHT_DIMS unless S3D_BENCH_PREFLIGHT says "nx,ny,nz" (the CPU tests) or "0" (none)."""
+    e = os.environ.get("S3D_BENCH_PREFLIGHT")
+    if e is None:
+        return PREFLIGHT_DIMS
+    if e.strip() in ("", "0"):
+        return None
+    return tuple(int(v) for v in e.split(","))
+
+
 def run_inprocess(args, dev):
     """N > 1 launched plainly: this ONE process drives the N GPUs -- one host thread per rank (thread r: GPU r), RCCL
     communicators from ncclCommInitAll (sift3d_amd_rccl_create_all), the C Z-slab driver on device-resident slabs.  The
     same transport and driver a relinked caller gets from sift3d_amd_set_num_gpus(&sift3d, N, 0); no launcher, no
-    torch.distributed, one RCCL instance."""
+    torch.distributed, one RCCL instance.
+
+    Fail-soft: a pre-flight job on a small volume runs over the RCCL transport first and is compared with one GPU's result;
+    if that, or later the timed job, fails on RCCL, the ranks run again over the library's loop-back transport (peer copies
+    behind a host barrier) and the line says so, with the error text -- a labelled number instead of exit status 3."""
     import threading
     from sift3d_amd import slab as S
     L = sift3d_amd.cdll()
@@ -358,35 +480,34 @@ def run_inprocess(args, dev):
         raise SystemExit(2)
     n = args.size
     dims = timed_dims(args, N)
+    RCCL_NAME = "RCCL, one process (ncclCommInitAll; ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip)"
+    LOOP_NAME = "in-process loop-back over hipMemcpy between the GPUs -- RCCL did NOT initialise"
+    fallback = None
     try:
         tr = S.rccl_all_transports(L, N)
         rccl = S.rccl_info(L, tr[0])
         if rccl[0] != N:
             log(f"bench.py: the RCCL communicator has {rccl[0]} ranks, not {N}")
             raise SystemExit(2)
-        tname = "RCCL, one process (ncclCommInitAll; ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip)"
+        tname = RCCL_NAME
     except RuntimeError as e:
         # N GPUs are there but RCCL is not: the N ranks still run, halos as peer copies behind a host barrier (the
         # library's loop-back transport).  The line says so -- it is NOT the RCCL number.
         log(f"bench.py: RCCL unavailable ({e}); falling back to the in-process loop-back transport (hipMemcpy between the GPUs)")
-        tr, rccl = S.loopback_transports(L, N), None
-        tname = "in-process loop-back over hipMemcpy between the GPUs -- RCCL did NOT initialise"
-    bar = threading.Barrier(N)
+        tr, rccl, tname = S.loopback_transports(L, N), None, LOOP_NAME
 
-    def job(r, what, steps, warmup, tag):
-        dev.check(dev.L.s3d_rt_set_device(r), "set_device")          # per thread
-
-        def sync_all():
-            dev.sync()
-            bar.wait()
-        return slab_job(L, dev, tr[r], what, steps, warmup, sync_all, tag)
-
-    def run(what, steps, warmup, tag):
+    def run(tr, what, steps, warmup, tag):
+        bar = threading.Barrier(N)
         out, err = [None] * N, [None] * N
 
         def body(r):
             try:
-                out[r] = job(r, what, steps, warmup, tag)
+                dev.check(dev.L.s3d_rt_set_device(r), "set_device")      # per thread
+
+                def sync_all():
+                    dev.sync()
+                    bar.wait()
+                out[r] = slab_job(L, dev, tr[r], what, steps, warmup, sync_all, tag)
             except BaseException as e:                                 # noqa: BLE001
                 err[r] = e
                 bar.abort()                                            # host barrier ...
@@ -399,38 +520,145 @@ def run_inprocess(args, dev):
             t.start()
         for t in th:
             t.join()
-        for r, e_ in enumerate(err):
-            if e_ is not None and not isinstance(e_, threading.BrokenBarrierError):
-                log(f"bench.py: rank {r} failed: {e_}")
+        bad = [(r, f"{type(e_).__name__}: {e_}") for r, e_ in enumerate(err)
+               if e_ is not None and not isinstance(e_, threading.BrokenBarrierError)]
+        for r, text in bad:
+            log(f"bench.py: rank {r} failed: {text}")
         if any(e_ is not None for e_ in err):
-            raise SystemExit(3)
+            raise RankFailure(bad or [(-1, "a rank left the barrier")])
         return out
 
-    per_rank = run(dims, args.steps, args.warmup, "timed")
-    extra = None
-    if not args.no_match and N in (2, 4, 8, 16) and n >= 512:
-        extra = run(extra_job(args, N)[0], 2, 1, extra_job(args, N)[1])
-    result = slab_result(args, per_rank, extra, dims, N, tname, rccl)
+    def to_loopback(why):
+        """the RCCL transports are given up (aborted by the failure, destroyed here); the ranks go on over peer copies"""
+        nonlocal tr, rccl, tname, fallback
+        log(f"bench.py: {why}; running the job again over the in-process loop-back transport (hipMemcpy between the GPUs)")
+        for r in range(N):
+            tr[r].destroy(tr[r].self)
+        fallback = {"intended": RCCL_NAME, "error": why, "measured_on": "in-process loop-back over hipMemcpy between the GPUs"}
+        tr, rccl, tname = S.loopback_transports(L, N), None, "in-process loop-back over hipMemcpy between the GPUs -- RCCL FAILED, see transport_fallback"
+
+    preflight = None
+    pdims = preflight_dims(N)
+    if pdims is not None:
+        dev.check(dev.L.s3d_rt_set_device(0), "set_device")
+        t0 = time.perf_counter()
+        arm_inject(L, "preflight")
+        try:
+            pr = run(tr, pdims, 1, 0, "preflight")
+            pb = parity_block(L, dev, pdims, pr)
+            preflight = {"volume": list(pdims), "ok": pb["ok"], "keypoints": pb["keypoints"], "expected": pb["expected"],
+                         "seconds": round(time.perf_counter() - t0, 2), "transport": "RCCL" if rccl is not None else "loop-back"}
+            if not pb["ok"]:
+                if rccl is None:
+                    log(f"bench.py: the pre-flight job disagrees with the single-GPU result on the loop-back transport: {pb}")
+                    raise SystemExit(4)
+                to_loopback(f"pre-flight on {pdims[0]}x{pdims[1]}x{pdims[2]} over RCCL: {pb['keypoints']} keypoints, single GPU {pb['expected']}")
+        except RankFailure as e:
+            if rccl is None:
+                log(f"bench.py: the pre-flight job failed on the loop-back transport: {e}")
+                raise SystemExit(3)
+            preflight = {"volume": list(pdims), "ok": False, "error": str(e), "transport": "RCCL"}
+            to_loopback(f"pre-flight over RCCL failed: {e}")
+
+    def timed():
+        per_rank = run(tr, dims, args.steps, args.warmup, "timed")
+        extra = None
+        if not args.no_match and N in (2, 4, 8, 16) and n >= 512:
+            extra = run(tr, extra_job(args, N)[0], 2, 1, extra_job(args, N)[1])
+        return per_rank, extra
+
+    arm_inject(L, "timed")
+    try:
+        per_rank, extra = timed()
+    except RankFailure as e:
+        if rccl is None:
+            log(f"bench.py: the job failed on the loop-back transport: {e}")
+            raise SystemExit(3)
+        to_loopback(f"the timed job failed over RCCL: {e}")
+        try:
+            per_rank, extra = timed()
+        except RankFailure as e2:
+            log(f"bench.py: the job failed on the loop-back transport as well: {e2}")
+            raise SystemExit(3)
     dev.check(dev.L.s3d_rt_set_device(0), "set_device")
+    parity = parity_block(L, dev, dims, per_rank)
+    result = slab_result(args, per_rank, extra, dims, N, tname, rccl, parity, preflight, fallback)
     if not args.no_roofline:
         add_roofline(result, dev, n)
     print(json.dumps(result), flush=True)
     for r in range(N):
         tr[r].destroy(tr[r].self)
+    if not parity["ok"]:
+        log(f"bench.py: PARITY FAILURE: the {N}-rank keypoint list differs from the single-GPU one: {parity}")
+        raise SystemExit(4)
+
+
+class StoreSync:
+    """Barriers of the torchrun ranks that a failed rank can break.  A gloo barrier cannot be left: a rank whose job has failed
+    would have to keep calling the same collectives as its peers, or everybody hangs.  These barriers are counters in the
+    rendezvous store (c10d TCPStore): arrive = add 1, wait = poll the counter AND the failure key of the current attempt; a
+    rank that fails sets the key, so that its peers leave their barrier with PeerFailure instead of waiting for it."""
+
+    class PeerFailure(Exception):
+        pass
+
+    def __init__(self, dist, rank, world):
+        self.store = dist.distributed_c10d._get_default_store()
+        self.rank, self.world, self.attempt, self.n = rank, world, 0, 0
+
+    def next_attempt(self):
+        self.attempt += 1
+        self.n = 0
+
+    def fail(self, text):
+        self.store.set(f"s3d/fail/{self.attempt}", f"rank {self.rank}: {text}")
+
+    def failure(self):
+        k = f"s3d/fail/{self.attempt}"
+        return self.store.get(k).decode() if self.store.check([k]) else None
+
+    def barrier(self, breakable=True, timeout_s=1800.0):
+        """breakable: the n-th barrier of the attempt (the ranks count alike while all goes well); not breakable: THE meeting point
+        of an attempt's survivors -- ranks get there from different barriers, so its key carries no count"""
+        if breakable:
+            self.n += 1
+        key = f"s3d/bar/{self.attempt}/{self.n}" if breakable else f"s3d/rdv/{self.attempt}"
+        self.store.add(key, 1)
+        t0 = time.perf_counter()
+        while self.store.add(key, 0) < self.world:
+            if breakable:
+                f = self.failure()
+                if f is not None:
+                    raise StoreSync.PeerFailure(f)
+            if time.perf_counter() - t0 > timeout_s:
+                raise StoreSync.PeerFailure(f"barrier {key}: a rank did not arrive within {timeout_s:.0f} s")
 
 
 def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
     """N > 1 under torchrun: one rank per GPU, the C Z-slab driver over RCCL (ncclSend/ncclRecv halos).  Timed
     workload: BASELINE configs[3] -- ONE --strong-size^3 volume (1024^3), nz/N slices per GPU, strong scaling (--weak: one
     n x n x (n*N) volume, n slices per GPU).  After the timed region, unless --no-match: the other of the two for two
-    untimed steps (config.weak_512xN / config.strong_1024)."""
+    untimed steps (config.weak_512xN / config.strong_1024).
+
+    Fail-soft (as run_inprocess): pre-flight job + comparison with one GPU before the timed job; a failure on RCCL at any
+    point after initialisation -- a rank's own error, or a peer's, noticed through the breakable barriers of StoreSync or
+    through SIFT3D_SLAB_TIMEOUT_S in the C driver -- makes every rank give up its RCCL transport and run the job again over
+    torch.distributed callbacks (gloo, staged through the host); the line is labelled and carries the error text."""
     import torch
     from sift3d_amd import slab as S
     L = sift3d_amd.cdll()
+    os.environ.setdefault("SIFT3D_SLAB_TIMEOUT_S", "30")       # a rank waits this long for a dead peer's halo before it fails too
     same_gpu = bool(os.environ.get("S3D_BENCH_SAME_GPU"))
-    tname, tr, keep = "RCCL, one process per GPU (ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip; id shipped over gloo)", None, None
+    on_gpu = torch.cuda.is_available()                          # False: the CPU tests (emulator build of the library, gloo only)
+    gloo_dev = f"cuda:{local_rank}" if on_gpu else None
+    RCCL_NAME = "RCCL, one process per GPU (ncclSend/ncclRecv, ncclAllReduce, ncclAllGather; csrc/s3d_rccl.hip; id shipped over gloo)"
+    GLOO_NAME = "torch.distributed callbacks (gloo, staged through the host)"
+    tname, tr, keep = RCCL_NAME, None, None
     ok = 0.0
-    if not same_gpu:
+    # S3D_BENCH_FAKE_RCCL (CPU tests only): the first transport is a gloo one that the protocol below treats as "the RCCL
+    # transport" -- there is no multi-process stand-in for librccl, and the give-up-and-go-on-over-gloo path wants a test
+    fake_rccl = bool(os.environ.get("S3D_BENCH_FAKE_RCCL")) and not on_gpu
+    if not same_gpu and not fake_rccl:
         try:
             tr = S.rccl_transport(L, dist, rank, world)
             ok = 1.0
@@ -438,51 +666,128 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
             log(f"[rank {rank}] RCCL transport unavailable: {e}")
     flag = torch.tensor([ok])                                # the process group is gloo: host tensors
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    rccl = None
-    if float(flag.item()) == 0.0:
-        keep = S.DistTransport(L, dist, device=f"cuda:{local_rank}", stage_via_host=True)
+    rccl, fallback = None, None
+    if fake_rccl:
+        keep = S.DistTransport(L, dist, device=gloo_dev, stage_via_host=on_gpu)
+        tr, rccl = keep.struct, (world, 0)
+    elif float(flag.item()) == 0.0:
+        if tr is not None and tr.destroy:
+            tr.destroy(tr.self)
+        keep = S.DistTransport(L, dist, device=gloo_dev, stage_via_host=on_gpu)
         tr = keep.struct
-        tname = "torch.distributed callbacks (gloo, staged through the host) -- RCCL did NOT initialise"
+        tname = GLOO_NAME + " -- RCCL did NOT initialise"
     else:
         rccl = S.rccl_info(L, tr)
         if rccl[0] != world:
             log(f"[rank {rank}] the RCCL communicator has {rccl[0]} ranks, not {world}")
             raise SystemExit(2)
+    sync = StoreSync(dist, rank, world)
 
-    def gather(m):
-        box = [None] * world
-        dist.all_gather_object(box, m)
-        return box
+    def sync_all():
+        if on_gpu:
+            torch.cuda.synchronize()                           # this rank's GPU has drained (every stream) ...
+        dev.check(dev.L.s3d_rt_sync(None))
+        sync.barrier()                                         # ... and so have the others'
 
     def job(what, steps, warmup, tag):
-        """A rank whose job fails has aborted its transport (the C driver does); its peers would run into
-        SIFT3D_SLAB_TIMEOUT_S.  Leaving at once with a non-zero status lets the launcher take the whole job down
-        instead: no number is better than a number after a two-minute wait for a dead rank."""
+        """This rank's share; RankFailure if it or any peer fails.  The results of all ranks (rank order) otherwise."""
         try:
-            return slab_job(L, dev, tr, what, steps, warmup, full_sync, tag)
-        except BaseException as e:                              # noqa: BLE001
-            log(f"[rank {rank}] {tag} job failed: {e}")
+            mine = slab_job(L, dev, tr, what, steps, warmup, sync_all, tag)
+            sync.barrier()                                      # everybody got through: the gloo gather below is matched
+        except StoreSync.PeerFailure as e:
             if tr is not None and tr.abort:
                 tr.abort(tr.self)
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(3)
+            raise RankFailure([(-1, str(e))])
+        except BaseException as e:                              # noqa: BLE001
+            text = f"{type(e).__name__}: {e}"
+            log(f"[rank {rank}] {tag} job failed: {text}")
+            sync.fail(f"{tag}: {text}")
+            if tr is not None and tr.abort:
+                tr.abort(tr.self)
+            raise RankFailure([(rank, text)])
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        return box
+
+    def to_gloo(why):
+        """collective: every rank has left its job with RankFailure; they meet here, drop RCCL and go on over gloo"""
+        nonlocal tr, keep, rccl, tname, fallback
+        sync.barrier(breakable=False, timeout_s=300.0)
+        why_all = sync.failure() or why
+        sync.next_attempt()
+        log(f"[rank {rank}] {why_all}; running the job again over torch.distributed callbacks (gloo)")
+        if keep is None and tr is not None and tr.destroy:
+            tr.destroy(tr.self)
+        fallback = {"intended": RCCL_NAME, "error": why_all, "measured_on": GLOO_NAME}
+        keep = S.DistTransport(L, dist, device=gloo_dev, stage_via_host=on_gpu)
+        tr, rccl, tname = keep.struct, None, GLOO_NAME + " -- RCCL FAILED, see transport_fallback"
+
+    def give_up(text):
+        log(f"[rank {rank}] {text}")
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)
 
     n = args.size
     dims = timed_dims(args, world)
-    per_rank = gather(job(dims, args.steps, args.warmup, "timed"))
-    extra = None
-    if not args.no_match and world in (2, 4, 8, 16) and n >= 512:
-        extra = gather(job(extra_job(args, world)[0], 2, 1, extra_job(args, world)[1]))
+    preflight = None
+    pdims = preflight_dims(world)
+    if pdims is not None:
+        t0 = time.perf_counter()
+        arm_inject(L, "preflight")
+        try:
+            pr = job(pdims, 1, 0, "preflight")
+            box = [parity_block(L, dev, pdims, pr) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            pb = box[0]
+            preflight = {"volume": list(pdims), "ok": pb["ok"], "keypoints": pb["keypoints"], "expected": pb["expected"],
+                         "seconds": round(time.perf_counter() - t0, 2), "transport": "RCCL" if rccl is not None else "gloo"}
+            if not pb["ok"]:
+                if rccl is None:
+                    give_up(f"the pre-flight job disagrees with the single-GPU result on the gloo transport: {pb}")
+                sync.fail(f"pre-flight on {pdims[0]}x{pdims[1]}x{pdims[2]} over RCCL: {pb['keypoints']} keypoints, single GPU {pb['expected']}")
+                to_gloo("pre-flight mismatch over RCCL")
+        except RankFailure as e:
+            if rccl is None:
+                give_up(f"the pre-flight job failed on the gloo transport: {e}")
+            preflight = {"volume": list(pdims), "ok": False, "error": str(e), "transport": "RCCL"}
+            to_gloo(f"pre-flight over RCCL failed: {e}")
+
+    def timed():
+        per_rank = job(dims, args.steps, args.warmup, "timed")
+        extra = None
+        if not args.no_match and world in (2, 4, 8, 16) and n >= 512:
+            extra = job(extra_job(args, world)[0], 2, 1, extra_job(args, world)[1])
+        return per_rank, extra
+
+    arm_inject(L, "timed")
+    try:
+        per_rank, extra = timed()
+    except RankFailure as e:
+        if rccl is None:
+            give_up(f"the job failed on the gloo transport: {e}")
+        to_gloo(f"the timed job failed over RCCL: {e}")
+        try:
+            per_rank, extra = timed()
+        except RankFailure as e2:
+            give_up(f"the job failed on the gloo transport as well: {e2}")
+    status = 0
     if rank == 0:
-        result = slab_result(args, per_rank, extra, dims, world, tname, rccl)
+        parity = parity_block(L, dev, dims, per_rank)
+        result = slab_result(args, per_rank, extra, dims, world, tname, rccl, parity, preflight, fallback)
         if not args.no_roofline:
             add_roofline(result, dev, n)
         print(json.dumps(result), flush=True)
-    dist.barrier()
+        if not parity["ok"]:
+            log(f"bench.py: PARITY FAILURE: the {world}-rank keypoint list differs from the single-GPU one: {parity}")
+            status = 4
+    box = [status]
+    dist.broadcast_object_list(box, src=0)
     if keep is None and tr is not None and tr.destroy:
         tr.destroy(tr.self)
     dist.destroy_process_group()
+    if box[0]:
+        raise SystemExit(box[0])
 
 
 def run_loopback(args, dev):
@@ -624,7 +929,8 @@ def main():
         # transport opens -- not PyTorch's bundled copy beside it
         if os.environ.get("S3D_BENCH_SAME_GPU"):
             local_rank = 0                                       # debugging aid for a 1-GPU box: all ranks share GPU 0
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():                            # (not in the CPU tests: emulator build of the library)
+            torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo")
 
     lib = sift3d_amd.load()

@@ -41,6 +41,30 @@ static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static Group *g_groups;
 static unsigned long g_next_id = 1;
 
+/* MOCK_RCCL_FAIL_AT=k: the k-th data operation of the process (an all-reduce, an all-gather or a completed group of sends /
+ * receives, counted over all ranks) fails with ncclSystemError on the rank that issues it and takes its communicator group
+ * down, as a link error in the middle of a run would: the peers' pending and later operations fail too. */
+static long g_ops;
+static int op_fails(Group *g)
+{
+    static long fail_at = -2;
+    long mine;
+    pthread_mutex_lock(&g_mu);
+    if (fail_at == -2) {
+        const char *e = getenv("MOCK_RCCL_FAIL_AT");
+        fail_at = e ? atol(e) : -1;
+    }
+    mine = ++g_ops;
+    pthread_mutex_unlock(&g_mu);
+    if (fail_at < 0 || mine != fail_at) return 0;
+    fprintf(stderr, "mock rccl: injected failure at operation %ld\n", mine);
+    pthread_mutex_lock(&g->mu);
+    g->aborted = 1;
+    pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->mu);
+    return 1;
+}
+
 static size_t dt_size(ncclDataType_t t)
 {
     switch (t) { case 0: case 1: return 1; case 2: case 3: case 7: return 4; case 4: case 5: case 8: return 8; case 6: return 2; }
@@ -154,6 +178,7 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
     float *tmp;
     (void)st;
     if (dt != 7 || op != 2) return ncclInvalidArgument;   /* the transport only takes the maximum of floats */
+    if (op_fails(g)) return ncclSystemError;
     pthread_mutex_lock(&g->mu);
     g->sbuf[c->rank] = send;
     pthread_mutex_unlock(&g->mu);
@@ -179,6 +204,7 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     const size_t bytes = count * dt_size(dt);
     (void)st;
     if (dt_size(dt) == 0) return ncclInvalidArgument;
+    if (op_fails(g)) return ncclSystemError;
     pthread_mutex_lock(&g->mu);
     g->sbuf[c->rank] = send;
     pthread_mutex_unlock(&g->mu);
@@ -195,6 +221,7 @@ static __thread int t_nops, t_depth;
 static ncclResult_t run_ops(void)
 {
     ncclResult_t rc = ncclSuccess;
+    if (t_nops > 0 && op_fails(t_ops[0].c->g)) { t_nops = 0; return ncclSystemError; }
     for (int i = 0; i < t_nops; i++) {                   /* post every send */
         const P2p *o = &t_ops[i];
         Group *g = o->c->g;

@@ -55,7 +55,8 @@ def test_absent_rank_times_out(emu):
 
 def _bench(args, env):
     e = dict(os.environ, PYTHONPATH=ROOT, SIFT3D_AMD_LIB=os.path.join(EMU_DIR, "libsift3d_emu.so"),
-             LD_PRELOAD=os.path.join(EMU_DIR, "mock", "librccl.so.1"), S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2", **env)
+             LD_PRELOAD=os.path.join(EMU_DIR, "mock", "librccl.so.1"), S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2")
+    e.update({"S3D_BENCH_PREFLIGHT": "0"}, **env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         if k not in env:
             e.pop(k, None)
@@ -76,6 +77,101 @@ def test_bench_gpus_n_without_a_launcher(emu):
     assert len(cfg["keypoints_per_rank"]) == 2 and sum(cfg["keypoints_per_rank"]) == cfg["keypoints"] > 0
     assert len(cfg["halo_wait_ms_per_rank"]) == 2 and len(cfg["comm_ms_per_rank"]) == 2
     assert "ncclCommInitAll" in cfg["parallelism"] and cfg["halo_MB_per_step_all_ranks"] > 0
+
+
+def _line(p):
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_n_gpu_line_validates_itself(emu):
+    """Every --gpus N line carries config.parity: the N ranks' gathered keypoint list against ONE GPU's -- here against a
+    single-GPU detect made in the same run (small volume), with a pre-flight job over the transport before the timed one."""
+    p = _bench(["--gpus", "2", "--strong-size", "64"], {"S3D_EMU_DEVICES": "2", "S3D_BENCH_PREFLIGHT": "24,24,64"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    cfg = _line(p)["config"]
+    par, pre = cfg["parity"], cfg["preflight"]
+    assert par["ok"] and par["kp_sha256_equals_single_gpu"] is True and par["keypoints"] == par["expected"] == cfg["keypoints"] > 0
+    assert len(par["kp_sha256"]) == 64 and any("single-GPU detect" in c for c in par["checked_against"])
+    assert pre["ok"] and pre["volume"] == [24, 24, 64] and pre["transport"] == "RCCL" and pre["keypoints"] == pre["expected"] > 0
+    assert "transport_fallback" not in cfg and cfg["rccl_ranks"] == 2
+
+
+def test_bench_parity_mismatch_is_an_error(emu, tmp_path):
+    """A committed single-GPU result that the run does not reproduce (S3D_BENCH_PARITY_GOLDEN points at a file with a wrong
+    hash): the line is printed with parity.ok false and the exit status is 4."""
+    g = tmp_path / "golden.json"
+    g.write_text(json.dumps({"volumes": {"64x64x64": {"keypoints": 1, "kp_sha256": "0" * 64, "source": "test"}}}))
+    p = _bench(["--gpus", "2", "--strong-size", "64"], {"S3D_EMU_DEVICES": "2", "S3D_BENCH_PARITY_GOLDEN": str(g)})
+    assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
+    par = _line(p)["config"]["parity"]
+    assert par["ok"] is False and par["expected"] == 1 and par["kp_sha256_equals_single_gpu"] is False and "PARITY FAILURE" in p.stderr
+
+
+@pytest.mark.parametrize("stage,env", [("timed", {"MOCK_RCCL_FAIL_AT": "3"}),
+                                       ("timed", {"S3D_BENCH_TEST_INJECT": "timed:1:3"}),
+                                       ("preflight", {"S3D_BENCH_TEST_INJECT": "preflight:0:4", "S3D_BENCH_PREFLIGHT": "24,24,64"})])
+def test_bench_rccl_failure_after_init_reruns_on_loopback(emu, stage, env):
+    """RCCL initialises and then fails -- the mock's k-th operation returns an error, or a rank fails inside the pyramid /
+    while the candidate lists are sized: no exit status 3 and no silence, the ranks run the job again over the loop-back
+    transport and the line says what happened (transport_fallback.error) and what it was measured on."""
+    p = _bench(["--gpus", "2", "--strong-size", "64"], dict({"S3D_EMU_DEVICES": "2"}, **env))
+    assert p.returncode == 0, p.stderr[-3000:]
+    cfg = _line(p)["config"]
+    fb = cfg["transport_fallback"]
+    assert "RCCL" in fb["intended"] and "loop-back" in fb["measured_on"] and fb["error"]
+    assert ("pre-flight" in fb["error"]) == (stage == "preflight")
+    assert "RCCL FAILED" in cfg["parallelism"] and "rccl_ranks" not in cfg
+    assert cfg["parity"]["ok"] and cfg["parity"]["kp_sha256_equals_single_gpu"] is True
+    if stage == "preflight":
+        assert cfg["preflight"]["ok"] is False and "error" in cfg["preflight"]
+    assert "running the job again over the in-process loop-back transport" in p.stderr
+
+
+def _torchrun_bench(extra_env, port_salt):
+    """bench.py --gpus 2 the way the driver launches it (torch.distributed.run, one process per rank), on the CPU: emulator build
+    of the library, gloo; the real librccl finds no device, so the ranks agree on the gloo transport."""
+    e = dict(os.environ, PYTHONPATH=ROOT, SIFT3D_AMD_LIB=os.path.join(EMU_DIR, "libsift3d_emu.so"), S3D_EMU_DEVICES="2",
+             S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2", S3D_BENCH_PREFLIGHT="24,24,64", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_PRELOAD"):
+        e.pop(k, None)
+    e.update(extra_env)
+    port = 29500 + (os.getpid() + port_salt) % 2000
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong-size", "64", "--size", "32",
+                           "--steps", "1", "--warmup", "0", "--no-roofline", "--no-cpu-baseline", "--no-match"],
+                          capture_output=True, text=True, timeout=1500, env=e)
+
+
+def test_bench_under_torchrun_validates_itself(emu):
+    """One process per rank: pre-flight + parity in the line, breakable store barriers instead of gloo barriers in the timed
+    region."""
+    p = _torchrun_bench({}, 11)
+    assert p.returncode == 0, p.stderr[-4000:]
+    rec = _line(p)
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and "RCCL did NOT initialise" in cfg["parallelism"]
+    assert cfg["parity"]["ok"] and cfg["parity"]["kp_sha256_equals_single_gpu"] is True and cfg["parity"]["keypoints"] == cfg["keypoints"] > 0
+    assert cfg["preflight"]["ok"] and cfg["preflight"]["transport"] == "gloo"
+
+
+def test_bench_under_torchrun_transport_failure_reruns_over_gloo(emu):
+    """The first transport fails after initialisation (rank 1's describe of the timed job; S3D_BENCH_FAKE_RCCL lets a gloo
+    transport play the RCCL one, there being no multi-process stand-in for librccl): rank 0 leaves its barrier through the failure
+    key, both ranks meet, drop the transport, and the job runs again over gloo -- a labelled line, exit status 0."""
+    p = _torchrun_bench({"S3D_BENCH_FAKE_RCCL": "1", "S3D_BENCH_TEST_INJECT": "timed:1:5"}, 12)
+    assert p.returncode == 0, p.stderr[-4000:]
+    cfg = _line(p)["config"]
+    fb = cfg["transport_fallback"]
+    assert "injected failure 5 on rank 1" in fb["error"] and "gloo" in fb["measured_on"] and "RCCL FAILED" in cfg["parallelism"]
+    assert cfg["parity"]["ok"] and cfg["preflight"]["ok"] and cfg["preflight"]["transport"] == "RCCL"
+
+
+def test_bench_under_torchrun_failure_on_the_last_transport_ends_the_job(emu):
+    """... and when the gloo transport itself is what fails there is nothing left to fall back to: every rank leaves with status 3
+    within seconds (no rank waits for a dead peer), and no line is printed."""
+    p = _torchrun_bench({"S3D_BENCH_TEST_INJECT": "timed:1:5"}, 13)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "the job failed on the gloo transport" in p.stderr
 
 
 def test_bench_without_rccl_falls_back_and_says_so(emu):
