@@ -319,8 +319,9 @@ def test_two_processes_share_one_gpu(hip, tmp_path):
 
 @pytest.mark.skipif(os.environ.get("S3D_TEST_1024") == "0", reason="S3D_TEST_1024=0")
 def test_config3_1024_cubed(hip):
-    """BASELINE configs[3]: one 1024^3 float32 volume (4 GiB).  (a) single GPU: the keypoint count of the reference
-    generator's volume (246 249, profiles/README.md), reference order, orthonormal R, unit-norm descriptors;
+    """BASELINE configs[3]: one 1024^3 float32 volume (4 GiB).  (a) single GPU: 246 249 keypoints -- THIS library's count for
+    the volume of the bench generator (the reference has not been run at this size in the test suite; see DESIGN.md section 2 for
+    what pins it), reference order, orthonormal R, unit-norm descriptors;
     (b) the same volume as eight 128-slice Z-slabs (loop-back ranks on this GPU): keypoints, R and descriptors
     bit-identical to (a)."""
     import hashlib
