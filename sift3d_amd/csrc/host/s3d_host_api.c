@@ -919,7 +919,14 @@ static int detect_single(SIFT3D *const sift3d, const float *host_dense, const fl
     /* (the upload of host_dense has completed: detect_dev synchronised the stream, and so does every failure path's
      * caller before it frees the buffer -- the stream is synchronised here for those) */
     if (rc != SIFT3D_SUCCESS) {
-        (void)s3d_rt_sync(sift_ctx(sift3d)->stream);
+        /* ... and so are the extrema stream and the octaves' own streams: build_gpyr_dev may have left mid-loop, before the
+         * caller's stream was made to wait for them, and a following call on this struct rewrites what their kernels read */
+        s3d_ctx *c = sift_ctx(sift3d);
+        (void)s3d_rt_sync(c->stream);
+        if (c->ext_stream) (void)s3d_rt_sync(c->ext_stream);
+        for (int o = 0; o < S3D_MAX_OCTAVES; o++)
+            if (c->oct_stream[o]) (void)s3d_rt_sync(c->oct_stream[o]);
+        c->extrema_enqueued = 0;
         return SIFT3D_FAILURE;
     }
     {   /* a caller that reads sift3d->gpyr / dog voxels as it would after the reference's call (sift.c:989-1071) */

@@ -304,6 +304,8 @@ void sift3d_amd_slab_destroy(sift3d_amd_slab *sl)
     free(sl);
 }
 
+static int halo_of_level(const sift3d_amd_slab *sl, int o, int k);
+
 static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_stream)
 {
     const int G = sl->t.world;
@@ -326,6 +328,18 @@ static int slab_build(sift3d_amd_slab *sl, const SIFT3D *params, void *hip_strea
          * window radius is 2 * 7.0711 * sd physical units (sift.c:1846-1847) with sd <= the scale of the last keypoint level */
         const double sd_max = g->sigma0 * pow(2.0, (double)(sl->nkp - 1) / sl->nkp);
         sl->H = (int)ceil(2.0 * 7.071067812 * sd_max / sl->units[2]) + 3;
+    }
+    {   /* ... and never fewer planes than any level's halo asks for (halo_of_level), the literal kernels' extra plane of a
+         * verbatim pass included: the levels are allocated with H planes per side, a wider reach would read unfilled ones */
+        const int was = sl->verbatim;
+        sl->verbatim = 1;
+        for (int o = 0; o < sl->no; o++)
+            for (int k = 0; k < sl->nl; k++) {
+                const int h = halo_of_level(sl, o, k);
+                if (h > sl->H) sl->H = h;
+            }
+        if (filter_reach(sl, &p->gss.first_gauss.f, 0) > sl->H) sl->H = filter_reach(sl, &p->gss.first_gauss.f, 0);
+        sl->verbatim = was;
     }
     if (plan_partition(sl)) return SIFT3D_FAILURE;
 
@@ -551,7 +565,7 @@ static int halo_of_level(const sift3d_amd_slab *sl, int o, int k)
         const int w = window_reach(sl, k);
         if (w > h) h = w;
     }
-    return h;
+    return h;                                               /* <= sl->H: slab_build sized H over all of these */
 }
 
 /* What a detect of this plan moves over the links: bytes this rank SENDS to its lower / upper neighbour (it receives the

@@ -234,6 +234,9 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
     static_assert(BW_TILE == 64 * BW_P, "a lane owns BW_P voxels of the wave's tile");
     __shared__ float mesh[S3D_MESH_FLOATS];
     __shared__ __attribute__((aligned(16))) float4 bufs[BW_WAVES][BUF];
+    /* 65.9 (HW = 6) ... 67.3 KB (HW = 9) of static LDS: more than the 64 KB a workgroup gets on earlier parts -- this relies on
+     * gfx950's 160 KB per CU, two workgroups of which are resident */
+    static_assert(sizeof(float) * S3D_MESH_FLOATS + sizeof(float4) * BW_WAVES * BUF <= 80 * 1024, "two workgroups per CU (160 KB of LDS)");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 *const buf = bufs[wv];
     for (int i = tid; i < S3D_MESH_FLOATS; i += 64 * BW_WAVES) mesh[i] = d_mesh[i];
