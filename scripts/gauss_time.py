@@ -9,6 +9,8 @@ import sift3d_amd                     # noqa: E402
 import bench                          # noqa: E402
 
 dev = sift3d_amd.load_device()
+if os.environ.get("GAUSS_MODE"):                      # s3d_k_gauss_set_mode bits (128: the guarded z kernel of rounds 1-5)
+    dev.L.s3d_k_gauss_set_mode(int(os.environ["GAUSS_MODE"]))
 apps = bench.gauss_roofline(dev, 512, [0.538701, 0.973294, 1.22627, 1.54501, 1.94659, 2.45255], reps=int(os.environ.get("REPS", "10")))
 print(os.environ.get("SIFT3D_AMD_LIB", "default"))
 for a in apps:

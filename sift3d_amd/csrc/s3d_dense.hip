@@ -487,27 +487,6 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
 #define S3D_LDS_REREAD() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
 #endif
 
-template <int HW, int R>
-__device__ __forceinline__ float4 ring_dot_r(const float4 (&ring)[R], const int U, const S3dTaps &taps)
-{
-#if defined(DM_EXP_TAPS)                                       /* timing experiment: fewer taps, same memory traffic */
-    constexpr int W = DM_EXP_TAPS;
-#else
-    constexpr int W = 2 * HW + 1;
-#endif
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-        const float4 s = ring[(U - k + 2 * R) % R];
-        const float t = taps.t[k];
-        acc.x = acc.x + t * s.x;
-        acc.y = acc.y + t * s.y;
-        acc.z = acc.z + t * s.z;
-        acc.w = acc.w + t * s.w;
-    }
-    return acc;
-}
-
 template <int HW, int D, bool POST>
 __global__ void __launch_bounds__(64 * (POST ? DM_PWAVES : DM_WAVES)) __attribute__((amdgpu_waves_per_eu(DM_EU)))
 k_dmarch(const float *__restrict__ src, float *__restrict__ dst, size_t ncol /* float4 columns per batch */,

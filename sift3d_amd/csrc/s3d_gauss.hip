@@ -563,6 +563,102 @@ k_gauss_z(const float *__restrict__ src, float *__restrict__ dst, int nx4, int n
     }
 }
 
+/* The z pass in the round-6 marching form.  MEASURED AND NOT MADE THE DEFAULT: at 512^3 it times like k_gauss_z (0.202-0.208 ms
+ * against 0.197-0.211 at widths 5-17, alternating runs on one box: profiles/r06_gauss_zs_ab.txt) -- the z pass of a single-channel
+ * volume already sits at what the marching access pattern gives (5.2-5.4 TB/s) -- so the pyramid keeps k_gauss_z (and its PMC
+ * record); this kernel serves the raw-image smoothing, which wants the maximum kept (MAXOUT), and mode bit 7 for A/B runs.
+ * k_gauss_z guards every load and store of its marching loop (is the plane real? is an output due?), and with a guard around
+ * a memory operation the compiler can no longer count the operations outstanding: it drains them all -- s_waitcnt vmcnt(0) --
+ * at every step, so the two planes "in flight" were waited for one step after their issue (SQ_WAIT_ANY 75 % of the wave cycles,
+ * profiles/r05_pmc_describe.md).  Here: a ring of W + D slots, the load of plane t + D straight into slot (t + D) % R (no
+ * register moves), the first 2 HW + D planes fetched up front, then STRAIGHT-LINE blocks of R steps -- load, dot product,
+ * store, nothing conditional: exact vmcnt(n) -- and a guarded tail for the blocks that touch the high end's blends or are
+ * shorter than a block.  Same arithmetic per output (ring_dot_r: tap order, two roundings): same bits. */
+#ifndef GZ_D
+#define GZ_D 4                           /* planes in flight per lane */
+#endif
+template <int HW, int D, bool MAXOUT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+k_gauss_zs(const float *__restrict__ src, float *__restrict__ dst, int nx4, int ny, int nz, int zbeg, int zend, int chunk,
+           S3dTaps taps, EdgeFrac ef, unsigned *__restrict__ maxout)
+{
+    constexpr int W = 2 * HW + 1, R = W + D;
+    const size_t ncol = (size_t)nx4 * ny;
+    size_t colid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (colid >= ncol) {
+        if (!MAXOUT) return;
+        colid = ncol - 1;                            /* the wave reduces its maximum: spare lanes redo the last column (same bytes) */
+    }
+    const unsigned loff = (unsigned)colid * 16u;
+    const char *const sbase = reinterpret_cast<const char *>(src);
+    char *const dbase = reinterpret_cast<char *>(dst);
+    const size_t sbytes = ncol * 16u;                /* bytes per z plane */
+    const int n = nz;
+    auto ldrow = [&](const int c) { return *reinterpret_cast<const float4 *>(sbase + (size_t)c * sbytes + loff); };
+    auto ext = [&](int c) {
+        if (c < 0) c = -c;
+        if (c <= n - 2) return ldrow(c);
+        const int j = c - (n - 1);
+        return blend4(ldrow(n - 2 - j), ldrow(n - 1 - j), ef.f[j]);
+    };
+    const int p0 = zbeg + blockIdx.y * chunk;
+    const int p1 = (p0 + chunk < zend) ? p0 + chunk : zend;
+    const int nout = p1 - p0;
+    unsigned vmax = 0u;
+    auto emit = [&](const int p, const float4 &acc) {
+        *reinterpret_cast<float4 *>(dbase + (size_t)p * sbytes + loff) = acc;
+        if (MAXOUT) {
+            const unsigned a = __float_as_uint(acc.x) & 0x7fffffffu, b = __float_as_uint(acc.y) & 0x7fffffffu,
+                           c = __float_as_uint(acc.z) & 0x7fffffffu, d = __float_as_uint(acc.w) & 0x7fffffffu;
+            const unsigned ab = a > b ? a : b, cd = c > d ? c : d, m4 = ab > cd ? ab : cd;
+            vmax = vmax > m4 ? vmax : m4;
+        }
+    };
+    /* row index i <-> coordinate p0 - HW + i, in ring slot (i - 2 HW) mod R: output step s = R q + u finds its newest row in slot u */
+    float4 ring[R];
+    const int c0 = p0 - HW;
+    const int last = nout - 1 + 2 * HW;
+#pragma unroll
+    for (int i = 0; i < 2 * HW + D; i++)
+        if (i <= last) ring[(i - 2 * HW + 2 * R) % R] = ext(c0 + i);
+    int sb = 0;
+    for (; sb + R <= nout && c0 + sb + R - 1 + 2 * HW <= n - 2; sb += R) {
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const int s = sb + u;
+            {
+                int c = c0 + s + 2 * HW + D;         /* (beyond the rows this block uses: clamped, used only if interior) */
+                if (c < 0) c = -c;
+                if (c > n - 2) c = n - 2;
+                ring[(u + D) % R] = ldrow(c);
+            }
+            emit(p0 + s, ring_dot_r<HW, R>(ring, u, taps));
+        }
+    }
+    if (sb < nout) {
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            if (sb > 0 && sb + d + 2 * HW <= last) ring[d % R] = ext(c0 + sb + d + 2 * HW);
+        for (; sb < nout; sb += R) {
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const int s = sb + u;
+                if (s < nout) {
+                    if (s + 2 * HW + D <= last) ring[(u + D) % R] = ext(c0 + s + 2 * HW + D);
+                    emit(p0 + s, ring_dot_r<HW, R>(ring, u, taps));
+                }
+            }
+        }
+    }
+    if (MAXOUT) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)vmax, m);
+            vmax = vmax > o ? vmax : o;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(maxout, vmax);
+    }
+}
+
 /* ---- interleaved multi-channel volumes, unit tap spacing (the 12-channel dense-descriptor blur) ------
  * Element (x, y, z, c) lives at ((z*ny + y)*nx + x)*nc + c.  A pass along y or z treats every (x, c) pair
  * alike, so those two passes see a single-channel volume nc*nx wide and march along it exactly like
@@ -878,6 +974,7 @@ static int fast_eligible(int nx, int ny, int nz, int nc, const float uf[3], int 
 }
 
 static thread_local int g_chunk_xy = 176, g_chunk_z = 176, g_gauss_mode = 0;   /* targets; see even_chunk().  Per calling thread. */
+static thread_local int g_new_z = 0;             /* mode bit 7: k_gauss_zs for every aligned z pass (A/B runs; default: the raw-image smoothing only) */
 static thread_local int g_chunk_user = 0;      /* s3d_k_gauss_set_chunks was called: the targets are taken literally */
 
 /* Steps per chunk of a marching pass over n steps: equal chunks of about `target` steps (512 -> 3 x 171).  A volume that
@@ -901,12 +998,13 @@ static int march_chunk(int n, int target, size_t waves_per_chunk, int hw)
  * dyadic y / z kernels apply (A/B runs); bit 6 = verbatim (see g_verbatim: the per-element kernel only, fused forms included) */
 extern "C" int s3d_k_gauss_get_mode(void)
 {
-    return g_verbatim ? 64 : (g_gauss_mode & 1) | (g_no_dyadic << 1) | (g_force_tab << 3) | (g_no_tab << 4) | (g_tab_over_dyadic << 5);
+    return g_verbatim ? 64 : (g_new_z << 7) | (g_gauss_mode & 1) | (g_no_dyadic << 1) | (g_force_tab << 3) | (g_no_tab << 4) | (g_tab_over_dyadic << 5);
 }
 
 extern "C" void s3d_k_gauss_set_mode(int mode)
 {
     g_verbatim = (mode >> 6) & 1;
+    g_new_z = (mode >> 7) & 1;
     if (g_verbatim) mode = 2;
     g_gauss_mode = mode & 1;
     g_no_dyadic = (mode >> 1) & 1;
@@ -965,8 +1063,11 @@ static int launch_fast(const float *d_src, float *d_dst, float *d_tmp, int nx, i
         hipLaunchKernelGGL((k_gauss_z<HW, false, true>), dim3(s3d_div_up(s3d_div_up(plane, 4), 256), ncz), dim3(256), 0, st,
                            d_tmp, d_dst, nx, ny, nz, z0, z1, cz, t, ez, (unsigned *)nullptr);
     else if (d_maxout)
-        hipLaunchKernelGGL((k_gauss_z<HW, false, false, true>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_gauss_zs<HW, 2, true>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
                            d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez, reinterpret_cast<unsigned *>(d_maxout));
+    else if (g_new_z && (size_t)(nx / 4) * ny * 16u < 0xffffffffull)
+        hipLaunchKernelGGL((k_gauss_zs<HW, GZ_D, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
+                           d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez, (unsigned *)nullptr);
     else if (!(g_gauss_mode & 1))
         hipLaunchKernelGGL((k_gauss_z<HW, false>), dim3(s3d_div_up((size_t)(nx / 4) * ny, 256), ncz), dim3(256), 0, st,
                            d_tmp, d_dst, nx / 4, ny, nz, z0, z1, cz, t, ez, (unsigned *)nullptr);
@@ -1404,6 +1505,7 @@ extern "C" int s3d_k_sep_fir_max(const float *d_src, float *d_dst, float *d_tmp,
     S3dTaps t;
     if (width < 1 || width > S3D_MAX_TAPS || !(width & 1) || nx < 1 || ny < 1 || nz < 1) return 1;
     if (!fast_eligible(nx, ny, nz, 1, uf, width) || (nx & 3) || d_tmp == d_src || d_tmp == d_dst) return 1;
+    if (width / 2 > 8) return 1;                 /* (the widest instantiation of the maximum-keeping z kernel spills registers) */
     if (check_taps(taps, width, &t)) return S3D_ERR;
     S3D_HIP(hipMemsetAsync(d_max, 0, sizeof(float), (hipStream_t)stream));
     return fast_dispatch(d_src, d_dst, d_tmp, nx, ny, nz, 0, nz, width / 2, t, (hipStream_t)stream, nullptr, d_max);

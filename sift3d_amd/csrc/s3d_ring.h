@@ -29,6 +29,28 @@ __device__ __forceinline__ float4 ring_dot(const float4 (&ring)[2 * HW + 1], con
     return acc;
 }
 
+/* the same over a ring of R >= 2 HW + 1 slots (the extra slots are loads in flight: k_gauss_zs, k_dmarch) */
+template <int HW, int R>
+__device__ __forceinline__ float4 ring_dot_r(const float4 (&ring)[R], const int U, const S3dTaps &taps)
+{
+#if defined(DM_EXP_TAPS)                                       /* timing experiment: fewer taps, same memory traffic */
+    constexpr int W = DM_EXP_TAPS;
+#else
+    constexpr int W = 2 * HW + 1;
+#endif
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const float4 s = ring[(U - k + 2 * R) % R];
+        const float t = taps.t[k];
+        acc.x = acc.x + t * s.x;
+        acc.y = acc.y + t * s.y;
+        acc.z = acc.z + t * s.z;
+        acc.w = acc.w + t * s.w;
+    }
+    return acc;
+}
+
 __device__ __forceinline__ float4 blend4(float4 a, float4 b, float f)
 {
     const float om = 1.0f - f;
