@@ -577,7 +577,7 @@ static int pyr_fir(s3d_ctx *c, s3d_stream st, float *tmp, const float *src, floa
     if (!c->verbatim) return s3d_k_sep_fir(src, dst, tmp, nx, ny, nz, 1, uf, f->kernel, f->width, st);
     {
         const int mode = s3d_k_gauss_get_mode();
-        s3d_k_gauss_set_mode(64);
+        s3d_k_gauss_set_mode(64 | (mode & (8 | 16)));
         rc = s3d_k_sep_fir_path(src, dst, tmp, nx, ny, nz, 1, uf, f->kernel, f->width, 1, st);
         s3d_k_gauss_set_mode(mode);
     }
@@ -1509,7 +1509,7 @@ static int smooth_scale_raw_dev(const SIFT3D *sift3d, s3d_ctx *c, const float *d
     }
     if (!rc && how == RAW_LITERAL) {
         const int mode = s3d_k_gauss_get_mode();
-        s3d_k_gauss_set_mode(64);
+        s3d_k_gauss_set_mode(64 | (mode & (8 | 16)));
         rc = s3d_k_sep_fir_path(d_in, d_out, d_tmp, nx, ny, nz, 1, uf, gauss.f.kernel, gauss.f.width, 1, c->stream) ||
              s3d_k_seqmax(d_out, NULL, n, d_max, c->d_red + RED_REC, c->stream) || s3d_k_scale_div(d_out, n, d_max, c->stream);
         s3d_k_gauss_set_mode(mode);
@@ -1733,7 +1733,7 @@ int sift3d_amd_extract_dense_dev(SIFT3D *const sift3d, const float *d_in, int nx
             const int mode = s3d_k_gauss_get_mode();
             rc = ctx_aux(c, 3, n * HIST_NUMEL) ||
                  (nf && smooth_scale_raw_dev(sift3d, c, d_in, c->d_aux[1], c->d_aux[2], nx, ny, nz, units, RAW_LITERAL));
-            if (nf) s3d_k_gauss_set_mode(64);
+            if (nf) s3d_k_gauss_set_mode(64 | (mode & (8 | 16)));
             rc = rc || s3d_rt_memset(c->d_aux[3], 0, n * HIST_NUMEL * sizeof(float), c->stream) ||
                  s3d_k_dense_bary(c->d_aux[1], nx, ny, nz, unitsf, c->d_mesh, c->d_aux[3], c->stream) ||
                  s3d_k_sep_fir_path(c->d_aux[3], d_out, c->d_aux[2], nx, ny, nz, HIST_NUMEL, uf, gauss.f.kernel, gauss.f.width,

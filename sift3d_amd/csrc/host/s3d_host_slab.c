@@ -845,7 +845,7 @@ static int slab_detect(sift3d_amd_slab *sl, const float *vol, int on_device, Key
     int rc = slab_detect_pass(sl, vol, on_device, kp);
     if (rc == SLAB_REDO_VERBATIM) {
         const int mode = s3d_k_gauss_get_mode();
-        s3d_k_gauss_set_mode(64);
+        s3d_k_gauss_set_mode(64 | (mode & (8 | 16)));
         sl->verbatim = 1;
         rc = slab_detect_pass(sl, vol, on_device, kp);
         sl->verbatim = 0;

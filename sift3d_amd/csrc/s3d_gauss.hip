@@ -381,7 +381,7 @@ static thread_local int g_verbatim = 0;
 
 /* s3d_gauss_tab.hip: 0 done, 1 not eligible, -1 error */
 extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
-                                   const float *taps, int width, float uf, int uhw, const float *d_div, s3d_stream stream);
+                                   const float *taps, int width, float uf, int uhw, const float *d_div, int literal, s3d_stream stream);
 extern "C" int s3d_k_conv_x_tab_available(int nx, int ny, int nz, int width, float uf, int uhw);
 
 /* one axis pass over the planes [z0, z1) of a volume addressed by global z (z0 = 0, z1 = nz: all) */
@@ -406,10 +406,19 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
     }
     if (d_src == d_dst) S3D_FAIL("in-place axis pass is not supported");
     if (d_div) {                                          /* only the table-driven x pass divides on load */
-        const int r = nc == 1 && axis == 0 ? s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, 0, z0, z1, taps, width, uf, uhw, d_div, st) : 1;
+        const int r = nc == 1 && axis == 0 ? s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, 0, z0, z1, taps, width, uf, uhw, d_div, g_verbatim, st) : 1;
         if (r == 0) return S3D_OK;
         if (r > 0) s3d_rt_set_error(__func__, "no dividing pass for this configuration");
         return S3D_ERR;
+    }
+    /* A verbatim pass (a volume with non-finite voxels): the table-driven kernels in their LITERAL form -- every tap as
+     * (1 - frac) * src[lo] + frac * src[lo + 1], zero fractions included: k_conv_axis's arithmetic bit for bit, any spacing (unit
+     * spacing too: the fused streaming kernels skip the zero-weight sample) -- where the volume is large enough for them; the
+     * per-element kernel below otherwise.  512^3 with one NaN voxel: the second pass 28 -> ~10 ms (profiles/r06_nonfinite_cost.txt). */
+    if (g_verbatim && nc == 1 && !g_no_tab && (g_force_tab || (size_t)nx * ny * (size_t)(z1 - z0) > (size_t)64 * 64 * 64)) {
+        const int r = s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, axis, z0, z1, taps, width, uf, uhw, nullptr, 1, st);
+        if (r < 0) return S3D_ERR;
+        if (r == 0) return S3D_OK;
     }
     const size_t ib = strides[2] * (size_t)z0, ie = strides[2] * (size_t)z1;
     const bool vec4 = axis != 0 && (strides[1] & 3) == 0 && !(((uintptr_t)d_src | (uintptr_t)d_dst) & 15);
@@ -443,7 +452,7 @@ static int conv_axis_range(const float *d_src, float *d_dst, int nx, int ny, int
      * (a pass over 32^3 voxels is a handful of waves walking the volume; the plain kernels below take a few us there) */
     if (nc == 1 && !g_no_dyadic && !g_no_tab &&
         (g_force_tab || (size_t)nx * ny * (size_t)(z1 - z0) > (size_t)64 * 64 * 64)) {
-        const int r = s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, axis, z0, z1, taps, width, uf, uhw, nullptr, st);
+        const int r = s3d_k_conv_axis_tab(d_src, d_dst, nx, ny, nz, axis, z0, z1, taps, width, uf, uhw, nullptr, 0, st);
         if (r < 0) return S3D_ERR;
         if (r == 0) return S3D_OK;
     }
@@ -998,14 +1007,14 @@ static int march_chunk(int n, int target, size_t waves_per_chunk, int hw)
  * dyadic y / z kernels apply (A/B runs); bit 6 = verbatim (see g_verbatim: the per-element kernel only, fused forms included) */
 extern "C" int s3d_k_gauss_get_mode(void)
 {
-    return g_verbatim ? 64 : (g_new_z << 7) | (g_gauss_mode & 1) | (g_no_dyadic << 1) | (g_force_tab << 3) | (g_no_tab << 4) | (g_tab_over_dyadic << 5);
+    return g_verbatim ? 64 | (g_force_tab << 3) | (g_no_tab << 4) : (g_new_z << 7) | (g_gauss_mode & 1) | (g_no_dyadic << 1) | (g_force_tab << 3) | (g_no_tab << 4) | (g_tab_over_dyadic << 5);
 }
 
 extern "C" void s3d_k_gauss_set_mode(int mode)
 {
     g_verbatim = (mode >> 6) & 1;
     g_new_z = (mode >> 7) & 1;
-    if (g_verbatim) mode = 2;
+    if (g_verbatim) mode = 2 | (mode & (8 | 16));       /* (the table-driven passes stay selectable: literal form) */
     g_gauss_mode = mode & 1;
     g_no_dyadic = (mode >> 1) & 1;
     g_tab_over_dyadic = (mode >> 5) & 1;

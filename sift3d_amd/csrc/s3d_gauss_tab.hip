@@ -231,7 +231,7 @@ template <int HW, int D>
 __global__ void __launch_bounds__(64 * TAB_MW)
 k_conv_march_tab(const float *__restrict__ src, float *__restrict__ dst, unsigned ncol4, size_t nflat, size_t stride,
                  size_t bstride, int p_begin, int p_end, int chunk, int rmin, int rmax, int W, int A,
-                 const int *__restrict__ tab, S3dTaps taps)
+                 const int *__restrict__ tab, S3dTaps taps, int literal /* see s3d_k_conv_axis_tab */)
 {
     constexpr int NT = 2 * HW + 1, MW = TAB_MW, TS = 4 * NT + 1;
     S3D_DYN_LDS(float4, ring);                             /* W rows of 64 float4 */
@@ -275,7 +275,7 @@ k_conv_march_tab(const float *__restrict__ src, float *__restrict__ dst, unsigne
     auto output = [&](int p) {
         const int *row = tab + (size_t)p * (size_t)TS;
         s3d_f2 lo2 = {0.0f, 0.0f}, hi2 = {0.0f, 0.0f};   /* (x, y) and (z, w) of the output: packed f32 operations */
-        if (row[4 * NT]) {
+        if (row[4 * NT] && !literal) {
             /* every tap of this row sits on a voxel (frac == 0: unit spacing away from the mirrored ends): the sample is
              * src[lo] -- the reference's 1.0f * src[lo] + 0.0f * src[lo + 1] up to the sign of a zero, which cannot
              * reach the sum (it starts at +0) */
@@ -340,7 +340,7 @@ template <int HW, int D, bool DIV>
 __global__ void __launch_bounds__(64)
 k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, size_t row_begin, size_t row_end,
              unsigned rows_per_wave, unsigned nstrips, int uhw, const int *__restrict__ xlo, const int *__restrict__ xfr,
-             S3dTaps taps, const float *__restrict__ d_div)
+             S3dTaps taps, const float *__restrict__ d_div, int literal)
 {
     float div = 1.0f;
     if (DIV) {
@@ -372,7 +372,7 @@ k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, siz
     bool zero = true;
 #pragma unroll
     for (int k = 0; k < NT; k++) zero = zero && fr[k] == 0.0f;
-    const bool allzero = __ballot(zero ? 0 : 1) == 0ull;   /* wave uniform */
+    const bool allzero = !literal && __ballot(zero ? 0 : 1) == 0ull;   /* wave uniform */
     auto clampx = [&](int i) { return i < 0 ? 0 : (i > nx - 1 ? nx - 1 : i); };
     const int i0 = clampx(g0 + lane), i1 = clampx(g0 + 64 + lane);
     const int slot1 = lane >= 1 ? XT_LINE + lane - 1 : 2 * XT_LINE - 1;
@@ -459,7 +459,7 @@ static int pick_chunk(int nout, int W, size_t waves_per_chunk)
 
 template <int HW>
 static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int ny, int nz, int axis, int z0, int z1,
-                      const S3dTaps &taps, hipStream_t st, const float *d_div)
+                      const S3dTaps &taps, hipStream_t st, const float *d_div, int literal)
 {
     constexpr int D = 4;
     const size_t plane = (size_t)nx * ny;
@@ -475,10 +475,10 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
         const dim3 grid((unsigned)(nchunks * strips));
         if (d_div)
             hipLaunchKernelGGL((k_conv_x_tab<HW, D, true>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
-                               t->d_xlo, t->d_xfr, taps, d_div);
+                               t->d_xlo, t->d_xfr, taps, d_div, literal);
         else
             hipLaunchKernelGGL((k_conv_x_tab<HW, D, false>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
-                               t->d_xlo, t->d_xfr, taps, (const float *)nullptr);
+                               t->d_xlo, t->d_xfr, taps, (const float *)nullptr, literal);
         S3D_CHECK_LAUNCH();
         return S3D_OK;
     }
@@ -488,7 +488,7 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
         const int chunk = pick_chunk(ny, t->W, (size_t)s3d_div_up(s3d_div_up((size_t)nx, 4), 64) * (size_t)(z1 - z0));
         hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up((size_t)nx, 4), 64), s3d_div_up(ny, chunk), z1 - z0),
                            dim3(64 * TAB_MW), lds, st, src + plane * z0, dst + plane * z0, s3d_div_up((size_t)nx, 4), (size_t)nx,
-                           (size_t)nx, plane, 0, ny, chunk, 0, ny - 1, t->W, A, t->d_m, taps);
+                           (size_t)nx, plane, 0, ny, chunk, 0, ny - 1, t->W, A, t->d_m, taps, literal);
         S3D_CHECK_LAUNCH();
         return S3D_OK;
     }
@@ -497,7 +497,7 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
     const int rmin = z0 - t->uhw - 1 > 0 ? z0 - t->uhw - 1 : 0, rmax = z1 + t->uhw < nz - 1 ? z1 + t->uhw : nz - 1;
     hipLaunchKernelGGL((k_conv_march_tab<HW, D>), dim3(s3d_div_up(s3d_div_up(plane, 4), 64), s3d_div_up(nzo, chunk), 1),
                        dim3(64 * TAB_MW), lds, st, src, dst, s3d_div_up(plane, 4), plane, plane, (size_t)0, z0, z1, chunk, rmin, rmax, t->W, A,
-                       t->d_m, taps);
+                       t->d_m, taps, literal);
     S3D_CHECK_LAUNCH();
     return S3D_OK;
 }
@@ -523,9 +523,14 @@ extern "C" int s3d_k_conv_x_tab_available(int nx, int ny, int nz, int width, flo
     return t != nullptr;
 }
 
-/* d_div != NULL (axis 0 only): the source is divided by *d_div as it is loaded */
+/* d_div != NULL (axis 0 only): the source is divided by *d_div as it is loaded.
+ * literal != 0: every tap is evaluated as the reference writes it, (1 - frac) * src[lo] + frac * src[lo + 1], ALSO where frac is 0
+ * (the rows / waves whose fractions are all zero otherwise read src[lo] alone): for finite voxels the same number, but
+ * 0 * NaN and 0 * inf are NaN, so with non-finite voxels in the volume only this form is the reference's filter
+ * (convolve_sep_gen, imutil.c:2316-2330).  The passes of a verbatim pyramid (volumes with non-finite voxels) run this way: bit for
+ * bit k_conv_axis, at a fraction of its cost. */
 extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int ny, int nz, int axis, int z0, int z1,
-                                   const float *taps, int width, float uf, int uhw, const float *d_div, s3d_stream stream)
+                                   const float *taps, int width, float uf, int uhw, const float *d_div, int literal, s3d_stream stream)
 {
     const int hw = width / 2;
     const int dims[3] = {nx, ny, nz};
@@ -539,7 +544,7 @@ extern "C" int s3d_k_conv_axis_tab(const float *d_src, float *d_dst, int nx, int
     hipStream_t st = (hipStream_t)stream;
     g_tab_launches++;
     switch (hw) {
-#define S3D_TB(H) case H: return launch_tab<H>(t, d_src, d_dst, nx, ny, nz, axis, z0, z1, tp, st, d_div);
+#define S3D_TB(H) case H: return launch_tab<H>(t, d_src, d_dst, nx, ny, nz, axis, z0, z1, tp, st, d_div, literal);
     S3D_TB(1) S3D_TB(2) S3D_TB(3) S3D_TB(4) S3D_TB(5) S3D_TB(6) S3D_TB(7) S3D_TB(8) S3D_TB(9)
 #undef S3D_TB
     default: break;

@@ -1149,12 +1149,22 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     /* ---- persistent workgroup: the first keypoint by block index, every further one from the shared counter (claimed at
      * the start of the keypoint before, so the atomic's round trip is never waited for).  One workgroup per CU stays
      * resident for the whole launch: no workgroup launch, table load or cold start between a CU's ~120 keypoints. ---- */
+    /* Keypoints are taken from the END of the list: the list is ordered by octave, level, z, y, x, windows grow with the level
+     * (x 2 in voxels per level) and most keypoints sit in octave 0, so walking backwards puts the big windows of octave 0's last
+     * level early and its smallest windows last -- the launch's tail is made of short jobs (a workgroup's last keypoint in list
+     * order was one of the largest: up to 0.6 ms during which the other workgroups had nothing left).  DW_ORD(k): list index of
+     * the k-th job. */
+#if defined(DW_FORWARD_ORDER)
+#define DW_ORD(k) (k)
+#else
+#define DW_ORD(k) (num - 1u - (k))
+#endif
     unsigned kid = blockIdx.x;
     for (unsigned turn = 0; kid < num; turn++) {
     if (tid == 0) sm.next[turn & 1] = gridDim.x + atomicAdd(work, 1u);
     s3d_desc_key key;
     if (turn == 0) {
-        key = keys[kid];
+        key = keys[DW_ORD(kid)];
     } else {                                                  /* workgroup-uniform: keep it in scalar registers */
         const uint32_t *kw = sm.nkey[turn & 1];               /* field by field: a memcpy through an array put `key` in scratch */
         key.cx = __uint_as_float(DW_UNIFORM(kw[0])); key.cy = __uint_as_float(DW_UNIFORM(kw[1]));
@@ -1313,7 +1323,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     uint32_t nkey_word = 0;
     {
         const unsigned nk = sm.next[turn & 1];
-        if (tz < KEY_WORDS && nk < num) nkey_word = reinterpret_cast<const uint32_t *>(keys + nk)[tz];
+        if (tz < KEY_WORDS && nk < num) nkey_word = reinterpret_cast<const uint32_t *>(keys + DW_ORD(nk))[tz];
     }
     if (use_tab) {
         /* entry i: the weight of a voxel at squared distance i * u^2, through the very float steps of sift.c:1890 */
@@ -1733,7 +1743,7 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const float ninv = (float)(1.0 / nn);
 #pragma unroll
         for (int q = 0; q < DW_NOUT; q++)
-            if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tm + q * DW_THREADS] = trunc * ninv;
+            if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)DW_ORD(kid) * out_stride + tm + q * DW_THREADS] = trunc * ninv;
         __syncthreads();                                      /* every thread has read the flag before the next keypoint clears it */
         break;
     }
@@ -1765,12 +1775,12 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     inv = (float)(1.0 / norm);
 #pragma unroll
     for (int q = 0; q < DW_NOUT; q++)
-        if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)kid * out_stride + tm + q * DW_THREADS] = v[q] * inv;
+        if (tm + q * DW_THREADS < S3D_DESC_NUMEL) out[(size_t)DW_ORD(kid) * out_stride + tm + q * DW_THREADS] = v[q] * inv;
     break;
     }
     if (COUNT_ONLY) {
         __syncthreads();                                      /* the window counters are in */
-        if (tid == 0) { stats[2 * (size_t)kid] = sm.win_vox; stats[2 * (size_t)kid + 1] = sm.win_chk; }
+        if (tid == 0) { stats[2 * (size_t)DW_ORD(kid)] = sm.win_vox; stats[2 * (size_t)DW_ORD(kid) + 1] = sm.win_chk; }
         __syncthreads();                                      /* before the next keypoint clears the counters */
     }
     /* every barrier above lies between thread 0's claim and this read; the slot alternates so that the next turn's claim

@@ -330,6 +330,26 @@ def test_nonfinite_voxels(emu, base, name, edits):
     parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name}")
 
 
+@pytest.mark.parametrize("base,name,edits", _nonfinite_subset({
+    ("iso48", "nan_first"), ("iso48", "nan_interior"), ("iso48", "nan_and_inf"), ("iso48", "nan_last"), ("aniso40", "nan_xband")}))
+def test_nonfinite_voxels_literal_table_passes(emu, base, name, edits):
+    """The same against the reference's answers with the verbatim pass on the TABLE-DRIVEN kernels in their literal form (every
+    tap as (1 - frac) * src[lo] + frac * src[lo + 1], zero fractions too) -- what volumes above 64^3 take since round 6 instead of the
+    per-element kernel; forced here on the small ones (mode bit 3)."""
+    L = parity.dev_of(emu).L
+    L.s3d_k_gauss_set_mode(8)
+    try:
+        want, g = parity.nonfinite_golden()
+        vol, units, params = parity.nonfinite_input_checked(g, base, name, edits)
+        L.s3d_k_gauss_tab_launches.restype = C.c_long
+        before = L.s3d_k_gauss_tab_launches()
+        got = parity.detect_describe_or_fail(emu, vol, units, params)
+        parity.assert_same_nonfinite_result(got, want[(base, name)], f"{base}/{name} (literal table passes)")
+        assert L.s3d_k_gauss_tab_launches() > before             # (the verbatim pass really took them)
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+
+
 def test_seqmax_kernels(emu):
     """s3d_k_seqmax = the reference's sequential maximum (im_max_abs / dogmax: a NaN replaces the running maximum, the next
     sample replaces the NaN), s3d_k_absmax = the order-free sticky one; |a| and |a - b| forms, NaN first / last / several /
