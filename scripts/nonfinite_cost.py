@@ -16,6 +16,7 @@ from sift3d_amd import abi, synth     # noqa: E402
 n = int(os.environ.get("N", "512"))
 dev = sift3d_amd.load_device()
 lib = sift3d_amd.load()
+dev.L.s3d_k_gauss_set_mode(int(os.environ.get("MODE", "0")))    # 16: the verbatim pass on the per-element kernel (rounds 5-)
 vol = synth.blobs(n, n, n, synth.default_nblobs(n, n, n), 0)
 for tag, edit in (("finite", None), ("NaN at the last voxel", (n - 1, n - 1, n - 1)), ("NaN at the first voxel", (0, 0, 0))):
     v = vol.copy()

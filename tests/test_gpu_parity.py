@@ -834,3 +834,34 @@ def test_tap_table_cache_evicts(libt, oracle):
     finally:
         L.s3d_k_gauss_set_mode(0)
         L.s3d_k_tap_tables_release()
+
+
+@pytest.mark.parametrize("dims,units,edits", [
+    ((112, 104, 96), (1.0, 1.0, 1.0), [((0, 0, 0), np.nan), ((95, 103, 111), np.inf)]),          # an infinity last: no keypoints
+    ((112, 104, 96), (1.0, 1.0, 1.0), [((0, 0, 0), np.nan), ((0, 0, 1), np.nan)]),               # NaNs first: the maximum of the rest
+    ((100, 96, 88), (1.0, 0.8, 1.5), [((40, 50, 60), np.nan)]),                                   # any spacing, NaN inside
+    ((112, 104, 96), (1.0, 1.0, 1.0), [((0, 0, 5), -np.inf), ((0, 1, 0), np.nan), ((95, 0, 0), np.nan)]),
+])
+def test_nonfinite_large_volume_vs_reference(lib, reference, dims, units, edits):
+    """Volumes above 64^3 with NaN / infinite voxels: their verbatim pass runs on the table-driven kernels in the literal form
+    (csrc/s3d_gauss.hip conv_axis_range, round 6) instead of the per-element kernel.  Against the unmodified reference run here on
+    the same volume (oracle/_ref), and against the per-element kernel (mode bit 4: never the table-driven passes): the same
+    failure or the same keypoints / orientations / descriptors."""
+    nx, ny, nz = dims
+    vol = synth.blobs(nx, ny, nz, max(50, nx * ny * nz // 2500), 3)
+    for (z, y, x), v in edits:
+        vol[z, y, x] = v
+    want = parity.detect_describe_or_fail(reference, vol, units)
+    got = parity.detect_describe_or_fail(lib, vol, units)
+    k = parity.assert_same_nonfinite_result(got, want, f"{dims} {units} table-driven literal")
+    L = parity.dev_of(lib).L
+    L.s3d_k_gauss_set_mode(16)
+    try:
+        got2 = parity.detect_describe_or_fail(lib, vol, units)
+    finally:
+        L.s3d_k_gauss_set_mode(0)
+    assert (got is None) == (got2 is None)
+    if got is not None:                                                          # (k may be 0: an infinity that the sequential
+        for a, b in zip(got, got2):                                              # maximum keeps scales the volume to zeros)
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))         # the two literal kernels: bit for bit
+
