@@ -467,7 +467,9 @@ k_bary_x_wave(const float *__restrict__ sm, float *__restrict__ dst, int nx, int
  * factor) is fetched one group ahead.  The number of steps is padded to a multiple of three (the padding steps compute on
  * stale ring slots and are masked at the store).  256^3: 1024 workgroups = 3072 waves, one round at 3 waves per SIMD; the
  * first cut (a wave on 63 columns = 21 voxels, lane 63 idle, wave-private staging) needed 3121 waves: a second round for 49. */
+#ifndef DM_WAVES
 #define DM_WAVES 4                                 /* waves per workgroup: y pass */
+#endif
 #define DM_PWAVES 3                                /* ... z pass + postproc_Hist */
 #define DM_PAD 2                                   /* float4 of padding between the staging rows */
 #ifndef DM_EU
@@ -655,7 +657,7 @@ static thread_local int g_dense_chunks = 0;        /* > 0: that many chunks (pro
 extern "C" void s3d_k_dense_set_chunks(int nchunks) { g_dense_chunks = nchunks; }
 static int dmarch_chunk(int n, size_t wgs, int hw, bool post)
 {
-    const size_t resident = 256 * (4 * DM_EU / (post ? DM_PWAVES : DM_WAVES));      /* workgroups the 256 CUs hold at DM_EU waves per SIMD */
+    const size_t resident = 256 * (size_t)(4 * DM_EU) / (post ? DM_PWAVES : DM_WAVES);      /* workgroups the 256 CUs hold at DM_EU waves per SIMD */
     int nch;
     if (g_dense_chunks > 0) nch = g_dense_chunks;
     else if (wgs > resident) nch = (int)s3d_div_up(n, 176);       /* many rounds anyway: the pyramid's chunk length */

@@ -178,7 +178,7 @@ def test_bench_without_rccl_falls_back_and_says_so(emu):
     """N "GPUs" but no usable RCCL (here: the real librccl.so.1 without a device, no mock preloaded): the N ranks still run,
     over the loop-back transport, and the line says that this is not the RCCL number."""
     e = dict(os.environ, PYTHONPATH=ROOT, SIFT3D_AMD_LIB=os.path.join(EMU_DIR, "libsift3d_emu.so"), S3D_EMU_DEVICES="2",
-             S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2")
+             S3D_BENCH_PARAMS="sigma_n=0.8,sigma0=1.2", S3D_BENCH_PREFLIGHT="24,24,64")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_PRELOAD"):
         e.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--weak", "--size", "32", "--steps", "1", "--warmup", "0",
@@ -186,6 +186,7 @@ def test_bench_without_rccl_falls_back_and_says_so(emu):
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["scaling"] == "weak" and rec["n_gpus"] == 2 and "RCCL did NOT initialise" in rec["config"]["parallelism"] and "rccl_ranks" not in rec["config"]
+    assert rec["config"]["preflight"]["ok"] and rec["config"]["preflight"]["transport"] == "loop-back" and rec["config"]["parity"]["ok"]
     assert "falling back" in p.stderr
 
 
