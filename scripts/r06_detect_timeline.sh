@@ -1,12 +1,12 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
-for v in early noearly; do
+for v in noearly; do
   if [ $v = noearly ]; then export S3D_NO_EARLY_EXTREMA=1; else unset S3D_NO_EARLY_EXTREMA; fi
   SIFT3D_AMD_LIB=$R/sift3d_amd/lib/libsift3d_amd_testing.so REPS=3 timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/tl_$v -o t -- python $R/scripts/detect_one.py > $R/gpurun_out/tl_$v.log 2>&1
   f=$(find $R/gpurun_out/tl_$v -name "*.db" | head -1)
   python $R/scripts/trace_timeline.py $f k_absmax > $R/gpurun_out/r06_detect_timeline_$v.md
   rm -rf $R/gpurun_out/tl_$v
 done
-grep -v "k_gauss3\|dyadic\|k_cb_\|fillBuffer\|k_decimate\|k_gauss_xy\|k_gauss_z" $R/gpurun_out/r06_detect_timeline_early.md | cut -c1-120 | tail -45
+
 echo ======
-grep -v "k_gauss3\|dyadic\|k_cb_\|fillBuffer\|k_decimate\|k_gauss_xy\|k_gauss_z" $R/gpurun_out/r06_detect_timeline_noearly.md | cut -c1-120 | tail -30
+
