@@ -647,7 +647,7 @@ def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
     import torch
     from sift3d_amd import slab as S
     L = sift3d_amd.cdll()
-    XX
+    os.environ.setdefault("SIFT3D_SLAB_TIMEOUT_S", "60")       # a rank waits this long for a dead peer's halo (and for RCCL's first connection set-up) before it fails too
     same_gpu = bool(os.environ.get("S3D_BENCH_SAME_GPU"))
     on_gpu = torch.cuda.is_available()                          # False: the CPU tests (emulator build of the library, gloo only)
     gloo_dev = f"cuda:{local_rank}" if on_gpu else None
