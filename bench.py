@@ -815,11 +815,15 @@ def run_loopback(args, dev):
         tr[r].destroy(tr[r].self)
     elapsed, cfg = slab_summary(per_rank, dims, args.steps, R, "in-process loop-back, all ranks on one GPU")
     cfg["workload"] = f"one {dims[0]}x{dims[1]}x{dims[2]} volume in {R} Z-slabs on ONE GPU (diagnostic, not a scaling number)"
+    cfg["parity"] = parity_block(L, dev, dims, per_rank)          # the R ranks' gathered list against one GPU's, as for --gpus N
     nvox = float(dims[0]) * dims[1] * dims[2]
     print(json.dumps({"metric": METRIC, "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvox/s", "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                       "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic", "config": cfg}), flush=True)
+    if not cfg["parity"]["ok"]:
+        log(f"bench.py: PARITY FAILURE: the {R}-rank keypoint list differs from the single-GPU one: {cfg['parity']}")
+        raise SystemExit(4)
 
 
 def add_roofline(result, dev, n):
