@@ -96,6 +96,14 @@ def test_bench_n_gpu_line_validates_itself(emu):
     assert "transport_fallback" not in cfg and cfg["rccl_ranks"] == 2
 
 
+def test_bench_loopback_diagnostic_carries_parity(emu):
+    """`bench.py --loopback R` (R ranks sharing one device: the decomposition's overhead, not scaling) validates its list too."""
+    p = _bench(["--loopback", "2", "--strong-size", "64"], {})
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = _line(p)
+    assert rec["n_gpus"] == 1 and rec["config"]["parity"]["ok"] and rec["config"]["parity"]["keypoints"] == rec["config"]["keypoints"] > 0
+
+
 def test_bench_parity_mismatch_is_an_error(emu, tmp_path):
     """A committed single-GPU result that the run does not reproduce (S3D_BENCH_PARITY_GOLDEN points at a file with a wrong
     hash): the line is printed with parity.ok false and the exit status is 4."""
