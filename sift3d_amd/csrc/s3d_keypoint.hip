@@ -1215,6 +1215,11 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
     /* closed-form x-interval of row (y, z) in voxels, widened by 1e-3 (float error at 2048^3 is 2e-4) */
     const float slab_hi = 4.0f / g.binf - g.half;
     const float a0 = g.r00 * g.uxf, a1 = g.r10 * g.uxf, a2 = g.r20 * g.uxf;
+    /* reciprocals once per keypoint: the closed form below is an ESTIMATE (widened by 1e-3 voxels, then settled by the exact tests),
+     * so a product with a rounded reciprocal (1e-7 relative) serves where a division per row and constraint stood (six of them
+     * were ~60 of a row's ~230 instructions) */
+    const float ia0 = fabsf(a0) > 1e-6f ? 1.0f / a0 : 0.0f, ia1 = fabsf(a1) > 1e-6f ? 1.0f / a1 : 0.0f,
+                ia2 = fabsf(a2) > 1e-6f ? 1.0f / a2 : 0.0f;
     const float inv_wy = 1.0f / (float)(wy > 0 ? wy : 1);
     /* A1: the accepted interval [lo, hi] of bounding-box row r = by + wy * bz; false: none */
     auto row_span = [&](int r, int *plo, int *phi, int *pby, int *pbz) -> bool {
@@ -1223,14 +1228,14 @@ k_describe_wg(s3d_pyramid_desc pyr, const s3d_desc_key *__restrict__ keys, uint3
         const int y = g.ys + by, z = g.zs + bz;
         const float dy = ((float)y - g.cy) * g.uyf, dz = ((float)z - g.cz) * g.uzf;
         const float s2 = g.rad2 - dy * dy - dz * dz;
-        const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) / g.uxf;
+        const float chord = sqrtf(s2 > 0.0f ? s2 : 0.0f) * iux;
         float lo_f = s2 < -1e-3f * g.rad2 ? 1.0f : -chord, hi_f = s2 < -1e-3f * g.rad2 ? -1.0f : chord;
         const float c0 = g.r01 * dy + g.r02 * dz, c1 = g.r11 * dy + g.r12 * dz, c2 = g.r21 * dy + g.r22 * dz;
-        const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2};
+        const float av[3] = {a0, a1, a2}, cv[3] = {c0, c1, c2}, iv[3] = {ia0, ia1, ia2};
 #pragma unroll
         for (int i = 0; i < 3; i++)
             if (fabsf(av[i]) > 1e-6f) {                      /* else: left to the exact tests below */
-                const float t0 = (-g.half - cv[i]) / av[i], t1 = (slab_hi - cv[i]) / av[i];
+                const float t0 = (-g.half - cv[i]) * iv[i], t1 = (slab_hi - cv[i]) * iv[i];
                 lo_f = fmaxf(lo_f, fminf(t0, t1));
                 hi_f = fminf(hi_f, fmaxf(t0, t1));
             }
