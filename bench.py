@@ -630,8 +630,11 @@ class StoreSync:
                 f = self.failure()
                 if f is not None:
                     raise StoreSync.PeerFailure(f)
-            if time.perf_counter() - t0 > timeout_s:
+            waited = time.perf_counter() - t0
+            if waited > timeout_s:
                 raise StoreSync.PeerFailure(f"barrier {key}: a rank did not arrive within {timeout_s:.0f} s")
+            if waited > 0.005:
+                time.sleep(0.0002)                   # (a long wait -- peers still synthesising -- need not hammer the store)
 
 
 def run_slab(args, dist, dev, rank, local_rank, world, full_sync):
