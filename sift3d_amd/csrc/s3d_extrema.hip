@@ -122,13 +122,16 @@ static bool div_magic(unsigned d, unsigned long long *m, unsigned *s)
  * reciprocals and the eight comparisons per voxel v_max3 / v_min3 forms (VALU was half busy; nothing measurable).  A
  * software-pipelined loop over four tiles per workgroup (loads of tile t + 1 in flight through the dependent gathers of
  * tile t) was built and was slower than one tile per workgroup at 8 waves per SIMD (0.84 vs 0.74). */
+#ifndef EXF_BLOCK
+#define EXF_BLOCK 256                  /* threads per workgroup of k_extrema_fused (64: one wave; measured, see profiles/r06_extrema_block.txt) */
+#endif
 template <int NKP, bool RUNMAX, bool RAGGED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(EXF_BLOCK)
 k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
                 const float *__restrict__ d_dogmax /* [NKP], per keypoint level */, unsigned *__restrict__ d_runmax)
 {
     /* voxels idx0 + 4*g .. +3 ; a wave covers 256 consecutive voxels = 4 bitmap words */
-    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    const unsigned g = blockIdx.x * (unsigned)EXF_BLOCK + threadIdx.x;
     const unsigned idx = idx0 + 4u * g;
     const int lane = threadIdx.x & 63;
     const unsigned plane = nx * ny;
@@ -259,7 +262,7 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
         }
     }
     if (RUNMAX) {                                          /* fold this workgroup's maxima into the running ones */
-        __shared__ float wmax[NKP][4];
+        __shared__ float wmax[NKP][EXF_BLOCK / 64];
 #pragma unroll
         for (int s = 0; s < NKP; s++) {
             float m = fmaxf(fmaxf(fabsf(d[s + 1][0]), fabsf(d[s + 1][1])), fmaxf(fabsf(d[s + 1][2]), fabsf(d[s + 1][3])));
@@ -272,7 +275,9 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
         __syncthreads();
         if (threadIdx.x < NKP) {
             const int s = threadIdx.x;
-            const float m = fmaxf(fmaxf(wmax[s][0], wmax[s][1]), fmaxf(wmax[s][2], wmax[s][3]));
+            float m = wmax[s][0];
+#pragma unroll
+            for (int w = 1; w < EXF_BLOCK / 64; w++) m = fmaxf(m, wmax[s][w]);
             if (m > seen[s]) atomicMax(&d_runmax[s], __float_as_uint(m));     /* rare once the bound has settled */
         }
     }
@@ -342,9 +347,9 @@ static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, i
     bool ragged = (nx & 3) != 0;
     for (int k = 0; k < 6; k++) ragged = ragged || (((uintptr_t)d_levels[k]) & 15) != 0;
     if (plane * (size_t)(z1 - z0) < 4) return 1;
-    const dim3 grid(s3d_div_up(s3d_div_up(plane * (size_t)(z1 - z0), 4), 256));
+    const dim3 grid(s3d_div_up(s3d_div_up(plane * (size_t)(z1 - z0), 4), EXF_BLOCK));
     const unsigned i0 = (unsigned)(plane * z0), i1 = (unsigned)(plane * z1);
-#define S3D_EXF(RM, RG, DM, RX) hipLaunchKernelGGL((k_extrema_fused<3, RM, RG>), grid, dim3(256), 0, (hipStream_t)st, a, (unsigned)nx, \
+#define S3D_EXF(RM, RG, DM, RX) hipLaunchKernelGGL((k_extrema_fused<3, RM, RG>), grid, dim3(EXF_BLOCK), 0, (hipStream_t)st, a, (unsigned)nx, \
                                                    (unsigned)ny, (unsigned)nz, i0, i1, peak_thresh, DM, RX)
     if (d_runmax) {
         if (ragged) S3D_EXF(true, true, (const float *)nullptr, d_runmax);
