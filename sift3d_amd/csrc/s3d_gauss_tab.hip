@@ -32,6 +32,12 @@
 #ifndef TAB_MW
 #define TAB_MW 4                          /* waves of a marching workgroup (they share a ring) */
 #endif
+#ifndef TAB_X_PAIRS
+#define TAB_X_PAIRS 1                     /* the x pass on pairs of rows (k_conv_x_tab2); 0: k_conv_x_tab */
+#endif
+#ifndef TAB_X_PAIRS_MAX_HW
+#define TAB_X_PAIRS_MAX_HW 5              /* ... for filters of up to 2 * 5 + 1 taps */
+#endif
 #define TAB_MAX_UHW ((62 - 2 - 2 * TAB_MW) / 2)   /* ring of 2*uhw+2+2*TAB_MW <= 62 rows (62 KB of LDS), x segment of 64+2*uhw+3 <= 128 floats: 26 */
 
 /* ---- the table -------------------------------------------------------------------------------------------------
@@ -440,6 +446,112 @@ k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, siz
     else march(S3dFalse());
 }
 
+/* The x pass on PAIRS of rows.  The taps of a lane -- (lo, frac) of its x -- are the same in every row, so a lane that works on
+ * rows r and r + 1 at once does each tap's five operations as packed ones on {row r, row r + 1} (v_pk_mul_f32 / v_pk_add_f32:
+ * element-wise, each element rounded like the scalar operation -- the same bits): half the VALU instructions per voxel of
+ * k_conv_x_tab, which that kernel's time was (5 per tap and 64 voxels: 140-167 us per 512 x 512 x 300 pass at widths 7-11,
+ * against the 100 us of its 8 B/voxel).  The staged line holds the two rows interleaved, {r[i], r'[i]} per entry, again twice --
+ * the second copy one entry to the left -- so that the four floats of a tap, {r[lo], r'[lo], r[lo + 1], r'[lo + 1]}, are one
+ * 16-byte aligned ds_read_b128 whatever the parity of lo.  An odd last row of a wave is its own second row (loaded and stored
+ * twice: no branch around a load or a store). */
+#define XT2_LINE 144                      /* entries (8 B) per staged copy: > 126, and 2 * XT2_LINE = 32 (mod 64) dwords */
+template <int HW, int D>
+__global__ void __launch_bounds__(64)
+k_conv_x_tab2(const float *__restrict__ src, float *__restrict__ dst, int nx, size_t row_begin, size_t row_end,
+              unsigned rows_per_wave, unsigned nstrips, int uhw, const int *__restrict__ xlo, const int *__restrict__ xfr,
+              S3dTaps taps, int literal)
+{
+    constexpr int NT = 2 * HW + 1;
+    __shared__ __attribute__((aligned(16))) float2 line[2 * XT2_LINE];   /* [0, XT2_LINE): seg[i] ; [XT2_LINE, ..): seg[i + 1] */
+    const int lane = threadIdx.x;
+    const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;              /* see k_conv_x_tab */
+    const unsigned chunk_id = xcd + 8u * (j / nstrips);
+    const int xs = (int)(j % nstrips) * 64;
+    const int x = xs + lane;
+    const int xc = x < nx ? x : nx - 1;
+    const int g0 = xs - uhw - 1;                           /* source index of segment slot 0 */
+    int addr[NT];
+    float fr[NT], om[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int i = xlo[(size_t)k * nx + xc] - g0;       /* 0 <= i, i + 1 < L (k_tap_table checked it) */
+        addr[k] = (i & 1) ? (XT2_LINE + i - 1) * 8 : i * 8;
+        fr[k] = __int_as_float(xfr[(size_t)k * nx + xc]);
+        om[k] = 1.0f - fr[k];
+    }
+    bool zero = true;
+#pragma unroll
+    for (int k = 0; k < NT; k++) zero = zero && fr[k] == 0.0f;
+    const bool allzero = !literal && __ballot(zero ? 0 : 1) == 0ull;   /* wave uniform */
+    auto clampx = [&](int i) { return i < 0 ? 0 : (i > nx - 1 ? nx - 1 : i); };
+    const int i0 = clampx(g0 + lane), i1 = clampx(g0 + 64 + lane);
+    const int slot1 = lane >= 1 ? XT2_LINE + lane - 1 : 2 * XT2_LINE - 1;
+    const size_t r0 = row_begin + (size_t)chunk_id * rows_per_wave;
+    const size_t r1 = r0 + rows_per_wave < row_end ? r0 + rows_per_wave : row_end;
+    if (r0 >= r1) return;
+    struct Raw { float a0, a1, b0, b1; };                  /* row r: slots lane, 64 + lane; row r + 1: the same */
+    const float *pld = src + r0 * (size_t)nx;
+    size_t rld = r0;
+    auto load_pair = [&]() -> Raw {                        /* pairs past the wave's last row stay on it (see k_conv_x_tab) */
+        Raw q;
+        const float *p2 = rld + 1 < r1 ? pld + nx : pld;
+        q.a0 = pld[i0];
+        q.a1 = pld[i1];
+        q.b0 = p2[i0];
+        q.b1 = p2[i1];
+        if (rld + 2 < r1) pld += 2 * (size_t)nx;
+        rld += 2;
+        return q;
+    };
+    Raw q[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) q[d] = load_pair();
+    const char *lineb = reinterpret_cast<const char *>(line);
+    float *pst = dst + r0 * (size_t)nx + xc;               /* lanes past the row end repeat the last voxel's store */
+    auto march = [&](auto ZERO) {
+        auto step = [&](Raw &qu, bool two) {
+            const float2 v0 = make_float2(qu.a0, qu.b0), v1 = make_float2(qu.a1, qu.b1);
+            line[lane] = v0;
+            line[slot1] = v0;
+            line[64 + lane] = v1;
+            line[XT2_LINE + 63 + lane] = v1;
+            qu = load_pair();
+            s3d_wave_lds_sync();
+            s3d_f2 acc = {0.0f, 0.0f};
+            if (decltype(ZERO)::value) {
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    const float2 a = *reinterpret_cast<const float2 *>(lineb + addr[k]);
+                    const s3d_f2 a2 = {a.x, a.y};
+                    acc = acc + taps.t[k] * a2;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    const float4 ab = *reinterpret_cast<const float4 *>(lineb + addr[k]);
+                    const s3d_f2 a2 = {ab.x, ab.y}, b2 = {ab.z, ab.w};
+                    acc = acc + taps.t[k] * (om[k] * a2 + fr[k] * b2);
+                }
+            }
+            s3d_wave_lds_sync();                           /* the next pair's staging must not overtake these reads */
+            float *pst2 = two ? pst + nx : pst;            /* a lone last row: the same value to the same place twice */
+            *pst = acc[0];
+            *pst2 = acc[1];
+            pst += 2 * (size_t)nx;
+        };
+        size_t r = r0;
+        for (; r + 2 * D <= r1; r += 2 * D) {
+#pragma unroll
+            for (int u = 0; u < D; u++) step(q[u], true);
+        }
+#pragma unroll
+        for (int u = 0; u < D; u++)
+            if (r + 2 * u < r1) step(q[u], r + 2 * u + 1 < r1);
+    };
+    if (allzero) march(S3dTrue());
+    else march(S3dFalse());
+}
+
 /* ---- dispatch ------------------------------------------------------------------------------------------------------ */
 static thread_local int g_chunk_tab = 128;                 /* outputs per marching chunk (target) */
 static thread_local long g_tab_launches = 0;
@@ -473,12 +585,19 @@ static int launch_tab(const TapTab *t, const float *src, float *dst, int nx, int
         const size_t nchunks = ((size_t)s3d_div_up(nrows, rpw) + 7) & ~(size_t)7;
         if (nchunks * strips > 0x7fffffffull) return 1;
         const dim3 grid((unsigned)(nchunks * strips));
-        if (d_div)
+        /* pairs of rows up to 11 taps; wider filters keep the row kernel (the pair kernel holds 4 more registers per tap: two
+         * waves per SIMD at 13+ taps, and was the slower one there -- profiles/r06_xtab_pairs.txt), and so does the pyramid's
+         * first filter (DIV: the divisions are its time, 142 against 146 us) */
+        constexpr bool PAIRS = TAB_X_PAIRS && HW <= TAB_X_PAIRS_MAX_HW;
+        if (PAIRS && !d_div)
+            hipLaunchKernelGGL((k_conv_x_tab2<PAIRS ? HW : 1, D>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
+                               t->d_xlo, t->d_xfr, taps, literal);
+        else if (d_div)
             hipLaunchKernelGGL((k_conv_x_tab<HW, D, true>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
                                t->d_xlo, t->d_xfr, taps, d_div, literal);
         else
-            hipLaunchKernelGGL((k_conv_x_tab<HW, D, false>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips, t->uhw,
-                               t->d_xlo, t->d_xfr, taps, (const float *)nullptr, literal);
+            hipLaunchKernelGGL((k_conv_x_tab<PAIRS ? 1 : HW, D, false>), grid, dim3(64), 0, st, src, dst, nx, rb, re, rpw, strips,
+                               t->uhw, t->d_xlo, t->d_xfr, taps, (const float *)nullptr, literal);
         S3D_CHECK_LAUNCH();
         return S3D_OK;
     }

@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The unmodified reference (oracle/_ref) reaches LAPACK through the OpenBLAS that scipy bundles.  On the many-core GPU boxes that
+# library's thread pool reported "BLAS : Bad memory unallocation!" during the registration tests and once took the interpreter
+# down at exit, after every test had passed.  The checker needs no BLAS threads (set before the library is first loaded).
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
