@@ -236,6 +236,15 @@ int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const u
                      const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
                      float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, uint32_t *d_fail,
                      s3d_stream stream);
+/* The two halves of s3d_k_orient_tab for callers that overlap them with other work: the tables depend on the pyramid's geometry
+ * (dims, units) and the levels' sigmas only, not on the voxels, so SIFT3D_detect_keypoints builds them on its extrema stream
+ * while the pyramid is being filtered (a wave per level for ~0.2 ms: off the critical path), and the window sums then run with
+ * tables that are already there.  The build must be complete, or ordered before `stream`, when s3d_k_orient_tab_built runs. */
+int s3d_k_orient_tab_build(const s3d_pyramid_desc *pyr, const double *d_sigma, void *d_tabs, s3d_stream stream);
+int s3d_k_orient_tab_built(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                           const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                           float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, uint32_t *d_fail,
+                           s3d_stream stream);
 /* Test / profiling knob of the calling thread: how s3d_k_orient_tab uses the tables -- 0 not at all, 1 one kernel that
  * replays or enumerates per candidate, 2 a table-walk kernel plus the general kernel for the candidates it flags; anything
  * else restores the default (S3D_ORI_MODE, else 0: measured at 512^3, the tables do not pay -- profiles/r03_orient_experiments.txt). */

@@ -87,6 +87,7 @@ typedef struct {
     float *d_R, *d_Rk;
     void *d_orient;         /* s3d_k_orient scratch for cand_cap candidates */
     void *d_oritab;         /* the levels' window tables (s3d_k_orient_tab), s3d_k_orient_tab_bytes of the last pyramid */
+    int oritab_built;       /* build_gpyr_dev has enqueued their build for the current pyramid on ext_stream (with the sigmas) */
     size_t oritab_bytes;
     int32_t *d_xyzos;
     double *d_sigma;
@@ -514,6 +515,17 @@ static void fill_pyr_desc(const Pyramid *g, float *const *levels, s3d_pyramid_de
     }
 }
 
+/* device memory for the orientation window tables of this pyramid */
+static int ensure_oritab(s3d_ctx *c, const s3d_pyramid_desc *pd)
+{
+    if (c->oritab_bytes >= s3d_k_orient_tab_bytes(pd)) return SIFT3D_SUCCESS;
+    dfree(&c->d_oritab);
+    c->oritab_bytes = 0;
+    DEV(s3d_rt_malloc(&c->d_oritab, s3d_k_orient_tab_bytes(pd)));
+    c->oritab_bytes = s3d_k_orient_tab_bytes(pd);
+    return SIFT3D_SUCCESS;
+}
+
 /* tap spacing per axis: unit / units[axis] as float (imutil.c:2286-2287), unit = -1 -> the image's own */
 static void unit_factors(const double units[3], double unit, float uf[3])
 {
@@ -681,6 +693,21 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
         es = c->ext_stream;
         DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), es));
     }
+    c->oritab_built = 0;
+    if (es) {
+        /* The orientation window tables (levels whose units are not one power of two) are a property of the pyramid's geometry,
+         * not of its voxels: a wave per level for ~0.2 ms, which used to sit between the extrema pass and the window sums.  Here
+         * they are built beside the first filters; detect_dev waits for this stream before it reads the candidate count. */
+        s3d_pyramid_desc pd;
+        fill_pyr_desc(g, c->d_level, &pd);
+        if (s3d_k_orient_wants_tab(&pd)) {
+            if (ensure_oritab(c, &pd)) return SIFT3D_FAILURE;
+            for (int i = 0; i < g->num_octaves * L; i++) c->h_sigma[i] = ori_sig_fctr * g->levels[i].s;
+            DEV(s3d_rt_h2d(c->d_sigma, c->h_sigma, sizeof(double) * (size_t)g->num_octaves * L, es));
+            DEV(s3d_k_orient_tab_build(&pd, c->d_sigma, c->d_oritab, es));
+            c->oritab_built = 1;
+        }
+    }
     unit_factors(units, 1.0, uf);
     if (c->in_src == NULL) API_FAIL("sift3d_amd: no input volume");
     if (!c->verbatim && s3d_k_sep_fir_div_eligible(l0->nx, l0->ny, l0->nz, uf, gss->first_gauss.f.width)) {
@@ -789,18 +816,20 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
 
     fill_pyr_desc(g, c->d_level, &pd);
     {
-        double *const sig = c->h_sigma;                   /* lives in the context: the copy below is asynchronous */
-        for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
-        DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
-        if (s3d_k_orient_wants_tab(&pd) && c->oritab_bytes < s3d_k_orient_tab_bytes(&pd)) {
-            dfree(&c->d_oritab);
-            c->oritab_bytes = 0;
-            DEV(s3d_rt_malloc(&c->d_oritab, s3d_k_orient_tab_bytes(&pd)));
-            c->oritab_bytes = s3d_k_orient_tab_bytes(&pd);
+        if (c->oritab_built && s3d_k_orient_wants_tab(&pd)) {
+            /* tables and sigmas went out on the extrema stream beside the pyramid (build_gpyr_dev); that stream has been waited
+             * for above */
+            DEV(s3d_k_orient_tab_built(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
+                                       c->d_R, c->d_keep, NULL, c->d_orient, c->d_oritab, c->d_count + 2, c->stream));
+        } else {
+            double *const sig = c->h_sigma;               /* lives in the context: the copy below is asynchronous */
+            for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
+            DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
+            if (s3d_k_orient_wants_tab(&pd) && ensure_oritab(c, &pd)) return SIFT3D_FAILURE;
+            DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
+                                 c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_wants_tab(&pd) ? c->d_oritab : NULL,
+                                 c->d_count + 2, c->stream));
         }
-        DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
-                             c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_wants_tab(&pd) ? c->d_oritab : NULL,
-                             c->d_count + 2, c->stream));
         DEV(s3d_k_compact_keys(&pd, c->d_cand_idx, c->d_cand_tag, c->d_R, c->d_keep, counts[0], c->d_xyzos,
                                c->d_Rk, c->d_count + 1, c->d_kscratch, c->stream));
         DEV(s3d_rt_d2h(counts + 1, c->d_count + 1, 2 * sizeof(uint32_t), c->stream));

@@ -705,10 +705,22 @@ extern "C" size_t s3d_k_orient_tab_bytes(const s3d_pyramid_desc *pyr)
     return sizeof(s3d_ori_tab) * (size_t)pyr->num_octaves * (size_t)pyr->num_levels;
 }
 
-extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
-                                const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
-                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, uint32_t *d_fail,
-                                s3d_stream st)
+/* the levels' window tables: a wave per level (PHASE 0); they depend on the pyramid's geometry and the levels' sigmas only --
+ * not on the voxels -- so a caller may build them on another stream while the pyramid is still being filtered */
+extern "C" int s3d_k_orient_tab_build(const s3d_pyramid_desc *pyr, const double *d_sigma, void *d_tabs, s3d_stream st)
+{
+    if (!d_tabs || !d_sigma) return S3D_ERR;
+    const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
+    hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, nlev, d_sigma, 0.0, (double *)nullptr,
+                       (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (s3d_ori_tab *)d_tabs);
+    S3D_CHECK_LAUNCH();
+    return S3D_OK;
+}
+
+static int orient_run(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag, const float *d_center,
+                      uint32_t num, const double *d_sigma, double corner_thresh, float *d_R, uint32_t *d_keep, double *d_conf,
+                      void *d_scratch, void *d_tabs, bool build, uint32_t *d_fail, s3d_stream st)
 {
     if (num == 0) return S3D_OK;
     if (!d_scratch) return S3D_ERR;
@@ -728,13 +740,7 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
      * of 0.7 x 0.7 x 1.5. */
     if (mode == 0 && tabs && s3d_k_orient_wants_tab(pyr)) mode = 1;
     if (mode == 0) tabs = nullptr;
-    if (tabs) {
-        const uint32_t nlev = (uint32_t)(pyr->num_octaves * pyr->num_levels);
-        hipLaunchKernelGGL((k_orient_wave<0>), dim3(nlev), dim3(64), 0, (hipStream_t)st, *pyr, (const uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, (const float *)nullptr, 0u, nlev, nlev, d_sigma, corner_thresh,
-                           (double *)nullptr, (float *)nullptr, (uint32_t *)nullptr, (double *)nullptr, tabs);
-        S3D_CHECK_LAUNCH();
-    }
+    if (tabs && build && s3d_k_orient_tab_build(pyr, d_sigma, tabs, st) != S3D_OK) return S3D_ERR;
     const uint32_t chunk = g_orient_chunk;
     for (uint32_t c0 = 0; c0 < num; c0 += chunk) {
         const uint32_t n = num - c0 < chunk ? num - c0 : chunk;
@@ -759,6 +765,24 @@ extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_i
         S3D_CHECK_LAUNCH();
     }
     return S3D_OK;
+}
+
+extern "C" int s3d_k_orient_tab(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                                const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                                float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs, uint32_t *d_fail,
+                                s3d_stream st)
+{
+    return orient_run(pyr, d_idx, d_tag, d_center, num, d_sigma, corner_thresh, d_R, d_keep, d_conf, d_scratch, d_tabs, true, d_fail, st);
+}
+
+/* s3d_k_orient_tab with tables that s3d_k_orient_tab_build has filled already (for this pyramid and these sigmas; the build
+ * must have completed, or be ordered before `st`) */
+extern "C" int s3d_k_orient_tab_built(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,
+                                      const float *d_center, uint32_t num, const double *d_sigma, double corner_thresh,
+                                      float *d_R, uint32_t *d_keep, double *d_conf, void *d_scratch, void *d_tabs,
+                                      uint32_t *d_fail, s3d_stream st)
+{
+    return orient_run(pyr, d_idx, d_tag, d_center, num, d_sigma, corner_thresh, d_R, d_keep, d_conf, d_scratch, d_tabs, false, d_fail, st);
 }
 
 extern "C" int s3d_k_orient(const s3d_pyramid_desc *pyr, const uint32_t *d_idx, const uint32_t *d_tag,

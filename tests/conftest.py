@@ -9,9 +9,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The unmodified reference (oracle/_ref) reaches LAPACK through the OpenBLAS that scipy bundles.  On the many-core GPU boxes that
-# library's thread pool reported "BLAS : Bad memory unallocation!" during the registration tests and once took the interpreter
-# down at exit, after every test had passed.  The checker needs no BLAS threads (set before the library is first loaded).
+# The unmodified reference (oracle/_ref) is an OpenMP program that calls LAPACK (the OpenBLAS scipy bundles) from inside its
+# parallel loops -- eigen_Mat_rm per keypoint candidate.  That OpenBLAS keeps a fixed table of 128 buffers: on the GPU boxes, with
+# a few hundred host threads, the reference overflowed it ("BLAS : Bad memory unallocation!", and once "Program is Terminated.
+# Because you tried to allocate too many memory regions" -- after every test had passed).  The checkers run on at most 32 OpenMP
+# threads with a single-threaded BLAS under them (set before either library is loaded; bench.py's cpu_baseline is not a test and
+# keeps all cores).
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 32)))
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
 
