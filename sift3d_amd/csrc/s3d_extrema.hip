@@ -278,7 +278,13 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
             float m = wmax[s][0];
 #pragma unroll
             for (int w = 1; w < EXF_BLOCK / 64; w++) m = fmaxf(m, wmax[s][w]);
-            if (m > seen[s]) atomicMax(&d_runmax[s], __float_as_uint(m));     /* rare once the bound has settled */
+            /* rare once the bound has settled -- and rarer with a fresh look at the bound: the snapshot `seen` is as old as the
+             * workgroup, and while the bound rises many workgroups hold a value above their snapshot that some other workgroup
+             * has sent already (the atomics of one address are served one after the other: 157 -> 140 us per dispatch,
+             * profiles/r06_extrema_atomics.txt).  Skipped only when the running word already is >= m: its final value -- the
+             * level's exact maximum -- is the same. */
+            if (m > seen[s] && m > __uint_as_float(__atomic_load_n(&d_runmax[s], __ATOMIC_RELAXED)))
+                atomicMax(&d_runmax[s], __float_as_uint(m));
         }
     }
     /* lanes 16w .. 16w+15 hold the 16 nibbles of word w: OR them together inside each 16-lane row */
