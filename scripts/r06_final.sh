@@ -14,8 +14,10 @@ tail -n 2 gpurun_out/r06_fuzz.log
 ( timeout 300 python scripts/fuzz_parity.py ${FUZZ_S:-100} ${FUZZ_SEED:-72} nonfinite > gpurun_out/r06_fuzz_nonfinite.log 2>&1; echo "fuzz exit $?" >> gpurun_out/r06_fuzz_nonfinite.log )
 tail -n 2 gpurun_out/r06_fuzz_nonfinite.log
 fi
+if [ -z "$SKIP_PMC" ]; then      # (profiles/pmc_gauss.json is keyed on the kernels' machine code: only s3d_gauss.hip edits need a new one)
 COMMIT=${COMMIT:-unknown} bash scripts/pmc_hbm.sh r06 > gpurun_out/r06_pmc.log 2>&1
 cp gpurun_out/r06_pmc_gauss.json profiles/pmc_gauss.json 2>/dev/null        # (this copy of the repo only: bench.py below reads it)
+fi
 ( timeout 900 python bench.py --steps 20 --warmup 2 > gpurun_out/r06_final_bench.json 2> gpurun_out/r06_final_bench.err; echo "bench exit $?" >> gpurun_out/r06_final_bench.err )
 python - <<'PY'
 import json
