@@ -15,7 +15,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # Because you tried to allocate too many memory regions" -- after every test had passed).  The checkers run on at most 32 OpenMP
 # threads with a single-threaded BLAS under them (set before either library is loaded; bench.py's cpu_baseline is not a test and
 # keeps all cores).
-os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 32)))
+if (os.cpu_count() or 1) > 32:                            # (left unset on small hosts: torchrun then gives its workers one thread each)
+    os.environ.setdefault("OMP_NUM_THREADS", "32")
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
 
