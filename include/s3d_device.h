@@ -70,6 +70,9 @@ int s3d_k_absmax(const float *d_v, size_t n, float *d_max, s3d_stream stream);
  * call until it has run.  s3d_k_seqmax_parts leaves there { sticky max bits, max bits behind the last NaN, index + 1 of the
  * last NaN as 64 bits (0: none) } for callers that combine several index ranges (the Z-slab ranks). */
 int s3d_k_seqmax(const float *d_a, const float *d_b, size_t n, float *d_max, void *d_rec16, s3d_stream stream);
+/* The same for the three DoG levels between four consecutive GSS levels, d_max3[s] = s3d_k_seqmax(d_levels[s], d_levels[s + 1]):
+ * the sticky maxima and last NaNs of all three from one pass over the four levels.  d_rec48: 48 bytes, 8-byte aligned. */
+int s3d_k_seqmax3(const float *const *d_levels, size_t n, float *d_max3, void *d_rec48, s3d_stream stream);
 int s3d_k_seqmax_parts(const float *d_a, const float *d_b, size_t n, void *d_rec16, s3d_stream stream);
 /* v[i] = v[i] / *d_max unless *d_max == 0   (im_scale, imutil/imutil.c:1977-1991; true division) */
 int s3d_k_scale_div(float *d_v, size_t n, const float *d_max, s3d_stream stream);
@@ -165,6 +168,12 @@ int s3d_k_extrema_slab(const float *d_l0, const float *d_l1, const float *d_l2, 
 int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
                         double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
                         s3d_stream stream);
+/* The same with every neighbour test written as its own comparison (no maximum / minimum of neighbours in between): the bitmaps
+ * of s3d_k_extrema_slab per level bit for bit also on levels that hold NaNs or infinities (a comparison with a NaN is false; the
+ * maximum of the other neighbours would still be compared).  The verbatim pass of volumes with non-finite voxels. */
+int s3d_k_extrema_fused_literal(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
+                                s3d_stream stream);
 /* The same without the DoG maxima being known beforehand, as two calls (a Z-slab rank all-reduces d_dogmax in between):
  * s3d_k_extrema_fused_runmax zeroes d_dogmax[0..nkp), finds a superset of the extrema of planes [z0, z1) under a running
  * lower bound of the maxima and leaves the exact maxima of those planes in d_dogmax; s3d_k_extrema_refilter applies the

@@ -136,7 +136,7 @@ typedef struct {
 #define RED_DOGMAX 1        /* 3 words: the DoG maxima of the octave in flight */
 #define RED_RAWMAX 5        /* raw-image / dense entry points: max |smoothed voxel| (im_scale's divisor) */
 #define RED_PROBE 6         /* volume_nonfinite's sticky maximum */
-#define RED_REC 40          /* 4 words, 8-byte aligned: the record of s3d_k_seqmax */
+#define RED_REC 40          /* 12 words, 8-byte aligned: the record of s3d_k_seqmax / the three of s3d_k_seqmax3 */
 #define RED_INMAX 55        /* max |input voxel| */
 #define RED_COUNT 56        /* 8 words: c->d_count */
 #define S3D_REDO_VERBATIM 2 /* detect_dev: the input held a non-finite voxel, run the pass again on the literal kernels */
@@ -626,6 +626,14 @@ static int pyr_fir(s3d_ctx *c, s3d_stream st, float *tmp, const float *src, floa
     return rc;
 }
 
+/* diagnostics (TESTING builds): S3D_VERBATIM_PER_LEVEL=1 keeps the verbatim pass on the per-level extrema kernel */
+static int verbatim_per_level(void)
+{
+    static int v = -1;
+    if (v < 0) v = S3D_DIAG_ENV("S3D_VERBATIM_PER_LEVEL") != NULL;
+    return v;
+}
+
 /* detect_extrema (sift.c:1074-1212) for one octave: DoG maxima, extrema bitmaps, ordered compaction into the candidate
  * list -- enqueued on `es` */
 static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es)
@@ -650,6 +658,25 @@ static int extrema_octave(SIFT3D *const sift3d, s3d_ctx *c, int o, s3d_stream es
             DEV(s3d_k_extrema_refilter((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
                                        c->d_red + RED_DOGMAX, bits, es));
         if (fused == 0)                                 /* the nkp bitmaps in one count / scan / emit */
+            DEV(s3d_k_compact_bits_multi(bits[0], nwords, nkp, c->bits_words, 0u, c->d_cand_idx, c->d_cand_tag,
+                                         ((uint32_t)o << 8) | 1u, c->cand_cap, c->d_count, c->d_scratch, es));
+    }
+    if (nkp <= S3D_FUSED_KP_MAX && c->verbatim && !verbatim_per_level()) {
+        /* a volume with non-finite voxels: the levels' DoG maxima as the reference's sequential scans leave them (s3d_k_seqmax,
+         * one record after the other on this stream), then all keypoint levels in one pass with the neighbour tests in their
+         * literal form -- until round 6 a pass per level over four GSS levels each (1.7 of the verbatim pass's 10 ms at 512^3) */
+        unsigned long long *bits[S3D_FUSED_KP_MAX];
+        for (int ks = 1; ks <= nkp; ks++) bits[ks - 1] = c->d_bits + (size_t)(ks - 1) * c->bits_words;
+        if (nkp == 3) {
+            DEV(s3d_k_seqmax3((const float *const *)(lp + 1), n, c->d_red + RED_DOGMAX, c->d_red + RED_REC, es));
+        } else {
+            for (int ks = 1; ks <= nkp; ks++)
+                DEV(s3d_k_seqmax(lp[ks], lp[ks + 1], n, c->d_red + RED_DOGMAX + (ks - 1), c->d_red + RED_REC, es));
+        }
+        fused = s3d_k_extrema_fused_literal((const float *const *)lp, nkp, lv->nx, lv->ny, lv->nz, 0, lv->nz, sift3d->peak_thresh,
+                                            c->d_red + RED_DOGMAX, bits, es);
+        if (fused < 0) API_FAIL("sift3d_amd: extrema failed: %s", s3d_rt_last_error());
+        if (fused == 0)
             DEV(s3d_k_compact_bits_multi(bits[0], nwords, nkp, c->bits_words, 0u, c->d_cand_idx, c->d_cand_tag,
                                          ((uint32_t)o << 8) | 1u, c->cand_cap, c->d_count, c->d_scratch, es));
     }

@@ -125,7 +125,10 @@ static bool div_magic(unsigned d, unsigned long long *m, unsigned *s)
 #ifndef EXF_BLOCK
 #define EXF_BLOCK 256                  /* threads per workgroup of k_extrema_fused (64: one wave; measured, see profiles/r06_extrema_block.txt) */
 #endif
-template <int NKP, bool RUNMAX, bool RAGGED>
+/* LITERAL: the neighbour tests of phase 1 as the reference writes them, one comparison per neighbour (sift.c:1180-1195), instead
+ * of their v_max3 / v_min3 forms -- the same thing on finite values, but a comparison with a NaN neighbour is false where the
+ * maximum of the other neighbours would still be compared: the form for the levels of a volume with non-finite voxels. */
+template <int NKP, bool RUNMAX, bool RAGGED, bool LITERAL>
 __global__ void __launch_bounds__(EXF_BLOCK)
 k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned idx0, unsigned n, double peak,
                 const float *__restrict__ d_dogmax /* [NKP], per keypoint level */, unsigned *__restrict__ d_runmax)
@@ -236,9 +239,14 @@ k_extrema_fused(ExtArgs<NKP> a, unsigned nx, unsigned ny, unsigned nz, unsigned 
                 /* strictly above (below) every neighbour <=> above their maximum (below their minimum): the same
                  * comparisons on the same values, in v_max3 / v_min3 form */
                 const bool live = inner[j] && fabsf(v) > thr;
-                const float hi4 = fmaxf(fmaxf(fmaxf(pv, nv), xm), xp), lo4 = fminf(fminf(fminf(pv, nv), xm), xp);
-                if (live && v > hi4) pmax |= 1u << (4 * s + j);
-                if (live && v < lo4) pmin |= 1u << (4 * s + j);
+                if (LITERAL) {
+                    if (live && v > pv && v > xp && v > xm && v > nv) pmax |= 1u << (4 * s + j);
+                    if (live && v < pv && v < xp && v < xm && v < nv) pmin |= 1u << (4 * s + j);
+                } else {
+                    const float hi4 = fmaxf(fmaxf(fmaxf(pv, nv), xm), xp), lo4 = fminf(fminf(fminf(pv, nv), xm), xp);
+                    if (live && v > hi4) pmax |= 1u << (4 * s + j);
+                    if (live && v < lo4) pmin |= 1u << (4 * s + j);
+                }
             }
         }
     }
@@ -334,7 +342,7 @@ extern "C" void s3d_k_extrema_test_decline(int on) { g_ext_decline = on; }
 #endif
 
 static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
-                                double peak_thresh, const float *d_dogmax, unsigned *d_runmax,
+                                double peak_thresh, const float *d_dogmax, unsigned *d_runmax, bool literal,
                                 unsigned long long *const *d_bits, s3d_stream st)
 {
     const size_t n = (size_t)nx * ny * nz, plane = (size_t)nx * ny;
@@ -355,11 +363,18 @@ static int extrema_fused_launch(const float *const *d_levels, int nkp, int nx, i
     if (plane * (size_t)(z1 - z0) < 4) return 1;
     const dim3 grid(s3d_div_up(s3d_div_up(plane * (size_t)(z1 - z0), 4), EXF_BLOCK));
     const unsigned i0 = (unsigned)(plane * z0), i1 = (unsigned)(plane * z1);
-#define S3D_EXF(RM, RG, DM, RX) hipLaunchKernelGGL((k_extrema_fused<3, RM, RG>), grid, dim3(EXF_BLOCK), 0, (hipStream_t)st, a, (unsigned)nx, \
+#define S3D_EXF(RM, RG, DM, RX) hipLaunchKernelGGL((k_extrema_fused<3, RM, RG, false>), grid, dim3(EXF_BLOCK), 0, (hipStream_t)st, a, (unsigned)nx, \
                                                    (unsigned)ny, (unsigned)nz, i0, i1, peak_thresh, DM, RX)
     if (d_runmax) {
         if (ragged) S3D_EXF(true, true, (const float *)nullptr, d_runmax);
         else S3D_EXF(true, false, (const float *)nullptr, d_runmax);
+    } else if (literal) {
+        if (ragged)
+            hipLaunchKernelGGL((k_extrema_fused<3, false, true, true>), grid, dim3(EXF_BLOCK), 0, (hipStream_t)st, a, (unsigned)nx,
+                               (unsigned)ny, (unsigned)nz, i0, i1, peak_thresh, d_dogmax, (unsigned *)nullptr);
+        else
+            hipLaunchKernelGGL((k_extrema_fused<3, false, false, true>), grid, dim3(EXF_BLOCK), 0, (hipStream_t)st, a, (unsigned)nx,
+                               (unsigned)ny, (unsigned)nz, i0, i1, peak_thresh, d_dogmax, (unsigned *)nullptr);
     } else {
         if (ragged) S3D_EXF(false, true, d_dogmax, (unsigned *)nullptr);
         else S3D_EXF(false, false, d_dogmax, (unsigned *)nullptr);
@@ -373,7 +388,17 @@ extern "C" int s3d_k_extrema_fused(const float *const *d_levels, int nkp, int nx
                                    double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
                                    s3d_stream st)
 {
-    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, d_dogmax, nullptr, d_bits, st);
+    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, d_dogmax, nullptr, false, d_bits, st);
+}
+
+/* s3d_k_extrema_fused with every neighbour test as its own comparison (LITERAL above): the bitmaps of s3d_k_extrema_slab per
+ * level, bit for bit, also when levels hold NaNs or infinities -- what the verbatim pass of a volume with non-finite voxels
+ * needs (its DoG maxima come from s3d_k_seqmax). */
+extern "C" int s3d_k_extrema_fused_literal(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,
+                                           double peak_thresh, const float *d_dogmax, unsigned long long *const *d_bits,
+                                           s3d_stream st)
+{
+    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, d_dogmax, nullptr, true, d_bits, st);
 }
 
 /* The same without knowing the DoG maxima beforehand, in two calls (a Z-slab rank all-reduces d_dogmax in between):
@@ -387,7 +412,7 @@ extern "C" int s3d_k_extrema_fused_runmax(const float *const *d_levels, int nkp,
 {
     if (nkp != 3 || nx < 4) return 1;
     S3D_HIP(hipMemsetAsync(d_dogmax, 0, 3 * sizeof(float), (hipStream_t)st));
-    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, nullptr, (unsigned *)d_dogmax, d_bits, st);
+    return extrema_fused_launch(d_levels, nkp, nx, ny, nz, z0, z1, peak_thresh, nullptr, (unsigned *)d_dogmax, false, d_bits, st);
 }
 
 extern "C" int s3d_k_extrema_refilter(const float *const *d_levels, int nkp, int nx, int ny, int nz, int z0, int z1,

@@ -517,6 +517,49 @@ def check_extrema_runmax(lib, dims, ranges, seed=3):
             dev.free(p)
 
 
+def check_seqmax3(lib, n=2051, seed=11):
+    """s3d_k_seqmax3 (the three DoG levels between four GSS levels in one pass) against the reference's sequential scan written
+    out literally (imutil.c:1959-1973 / sift.c:1161-1166) per level: NaNs first / last / scattered / in one level only / none,
+    infinities; n not a multiple of 4 (the scalar tail) and, on a larger n, many blocks."""
+    dev = dev_of(lib)
+    L = dev.L
+    L.s3d_k_seqmax3.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(seed)
+
+    def seq(v):
+        a = np.abs(v)
+        nan = np.flatnonzero(np.isnan(a))
+        if len(nan) == 0:
+            return a.max() if len(a) else np.float32(0)
+        last = nan[-1]
+        if last == len(a) - 1:
+            return np.float32(np.nan)
+        return a[last + 1:].max()                        # a NaN replaces the running maximum, the next sample replaces the NaN
+
+    base = [rng.standard_normal(n).astype(np.float32) for _ in range(4)]
+    edits = [[], [(0, 0, np.nan)], [(3, n - 1, np.nan)], [(1, 7, np.nan), (1, n // 2, np.nan)], [(2, n - 2, np.nan)],
+             [(0, 5, np.inf)], [(1, 5, np.inf), (2, n // 2, np.nan)], [(3, n // 3, -np.inf), (0, n // 2, np.nan)],
+             [(k, i, np.nan) for k in (1, 2) for i in range(n // 4, n // 2)]]
+    d_lv = [dev.malloc(4 * n) for _ in range(4)]
+    d_m, d_rec = dev.malloc(12), dev.malloc(48)
+    P4 = (C.c_void_p * 4)(*d_lv)
+    try:
+        for ed in edits:
+            lv = [b.copy() for b in base]
+            for k, i, v in ed:
+                lv[k][i] = v
+            for k in range(4):
+                L.s3d_rt_h2d(C.c_void_p(d_lv[k]), lv[k].ctypes.data_as(C.c_void_p), 4 * n, None)
+            assert L.s3d_k_seqmax3(P4, n, d_m, d_rec, None) == 0 and L.s3d_rt_sync(None) == 0
+            got = dev.download(d_m, (3,))
+            for s_ in range(3):
+                want = seq(lv[s_] - lv[s_ + 1])
+                assert (np.isnan(got[s_]) and np.isnan(want)) or got[s_] == want, (ed[:2], s_, got[s_], want)
+    finally:
+        for p_ in d_lv + [d_m, d_rec]:
+            dev.free(p_)
+
+
 def check_sep_fir_div(lib, oracle, dims, sigmas, splits, zero=False, units=(1, 1, 1), mode=0):
     """s3d_k_sep_fir_div (im_scale folded into the loads of the first filter) against the explicit sequence maximum ->
     s3d_k_scale_div -> filter, bit for bit, whole volume and plane ranges; an all-zero volume stays all zero (the reference

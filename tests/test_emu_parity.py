@@ -395,6 +395,13 @@ def test_seqmax_kernels(emu):
             dev.free(p_)
 
 
+@pytest.mark.parametrize("n", [2051, 70000])
+def test_seqmax3(emu, n):
+    """The sequential maxima of an octave's three DoG levels from one pass over its four GSS levels (the verbatim pass of
+    volumes with non-finite voxels) = the reference's scan, level by level."""
+    parity.check_seqmax3(emu, n)
+
+
 def test_tap_table_cache_evicts(emu, oracle):
     """The table cache of the table-driven Gaussian passes holds 256 tables.  A process that walks through more distinct
     (extent, filter, spacing) triples than that keeps getting tables -- the least recently used one goes -- instead of being

@@ -864,4 +864,12 @@ def test_nonfinite_large_volume_vs_reference(lib, reference, dims, units, edits)
     if got is not None:                                                          # (k may be 0: an infinity that the sequential
         for a, b in zip(got, got2):                                              # maximum keeps scales the volume to zeros)
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8))         # the two literal kernels: bit for bit
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2051, 70000, 5000003])
+def test_seqmax3(lib, n):
+    """The sequential maxima of an octave's three DoG levels from one pass over its four GSS levels (the verbatim pass of
+    volumes with non-finite voxels) = the reference's scan, level by level."""
+    parity.check_seqmax3(lib, n)
+
+
 
