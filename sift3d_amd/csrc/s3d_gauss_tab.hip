@@ -455,6 +455,8 @@ k_conv_x_tab(const float *__restrict__ src, float *__restrict__ dst, int nx, siz
  * 16-byte aligned ds_read_b128 whatever the parity of lo.  An odd last row of a wave is its own second row (loaded and stored
  * twice: no branch around a load or a store). */
 #define XT2_LINE 144                      /* entries (8 B) per staged copy: > 126, and 2 * XT2_LINE = 32 (mod 64) dwords */
+static_assert(64 + 2 * TAB_MAX_UHW + 3 <= 128, "a wave stages 128 source positions per row: the taps of its 64 outputs must stay inside");
+static_assert(XT2_LINE > 126 + 1 && XT_LINE > 126 + 1, "the shifted copy of a staged line ends at entry LINE + 126; its last entry parks lane 0's spare store");
 template <int HW, int D>
 __global__ void __launch_bounds__(64)
 k_conv_x_tab2(const float *__restrict__ src, float *__restrict__ dst, int nx, size_t row_begin, size_t row_end,
