@@ -87,7 +87,8 @@ typedef struct {
     float *d_R, *d_Rk;
     void *d_orient;         /* s3d_k_orient scratch for cand_cap candidates */
     void *d_oritab;         /* the levels' window tables (s3d_k_orient_tab), s3d_k_orient_tab_bytes of the last pyramid */
-    int oritab_built;       /* build_gpyr_dev has enqueued their build for the current pyramid on ext_stream (with the sigmas) */
+    int oritab_built;       /* build_gpyr_dev has enqueued their build for the current pyramid on ext_stream */
+    int sigma_sent;         /* ... and the levels' orientation sigmas (d_sigma), tables or not */
     size_t oritab_bytes;
     int32_t *d_xyzos;
     double *d_sigma;
@@ -720,17 +721,19 @@ static int build_gpyr_dev(SIFT3D *const sift3d, s3d_ctx *c, int with_extrema)
         es = c->ext_stream;
         DEV(s3d_rt_memset(c->d_count, 0, 8 * sizeof(uint32_t), es));
     }
-    c->oritab_built = 0;
+    c->oritab_built = c->sigma_sent = 0;
     if (es) {
-        /* The orientation window tables (levels whose units are not one power of two) are a property of the pyramid's geometry,
-         * not of its voxels: a wave per level for ~0.2 ms, which used to sit between the extrema pass and the window sums.  Here
-         * they are built beside the first filters; detect_dev waits for this stream before it reads the candidate count. */
+        /* What the orientation step needs besides the candidates does not depend on the voxels: the levels' sigmas, and -- for
+         * levels whose units are not one power of two -- the window tables (a wave per level for ~0.2 ms).  Both used to sit
+         * between the extrema pass and the window sums; here they go out beside the first filters, and detect_dev waits for this
+         * stream before it reads the candidate count. */
         s3d_pyramid_desc pd;
         fill_pyr_desc(g, c->d_level, &pd);
+        for (int i = 0; i < g->num_octaves * L; i++) c->h_sigma[i] = ori_sig_fctr * g->levels[i].s;
+        DEV(s3d_rt_h2d(c->d_sigma, c->h_sigma, sizeof(double) * (size_t)g->num_octaves * L, es));
+        c->sigma_sent = 1;
         if (s3d_k_orient_wants_tab(&pd)) {
             if (ensure_oritab(c, &pd)) return SIFT3D_FAILURE;
-            for (int i = 0; i < g->num_octaves * L; i++) c->h_sigma[i] = ori_sig_fctr * g->levels[i].s;
-            DEV(s3d_rt_h2d(c->d_sigma, c->h_sigma, sizeof(double) * (size_t)g->num_octaves * L, es));
             DEV(s3d_k_orient_tab_build(&pd, c->d_sigma, c->d_oritab, es));
             c->oritab_built = 1;
         }
@@ -849,9 +852,11 @@ static int detect_dev(SIFT3D *const sift3d, s3d_ctx *c, Keypoint_store *const kp
             DEV(s3d_k_orient_tab_built(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
                                        c->d_R, c->d_keep, NULL, c->d_orient, c->d_oritab, c->d_count + 2, c->stream));
         } else {
-            double *const sig = c->h_sigma;               /* lives in the context: the copy below is asynchronous */
-            for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
-            DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
+            if (!c->sigma_sent) {
+                double *const sig = c->h_sigma;           /* lives in the context: the copy below is asynchronous */
+                for (int i = 0; i < g->num_octaves * L; i++) sig[i] = ori_sig_fctr * g->levels[i].s;
+                DEV(s3d_rt_h2d(c->d_sigma, sig, sizeof(double) * (size_t)g->num_octaves * L, c->stream));
+            }
             if (s3d_k_orient_wants_tab(&pd) && ensure_oritab(c, &pd)) return SIFT3D_FAILURE;
             DEV(s3d_k_orient_tab(&pd, c->d_cand_idx, c->d_cand_tag, NULL, counts[0], c->d_sigma, sift3d->corner_thresh,
                                  c->d_R, c->d_keep, NULL, c->d_orient, s3d_k_orient_wants_tab(&pd) ? c->d_oritab : NULL,
